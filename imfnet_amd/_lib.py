@@ -1,0 +1,78 @@
+"""ctypes binding of libimfnet_hip.so (include/imfnet_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libimfnet_hip.so")
+
+TILE_ROWS = 64
+MASK_WORDS = 4
+MAX_KVOL = 125
+
+
+class ImfError(RuntimeError):
+    pass
+
+
+class ConvArgs(C.Structure):
+    """struct imf_conv_args (include/imfnet_hip.h)."""
+    _fields_ = [
+        ("in_a", C.c_void_p), ("in_b", C.c_void_p),
+        ("c_a", C.c_int32), ("c_b", C.c_int32),
+        ("w_packed", C.c_void_p),
+        ("kvol", C.c_int32), ("cout", C.c_int32),
+        ("tile_rows", C.c_void_p), ("nbr", C.c_void_p),
+        ("tile_mask", C.c_void_p),
+        ("n_slots", C.c_int64), ("n_out", C.c_int64),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
+        ("relu", C.c_int32), ("l2norm", C.c_int32),
+        ("out", C.c_void_p),
+    ]
+
+
+_P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/imfnet_hip.h declares
+SIGNATURES = {
+    "imf_version": (_I, []),
+    "imf_last_error": (C.c_char_p, []),
+    "imf_hash_capacity": (_L, [_L]),
+    "imf_unique_workspace_bytes": (_Z, [_L]),
+    "imf_voxelize": (_I, [_P, _I, _L, _D, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
+    "imf_downsample": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _L, _P, _P]),
+    "imf_rulebook_slots": (_L, [_L]),
+    "imf_rulebook_conv": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "imf_rulebook_transpose_slots": (_L, [_L]),
+    "imf_rulebook_transpose": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P]),
+    "imf_packed_weight_floats": (_L, [_I, _I, _I]),
+    "imf_pack_weights": (_I, [_P, _I, _I, _I, _P, _P]),
+    "imf_spconv_fwd": (_I, [C.POINTER(ConvArgs), _P]),
+    "imf_spconv_small_cin": (_I, [_P, _I, _P, _I, _I, _P, _L, _L, _P, _P, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises ImfError (never falls back) if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImfError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C imfnet_amd/csrc`.  imfnet_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().imf_last_error().decode("utf-8", "replace")
+        raise ImfError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,88 @@
+// Shared helpers for libimfnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/imfnet_hip.h"
+
+namespace imf {
+
+void set_error(const char *fmt, ...);
+
+#define IMF_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      imf::set_error(__VA_ARGS__);      \
+      return IMF_EINVAL;                \
+    }                                   \
+  } while (0)
+
+#define IMF_CHECK_LAUNCH(what)                                                   \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      imf::set_error("%s: %s", what, hipGetErrorString(e_));                     \
+      return IMF_ELAUNCH;                                                        \
+    }                                                                            \
+  } while (0)
+
+#define IMF_CHECK_HIP(expr)                                                      \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      imf::set_error("%s: %s", #expr, hipGetErrorString(e_));                    \
+      return IMF_ELAUNCH;                                                        \
+    }                                                                            \
+  } while (0)
+
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kCoordBits = 18;
+constexpr int kCoordLim = 1 << (kCoordBits - 1);  // coordinates in [-2^17, 2^17)
+
+__device__ __forceinline__ uint64_t pack_key(int b, int x, int y, int z) {
+  return ((uint64_t)(uint32_t)b << (3 * kCoordBits)) | ((uint64_t)(x & 0x3FFFF) << (2 * kCoordBits)) |
+         ((uint64_t)(y & 0x3FFFF) << kCoordBits) | (uint64_t)(z & 0x3FFFF);
+}
+
+__device__ __forceinline__ bool coord_in_range(int x, int y, int z) {
+  return x >= -kCoordLim && x < kCoordLim && y >= -kCoordLim && y < kCoordLim && z >= -kCoordLim &&
+         z < kCoordLim;
+}
+
+__device__ __forceinline__ uint32_t hash64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+// Returns the slot that holds `key` after the call (inserting it if absent).
+__device__ __forceinline__ uint32_t hash_insert(uint64_t *keys, uint32_t capmask, uint64_t key) {
+  uint32_t s = hash64(key) & capmask;
+  while (true) {
+    unsigned long long prev =
+        atomicCAS(reinterpret_cast<unsigned long long *>(keys + s), (unsigned long long)kEmptyKey,
+                  (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) return s;
+    s = (s + 1) & capmask;
+  }
+}
+
+__device__ __forceinline__ int hash_find(const uint64_t *__restrict__ keys,
+                                         const int32_t *__restrict__ vals, uint32_t capmask,
+                                         uint64_t key) {
+  uint32_t s = hash64(key) & capmask;
+  while (true) {
+    uint64_t k = keys[s];
+    if (k == key) return vals[s];
+    if (k == kEmptyKey) return -1;
+    s = (s + 1) & capmask;
+  }
+}
+
+inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace imf

@@ -1,0 +1,367 @@
+// Geometry kernels: voxel hash build, first-occurrence unique, pyramid levels, rulebooks.
+// Integer / byte work, HBM- and L2-latency bound: coalesced streams over points and slots,
+// random probes into an L2-resident open-addressing table.  No MFMA here by design.
+#include "common.h"
+
+namespace imf {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kScanThreads * kScanItems;  // 1024 rows per block
+
+__device__ __forceinline__ int floor_div(int a, int s) {
+  return a >= 0 ? a / s : -((-a + s - 1) / s);
+}
+
+// ---- K1: quantise + insert (atomicCAS on the key, atomicMin on the row index) -----------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch,
+                uint64_t *keys, int32_t *vals, uint32_t capmask, int32_t *slot_of, int32_t *err) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // util/misc.py:82 -- np.floor(xyz / voxel_size) in float64 (IEEE division, exact floor)
+  double fx = floor((double)xyz[3 * i + 0] / voxel);
+  double fy = floor((double)xyz[3 * i + 1] / voxel);
+  double fz = floor((double)xyz[3 * i + 2] / voxel);
+  bool ok = fx >= -kCoordLim && fx < kCoordLim && fy >= -kCoordLim && fy < kCoordLim &&
+            fz >= -kCoordLim && fz < kCoordLim;   // also false for NaN
+  if (!ok) {
+    atomicOr(err, 1);
+    fx = fy = fz = 0.0;
+  }
+  uint64_t key = pack_key(batch, (int)fx, (int)fy, (int)fz);
+  uint32_t s = hash_insert(keys, capmask, key);
+  atomicMin(vals + s, (int32_t)i);
+  slot_of[i] = (int32_t)s;
+}
+
+__global__ void __launch_bounds__(256)
+k_insert_coords(const int32_t *__restrict__ cin, const int32_t *__restrict__ n_dev, int stride,
+                uint64_t *keys, int32_t *vals, uint32_t capmask, int32_t *slot_of) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *n_dev) return;
+  int4 c = reinterpret_cast<const int4 *>(cin)[i];
+  int x = floor_div(c.y, stride) * stride;
+  int y = floor_div(c.z, stride) * stride;
+  int z = floor_div(c.w, stride) * stride;
+  uint32_t s = hash_insert(keys, capmask, pack_key(c.x, x, y, z));
+  atomicMin(vals + s, (int32_t)i);
+  slot_of[i] = (int32_t)s;
+}
+
+// ---- K2: first-occurrence flag (sign of slot_of) + per-block count -----------------------------
+__device__ __forceinline__ int block_sum_256(int v, int *lds4) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) lds4[w] = v;
+  __syncthreads();
+  return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+__global__ void __launch_bounds__(kScanThreads)
+k_flag_first(int32_t *slot_of, const int32_t *__restrict__ vals, int64_t n_static,
+             const int32_t *__restrict__ n_dev, int32_t *block_sums) {
+  __shared__ int lds4[4];
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_static;
+  int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  int cnt = 0;
+#pragma unroll
+  for (int e = 0; e < kScanItems; ++e) {
+    int64_t i = base + e;
+    if (i < n) {
+      int s = slot_of[i];
+      bool first = vals[s] == (int32_t)i;
+      slot_of[i] = first ? s : ~s;
+      cnt += first;
+    }
+  }
+  int tot = block_sum_256(cnt, lds4);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// ---- K3: exclusive scan of the block counts (one block), total -> m_out ------------------------
+__global__ void __launch_bounds__(256)
+k_scan_block_sums(int32_t *block_sums, int nb, int32_t *m_out) {
+  __shared__ int part[256];
+  const int t = threadIdx.x;
+  const int per = (nb + 255) / 256;
+  const int lo = t * per, hi = min(nb, lo + per);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += block_sums[i];
+  part[t] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 256 partials
+  for (int o = 1; o < 256; o <<= 1) {
+    int v = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;  // exclusive prefix of this thread's chunk
+  for (int i = lo; i < hi; ++i) {
+    int v = block_sums[i];
+    block_sums[i] = run;
+    run += v;
+  }
+  if (t == 255) *m_out = part[255];
+}
+
+// ---- K4: order-preserving compaction: row r = rank of the first-occurrence point ---------------
+__global__ void __launch_bounds__(kScanThreads)
+k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ keys, int32_t *vals,
+              int64_t n_static, const int32_t *__restrict__ n_dev,
+              const int32_t *__restrict__ block_offs, int32_t *coords_out, int32_t *first_idx) {
+  __shared__ int wsum[4];
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_static;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int64_t base = (int64_t)blockIdx.x * kScanTile + t * kScanItems;
+  int s[kScanItems];
+  int cnt = 0;
+#pragma unroll
+  for (int e = 0; e < kScanItems; ++e) {
+    int64_t i = base + e;
+    s[e] = (i < n) ? slot_of[i] : -1;
+    cnt += s[e] >= 0;
+  }
+  // wave inclusive scan
+  int inc = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    int v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int q = 0; q < w; ++q) woff += wsum[q];
+  int r = block_offs[blockIdx.x] + woff + inc - cnt;
+#pragma unroll
+  for (int e = 0; e < kScanItems; ++e) {
+    if (s[e] >= 0) {
+      uint64_t key = keys[s[e]];
+      int4 c;
+      c.x = (int)(key >> (3 * kCoordBits));
+      c.y = ((int)((key >> (2 * kCoordBits)) & 0x3FFFF) << 14) >> 14;   // sign-extend 18 bits
+      c.z = ((int)((key >> kCoordBits) & 0x3FFFF) << 14) >> 14;
+      c.w = ((int)(key & 0x3FFFF) << 14) >> 14;
+      reinterpret_cast<int4 *>(coords_out)[r] = c;
+      if (first_idx) first_idx[r] = (int32_t)(base + e);
+      vals[s[e]] = r;   // the table now maps voxel -> row
+      ++r;
+    }
+  }
+}
+
+static int run_unique_tail(int32_t *slot_of, int32_t *block_sums, uint64_t *keys, int32_t *vals,
+                           int64_t n_max, const int32_t *n_dev, int32_t *coords_out,
+                           int32_t *first_idx, int32_t *m_out, hipStream_t st) {
+  const int nb = (int)div_up(n_max, kScanTile);
+  k_flag_first<<<nb, kScanThreads, 0, st>>>(slot_of, vals, n_max, n_dev, block_sums);
+  k_scan_block_sums<<<1, 256, 0, st>>>(block_sums, nb, m_out);
+  k_emit_unique<<<nb, kScanThreads, 0, st>>>(slot_of, keys, vals, n_max, n_dev, block_sums,
+                                             coords_out, first_idx);
+  IMF_CHECK_LAUNCH("unique pipeline");
+  return IMF_OK;
+}
+
+static int init_table(uint64_t *keys, int32_t *vals, int64_t capacity, hipStream_t st) {
+  IMF_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)capacity * sizeof(uint64_t), st));
+  IMF_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)vals, 0x7FFFFFFF, (size_t)capacity, st));
+  return IMF_OK;
+}
+
+// ---- rulebooks ---------------------------------------------------------------------------------
+__device__ __forceinline__ void kernel_offset(int k, int ksize, int &dx, int &dy, int &dz) {
+  const int r = ksize >> 1;              // ME kernel_region: axis 0 (x) fastest
+  dx = k % ksize - r;
+  dy = (k / ksize) % ksize - r;
+  dz = k / (ksize * ksize) - r;
+}
+
+// One thread per (slot, k), slot fastest: a wavefront covers 64 consecutive slots (= one tile) of
+// one offset, so the nbr store is one coalesced 256 B line and the tile mask is a ballot.
+// SIGN = +1: in = out + off*ts (conv); SIGN = -1: coarse = fine - off*ts (transposed conv).
+template <int SIGN, bool INDIRECT>
+__global__ void __launch_bounds__(256)
+k_rulebook(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, uint32_t capmask,
+           const int32_t *__restrict__ out_coords, int64_t n_out, int ts, int ksize, int kvol,
+           int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_slots * kvol) return;     // n_slots % 64 == 0 -> whole wavefronts exit together
+  const int k = (int)(idx / n_slots);
+  const int64_t slot = idx - (int64_t)k * n_slots;
+  int row;
+  if (INDIRECT) {
+    row = tile_rows[slot];
+  } else {
+    row = slot < n_out ? (int)slot : -1;
+    if (k == 0) tile_rows[slot] = row;
+  }
+  int found = -1;
+  if (row >= 0) {
+    int4 c = reinterpret_cast<const int4 *>(out_coords)[row];
+    int dx, dy, dz;
+    kernel_offset(k, ksize, dx, dy, dz);
+    int x = c.y + SIGN * dx * ts, y = c.z + SIGN * dy * ts, z = c.w + SIGN * dz * ts;
+    if (coord_in_range(x, y, z)) found = hash_find(keys, vals, capmask, pack_key(c.x, x, y, z));
+  }
+  nbr[idx] = found;
+  unsigned long long any = __ballot(found >= 0);
+  if (any != 0ull && (threadIdx.x & 63) == 0)
+    atomicOr(tile_mask + (slot >> 6) * IMF_MASK_WORDS + (k >> 5), 1u << (k & 31));
+}
+
+// Transposed conv: group fine rows by the parity of (coord / ts) per axis (8 classes).
+__device__ __forceinline__ int parity_class(int4 c, int ts) {
+  return (((c.y / ts) & 1)) | (((c.z / ts) & 1) << 1) | (((c.w / ts) & 1) << 2);
+}
+
+__global__ void __launch_bounds__(256)
+k_class_count(const int32_t *__restrict__ coords, int64_t n, int ts, int32_t *counters) {
+  __shared__ int cnt[8];
+  if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&cnt[parity_class(reinterpret_cast<const int4 *>(coords)[i], ts)], 1);
+  __syncthreads();
+  if (threadIdx.x < 8 && cnt[threadIdx.x]) atomicAdd(counters + threadIdx.x, cnt[threadIdx.x]);
+}
+
+__global__ void k_class_bases(int32_t *counters) {
+  // counters[0..7] = counts -> cursors (0); counters[8..15] = tile-aligned class bases
+  int base = 0;
+  for (int p = 0; p < 8; ++p) {
+    int c = counters[p];
+    counters[8 + p] = base;
+    counters[p] = 0;
+    base += (c + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_class_assign(const int32_t *__restrict__ coords, int64_t n, int ts, int32_t *counters,
+               int32_t *tile_rows) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int p = parity_class(reinterpret_cast<const int4 *>(coords)[i], ts);
+  int pos = counters[8 + p] + atomicAdd(counters + p, 1);
+  tile_rows[pos] = (int32_t)i;
+}
+
+}  // namespace imf
+
+using namespace imf;
+
+extern "C" {
+
+int64_t imf_hash_capacity(int64_t n) {
+  int64_t cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  return cap;
+}
+
+size_t imf_unique_workspace_bytes(int64_t n) {
+  return (size_t)(n + div_up(n, kScanTile) + 16) * sizeof(int32_t);
+}
+
+int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
+                 int32_t *coords, int32_t *first_idx, int32_t *m_out, uint64_t *keys, int32_t *vals,
+                 int64_t capacity, void *workspace, int32_t *err_out, void *stream) {
+  IMF_REQUIRE(xyz && coords && first_idx && m_out && keys && vals && workspace && err_out,
+              "imf_voxelize: null pointer");
+  IMF_REQUIRE(n > 0 && n < (1ll << 31) - 2048, "imf_voxelize: n=%lld out of range", (long long)n);
+  IMF_REQUIRE(voxel_size > 0.0, "imf_voxelize: voxel_size must be > 0");
+  IMF_REQUIRE(batch_index >= 0 && batch_index < 512, "imf_voxelize: batch_index out of [0,512)");
+  IMF_REQUIRE(capacity >= 2 * n && (capacity & (capacity - 1)) == 0 && capacity <= (1ll << 32),
+              "imf_voxelize: capacity must be a power of two >= 2n");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t *slot_of = (int32_t *)workspace;
+  int32_t *block_sums = slot_of + n;
+  int rc = init_table(keys, vals, capacity, st);
+  if (rc) return rc;
+  const int nblk = (int)div_up(n, 256);
+  if (xyz_is_f64)
+    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index,
+                                                  keys, vals, (uint32_t)(capacity - 1), slot_of,
+                                                  err_out);
+  else
+    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index,
+                                                 keys, vals, (uint32_t)(capacity - 1), slot_of,
+                                                 err_out);
+  IMF_CHECK_LAUNCH("k_insert_points");
+  return run_unique_tail(slot_of, block_sums, keys, vals, n, nullptr, coords, first_idx, m_out, st);
+}
+
+int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_in_max,
+                   int out_stride, int32_t *coords_out, int32_t *m_out, uint64_t *keys,
+                   int32_t *vals, int64_t capacity, void *workspace, void *stream) {
+  IMF_REQUIRE(coords_in && n_in_dev && coords_out && m_out && keys && vals && workspace,
+              "imf_downsample: null pointer");
+  IMF_REQUIRE(n_in_max > 0 && n_in_max < (1ll << 31) - 2048, "imf_downsample: n out of range");
+  IMF_REQUIRE(out_stride >= 1, "imf_downsample: out_stride must be >= 1");
+  IMF_REQUIRE(capacity >= 2 * n_in_max && (capacity & (capacity - 1)) == 0 && capacity <= (1ll << 32),
+              "imf_downsample: capacity must be a power of two >= 2n");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t *slot_of = (int32_t *)workspace;
+  int32_t *block_sums = slot_of + n_in_max;
+  int rc = init_table(keys, vals, capacity, st);
+  if (rc) return rc;
+  k_insert_coords<<<(int)div_up(n_in_max, 256), 256, 0, st>>>(
+      coords_in, n_in_dev, out_stride, keys, vals, (uint32_t)(capacity - 1), slot_of);
+  IMF_CHECK_LAUNCH("k_insert_coords");
+  return run_unique_tail(slot_of, block_sums, keys, vals, n_in_max, n_in_dev, coords_out, nullptr,
+                         m_out, st);
+}
+
+int64_t imf_rulebook_slots(int64_t n_out) { return div_up(n_out, IMF_TILE_ROWS) * IMF_TILE_ROWS; }
+
+int imf_rulebook_conv(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+                      const int32_t *out_coords, int64_t n_out, int ts_in, int ksize,
+                      int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream) {
+  IMF_REQUIRE(in_keys && in_vals && out_coords && tile_rows && nbr && tile_mask,
+              "imf_rulebook_conv: null pointer");
+  IMF_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "imf_rulebook_conv: ksize must be 1, 3 or 5");
+  IMF_REQUIRE(n_out > 0 && ts_in >= 1, "imf_rulebook_conv: bad n_out / ts_in");
+  IMF_REQUIRE((in_capacity & (in_capacity - 1)) == 0, "imf_rulebook_conv: capacity not a power of 2");
+  hipStream_t st = (hipStream_t)stream;
+  const int kvol = ksize * ksize * ksize;
+  const int64_t n_slots = imf_rulebook_slots(n_out);
+  IMF_CHECK_HIP(hipMemsetAsync(tile_mask, 0, (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS * 4, st));
+  k_rulebook<+1, false><<<(unsigned)div_up(n_slots * kvol, 256), 256, 0, st>>>(
+      in_keys, in_vals, (uint32_t)(in_capacity - 1), out_coords, n_out, ts_in, ksize, kvol,
+      tile_rows, nbr, tile_mask, n_slots);
+  IMF_CHECK_LAUNCH("k_rulebook");
+  return IMF_OK;
+}
+
+int64_t imf_rulebook_transpose_slots(int64_t n_fine) {
+  return (div_up(n_fine, IMF_TILE_ROWS) + 8) * IMF_TILE_ROWS;
+}
+
+int imf_rulebook_transpose(const uint64_t *coarse_keys, const int32_t *coarse_vals,
+                           int64_t coarse_capacity, const int32_t *fine_coords, int64_t n_fine,
+                           int ts_fine, int ksize, int32_t *tile_rows, int32_t *nbr,
+                           uint32_t *tile_mask, int64_t n_slots, int32_t *counters, void *stream) {
+  IMF_REQUIRE(coarse_keys && coarse_vals && fine_coords && tile_rows && nbr && tile_mask && counters,
+              "imf_rulebook_transpose: null pointer");
+  IMF_REQUIRE(ksize == 3, "imf_rulebook_transpose: only kernel_size 3 / stride 2 is supported");
+  IMF_REQUIRE(n_fine > 0 && ts_fine >= 1, "imf_rulebook_transpose: bad n_fine / ts_fine");
+  IMF_REQUIRE(n_slots == imf_rulebook_transpose_slots(n_fine), "imf_rulebook_transpose: n_slots");
+  IMF_REQUIRE((coarse_capacity & (coarse_capacity - 1)) == 0, "capacity not a power of 2");
+  hipStream_t st = (hipStream_t)stream;
+  const int kvol = 27;
+  IMF_CHECK_HIP(hipMemsetAsync(counters, 0, 16 * sizeof(int32_t), st));
+  IMF_CHECK_HIP(hipMemsetAsync(tile_rows, 0xFF, (size_t)n_slots * sizeof(int32_t), st));
+  IMF_CHECK_HIP(hipMemsetAsync(tile_mask, 0, (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS * 4, st));
+  const unsigned nb = (unsigned)div_up(n_fine, 256);
+  k_class_count<<<nb, 256, 0, st>>>(fine_coords, n_fine, ts_fine, counters);
+  k_class_bases<<<1, 1, 0, st>>>(counters);
+  k_class_assign<<<nb, 256, 0, st>>>(fine_coords, n_fine, ts_fine, counters, tile_rows);
+  k_rulebook<-1, true><<<(unsigned)div_up(n_slots * kvol, 256), 256, 0, st>>>(
+      coarse_keys, coarse_vals, (uint32_t)(coarse_capacity - 1), fine_coords, n_fine, ts_fine, ksize,
+      kvol, tile_rows, nbr, tile_mask, n_slots);
+  IMF_CHECK_LAUNCH("transpose rulebook");
+  return IMF_OK;
+}
+
+}  // extern "C"

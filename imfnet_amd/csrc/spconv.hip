@@ -1,0 +1,293 @@
+// Sparse convolution on gfx950: output-stationary gather -> fp32 MFMA small-GEMM per rulebook
+// tile, fused BatchNorm / bias / residual / ReLU / L2-norm epilogue.
+//
+// Work decomposition (one workgroup = 4 wavefronts = one 64-row rulebook tile x one 32/64-wide
+// slab of output channels):
+//   wavefront w owns output rows [16w, 16w+16) of the tile and all CO_BLK 16-column blocks of the
+//   slab: CO_BLK accumulators of v_mfma_f32_16x16x4_f32 (4 VGPRs each).
+//   for every kernel offset k that is active in the tile (tile_mask), for every 32/64-channel
+//   chunk of the input:
+//     - the packed weight stage (<= 16 KiB, already in MFMA B-fragment order) is copied to LDS;
+//     - every lane gathers its A fragments straight from the input rows as float4 (lane l holds
+//       channels 16j + 4(l>>4) + 0..3 of row nbr[k][l&15]) -- no LDS round trip for A;
+//     - a wavefront whose 16 rows have no input at offset k skips the MFMAs (wave-uniform).
+//   The accumulation order per output element is fixed (k ascending, then input channel in
+//   fragment order), so results are bit-reproducible run to run; there are no atomics.
+#include "common.h"
+
+namespace imf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+  const float *in_a, *in_b;
+  int c_a, c_b;
+  const float *w_packed;
+  int kvol, cout;
+  const int32_t *tile_rows, *nbr;
+  const uint32_t *tile_mask;
+  long long n_slots;
+  const float *scale, *shift, *residual;
+  int relu, l2norm;
+  float *out;
+};
+
+// Packed weight image: [y][k][cc][j][cb][lane][t] with
+//   ci = cc*CI_CHUNK + 16 j + 4 (lane>>4) + t,  co = y*CW + 16 cb + (lane&15)
+// i.e. one "stage" (y,k,cc) is J*CO_BLK B-fragment quads, each 64 lanes x float4, contiguous.
+__host__ __device__ inline int ci_chunk_of(int cin) { return (cin % 64 == 0) ? 64 : 32; }
+__host__ __device__ inline int co_blk_of(int cout) { return (cout % 64 == 0) ? 4 : 2; }
+
+__global__ void __launch_bounds__(256)
+k_pack_weights(const float *__restrict__ w, int kvol, int cin, int cout, float *__restrict__ packed) {
+  const long long total = (long long)kvol * cin * cout;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int CI = ci_chunk_of(cin), J = CI / 16, CB = co_blk_of(cout), CW = 16 * CB;
+  const int ncc = cin / CI;
+  long long r = idx;
+  const int t = r & 3; r >>= 2;
+  const int lane = r & 63; r >>= 6;
+  const int cb = r % CB; r /= CB;
+  const int j = r % J; r /= J;
+  const int cc = r % ncc; r /= ncc;
+  const int k = r % kvol; r /= kvol;
+  const int y = (int)r;
+  const int ci = cc * CI + 16 * j + 4 * (lane >> 4) + t;
+  const int co = y * CW + 16 * cb + (lane & 15);
+  packed[idx] = w[((long long)k * cin + ci) * cout + co];
+}
+
+template <int CO_BLK, int J>
+__global__ void __launch_bounds__(256)
+k_spconv_mfma(const ConvParams p) {
+  constexpr int STAGE_F4 = J * CO_BLK * 64;          // float4 per weight stage (<= 1024 = 16 KiB)
+  __shared__ float4 wlds[STAGE_F4];
+
+  const int tile = blockIdx.x, y = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int cin = p.c_a + p.c_b;
+  const int ncc = cin / (16 * J);
+  const int CW = 16 * CO_BLK;
+
+  uint32_t mask[IMF_MASK_WORDS];
+#pragma unroll
+  for (int w = 0; w < IMF_MASK_WORDS; ++w) mask[w] = p.tile_mask[tile * IMF_MASK_WORDS + w];
+  if ((mask[0] | mask[1] | mask[2] | mask[3]) == 0u) return;   // padding tile
+
+  const long long my_slot = (long long)tile * IMF_TILE_ROWS + wave * 16 + r16;
+
+  f32x4 acc[CO_BLK];
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float4 *wbase = reinterpret_cast<const float4 *>(p.w_packed) +
+                        (long long)y * p.kvol * ncc * STAGE_F4;
+
+#pragma unroll 1
+  for (int w = 0; w < IMF_MASK_WORDS; ++w) {
+    uint32_t m = mask[w];
+#pragma unroll 1
+    while (m) {
+      const int k = w * 32 + __builtin_ctz(m);
+      m &= m - 1;
+      const int irow = p.nbr ? p.nbr[(long long)k * p.n_slots + my_slot] : p.tile_rows[my_slot];
+      const bool wave_active = __any(irow >= 0);
+#pragma unroll 1
+      for (int cc = 0; cc < ncc; ++cc) {
+        __syncthreads();                      // previous stage fully consumed
+        const float4 *src = wbase + ((long long)k * ncc + cc) * STAGE_F4;
+#pragma unroll
+        for (int q = 0; q < STAGE_F4 / 256; ++q) wlds[q * 256 + tid] = src[q * 256 + tid];
+
+        float4 a[J];
+        if (wave_active) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const int ci = cc * 16 * J + 16 * j + 4 * q4;
+            a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (irow >= 0) {
+              const float *src_row = (ci < p.c_a) ? p.in_a + (long long)irow * p.c_a + ci
+                                                  : p.in_b + (long long)irow * p.c_b + (ci - p.c_a);
+              a[j] = *reinterpret_cast<const float4 *>(src_row);
+            }
+          }
+        }
+        __syncthreads();                      // stage visible
+        if (wave_active) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+#pragma unroll
+            for (int cb = 0; cb < CO_BLK; ++cb) {
+              const float4 b = wlds[(j * CO_BLK + cb) * 64 + lane];
+              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b.x, acc[cb], 0, 0, 0);
+              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b.y, acc[cb], 0, 0, 0);
+              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b.z, acc[cb], 0, 0, 0);
+              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b.w, acc[cb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: acc[cb][r] = out[row 4*q4 + r][col 16*cb + r16] ------------------------------
+  int orow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    orow[r] = p.tile_rows[(long long)tile * IMF_TILE_ROWS + wave * 16 + q4 * 4 + r];
+
+  float v[CO_BLK][4];
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb) {
+    const int col = y * CW + cb * 16 + r16;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = acc[cb][r] * sc + sh;
+      if (p.residual && orow[r] >= 0) x += p.residual[(long long)orow[r] * p.cout + col];
+      if (p.relu) x = fmaxf(x, 0.f);
+      v[cb][r] = x;
+    }
+  }
+  if (p.l2norm) {   // whole row lives in this workgroup slab (cout == CW): reduce over 16 lanes
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float ss = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) ss += v[cb][r] * v[cb][r];
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
+      ss += __shfl_xor(ss, 8, 64);
+      const float nrm = sqrtf(ss);
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) v[cb][r] = v[cb][r] / nrm;   // no eps: resunet.py:230
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb) {
+    const int col = y * CW + cb * 16 + r16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (orow[r] >= 0) p.out[(long long)orow[r] * p.cout + col] = v[cb][r];
+  }
+}
+
+// ---- first layer: tiny Cin (all-ones occupancy feature), one thread per output row -------------
+template <int COUT>
+__global__ void __launch_bounds__(256)
+k_spconv_small_cin(const float *__restrict__ in, int cin, const float *__restrict__ w, int kvol,
+                   const int32_t *__restrict__ nbr, long long n_slots, long long n_out,
+                   const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                   float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const int nw = kvol * cin * COUT;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) wl[i] = w[i];
+  __syncthreads();
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+  for (int k = 0; k < kvol; ++k) {
+    const int i = (row < n_out) ? nbr[(long long)k * n_slots + row] : -1;
+    if (i >= 0) {
+      for (int ci = 0; ci < cin; ++ci) {
+        const float x = in[(long long)i * cin + ci];
+        const float4 *wk = reinterpret_cast<const float4 *>(wl + (k * cin + ci) * COUT);
+#pragma unroll
+        for (int c4 = 0; c4 < COUT / 4; ++c4) {
+          const float4 ww = wk[c4];
+          acc[4 * c4 + 0] = fmaf(x, ww.x, acc[4 * c4 + 0]);
+          acc[4 * c4 + 1] = fmaf(x, ww.y, acc[4 * c4 + 1]);
+          acc[4 * c4 + 2] = fmaf(x, ww.z, acc[4 * c4 + 2]);
+          acc[4 * c4 + 3] = fmaf(x, ww.w, acc[4 * c4 + 3]);
+        }
+      }
+    }
+  }
+  if (row >= n_out) return;
+  float4 *o = reinterpret_cast<float4 *>(out + row * COUT);
+#pragma unroll
+  for (int c4 = 0; c4 < COUT / 4; ++c4) {
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * c4 + e;
+      float x = acc[c] * (scale ? scale[c] : 1.f) + (shift ? shift[c] : 0.f);
+      y[e] = relu ? fmaxf(x, 0.f) : x;
+    }
+    o[c4] = make_float4(y[0], y[1], y[2], y[3]);
+  }
+}
+
+}  // namespace imf
+
+using namespace imf;
+
+extern "C" {
+
+int64_t imf_packed_weight_floats(int kvol, int cin, int cout) { return (int64_t)kvol * cin * cout; }
+
+int imf_pack_weights(const float *w, int kvol, int cin, int cout, float *packed, void *stream) {
+  IMF_REQUIRE(w && packed, "imf_pack_weights: null pointer");
+  IMF_REQUIRE(kvol >= 1 && kvol <= IMF_MAX_KVOL, "imf_pack_weights: kvol=%d", kvol);
+  IMF_REQUIRE(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0,
+              "imf_pack_weights: cin=%d cout=%d must be multiples of 32", cin, cout);
+  const long long total = (long long)kvol * cin * cout;
+  k_pack_weights<<<(unsigned)div_up(total, 256), 256, 0, (hipStream_t)stream>>>(w, kvol, cin, cout,
+                                                                                packed);
+  IMF_CHECK_LAUNCH("k_pack_weights");
+  return IMF_OK;
+}
+
+int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
+  IMF_REQUIRE(a, "imf_spconv_fwd: null args");
+  IMF_REQUIRE(a->in_a && a->w_packed && a->tile_rows && a->tile_mask && a->out,
+              "imf_spconv_fwd: null pointer");
+  IMF_REQUIRE(a->kvol >= 1 && a->kvol <= IMF_MAX_KVOL, "imf_spconv_fwd: kvol=%d", a->kvol);
+  IMF_REQUIRE(a->nbr || a->kvol == 1, "imf_spconv_fwd: nbr may be NULL only when kvol == 1");
+  IMF_REQUIRE(a->c_a > 0 && a->c_a % 32 == 0 && a->c_b >= 0 && a->c_b % 32 == 0,
+              "imf_spconv_fwd: c_a=%d c_b=%d must be multiples of 32", a->c_a, a->c_b);
+  IMF_REQUIRE((a->c_b == 0) == (a->in_b == nullptr), "imf_spconv_fwd: in_b / c_b mismatch");
+  IMF_REQUIRE(a->cout > 0 && a->cout % 32 == 0, "imf_spconv_fwd: cout=%d", a->cout);
+  IMF_REQUIRE(a->n_slots > 0 && a->n_slots % IMF_TILE_ROWS == 0, "imf_spconv_fwd: n_slots");
+  IMF_REQUIRE(a->n_out > 0, "imf_spconv_fwd: n_out");
+  const int cin = a->c_a + a->c_b;
+  const int J = ci_chunk_of(cin) / 16, CB = co_blk_of(a->cout);
+  IMF_REQUIRE(!a->l2norm || a->cout == 16 * CB, "imf_spconv_fwd: l2norm needs cout in {32, 64}");
+  ConvParams p{a->in_a, a->in_b, a->c_a, a->c_b, a->w_packed, a->kvol, a->cout, a->tile_rows,
+               a->nbr, a->tile_mask, (long long)a->n_slots, a->scale, a->shift, a->residual,
+               a->relu, a->l2norm, a->out};
+  dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)));
+  hipStream_t st = (hipStream_t)stream;
+  if (CB == 4 && J == 4)      k_spconv_mfma<4, 4><<<grid, 256, 0, st>>>(p);
+  else if (CB == 4 && J == 2) k_spconv_mfma<4, 2><<<grid, 256, 0, st>>>(p);
+  else if (CB == 2 && J == 4) k_spconv_mfma<2, 4><<<grid, 256, 0, st>>>(p);
+  else                        k_spconv_mfma<2, 2><<<grid, 256, 0, st>>>(p);
+  IMF_CHECK_LAUNCH("k_spconv_mfma");
+  return IMF_OK;
+}
+
+int imf_spconv_small_cin(const float *in, int cin, const float *w, int kvol, int cout,
+                         const int32_t *nbr, int64_t n_slots, int64_t n_out, const float *scale,
+                         const float *shift, int relu, float *out, void *stream) {
+  IMF_REQUIRE(in && w && nbr && out, "imf_spconv_small_cin: null pointer");
+  IMF_REQUIRE(cin >= 1 && cin <= 4, "imf_spconv_small_cin: cin=%d not in [1,4]", cin);
+  IMF_REQUIRE(cout == 32 || cout == 64, "imf_spconv_small_cin: cout=%d not in {32,64}", cout);
+  IMF_REQUIRE(kvol >= 1 && kvol <= IMF_MAX_KVOL, "imf_spconv_small_cin: kvol=%d", kvol);
+  const size_t lds = (size_t)kvol * cin * cout * sizeof(float);
+  IMF_REQUIRE(lds <= 64 * 1024, "imf_spconv_small_cin: kernel does not fit 64 KiB of LDS");
+  IMF_REQUIRE(n_out > 0 && n_slots >= n_out, "imf_spconv_small_cin: n_out / n_slots");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = (unsigned)div_up(n_out, 256);
+  if (cout == 32)
+    k_spconv_small_cin<32><<<nb, 256, lds, st>>>(in, cin, w, kvol, nbr, n_slots, n_out, scale, shift, relu, out);
+  else
+    k_spconv_small_cin<64><<<nb, 256, lds, st>>>(in, cin, w, kvol, nbr, n_slots, n_out, scale, shift, relu, out);
+  IMF_CHECK_LAUNCH("k_spconv_small_cin");
+  return IMF_OK;
+}
+
+}  // extern "C"

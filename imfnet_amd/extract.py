@@ -1,0 +1,87 @@
+"""`extract_features` -- the harness function the reference times (util/misc.py:21-104,
+called from scripts/generate_desc.py:100).
+
+Same signature and return convention:  (xyz_down float64 [M,3] on the host, F float32 [M,32] on the
+device), row i of F describing row i of xyz_down.  What differs is where the work happens: the
+reference voxelises on the host (np.floor + ME.utils.sparse_quantize) and uploads coordinates; here
+the raw points are uploaded once and quantisation, first-occurrence unique, the pyramid and the
+rulebooks are all built on the GPU (imf_voxelize & co.), bit-identical to the host result.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from . import sparse as ME
+from ._lib import ImfError
+
+
+def _as_device_points(xyz, device):
+    if torch.is_tensor(xyz):
+        t = xyz
+    else:
+        a = np.asarray(xyz)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.double()
+    return t.to(device, non_blocking=True).contiguous()
+
+
+def sparse_tensor_from_points(xyz, voxel_size, device, feats=None):
+    """Voxelise raw points on the GPU.  Returns (SparseTensor with all-ones / gathered features,
+    inds int64 CUDA tensor of each voxel's first point)."""
+    pts = _as_device_points(xyz, device)
+    lv = ops.voxelize(pts, voxel_size, 0)
+    cm = ME.CoordinateManager(lv)
+    cm.build_pyramid(8)                               # one host sync for all four row counts
+    inds = lv.first_idx.long()
+    if feats is None:
+        f = torch.ones((lv.n, 1), dtype=torch.float32, device=pts.device)        # util/misc.py:76-79
+    else:
+        f = torch.as_tensor(feats, dtype=torch.float32).to(pts.device)[inds]      # :89
+    st = ME.SparseTensor(f, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm)
+    return st, inds
+
+
+def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=None,
+                     skip_check=False, is_eval=True, image=None):
+    """xyz: [N,3] points (numpy float64/float32, or a tensor already on the device).
+    rgb in [0,1] / normal in [-1,1] are optional per-point inputs (concatenated as rgb-0.5, normal/2);
+    with neither, the input feature is a column of ones.  image: [1,3,H,W] float32."""
+    if is_eval:
+        model.eval()
+    if not skip_check:
+        assert xyz.shape[1] == 3
+        N = xyz.shape[0]
+        if rgb is not None:
+            assert N == len(rgb) and rgb.shape[1] == 3
+            if np.any(rgb > 1):
+                raise ValueError('Invalid color. Color must range from [0, 1]')
+        if normal is not None:
+            assert N == len(normal) and normal.shape[1] == 3
+            if np.any(normal > 1):
+                raise ValueError('Invalid normal. Normal must range from [-1, 1]')
+    if device is None:
+        device = torch.device('cuda:0')
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise ImfError('imfnet_amd runs on the GPU only; there is no CPU fallback')
+
+    feats = []
+    if rgb is not None:
+        feats.append(np.asarray(rgb) - 0.5)
+    if normal is not None:
+        feats.append(np.asarray(normal) / 2)
+    feats = np.hstack(feats) if feats else None
+
+    stensor, inds = sparse_tensor_from_points(xyz, voxel_size, device, feats)
+    image = torch.as_tensor(image, dtype=torch.float32, device=device)
+    F = model(stensor, image).F
+
+    inds_host = inds.cpu().numpy()
+    if torch.is_tensor(xyz):
+        return_coords = xyz.detach().cpu().numpy().astype(np.float64)[inds_host]
+    else:
+        return_coords = np.asarray(xyz)[inds_host]
+    return return_coords, F

@@ -1,0 +1,178 @@
+"""IMFNet's sparse ResUNet with bottleneck image fusion, executed on MI355X.
+
+Interface parity with the reference's model/resunet.py:
+  * class names `ResUNet2`, `ResUNetBN2[B-E]`, `ResUNetIN2[B-E]` with the same CHANNELS /
+    TR_CHANNELS tables (resunet.py:276-326);
+  * constructor `(in_channels, out_channels, bn_momentum, normalize_feature, conv1_kernel_size,
+    D, config)` (resunet.py:25-32) and sub-module names, hence the 361-key state_dict of SURVEY
+    App. B loads with strict=True;
+  * `forward(x, image) -> SparseTensor` with `.F` [M,out] row-aligned with the input coordinates
+    (resunet.py:163-235) and `transformer(images, F, xyz)` (resunet.py:237-273).
+
+Execution is NOT a layer-by-layer walk: in eval mode `forward` runs the fused plan
+  geometry (hash pyramid + 8 rulebooks, built once per fragment in HBM)
+  -> 23 sparse-conv launches whose epilogues carry BatchNorm (folded), ReLU, residual add,
+     the three ME.cat's (two-source gather), the `final` bias and the L2 normalisation.
+`forward_layers` keeps the reference's op-by-op order for tests and training-mode statistics.
+"""
+import torch
+import torch.nn as nn
+
+from .. import sparse as ME
+from .fusion import AttentionFusion
+from .image_encoder import ImageEncoder
+from .layers import get_block, get_norm
+
+MEF = ME.MinkowskiFunctional
+
+
+class ResUNet2(ME.MinkowskiNetwork):
+    NORM_TYPE = None
+    BLOCK_NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 32, 64, 64, 128]
+    IMG_CHANNELS = [None, 0, 0, 0, 0]       # multi-scale fusion is disabled upstream (resunet.py:20-21)
+
+    def __init__(self, in_channels=3, out_channels=32, bn_momentum=0.1, normalize_feature=None,
+                 conv1_kernel_size=None, D=3, config=None):
+        super().__init__(D)
+        C, T, I = self.CHANNELS, self.TR_CHANNELS, self.IMG_CHANNELS
+        self.normalize_feature = normalize_feature
+        conv, conv_tr = ME.MinkowskiConvolution, ME.MinkowskiConvolutionTranspose
+
+        def stage(idx, suffix, cls, cin, cout, ksize, stride):
+            setattr(self, f'conv{idx}{suffix}', cls(in_channels=cin, out_channels=cout, kernel_size=ksize,
+                                                    stride=stride, dilation=1, bias=False, dimension=D))
+            setattr(self, f'norm{idx}{suffix}', get_norm(self.NORM_TYPE, cout, bn_momentum=bn_momentum, D=D))
+            setattr(self, f'block{idx}{suffix}',
+                    get_block(self.BLOCK_NORM_TYPE, cout, cout, bn_momentum=bn_momentum, D=D))
+
+        # encoder: conv(k5|k3, stride 1|2) - norm - residual block, tensor stride 1 -> 8
+        stage(1, '', conv, in_channels, C[1], conv1_kernel_size, 1)
+        stage(2, '', conv, C[1], C[2], 3, 2)
+        stage(3, '', conv, C[2], C[3], 3, 2)
+        stage(4, '', conv, C[3], C[4], 3, 2)
+        # bottleneck: image tokens (128-d) attend into the stride-8 point features (resunet.py:91-100)
+        self.attention_fusion = AttentionFusion(dim=128, depth=0, latent_dim=C[4], cross_heads=1,
+                                                latent_heads=8, cross_dim_head=C[4] // 2,
+                                                latent_dim_head=C[4] // 2)
+        # decoder: transposed conv (stride 2) - norm - block, skip concatenation before each
+        stage(4, '_tr', conv_tr, C[4], T[4], 3, 2)
+        stage(3, '_tr', conv_tr, C[3] + T[4] + I[1], T[3], 3, 2)
+        stage(2, '_tr', conv_tr, C[2] + T[3] + I[2], T[2], 3, 2)
+        self.conv1_tr = conv(in_channels=C[1] + T[2] + I[3], out_channels=T[1], kernel_size=1, stride=1,
+                             dilation=1, bias=False, dimension=D)
+        self.final = conv(in_channels=T[1], out_channels=out_channels, kernel_size=1, stride=1,
+                          dilation=1, bias=True, dimension=D)
+        self.img_encoder = ImageEncoder()
+        self._folded = None
+
+    # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._folded = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._folded = None
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode=True):
+        self._folded = None
+        return super().train(mode)
+
+    def _bn(self):
+        if self._folded is None:
+            with torch.no_grad():
+                self._folded = {name: m.folded() for name, m in self.named_modules()
+                                if isinstance(m, ME.MinkowskiBatchNorm)}
+        return self._folded
+
+    def _can_fuse(self):
+        return (not self.training and self.NORM_TYPE == 'BN' and self.BLOCK_NORM_TYPE == 'BN')
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, x, image):
+        if not self._can_fuse():
+            return self.forward_layers(x, image)
+        bn = self._bn()
+        x.coordinate_manager.build_pyramid(8)
+        image = self.img_encoder(image)
+
+        def down(idx, t):            # conv - norm (no ReLU, resunet.py:168-169) - block
+            f, ts = getattr(self, f'conv{idx}').run(t, scale=bn[f'norm{idx}'][0], shift=bn[f'norm{idx}'][1])
+            return getattr(self, f'block{idx}').fused(t._like(f, ts), bn[f'block{idx}.norm1'],
+                                                      bn[f'block{idx}.norm2'])
+
+        def up(idx, t, skip):        # [cat] - transposed conv - norm - block
+            n = f'norm{idx}_tr'
+            f, ts = getattr(self, f'conv{idx}_tr').run(t, in_b=None if skip is None else skip.F,
+                                                       scale=bn[n][0], shift=bn[n][1])
+            return getattr(self, f'block{idx}_tr').fused(t._like(f, ts), bn[f'block{idx}_tr.norm1'],
+                                                         bn[f'block{idx}_tr.norm2'])
+
+        out_s1 = down(1, x)          # blocks end in ReLU, so the extra MEF.relu (:171) is the identity
+        out_s2 = down(2, out_s1)
+        out_s4 = down(3, out_s2)
+        out = down(4, out_s4)
+        out._F = self.transformer(images=image, F=out.F, xyz=out.C)                   # :189
+        out = up(4, out, None)
+        out = up(3, out, out_s4)                                                     # ME.cat :197
+        out = up(2, out, out_s2)                                                     # :208
+        f, _ = self.conv1_tr.run(out, in_b=out_s1.F, relu=True)                      # :219-225
+        f, _ = self.final.run(out._like(f), l2norm=bool(self.normalize_feature))     # :226-233
+        return out._like(f)
+
+    def forward_layers(self, x, image):
+        """Op-by-op order of the reference's forward (resunet.py:163-235)."""
+        image = self.img_encoder(image)
+        out_s1 = self.block1(self.norm1(self.conv1(x)))
+        out = MEF.relu(out_s1)
+        out_s2 = self.block2(self.norm2(self.conv2(out)))
+        out = MEF.relu(out_s2)
+        out_s4 = self.block3(self.norm3(self.conv3(out)))
+        out = MEF.relu(out_s4)
+        out_s8 = self.block4(self.norm4(self.conv4(out)))
+        out = MEF.relu(out_s8)
+        out._F = self.transformer(images=image, F=out.F, xyz=out.C)
+        out = MEF.relu(self.block4_tr(self.norm4_tr(self.conv4_tr(out))))
+        out = ME.cat(out, out_s4)
+        out = MEF.relu(self.block3_tr(self.norm3_tr(self.conv3_tr(out))))
+        out = ME.cat(out, out_s2)
+        out = MEF.relu(self.block2_tr(self.norm2_tr(self.conv2_tr(out))))
+        out = ME.cat(out, out_s1)
+        out = MEF.relu(self.conv1_tr(out))
+        out = self.final(out)
+        if self.normalize_feature:
+            return out._like(out.F / torch.norm(out.F, p=2, dim=1, keepdim=True))
+        return out
+
+    def transformer(self, images, F, xyz):
+        """Per batch item: the item's stride-8 rows attend over that item's image tokens
+        (resunet.py:237-273).  Rows are grouped by batch index.  With one image there is no
+        device->host traffic (the reference syncs three times here)."""
+        tokens = images.flatten(2).transpose(1, 2)                    # [B, H*W, C]  (:257-261)
+        if images.shape[0] == 1:
+            return self.attention_fusion(tokens, queries_encoder=F.unsqueeze(0))[0]
+        counts = torch.bincount(xyz[:, 0].long(), minlength=images.shape[0]).cpu().tolist()
+        parts, start = [], 0
+        for b, n in enumerate(counts):
+            parts.append(self.attention_fusion(tokens[b:b + 1], queries_encoder=F[start:start + n].unsqueeze(0))[0])
+            start += n
+        return torch.cat(parts, dim=0)
+
+
+def _variant(name, base, **attrs):
+    return type(name, (base,), dict(attrs, __doc__=f"{name}: see model/resunet.py:276-326 of the reference."))
+
+
+ResUNetBN2 = _variant('ResUNetBN2', ResUNet2, NORM_TYPE='BN')
+ResUNetBN2B = _variant('ResUNetBN2B', ResUNet2, NORM_TYPE='BN', TR_CHANNELS=[None, 64, 64, 64, 64])
+ResUNetBN2C = _variant('ResUNetBN2C', ResUNet2, NORM_TYPE='BN', TR_CHANNELS=[None, 64, 64, 64, 128])
+ResUNetBN2D = _variant('ResUNetBN2D', ResUNet2, NORM_TYPE='BN', TR_CHANNELS=[None, 64, 64, 128, 128])
+ResUNetBN2E = _variant('ResUNetBN2E', ResUNet2, NORM_TYPE='BN', CHANNELS=[None, 128, 128, 128, 256],
+                       TR_CHANNELS=[None, 64, 128, 128, 128])
+ResUNetIN2 = _variant('ResUNetIN2', ResUNet2, NORM_TYPE='BN', BLOCK_NORM_TYPE='IN')
+ResUNetIN2B = _variant('ResUNetIN2B', ResUNetBN2B, BLOCK_NORM_TYPE='IN')
+ResUNetIN2C = _variant('ResUNetIN2C', ResUNetBN2C, BLOCK_NORM_TYPE='IN')
+ResUNetIN2D = _variant('ResUNetIN2D', ResUNetBN2D, BLOCK_NORM_TYPE='IN')
+ResUNetIN2E = _variant('ResUNetIN2E', ResUNetBN2E, BLOCK_NORM_TYPE='IN')

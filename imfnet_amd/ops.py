@@ -1,0 +1,217 @@
+"""Tensor-level wrappers over the C ABI (include/imfnet_hip.h).  torch is used only for device
+memory and streams; every computation below happens in libimfnet_hip.so on the GPU."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, ImfError, TILE_ROWS, MASK_WORDS, check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t, dtype, name, ndim=None):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise ImfError(f"{name} must be a CUDA(HIP) tensor -- imfnet_amd has no CPU path")
+    if t.dtype != dtype:
+        raise ImfError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ImfError(f"{name} must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise ImfError(f"{name} must be {ndim}-D")
+    return t
+
+
+class Level:
+    """One coordinate map: rows `coords[:n]` (int32 (b,x,y,z)) at tensor stride `ts`, and the
+    voxel hash (keys/vals) mapping a coordinate to its row."""
+    __slots__ = ("coords_buf", "n_dev", "n", "keys", "vals", "capacity", "ts", "first_idx_buf")
+
+    def __init__(self, coords_buf, n_dev, keys, vals, capacity, ts, first_idx_buf=None):
+        self.coords_buf, self.n_dev, self.n = coords_buf, n_dev, None
+        self.keys, self.vals, self.capacity, self.ts = keys, vals, capacity, ts
+        self.first_idx_buf = first_idx_buf
+
+    @property
+    def coords(self):
+        return self.coords_buf[: self.n]
+
+    @property
+    def first_idx(self):
+        return self.first_idx_buf[: self.n]
+
+
+class Rulebook:
+    """Tiled kernel map (see include/imfnet_hip.h)."""
+    __slots__ = ("tile_rows", "nbr", "tile_mask", "n_slots", "n_out", "kvol")
+
+    def __init__(self, tile_rows, nbr, tile_mask, n_slots, n_out, kvol):
+        self.tile_rows, self.nbr, self.tile_mask = tile_rows, nbr, tile_mask
+        self.n_slots, self.n_out, self.kvol = n_slots, n_out, kvol
+
+
+def _new_table(n, device):
+    L = _lib.lib()
+    cap = L.imf_hash_capacity(n)
+    keys = torch.empty(cap, dtype=torch.int64, device=device)
+    vals = torch.empty(cap, dtype=torch.int32, device=device)
+    ws = torch.empty(L.imf_unique_workspace_bytes(n), dtype=torch.uint8, device=device)
+    return cap, keys, vals, ws
+
+
+def voxelize(xyz, voxel_size, batch_index=0):
+    """util/misc.py:82-87 on the GPU.  xyz: CUDA [N,3] float64 or float32.  Asynchronous: the
+    returned Level has n=None until `sync_levels` reads the counts back."""
+    if xyz.dtype not in (torch.float64, torch.float32):
+        raise ImfError(f"xyz must be float64/float32, got {xyz.dtype}")
+    _req(xyz, xyz.dtype, "xyz", 2)
+    n, dev = xyz.shape[0], xyz.device
+    if n == 0 or xyz.shape[1] != 3:
+        raise ImfError(f"xyz must be [N>0, 3], got {tuple(xyz.shape)}")
+    cap, keys, vals, ws = _new_table(n, dev)
+    coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    first = torch.empty(n, dtype=torch.int32, device=dev)
+    meta = torch.zeros(2, dtype=torch.int32, device=dev)           # [m, err]
+    check(_lib.lib().imf_voxelize(xyz.data_ptr(), int(xyz.dtype == torch.float64), n, float(voxel_size),
+                                  int(batch_index), coords.data_ptr(), first.data_ptr(),
+                                  meta[0:1].data_ptr(), keys.data_ptr(), vals.data_ptr(), cap,
+                                  ws.data_ptr(), meta[1:2].data_ptr(), _stream()), "imf_voxelize")
+    lv = Level(coords, meta, keys, vals, cap, 1, first)
+    return lv
+
+
+def downsample(level, out_stride, n_in_max=None):
+    """coordinate_manager.stride(): level at tensor stride `out_stride` (asynchronous)."""
+    n_max = int(n_in_max if n_in_max is not None else level.n)
+    dev = level.coords_buf.device
+    cap, keys, vals, ws = _new_table(n_max, dev)
+    coords = torch.empty((n_max, 4), dtype=torch.int32, device=dev)
+    m = torch.zeros(2, dtype=torch.int32, device=dev)               # [m, unused]
+    check(_lib.lib().imf_downsample(level.coords_buf.data_ptr(), level.n_dev.data_ptr(), n_max,
+                                    int(out_stride), coords.data_ptr(), m.data_ptr(), keys.data_ptr(),
+                                    vals.data_ptr(), cap, ws.data_ptr(), _stream()), "imf_downsample")
+    return Level(coords, m, keys, vals, cap, out_stride)
+
+
+def level_from_coords(coords):
+    """Coordinate map of caller-supplied int32 (b,x,y,z) rows (ME.SparseTensor(coordinates=...),
+    util/misc.py:95).  Duplicates collapse to their first occurrence."""
+    _req(coords, torch.int32, "coordinates", 2)
+    n = coords.shape[0]
+    n_dev = torch.tensor([n, 0], dtype=torch.int32, device=coords.device)
+    src = Level(coords, n_dev, None, None, 0, 1)
+    src.n = n
+    lv = downsample(src, 1)
+    lv.ts = 1
+    return lv
+
+
+def sync_levels(levels):
+    """One host synchronisation: read the row counts of `levels` back."""
+    counts = torch.cat([lv.n_dev for lv in levels]).cpu().tolist()      # [m, err] per level
+    for i, lv in enumerate(levels):
+        if counts[2 * i + 1] != 0:
+            raise ImfError("voxelize: a coordinate fell outside [-2^17, 2^17) voxels (or was NaN)")
+        lv.n = int(counts[2 * i])
+
+
+def rulebook_conv(in_level, out_level, ksize):
+    """Kernel map of ME.MinkowskiConvolution(kernel_size=ksize) from in_level to out_level."""
+    L = _lib.lib()
+    n_out, dev = out_level.n, out_level.coords_buf.device
+    kvol = ksize ** 3
+    n_slots = L.imf_rulebook_slots(n_out)
+    tile_rows = torch.empty(n_slots, dtype=torch.int32, device=dev)
+    nbr = torch.empty(kvol * n_slots, dtype=torch.int32, device=dev)
+    mask = torch.empty(n_slots // TILE_ROWS * MASK_WORDS, dtype=torch.int32, device=dev)
+    check(L.imf_rulebook_conv(in_level.keys.data_ptr(), in_level.vals.data_ptr(), in_level.capacity,
+                              out_level.coords_buf.data_ptr(), n_out, in_level.ts, ksize,
+                              tile_rows.data_ptr(), nbr.data_ptr(), mask.data_ptr(), _stream()),
+          "imf_rulebook_conv")
+    return Rulebook(tile_rows, nbr, mask, n_slots, n_out, kvol)
+
+
+def rulebook_transpose(coarse_level, fine_level, ksize=3):
+    """Kernel map of ME.MinkowskiConvolutionTranspose(kernel_size=3, stride=2): coarse -> fine."""
+    L = _lib.lib()
+    n_fine, dev = fine_level.n, fine_level.coords_buf.device
+    kvol = ksize ** 3
+    n_slots = L.imf_rulebook_transpose_slots(n_fine)
+    tile_rows = torch.empty(n_slots, dtype=torch.int32, device=dev)
+    nbr = torch.empty(kvol * n_slots, dtype=torch.int32, device=dev)
+    mask = torch.empty(n_slots // TILE_ROWS * MASK_WORDS, dtype=torch.int32, device=dev)
+    counters = torch.empty(16, dtype=torch.int32, device=dev)
+    check(L.imf_rulebook_transpose(coarse_level.keys.data_ptr(), coarse_level.vals.data_ptr(),
+                                   coarse_level.capacity, fine_level.coords_buf.data_ptr(), n_fine,
+                                   fine_level.ts, ksize, tile_rows.data_ptr(), nbr.data_ptr(),
+                                   mask.data_ptr(), n_slots, counters.data_ptr(), _stream()),
+          "imf_rulebook_transpose")
+    return Rulebook(tile_rows, nbr, mask, n_slots, n_fine, kvol)
+
+
+def rulebook_identity(n_out, device):
+    """kvol == 1 (pointwise) 'rulebook': slot == row, every tile active at offset 0."""
+    n_slots = _lib.lib().imf_rulebook_slots(n_out)
+    tile_rows = torch.arange(n_slots, dtype=torch.int32, device=device)
+    tile_rows[n_out:] = -1
+    mask = torch.zeros(n_slots // TILE_ROWS, MASK_WORDS, dtype=torch.int32, device=device)
+    mask[:, 0] = 1
+    return Rulebook(tile_rows, None, mask.reshape(-1), n_slots, n_out, 1)
+
+
+def pack_weights(kernel):
+    """ME kernel tensor [kvol,cin,cout] (or [cin,cout]) -> MFMA fragment-major image."""
+    k = kernel.detach()
+    if k.dim() == 2:
+        k = k.unsqueeze(0)
+    k = _req(k.contiguous().float(), torch.float32, "kernel", 3)
+    kvol, cin, cout = k.shape
+    packed = torch.empty(kvol * cin * cout, dtype=torch.float32, device=k.device)
+    check(_lib.lib().imf_pack_weights(k.data_ptr(), kvol, cin, cout, packed.data_ptr(), _stream()),
+          "imf_pack_weights")
+    return packed
+
+
+def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual=None,
+           relu=False, l2norm=False, out=None):
+    """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd."""
+    _req(in_a, torch.float32, "in_a", 2)
+    if in_b is not None:
+        _req(in_b, torch.float32, "in_b", 2)
+    if out is None:
+        out = torch.empty((rb.n_out, cout), dtype=torch.float32, device=in_a.device)
+    a = ConvArgs()
+    a.in_a, a.in_b = in_a.data_ptr(), _ptr(in_b)
+    a.c_a, a.c_b = in_a.shape[1], (0 if in_b is None else in_b.shape[1])
+    a.w_packed, a.kvol, a.cout = w_packed.data_ptr(), rb.kvol, cout
+    a.tile_rows, a.nbr, a.tile_mask = rb.tile_rows.data_ptr(), _ptr(rb.nbr), rb.tile_mask.data_ptr()
+    a.n_slots, a.n_out = rb.n_slots, rb.n_out
+    a.scale, a.shift, a.residual = _ptr(scale), _ptr(shift), _ptr(residual)
+    a.relu, a.l2norm = int(bool(relu)), int(bool(l2norm))
+    a.out = out.data_ptr()
+    if w_packed.numel() != rb.kvol * (a.c_a + a.c_b) * cout:
+        raise ImfError(f"packed weight has {w_packed.numel()} floats, expected "
+                       f"{rb.kvol}x{a.c_a + a.c_b}x{cout}")
+    check(_lib.lib().imf_spconv_fwd(C.byref(a), _stream()), "imf_spconv_fwd")
+    return out
+
+
+def spconv_small_cin(feat, kernel, rb, scale=None, shift=None, relu=False):
+    """First-layer conv for cin <= 4 (unpacked ME kernel [kvol,cin,cout])."""
+    _req(feat, torch.float32, "feat", 2)
+    k = _req(kernel.detach().contiguous(), torch.float32, "kernel", 3)
+    kvol, cin, cout = k.shape
+    if feat.shape[1] != cin or kvol != rb.kvol:
+        raise ImfError("spconv_small_cin: feature / kernel / rulebook mismatch")
+    out = torch.empty((rb.n_out, cout), dtype=torch.float32, device=feat.device)
+    check(_lib.lib().imf_spconv_small_cin(feat.data_ptr(), cin, k.data_ptr(), kvol, cout,
+                                          rb.nbr.data_ptr(), rb.n_slots, rb.n_out, _ptr(scale),
+                                          _ptr(shift), int(bool(relu)), out.data_ptr(), _stream()),
+          "imf_spconv_small_cin")
+    return out

@@ -1,0 +1,168 @@
+/* imfnet_hip.h -- C ABI of libimfnet_hip.so: the MI355X (gfx950) sparse-3D-convolution engine
+ * behind IMFNet's descriptor-generation path.
+ *
+ * The reference (XiaoshuiHuang/IMFNet) has no FFI of its own: its hot path calls the
+ * MinkowskiEngine 0.5.4 Python API (requirements.txt:5).  Each entry point below states which
+ * reference call site(s) it replaces (file:line under /root/reference).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked [host]; the library never
+ *     allocates or frees caller-visible memory and keeps no global mutable state (re-entrant per
+ *     stream);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return value: 0 on success, negative IMF_E* on error; imf_last_error() gives the message of
+ *     the last failing call on the calling thread;
+ *   - coordinates are int32 rows (b, x, y, z); b in [0,512), x/y/z in [-2^17, 2^17) in voxel units;
+ *   - feature matrices are row-major float32 [rows, C];
+ *   - all kernels are launched asynchronously; counts the caller needs on the host are written to
+ *     device int32 words the caller reads back when it chooses to synchronise.
+ */
+#ifndef IMFNET_HIP_H
+#define IMFNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMF_OK            0
+#define IMF_EINVAL       -1   /* bad argument (null pointer, unsupported channel count, ...) */
+#define IMF_ELAUNCH      -2   /* HIP launch / runtime error */
+#define IMF_EUNSUPPORTED -3
+
+#define IMF_TILE_ROWS    64   /* output rows per rulebook tile (= 4 wavefronts x 16-row MFMA blocks) */
+#define IMF_MAX_KVOL     125  /* largest kernel volume (5x5x5, config_3dmatch.py:68) */
+#define IMF_MASK_WORDS   4    /* 128-bit active-offset mask per tile */
+
+int imf_version(void);
+const char *imf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Voxel hash.  Open-addressing table of `capacity` slots (power of two):
+ *   keys  uint64[capacity]   packed (b,x,y,z), 0xFFFF... = empty
+ *   vals  int32 [capacity]   row index of that voxel in its level
+ * Capacity to use for n keys: imf_hash_capacity(n).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t imf_hash_capacity(int64_t n);
+
+/* Bytes of scratch imf_voxelize / imf_downsample need for n input rows. */
+size_t imf_unique_workspace_bytes(int64_t n);
+
+/* Replaces: util/misc.py:82-87  coords = np.floor(xyz / voxel_size);
+ *           ME.utils.sparse_quantize(coords, return_index=True); ME.utils.batched_coordinates;
+ *           and the coordinate-manager insert of ME.SparseTensor(...) at util/misc.py:95.
+ * xyz: [n,3] float64 (xyz_is_f64=1) or float32 (=0; widened to double before the division, which is
+ *      what Open3D does to the float32 PLY at scripts/generate_desc.py:83,102).
+ * Division is IEEE float64, floor() exact => voxel indices are bit-identical to the reference.
+ * Output rows are in FIRST-OCCURRENCE order (ascending first point index):
+ *   coords     int32[n,4]  (only the first *m_out rows are written)
+ *   first_idx  int32[n]    index of the first point falling in each voxel (`inds`)
+ *   m_out      int32[1]    number of voxels M
+ *   keys/vals  hash of the M voxels (capacity = imf_hash_capacity(n)), vals = row
+ *   err_out    int32[1]    set non-zero if a coordinate was out of range (caller zeroes it)
+ */
+int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
+                 int32_t *coords, int32_t *first_idx, int32_t *m_out,
+                 uint64_t *keys, int32_t *vals, int64_t capacity,
+                 void *workspace, int32_t *err_out, void *stream);
+
+/* Replaces: the implicit coordinate_manager.stride() inside every stride-2
+ *           ME.MinkowskiConvolution (model/resunet.py:54-85): coarse = floor(c / out_stride) *
+ *           out_stride, unique rows, first-occurrence order.
+ * n_in_dev: device int32 holding the actual number of input rows (<= n_in_max, which sizes the
+ *           grid, the workspace and the table). */
+int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_in_max,
+                   int out_stride,
+                   int32_t *coords_out, int32_t *m_out,
+                   uint64_t *keys, int32_t *vals, int64_t capacity,
+                   void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rulebook (MinkowskiEngine "kernel map"), tiled for the MFMA kernel:
+ *   tile_rows int32[n_slots]             output row of every slot, -1 = padding
+ *                                        (n_slots = n_tiles * IMF_TILE_ROWS)
+ *   nbr       int32[kvol * n_slots]      nbr[k * n_slots + slot] = input row feeding that output
+ *                                        row through kernel offset k, -1 = none
+ *   tile_mask uint32[n_tiles * 4]        bit k set <=> some row of the tile has an input at offset k
+ * Kernel offset order: k = (dx+r) + K1*(dy+r) + K1^2*(dz+r), x fastest (ME kernel_region.hpp).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Identity slot order (slot == output row), padded to a whole tile. */
+int64_t imf_rulebook_slots(int64_t n_out);
+
+/* Replaces: the kernel-map generation implicit in ME.MinkowskiConvolution(kernel_size=ksize,
+ *           stride in {1,2}) -- model/resunet.py:42-88,140-158, model/residual_block.py:23-33.
+ *   in  = out + off_k * ts_in    (ts_in = tensor stride of the INPUT level)
+ * in_keys/in_vals/in_capacity: hash of the input level.  out_coords: the n_out output rows. */
+int imf_rulebook_conv(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+                      const int32_t *out_coords, int64_t n_out, int ts_in, int ksize,
+                      int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream);
+
+/* Upper bound of slots for the transposed rulebook (rows grouped into 8 parity classes, every
+ * class padded to whole tiles). */
+int64_t imf_rulebook_transpose_slots(int64_t n_fine);
+
+/* Replaces: the kernel map of ME.MinkowskiConvolutionTranspose(kernel_size=3, stride=2)
+ *           (model/resunet.py:101-134): the forward fine->coarse map with in/out swapped, same k:
+ *           out[f] += in[c] @ W[k]  for  f = c + off_k * ts_fine.
+ * Output rows (fine voxels) are grouped by the parity of (coord / ts_fine) so that a tile shares
+ * its (at most 8) active offsets.  counters: int32[16] scratch. */
+int imf_rulebook_transpose(const uint64_t *coarse_keys, const int32_t *coarse_vals,
+                           int64_t coarse_capacity,
+                           const int32_t *fine_coords, int64_t n_fine, int ts_fine, int ksize,
+                           int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask,
+                           int64_t n_slots, int32_t *counters, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse convolution.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Number of floats of the packed ("fragment-major") weight image for a [kvol, cin, cout] kernel. */
+int64_t imf_packed_weight_floats(int kvol, int cin, int cout);
+
+/* Re-lays a MinkowskiEngine kernel tensor W[kvol][cin][cout] (state_dict key '*.kernel';
+ * [cin][cout] when kvol == 1) into the order the MFMA kernel streams it.  Done once per model
+ * load.  cin % 32 == 0, cout % 32 == 0. */
+int imf_pack_weights(const float *w, int kvol, int cin, int cout, float *packed, void *stream);
+
+typedef struct imf_conv_args {
+  const float *in_a;      /* [n_in, c_a]                                                      */
+  const float *in_b;      /* [n_in, c_b] or NULL: second source of a fused ME.cat(a, b)       */
+  int32_t c_a, c_b;       /* cin = c_a + c_b; c_a % 32 == 0, c_b % 32 == 0                    */
+  const float *w_packed;  /* imf_pack_weights image                                           */
+  int32_t kvol, cout;
+  const int32_t *tile_rows, *nbr;   /* rulebook (nbr may be NULL when kvol == 1: in row == out row) */
+  const uint32_t *tile_mask;
+  int64_t n_slots, n_out;
+  const float *scale;     /* [cout] or NULL   y = acc * scale + shift  (folded eval BatchNorm /   */
+  const float *shift;     /* [cout] or NULL                             bias)                     */
+  const float *residual;  /* [n_out, cout] or NULL   y += residual                                */
+  int32_t relu;           /* y = max(y, 0)                                                        */
+  int32_t l2norm;         /* y /= ||y||_2 over the row (requires cout <= 64)                      */
+  float *out;             /* [n_out, cout]                                                        */
+} imf_conv_args;
+
+/* Replaces: ME.MinkowskiConvolution / ME.MinkowskiConvolutionTranspose forward
+ *           (model/resunet.py:168-226, model/residual_block.py:40-48) with the following
+ *           ME.MinkowskiBatchNorm (eval), MEF.relu, residual `out += residual`
+ *           (residual_block.py:50), ME.cat (resunet.py:197,208,219), `final` bias and the
+ *           L2 normalisation (resunet.py:228-233) fused as prologue / epilogue.
+ * out[o] = epilogue( sum_k in[nbr[k][o]] @ W[k] ), fp32 MFMA (v_mfma_f32_16x16x4_f32: exact f32
+ * FMA chain, ordered by k then input channel => deterministic). */
+int imf_spconv_fwd(const imf_conv_args *args /* [host] */, void *stream);
+
+/* First-layer convolution for a small number of input channels (cin <= 4, e.g. the all-ones
+ * occupancy feature of util/misc.py:76-79 through conv1 k=5, model/resunet.py:42-49).
+ * w is the UNPACKED ME kernel [kvol][cin][cout], cout in {32, 64}.  Identity slot order. */
+int imf_spconv_small_cin(const float *in, int cin, const float *w, int kvol, int cout,
+                         const int32_t *nbr, int64_t n_slots, int64_t n_out,
+                         const float *scale, const float *shift, int relu,
+                         float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMFNET_HIP_H */

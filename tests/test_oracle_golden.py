@@ -1,0 +1,106 @@
+"""CPU tests: the oracle (oracle/imf_oracle.py) against every golden vector the reference offers
+for this path and against outputs of the reference's own model code
+(tests/golden/gen_golden.py).  No GPU, no /root/reference at run time."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import imf_oracle as O
+from conftest import GOLDEN
+
+
+def test_voxelize_matches_reference_head_map(clouds, head_map):
+    """files/3D_head_map.ply == xyz[inds] of sparse_quantize(floor(xyz/0.025)) -- the one result of
+    the path the reference itself pins (first-occurrence order, fp64 division)."""
+    xyz = clouds[0].astype(np.float64)
+    coords, inds = O.voxelize(xyz, 0.025)
+    assert coords.shape == (18977, 4) and coords.dtype == np.int32
+    assert (np.diff(inds) > 0).all()
+    assert (xyz[inds].astype(np.float32) == head_map).all()
+    # fp32 arithmetic is NOT equivalent: guards against "optimising" the division
+    c32 = np.floor(clouds[0] / np.float32(0.025)).astype(np.int64)
+    assert (c32 != np.floor(xyz / 0.025).astype(np.int64)).any()
+
+
+def test_voxel_counts_of_survey(clouds):
+    for i, vs, m in ((0, 0.05, 5182), (1, 0.05, 5140), (0, 0.025, 18977), (1, 0.025, 19082)):
+        assert len(O.voxelize(clouds[i].astype(np.float64), vs)[0]) == m
+    assert len(O.voxelize(clouds[0].astype(np.float64) * 1.7, 0.025)[0]) == 51232
+
+
+def test_pyramid_and_rulebook_counts_of_survey(clouds):
+    """SURVEY Appendix C pair counts (S5)."""
+    coords, _ = O.voxelize(clouds[0].astype(np.float64), 0.05)
+    g = O.Geometry(coords)
+    assert [len(l) for l in g.levels] == [5182, 1453, 413, 112]
+    assert (g.k_first >= 0).sum() == 208506
+    assert [(r >= 0).sum() for r in g.k3] == [71848, 20117, 5803, 1544]
+    assert [(r >= 0).sum() for r in g.down] == [14244, 4077, 1141]
+    # transposed maps are the forward maps with in/out swapped (same pair multiset)
+    for lv in range(3):
+        fwd = {(int(r), o, k) for o, row in enumerate(g.down[lv]) for k, r in enumerate(row) if r >= 0}
+        tr = {(f, int(c), k) for f, row in enumerate(g.up[lv]) for k, c in enumerate(row) if c >= 0}
+        assert fwd == tr
+
+
+def test_kernel_offset_order():
+    o = O.kernel_offsets(3)
+    assert o[0].tolist() == [-1, -1, -1] and o[1].tolist() == [0, -1, -1] and o[13].tolist() == [0, 0, 0]
+    assert o[3].tolist() == [-1, 0, -1] and o[9].tolist() == [-1, -1, 0]
+    assert len(O.kernel_offsets(5)) == 125
+
+
+def test_downsample_floor_semantics():
+    c = np.array([[0, -1, -2, -3], [0, 1, 2, 3], [0, -4, 0, 5], [0, -1, -1, -3]], np.int32)
+    coarse, parent = O.downsample(c, 2)
+    assert coarse.tolist() == [[0, -2, -2, -4], [0, 0, 2, 2], [0, -4, 0, 4]]
+    assert parent.tolist() == [0, 1, 2, 0]
+
+
+def test_restatement_matches_reference_wiring_S5(clouds, images, golden, seeded_sd):
+    """Full forward of the restatement vs the reference's model/*.py run verbatim (golden)."""
+    xyz = clouds[0].astype(np.float64)
+    xyz_down, F = O.extract_features(seeded_sd, xyz, 0.05, images[0])
+    assert F.shape == (5182, 32)
+    assert np.abs(F.numpy() - golden["S5_F"]).max() < 2e-6
+    assert (xyz_down.astype(np.float32) == golden["S5_xyz_down_f32"]).all()
+    assert np.allclose(np.linalg.norm(F.numpy(), axis=1), 1.0, atol=1e-5)
+
+
+def test_restatement_attention_and_image_encoder(golden, images, seeded_sd):
+    sd = {k: torch.as_tensor(v) for k, v in seeded_sd.items()}
+    out = O.attention_fusion(torch.as_tensor(golden["af_ctx"]), torch.as_tensor(golden["af_in"]), sd)
+    assert np.abs(out.numpy() - golden["af_out"]).max() < 2e-5
+    img = O.image_encoder(images[0], sd)
+    assert img.shape == (1, 128, 15, 20)
+    assert np.abs(img.numpy() - golden["img_out"]).max() < 1e-5
+
+
+def test_state_dict_schema_matches_reference(seeded_sd):
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_schema.json")))
+    assert len(ref) == 361
+    assert set(seeded_sd) == set(ref)
+    assert all(list(seeded_sd[k].shape) == ref[k] for k in ref)
+
+
+def test_resize_is_centre_average_for_4x(golden):
+    """640x480 -> 160x120 INTER_LINEAR == mean of the centre 2x2 of each 4x4 block."""
+    rng = np.random.default_rng(0)
+    img = rng.random((480, 640, 3), dtype=np.float32)
+    out = O.resize_bilinear(img, 120, 160)
+    ref = 0.25 * (img[1::4, 1::4] + img[1::4, 2::4] + img[2::4, 1::4] + img[2::4, 2::4])
+    assert np.abs(out - ref).max() < 1e-6
+
+
+def test_fnv_hash_known_answer():
+    # FNV-1a-64 of the single column value 0 and of (1,2,3), by hand
+    h0 = (14695981039346656037 * 1099511628211) % 2 ** 64
+    assert int(O.fnv_hash_vec(np.array([[0]]))[0]) == h0
+    h = 14695981039346656037
+    for v in (1, 2, 3):
+        h = ((h * 1099511628211) % 2 ** 64) ^ v
+    assert int(O.fnv_hash_vec(np.array([[1, 2, 3]]))[0]) == h
+    neg = O.fnv_hash_vec(np.array([[-1, 0, 5]]))
+    assert neg.dtype == np.uint64
