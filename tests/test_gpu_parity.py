@@ -1,0 +1,349 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (imfnet_amd.ops ->
+libimfnet_hip.so), against the CPU oracle on the same seeded inputs and against the committed
+golden vectors.  Integer work (voxel indices, pyramid, rulebooks) must be bit-exact; fp32 features
+within the tolerances written in each test (north_star: 1e-4 on descriptors)."""
+import numpy as np
+import pytest
+import torch
+
+import imf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from imfnet_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _ops
+
+
+def _voxelize_gpu(ops, xyz_t, vs):
+    lv = ops.voxelize(xyz_t, vs)
+    ops.sync_levels([lv])
+    return lv
+
+
+def _build_levels(ops, lv0):
+    from imfnet_amd import sparse as ME
+    cm = ME.CoordinateManager(lv0)
+    cm.build_pyramid(8)
+    return cm
+
+
+# ------------------------------------------------------------------ voxelisation (bit-exact)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_voxelize_reference_head_map(ops, clouds, head_map, dtype):
+    """The reference-pinned vector: files/3D_head_map.ply rows == xyz[inds] @ 2.5 cm."""
+    xyz = torch.as_tensor(clouds[0]).to(DEV, dtype)
+    lv = _voxelize_gpu(ops, xyz, 0.025)
+    assert lv.n == 18977
+    inds = lv.first_idx.cpu().numpy()
+    assert (clouds[0][inds] == head_map).all()
+    c_ref, i_ref = O.voxelize(clouds[0].astype(np.float64), 0.025)
+    assert (lv.coords.cpu().numpy() == c_ref).all()
+    assert (inds == i_ref).all()
+
+
+@pytest.mark.parametrize("cloud,scale,vs,m", [(0, 1.0, 0.05, 5182), (1, 1.0, 0.05, 5140),
+                                               (1, 1.0, 0.025, 19082), (0, 1.7, 0.025, 51232)])
+def test_voxelize_counts_and_order(ops, clouds, cloud, scale, vs, m):
+    xyz64 = clouds[cloud].astype(np.float64) * scale
+    lv = _voxelize_gpu(ops, torch.as_tensor(xyz64).to(DEV), vs)
+    c_ref, i_ref = O.voxelize(xyz64, vs)
+    assert lv.n == m == len(c_ref)
+    assert (lv.coords.cpu().numpy() == c_ref).all()
+    assert (lv.first_idx.cpu().numpy() == i_ref).all()
+
+
+def test_voxelize_edge_cases(ops):
+    # negatives, exact voxel boundaries, duplicates, a single point, batch index
+    pts = np.array([[-0.025, 0.0, 0.05], [-1e-12, 0.0249999, 0.05], [0.0, 0.0, 0.0], [-0.025, 0.0, 0.05],
+                    [3.2, -3.2, 1e-9], [-0.0250001, 0.0, 0.05]], np.float64)
+    lv = ops.voxelize(torch.as_tensor(pts).to(DEV), 0.025, batch_index=3)
+    ops.sync_levels([lv])
+    c_ref, i_ref = O.voxelize(pts, 0.025, batch_index=3)
+    assert (lv.coords.cpu().numpy() == c_ref).all() and (lv.first_idx.cpu().numpy() == i_ref).all()
+    one = ops.voxelize(torch.zeros(1, 3, dtype=torch.float64, device=DEV), 0.3)
+    ops.sync_levels([one])
+    assert one.n == 1 and one.coords.cpu().tolist() == [[0, 0, 0, 0]]
+    from imfnet_amd import ImfError
+    far = ops.voxelize(torch.full((4, 3), 1e6, dtype=torch.float64, device=DEV), 0.025)
+    with pytest.raises(ImfError):
+        ops.sync_levels([far])
+    with pytest.raises(ImfError):
+        ops.voxelize(torch.zeros(0, 3, dtype=torch.float64, device=DEV), 0.025)
+    with pytest.raises(ImfError):
+        ops.voxelize(torch.zeros(4, 3, dtype=torch.float64), 0.025)      # CPU tensor: no fallback
+
+
+def test_voxelize_random_large(ops):
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(400_000, 3)) * 3.0
+    lv = _voxelize_gpu(ops, torch.as_tensor(pts).to(DEV), 0.1)
+    c_ref, i_ref = O.voxelize(pts, 0.1)
+    assert lv.n == len(c_ref)
+    assert (lv.coords.cpu().numpy() == c_ref).all() and (lv.first_idx.cpu().numpy() == i_ref).all()
+
+
+# ------------------------------------------------------------------ pyramid + rulebooks (bit-exact)
+@pytest.fixture(scope="module")
+def geom_s5(ops, clouds):
+    xyz64 = clouds[0].astype(np.float64)
+    cm = _build_levels(ops, ops.voxelize(torch.as_tensor(xyz64).to(DEV), 0.05))
+    g = O.Geometry(O.voxelize(xyz64, 0.05)[0])
+    return cm, g
+
+
+def test_pyramid_levels(ops, geom_s5):
+    cm, g = geom_s5
+    for i, ts in enumerate((1, 2, 4, 8)):
+        assert (cm.coords(ts).cpu().numpy() == g.levels[i]).all(), f"level {ts}"
+
+
+def _check_rulebook(rb, nbr_ref, identity_rows):
+    n_out, kvol = nbr_ref.shape
+    rows = rb.tile_rows.cpu().numpy()
+    nbr = rb.nbr.cpu().numpy().reshape(kvol, rb.n_slots)
+    valid = rows >= 0
+    assert sorted(rows[valid].tolist()) == list(range(n_out))
+    if identity_rows:
+        assert (rows[:n_out] == np.arange(n_out)).all()
+    assert (nbr[:, valid].T == nbr_ref[rows[valid]]).all()
+    assert (nbr[:, ~valid] == -1).all()
+    mask = rb.tile_mask.cpu().numpy().view(np.uint32).reshape(-1, 4)
+    act = (nbr.reshape(kvol, -1, 64) >= 0).any(axis=2)                   # [kvol, tiles]
+    for k in range(kvol):
+        assert (((mask[:, k // 32] >> (k % 32)) & 1).astype(bool) == act[k]).all()
+    return mask
+
+
+def test_rulebooks_conv(ops, geom_s5):
+    cm, g = geom_s5
+    _check_rulebook(cm.conv_rulebook(1, 5, 1), g.k_first, True)
+    for i in range(4):
+        _check_rulebook(cm.conv_rulebook(1 << i, 3, 1), g.k3[i], True)
+    for i in range(3):
+        _check_rulebook(cm.conv_rulebook(1 << i, 3, 2), g.down[i], True)
+
+
+def test_rulebooks_transpose(ops, geom_s5):
+    cm, g = geom_s5
+    for i in range(3):
+        mask = _check_rulebook(cm.transpose_rulebook(2 << i, 3, 2), g.up[i], False)
+        pop = np.array([bin(int(w)).count("1") for w in mask.reshape(-1)]).reshape(-1, 4).sum(1)
+        assert pop.max() <= 8          # parity-class grouping: at most 8 offsets per tile
+
+
+# ------------------------------------------------------------------ sparse convolution (fp32)
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def test_pack_weights_layout(ops):
+    for kvol, cin, cout in ((27, 32, 32), (3, 64, 128), (1, 96, 64), (2, 256, 64)):
+        w = _rand((kvol, cin, cout), 1)
+        CI = 64 if cin % 64 == 0 else 32
+        J, CB = CI // 16, (4 if cout % 64 == 0 else 2)
+        ref = (w.view(kvol, cin // CI, J, 4, 4, cout // (16 * CB), CB, 16)      # k cc j q t y cb c
+                .permute(5, 0, 1, 2, 6, 3, 7, 4).reshape(-1))                  # y k cc j cb q c t
+        got = ops.pack_weights(w.to(DEV)).cpu()
+        assert torch.equal(got, ref)
+
+
+CONV_CASES = [  # (cin_a, cin_b, cout, which rulebook)
+    (32, 0, 32, ("k3", 0)), (32, 0, 64, ("down", 0)), (64, 0, 64, ("k3", 1)), (64, 0, 128, ("down", 1)),
+    (128, 0, 128, ("k3", 2)), (128, 0, 256, ("down", 2)), (256, 0, 256, ("k3", 3)),
+    (256, 0, 128, ("up", 2)), (128, 128, 64, ("up", 1)), (64, 64, 64, ("up", 0)),
+    (64, 32, 64, ("k1", 0)), (64, 0, 32, ("k1", 0)),
+]
+
+
+def _rb_and_ref(cm, g, which):
+    kind, i = which
+    if kind == "k3":
+        return cm.conv_rulebook(1 << i, 3, 1), g.k3[i], len(g.levels[i])
+    if kind == "down":
+        return cm.conv_rulebook(1 << i, 3, 2), g.down[i], len(g.levels[i])
+    if kind == "up":
+        return cm.transpose_rulebook(2 << i, 3, 2), g.up[i], len(g.levels[i + 1])
+    return cm.conv_rulebook(1, 1, 1), None, len(g.levels[0])
+
+
+@pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
+def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which):
+    """Plain convolution (no epilogue) vs the oracle; error measured against an fp64 evaluation and
+    required to be of fp32-roundoff size: <= 2e-6 * sum|a*b| bound (MFMA = ordered fmaf chain)."""
+    cm, g = geom_s5
+    rb, nbr_ref, n_in = _rb_and_ref(cm, g, which)
+    kvol = 1 if nbr_ref is None else nbr_ref.shape[1]
+    fa, fb = _rand((n_in, ca), 10), (_rand((n_in, cb), 11) if cb else None)
+    w = _rand((kvol, ca + cb, cout), 12, 1.0 / np.sqrt(kvol * (ca + cb)))
+    out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV)), cout, rb,
+                     in_b=None if fb is None else fb.to(DEV)).cpu()
+    fin = fa if fb is None else torch.cat([fa, fb], 1)
+    wk = w if kvol > 1 else w[0]
+    ref32 = O.spconv(fin, wk, nbr_ref)
+    ref64 = O.spconv_f64(fin, wk, nbr_ref)
+    bound = O.spconv_f64(fin.abs(), wk.abs(), nbr_ref) * 2e-6 + 1e-7
+    assert out.shape == ref32.shape
+    assert ((out.double() - ref64).abs() <= bound).all()
+    assert (out - ref32).abs().max() < 5e-5
+
+
+def test_spconv_epilogues(ops, geom_s5):
+    cm, g = geom_s5
+    rb, nbr_ref = cm.conv_rulebook(1, 3, 1), g.k3[0]
+    n = len(g.levels[0])
+    f, w = _rand((n, 32), 20), _rand((27, 32, 32), 21, 0.05)
+    sc, sh, res = _rand((32,), 22).abs() + 0.5, _rand((32,), 23), _rand((n, 32), 24)
+    wp = ops.pack_weights(w.to(DEV))
+    base = O.spconv(f, w, nbr_ref)
+    got = ops.spconv(f.to(DEV), wp, 32, rb, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV),
+                     relu=True).cpu()
+    assert (got - torch.relu(base * sc + sh + res)).abs().max() < 5e-5
+    got = ops.spconv(f.to(DEV), wp, 32, rb, shift=sh.to(DEV), l2norm=True).cpu()
+    ref = base + sh
+    ref = ref / ref.norm(dim=1, keepdim=True)
+    assert (got - ref).abs().max() < 5e-6
+    assert torch.allclose(got.norm(dim=1), torch.ones(n), atol=1e-5)
+
+
+def test_spconv_deterministic(ops, geom_s5):
+    cm, g = geom_s5
+    rb = cm.conv_rulebook(1, 3, 1)
+    f = _rand((len(g.levels[0]), 64), 30).to(DEV)
+    wp = ops.pack_weights(_rand((27, 64, 64), 31, 0.03).to(DEV))
+    a = ops.spconv(f, wp, 64, rb)
+    b = ops.spconv(f, wp, 64, rb)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cin,cout,ks", [(1, 32, 5), (1, 32, 3), (3, 32, 3), (4, 64, 3)])
+def test_spconv_small_cin(ops, geom_s5, cin, cout, ks):
+    cm, g = geom_s5
+    rb = cm.conv_rulebook(1, ks, 1)
+    nbr_ref = g.k_first if ks == 5 else g.k3[0]
+    n = len(g.levels[0])
+    f = torch.ones(n, cin) if cin == 1 else _rand((n, cin), 40)
+    w = _rand((ks ** 3, cin, cout), 41, 0.1)
+    sc, sh = _rand((cout,), 42).abs() + 0.5, _rand((cout,), 43)
+    got = ops.spconv_small_cin(f.to(DEV), w.to(DEV), rb, sc.to(DEV), sh.to(DEV), relu=True).cpu()
+    ref = torch.relu(O.spconv(f, w, nbr_ref) * sc + sh)
+    assert (got - ref).abs().max() < 2e-5
+
+
+def test_spconv_argument_errors(ops, geom_s5):
+    from imfnet_amd import ImfError
+    cm, g = geom_s5
+    rb = cm.conv_rulebook(1, 3, 1)
+    f = torch.zeros(len(g.levels[0]), 48, device=DEV)
+    with pytest.raises(ImfError):
+        ops.spconv(f, torch.zeros(27 * 48 * 32, device=DEV), 32, rb)        # cin % 32 != 0
+    with pytest.raises(ImfError):
+        ops.spconv(f[:, :32].contiguous(), torch.zeros(5, device=DEV), 32, rb)   # wrong weight size
+
+
+# ------------------------------------------------------------------ whole model
+@pytest.fixture(scope="module")
+def model(seeded_sd):
+    from imfnet_amd.model import load_model
+    Model = load_model("ResUNetBN2C")
+    m = Model(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3, config=None)
+    missing = m.load_state_dict(seeded_sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m.eval().to(DEV)
+
+
+def test_forward_matches_reference_golden_S5(model, clouds, images, golden):
+    """Config 1: cloud_bin_0 @ 5 cm.  Golden = the reference's own model code (CPU stand-in ops)."""
+    from imfnet_amd.extract import extract_features
+    with torch.no_grad():
+        xyz_down, F = extract_features(model, clouds[0].astype(np.float64), voxel_size=0.05,
+                                       device=torch.device(DEV), skip_check=True, image=images[0])
+    assert F.is_cuda and F.shape == (5182, 32)
+    assert (xyz_down.astype(np.float32) == golden["S5_xyz_down_f32"]).all()
+    assert np.abs(F.cpu().numpy() - golden["S5_F"]).max() < 1e-4            # north_star tolerance
+
+
+def test_forward_matches_reference_golden_crop(model, clouds, images, golden):
+    from imfnet_amd.extract import extract_features
+    crop = clouds[0].astype(np.float64)[golden["crop_sel_idx"]]
+    with torch.no_grad():
+        _, F = extract_features(model, crop, voxel_size=0.025, device=torch.device(DEV),
+                                skip_check=True, image=images[0])
+    assert np.abs(F.cpu().numpy() - golden["crop_F"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_forward_full_fragment_S25(model, clouds, images, golden, i):
+    """Config 2: the pair @ 2.5 cm; golden keeps column sums and 256 sampled rows."""
+    from imfnet_amd.extract import extract_features
+    with torch.no_grad():
+        xyz_down, F = extract_features(model, clouds[i].astype(np.float64), voxel_size=0.025,
+                                       device=torch.device(DEV), skip_check=True, image=images[i])
+    F = F.cpu().numpy()
+    M = int(golden[f"S25_{i}_M"])
+    assert F.shape == (M, 32)
+    rows = F[:: max(1, M // 256)][:256]
+    assert np.abs(rows - golden[f"S25_{i}_rows"]).max() < 1e-4
+    assert np.abs(F.astype(np.float64).sum(0) - golden[f"S25_{i}_colsum"]).max() < 1e-4 * M ** 0.5 * 10
+
+
+def test_fused_equals_layerwise(model, clouds, images):
+    """The fused plan and the op-by-op walk (forward_layers) agree."""
+    from imfnet_amd.extract import sparse_tensor_from_points
+    xyz = clouds[1].astype(np.float64)
+    img = torch.as_tensor(images[1]).to(DEV)
+    with torch.no_grad():
+        st, _ = sparse_tensor_from_points(xyz, 0.05, torch.device(DEV))
+        a = model(st, img).F
+        st2, _ = sparse_tensor_from_points(xyz, 0.05, torch.device(DEV))
+        b = model.forward_layers(st2, img).F
+    assert (a - b).abs().max() < 2e-5
+
+
+def test_forward_from_coordinates_api(model, clouds, images, golden):
+    """The reference's call shape: ME.SparseTensor(feats, coordinates=coords, device) -> model(...)."""
+    import imfnet_amd.sparse as ME
+    xyz = clouds[0].astype(np.float64)
+    coords, inds = ME.utils.sparse_quantize(np.floor(xyz / 0.05), return_index=True)
+    assert (xyz[inds].astype(np.float32) == golden["S5_xyz_down_f32"]).all()
+    coords = ME.utils.batched_coordinates([coords])
+    st = ME.SparseTensor(torch.ones(len(coords), 1), coordinates=coords, device=DEV)
+    with torch.no_grad():
+        F = model(st, torch.as_tensor(images[0]).to(DEV)).F
+    assert np.abs(F.cpu().numpy() - golden["S5_F"]).max() < 1e-4
+    assert (st.C.cpu().numpy() == coords.numpy()).all()
+
+
+def test_batched_forward_matches_single(model, clouds, images):
+    """Two fragments in one batch (rows grouped by batch index, one image each, resunet.py:241-250)."""
+    import imfnet_amd.sparse as ME
+    from imfnet_amd.extract import extract_features
+    cs, single = [], []
+    with torch.no_grad():
+        for i in (0, 1):
+            xyz = clouds[i].astype(np.float64)[::3]
+            c, _ = O.voxelize(xyz, 0.05)
+            cs.append(c[:, 1:])
+            _, F = extract_features(model, xyz, voxel_size=0.05, device=torch.device(DEV), skip_check=True,
+                                    image=images[i])
+            single.append(F)
+        coords = ME.utils.batched_coordinates(cs)
+        st = ME.SparseTensor(torch.ones(len(coords), 1), coordinates=coords, device=DEV)
+        img = torch.as_tensor(np.concatenate([images[0], images[1]])).to(DEV)
+        Fb = model(st, img).F
+    assert (Fb - torch.cat(single)).abs().max() < 2e-5
+
+
+def test_determinism_end_to_end(model, clouds, images):
+    from imfnet_amd.extract import extract_features
+    with torch.no_grad():
+        a = extract_features(model, clouds[0], voxel_size=0.05, device=torch.device(DEV), skip_check=True,
+                             image=images[0])[1]
+        b = extract_features(model, clouds[0], voxel_size=0.05, device=torch.device(DEV), skip_check=True,
+                             image=images[0])[1]
+    assert torch.equal(a, b)
