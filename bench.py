@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- descriptors/sec of IMFNet's descriptor-generation hot path on MI355X.
+
+A "step" = one full pass of the path over one fragment whose raw points and image are already
+resident in HBM: voxelise (fp64 quantise + hash + first-occurrence unique) -> 4-level pyramid ->
+8 rulebooks -> image encoder -> 23 sparse convolutions + fusion attention -> L2-normalised
+[M,32] descriptors in HBM.  Nothing is cached between steps (every fragment is new geometry in
+the real workload).  Workload at N=1: BASELINE.json configs[1] scaled to the 3DMatch-shaped size
+its metric is quoted on (SURVEY §8d "S50k": fixture fragment cloud_bin_0 x1.7 @ 2.5 cm voxels,
+51,232 voxels).  Weights are seeded random (no checkpoint is reachable), data says so.
+
+  python bench.py [--gpus N --steps K --warmup W]        one JSON line on rank 0
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def load_workload(scale, voxel):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "fixture_clouds.npz"))
+    xyz = z["cloud_bin_0"].astype(np.float64) * scale
+    img = np.load(os.path.join(ROOT, "tests", "golden", "fixture_images.npz"))["image_0"]
+    img = np.transpose(img, (2, 0, 1))[None].copy()
+    return xyz, img, voxel
+
+
+def algorithmic_bytes(rec):
+    """pairs*(Cin+Cout)*4 + pairs*8 (rulebook index) + kvol*Cin*Cout*4 (weights)."""
+    rb = rec["rb"]
+    pairs = int((rb.nbr >= 0).sum().item()) if rb.nbr is not None else rb.n_out
+    return pairs * (rec["cin"] + rec["cout"]) * 4 + pairs * 8 + rec["kvol"] * rec["cin"] * rec["cout"] * 4, pairs
+
+
+def cpu_baseline(xyz, img, voxel, sd, seconds_budget=20.0):
+    """The oracle (C geometry + torch-CPU convolutions = MinkowskiEngine's CPU algorithm restated)
+    timed on this box's host cores over a bounded sample of the same workload."""
+    import imf_oracle as O
+    import imf_oracle_cbind as OC
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def once():
+        t0 = time.perf_counter()
+        coords, inds = OC.voxelize(xyz, voxel)
+        geom = OC.Geometry(coords)
+        F = O.resunet_forward(sd, coords, img, geometry=geom)
+        return time.perf_counter() - t0, F.shape[0]
+
+    once()                                             # warm-up (page-in, thread pools)
+    times, m, spent = [], 0, 0.0
+    while spent < seconds_budget and len(times) < 12:
+        dt, m = once()
+        times.append(dt)
+        spent += dt
+    med = statistics.median(times)
+    return {"value": m / med, "unit": "descriptors/s", "cores": cores, "kind": "port",
+            "sample": f"same fragment (M={m}), full path on the host, median of {len(times)} runs "
+                      f"({med * 1e3:.0f} ms each): C hash-map voxelise/pyramid/rulebooks (OpenMP) + "
+                      f"torch-CPU gather-GEMM-scatter convolutions, image encoder and attention"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scale", type=float, default=1.7)
+    ap.add_argument("--voxel", type=float, default=0.025)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from imfnet_amd import dist as idist
+    from imfnet_amd import ops
+    from imfnet_amd.extract import sparse_tensor_from_points
+    from imfnet_amd.model import load_model
+    import imf_oracle as O                              # seeded weights + cpu_baseline only
+
+    rank, world, local = idist.init_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    xyz, img, voxel = load_workload(args.scale, args.voxel)
+    sd = O.seeded_state_dict(seed=0, with_unused_image_layers=True)
+    model = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True,
+                                      conv1_kernel_size=5, D=3, config=None)
+    model.load_state_dict(sd, strict=True)
+    model = model.eval().to(dev)
+    xyz_d = torch.as_tensor(xyz).to(dev)               # inputs resident in HBM before timing
+    img_d = torch.as_tensor(img).to(dev)
+
+    def step():
+        st, _ = sparse_tensor_from_points(xyz_d, voxel, dev)
+        return model(st, img_d).F
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            F = step()
+        M = F.shape[0]
+
+        ops.TRACE = []
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            F = step()
+        gathered = idist.gather_blocks(F, dst=0)        # the path's one exchange (RCCL over xGMI)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        trace, ops.TRACE = ops.TRACE, None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total_m = sum(g.shape[0] for g in gathered) if rank == 0 else 0
+    else:
+        total_m = M
+    elapsed = float(t.item())
+
+    if rank == 0:
+        # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
+        groups = {}
+        bytes_cache = {}
+        for rec in trace:
+            ms = rec["start"].elapsed_time(rec["end"])
+            key = id(rec["rb"]), rec["cin"], rec["cout"]
+            if key not in bytes_cache:
+                bytes_cache[key] = algorithmic_bytes(rec)
+            g = groups.setdefault(rec["kernel"], {"ms": 0.0, "bytes": 0, "n": 0, "flops": 0})
+            g["ms"] += ms
+            g["bytes"] += bytes_cache[key][0]
+            g["flops"] += 2 * bytes_cache[key][1] * rec["cin"] * rec["cout"]
+            g["n"] += 1
+        dom = max(groups, key=lambda k: groups[k]["ms"])
+        g = groups[dom]
+        achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+        conv_ms = sum(v["ms"] for v in groups.values()) / args.steps
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches_per_step": g["n"] // args.steps,
+                    "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),
+                    "algorithmic_bytes_per_launch": g["bytes"] // g["n"],
+                    "achieved_tflops_useful": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2),
+                    "all_sparse_conv_ms_per_step": round(conv_ms, 3)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(xyz, img, voxel, sd)
+        out = {
+            "metric": "descriptors/sec (32-D) on 3DMatch fragments",
+            "value": round(total_m * args.steps / elapsed, 1) if world == 1
+            else round(total_m * args.steps / elapsed, 1),
+            "unit": "descriptors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (reference fixture fragment cloud_bin_0 scaled x%.2f, seeded random weights)" % args.scale,
+            "config": {"workload": f"3DMatch-shaped fragment: {xyz.shape[0]} points -> {M} voxels @ "
+                                   f"{voxel * 100:.1f} cm, image 120x160, ResUNetBN2C 32-D, conv1 k5; "
+                                   f"one fragment per step per GPU, geometry rebuilt every step",
+                       "voxels_per_fragment": M, "points_per_fragment": int(xyz.shape[0]),
+                       "fragments_per_step": world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

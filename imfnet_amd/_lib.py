@@ -30,6 +30,8 @@ class ConvArgs(C.Structure):
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
         ("relu", C.c_int32), ("l2norm", C.c_int32),
         ("out", C.c_void_p),
+        ("split_k", C.c_int32), ("variant", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -49,6 +51,8 @@ SIGNATURES = {
     "imf_rulebook_transpose": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P]),
     "imf_packed_weight_floats": (_L, [_I, _I, _I]),
     "imf_pack_weights": (_I, [_P, _I, _I, _I, _P, _P]),
+    "imf_spconv_auto_split": (_I, [_L, _I, _I]),
+    "imf_spconv_workspace_bytes": (_Z, [_L, _I, _I]),
     "imf_spconv_fwd": (_I, [C.POINTER(ConvArgs), _P]),
     "imf_spconv_small_cin": (_I, [_P, _I, _P, _I, _I, _P, _L, _L, _P, _P, _I, _P, _P]),
 }

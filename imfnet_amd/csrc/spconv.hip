@@ -2,17 +2,21 @@
 // tile, fused BatchNorm / bias / residual / ReLU / L2-norm epilogue.
 //
 // Work decomposition (one workgroup = 4 wavefronts = one 64-row rulebook tile x one 32/64-wide
-// slab of output channels):
+// slab of output channels x one partition of the tile's active kernel offsets):
 //   wavefront w owns output rows [16w, 16w+16) of the tile and all CO_BLK 16-column blocks of the
 //   slab: CO_BLK accumulators of v_mfma_f32_16x16x4_f32 (4 VGPRs each).
-//   for every kernel offset k that is active in the tile (tile_mask), for every 32/64-channel
-//   chunk of the input:
-//     - the packed weight stage (<= 16 KiB, already in MFMA B-fragment order) is copied to LDS;
+//   The K dimension (kernel offset k, input-channel chunk cc) is walked in 16 KiB "macro stages" of
+//   packed weights.  Per macro stage:
+//     - the weights (already in MFMA B-fragment order in HBM/L2) are prefetched global->VGPR one
+//       stage ahead and written to one of two LDS buffers: ONE barrier per stage, loads of stage
+//       n+1 in flight under the MFMAs of stage n;
 //     - every lane gathers its A fragments straight from the input rows as float4 (lane l holds
-//       channels 16j + 4(l>>4) + 0..3 of row nbr[k][l&15]) -- no LDS round trip for A;
+//       channels 16j + 4(l>>4) + 0..3 of row nbr[k][l&15]) -- no LDS round trip for A; the tile's
+//       slice of the neighbour table is cached in LDS once;
 //     - a wavefront whose 16 rows have no input at offset k skips the MFMAs (wave-uniform).
-//   The accumulation order per output element is fixed (k ascending, then input channel in
-//   fragment order), so results are bit-reproducible run to run; there are no atomics.
+//   Levels with few tiles are latency-bound, so their offsets are split over gridDim.z workgroups
+//   that write raw partial sums; k_spconv_reduce adds them in a fixed order and applies the
+//   epilogue.  The accumulation order per output element is fixed => bit-reproducible, no atomics.
 #include "common.h"
 
 namespace imf {
@@ -26,10 +30,11 @@ struct ConvParams {
   int kvol, cout;
   const int32_t *tile_rows, *nbr;
   const uint32_t *tile_mask;
-  long long n_slots;
+  long long n_slots, n_out;
   const float *scale, *shift, *residual;
   int relu, l2norm;
   float *out;
+  float *partial;   // split-K partial sums [S][n_slots][cout] (S = gridDim.z > 1)
 };
 
 // Packed weight image: [y][k][cc][j][cb][lane][t] with
@@ -58,84 +63,27 @@ k_pack_weights(const float *__restrict__ w, int kvol, int cin, int cout, float *
   packed[idx] = w[((long long)k * cin + ci) * cout + co];
 }
 
-template <int CO_BLK, int J>
-__global__ void __launch_bounds__(256)
-k_spconv_mfma(const ConvParams p) {
-  constexpr int STAGE_F4 = J * CO_BLK * 64;          // float4 per weight stage (<= 1024 = 16 KiB)
-  __shared__ float4 wlds[STAGE_F4];
+__device__ __forceinline__ int row_of_slot(const ConvParams &p, long long slot) {
+  if (p.tile_rows) return p.tile_rows[slot];
+  return slot < p.n_out ? (int)slot : -1;
+}
 
-  const int tile = blockIdx.x, y = blockIdx.y;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
-  const int cin = p.c_a + p.c_b;
-  const int ncc = cin / (16 * J);
+__device__ __forceinline__ float4 gather_a(const ConvParams &p, int irow, int ci) {
+  if (irow < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float *src = (ci < p.c_a) ? p.in_a + (long long)irow * p.c_a + ci
+                                  : p.in_b + (long long)irow * p.c_b + (ci - p.c_a);
+  return *reinterpret_cast<const float4 *>(src);
+}
+
+// acc[cb][r] = out[row 4*q4 + r of the wavefront's 16][col 16*cb + r16]
+template <int CO_BLK>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (&acc)[CO_BLK], int tile,
+                                              int y, int wave, int r16, int q4) {
   const int CW = 16 * CO_BLK;
-
-  uint32_t mask[IMF_MASK_WORDS];
-#pragma unroll
-  for (int w = 0; w < IMF_MASK_WORDS; ++w) mask[w] = p.tile_mask[tile * IMF_MASK_WORDS + w];
-  if ((mask[0] | mask[1] | mask[2] | mask[3]) == 0u) return;   // padding tile
-
-  const long long my_slot = (long long)tile * IMF_TILE_ROWS + wave * 16 + r16;
-
-  f32x4 acc[CO_BLK];
-#pragma unroll
-  for (int cb = 0; cb < CO_BLK; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const float4 *wbase = reinterpret_cast<const float4 *>(p.w_packed) +
-                        (long long)y * p.kvol * ncc * STAGE_F4;
-
-#pragma unroll 1
-  for (int w = 0; w < IMF_MASK_WORDS; ++w) {
-    uint32_t m = mask[w];
-#pragma unroll 1
-    while (m) {
-      const int k = w * 32 + __builtin_ctz(m);
-      m &= m - 1;
-      const int irow = p.nbr ? p.nbr[(long long)k * p.n_slots + my_slot] : p.tile_rows[my_slot];
-      const bool wave_active = __any(irow >= 0);
-#pragma unroll 1
-      for (int cc = 0; cc < ncc; ++cc) {
-        __syncthreads();                      // previous stage fully consumed
-        const float4 *src = wbase + ((long long)k * ncc + cc) * STAGE_F4;
-#pragma unroll
-        for (int q = 0; q < STAGE_F4 / 256; ++q) wlds[q * 256 + tid] = src[q * 256 + tid];
-
-        float4 a[J];
-        if (wave_active) {
-#pragma unroll
-          for (int j = 0; j < J; ++j) {
-            const int ci = cc * 16 * J + 16 * j + 4 * q4;
-            a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (irow >= 0) {
-              const float *src_row = (ci < p.c_a) ? p.in_a + (long long)irow * p.c_a + ci
-                                                  : p.in_b + (long long)irow * p.c_b + (ci - p.c_a);
-              a[j] = *reinterpret_cast<const float4 *>(src_row);
-            }
-          }
-        }
-        __syncthreads();                      // stage visible
-        if (wave_active) {
-#pragma unroll
-          for (int j = 0; j < J; ++j) {
-#pragma unroll
-            for (int cb = 0; cb < CO_BLK; ++cb) {
-              const float4 b = wlds[(j * CO_BLK + cb) * 64 + lane];
-              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b.x, acc[cb], 0, 0, 0);
-              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b.y, acc[cb], 0, 0, 0);
-              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b.z, acc[cb], 0, 0, 0);
-              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b.w, acc[cb], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-  }
-
-  // ---- epilogue: acc[cb][r] = out[row 4*q4 + r][col 16*cb + r16] ------------------------------
   int orow[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    orow[r] = p.tile_rows[(long long)tile * IMF_TILE_ROWS + wave * 16 + q4 * 4 + r];
+    orow[r] = row_of_slot(p, (long long)tile * IMF_TILE_ROWS + wave * 16 + q4 * 4 + r);
 
   float v[CO_BLK][4];
 #pragma unroll
@@ -173,6 +121,249 @@ k_spconv_mfma(const ConvParams p) {
     for (int r = 0; r < 4; ++r)
       if (orow[r] >= 0) p.out[(long long)orow[r] * p.cout + col] = v[cb][r];
   }
+}
+
+// ---- variant 1: simple reference kernel (single LDS buffer, two barriers per stage) -----------
+template <int CO_BLK, int J>
+__global__ void __launch_bounds__(256)
+k_spconv_mfma_simple(const ConvParams p) {
+  constexpr int STAGE_F4 = J * CO_BLK * 64;          // float4 per weight stage (<= 1024 = 16 KiB)
+  __shared__ float4 wlds[STAGE_F4];
+
+  const int tile = blockIdx.x, y = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int cin = p.c_a + p.c_b;
+  const int ncc = cin / (16 * J);
+
+  uint32_t mask[IMF_MASK_WORDS] = {1u, 0u, 0u, 0u};
+  if (p.tile_mask) {
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) mask[w] = p.tile_mask[tile * IMF_MASK_WORDS + w];
+  }
+  if ((mask[0] | mask[1] | mask[2] | mask[3]) == 0u) return;   // padding tile
+
+  const long long my_slot = (long long)tile * IMF_TILE_ROWS + wave * 16 + r16;
+
+  f32x4 acc[CO_BLK];
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float4 *wbase = reinterpret_cast<const float4 *>(p.w_packed) +
+                        (long long)y * p.kvol * ncc * STAGE_F4;
+
+#pragma unroll 1
+  for (int w = 0; w < IMF_MASK_WORDS; ++w) {
+    uint32_t m = mask[w];
+#pragma unroll 1
+    while (m) {
+      const int k = w * 32 + __builtin_ctz(m);
+      m &= m - 1;
+      const int irow = p.nbr ? p.nbr[(long long)k * p.n_slots + my_slot] : row_of_slot(p, my_slot);
+      const bool wave_active = __any(irow >= 0);
+#pragma unroll 1
+      for (int cc = 0; cc < ncc; ++cc) {
+        __syncthreads();                      // previous stage fully consumed
+        const float4 *src = wbase + ((long long)k * ncc + cc) * STAGE_F4;
+#pragma unroll
+        for (int q = 0; q < STAGE_F4 / 256; ++q) wlds[q * 256 + tid] = src[q * 256 + tid];
+
+        float4 a[J];
+        if (wave_active) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) a[j] = gather_a(p, irow, cc * 16 * J + 16 * j + 4 * q4);
+        }
+        __syncthreads();                      // stage visible
+        if (wave_active) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+#pragma unroll
+            for (int cb = 0; cb < CO_BLK; ++cb) {
+              const float4 b = wlds[(j * CO_BLK + cb) * 64 + lane];
+              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b.x, acc[cb], 0, 0, 0);
+              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b.y, acc[cb], 0, 0, 0);
+              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b.z, acc[cb], 0, 0, 0);
+              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b.w, acc[cb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  conv_epilogue<CO_BLK>(p, acc, tile, y, wave, r16, q4);
+}
+
+// ---- variant 0: pipelined kernel ------------------------------------------------------------
+constexpr int kKCache = 28;   // active offsets cached per workgroup (kvol <= 27 uses this kernel)
+
+template <int CO_BLK, int J>
+__global__ void __launch_bounds__(256)
+k_spconv_mfma(const ConvParams p) {
+  constexpr int SUB_F4 = J * CO_BLK * 64;            // float4 per (k, cc) sub-stage
+  constexpr int KG = 1024 / SUB_F4;                  // sub-stages per 16 KiB macro stage: 1, 2 or 4
+  constexpr int QPS = SUB_F4 / 256;                  // float4 per thread per sub-stage: 4, 2 or 1
+  __shared__ float4 wlds[2][1024];
+  __shared__ int nbr_lds[kKCache][IMF_TILE_ROWS];
+  __shared__ int klist[kKCache];
+
+  const int tile = blockIdx.x, y = blockIdx.y, z = blockIdx.z, S = gridDim.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int cin = p.c_a + p.c_b;
+  const int ncc = cin / (16 * J);
+
+  uint32_t mask[IMF_MASK_WORDS] = {1u, 0u, 0u, 0u};
+  if (p.tile_mask) {
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) mask[w] = p.tile_mask[tile * IMF_MASK_WORDS + w];
+  }
+  const int total = __builtin_popcount(mask[0]) + __builtin_popcount(mask[1]) +
+                    __builtin_popcount(mask[2]) + __builtin_popcount(mask[3]);
+  if (total == 0 && S == 1) return;                  // padding tile
+  const int lo = (int)((long long)z * total / S), hi = (int)((long long)(z + 1) * total / S);
+  const int nk = hi - lo;
+
+  if (tid == 0) {
+    int ord = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) {
+      uint32_t m = mask[w];
+      while (m) {
+        const int k = w * 32 + __builtin_ctz(m);
+        m &= m - 1;
+        if (ord >= lo && ord < hi) klist[n++] = k;
+        ++ord;
+      }
+    }
+  }
+  __syncthreads();
+  const long long tile_slot0 = (long long)tile * IMF_TILE_ROWS;
+  for (int j = wave; j < nk; j += 4)
+    nbr_lds[j][lane] = p.nbr ? p.nbr[(long long)klist[j] * p.n_slots + tile_slot0 + lane]
+                             : row_of_slot(p, tile_slot0 + lane);
+  __syncthreads();
+
+  f32x4 acc[CO_BLK];
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float4 *wbase = reinterpret_cast<const float4 *>(p.w_packed) +
+                        (long long)y * p.kvol * ncc * SUB_F4;
+  const int n_sub = nk * ncc;
+  const int n_macro = (n_sub + KG - 1) / KG;
+
+  // Prefetch registers.  The four weight quads are NAMED scalars on purpose: as an array they are
+  // left in scratch memory by hipcc (ROCm 7.2), which serialises the prefetch behind vmcnt waits.
+  float4 w0, w1, w2, w3;
+  float4 a_next[KG][J];
+  bool act_next[KG];
+  const float4 *sp[KG];
+
+  // prefetch of macro stage n: weights -> w0..w3, A fragments -> a_next
+#define IMF_PREFETCH(n)                                                                           \
+  {                                                                                                \
+    _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                              \
+      const int t = (n) * KG + g;                                                                  \
+      const int tc = t < n_sub ? t : n_sub - 1;   /* tail: reload the last sub-stage, unused */    \
+      const int jk = tc / ncc, cc = tc - jk * ncc;                                                 \
+      sp[g] = wbase + ((long long)klist[jk] * ncc + cc) * SUB_F4 + tid;                            \
+      const int irow = nbr_lds[jk][wave * 16 + r16];                                               \
+      act_next[g] = (t < n_sub) && __any(irow >= 0);                                               \
+      _Pragma("unroll") for (int j = 0; j < J; ++j)                                                \
+          a_next[g][j] = gather_a(p, irow, cc * 16 * J + 16 * j + 4 * q4);                         \
+    }                                                                                              \
+    w0 = sp[0 / QPS][(0 % QPS) * 256];                                                             \
+    w1 = sp[1 / QPS][(1 % QPS) * 256];                                                             \
+    w2 = sp[2 / QPS][(2 % QPS) * 256];                                                             \
+    w3 = sp[3 / QPS][(3 % QPS) * 256];                                                             \
+  }
+
+  if (n_macro > 0) IMF_PREFETCH(0)
+#pragma unroll 1
+  for (int n = 0; n < n_macro; ++n) {
+    float4 *wbuf = wlds[n & 1];
+    wbuf[0 * 256 + tid] = w0;
+    wbuf[1 * 256 + tid] = w1;
+    wbuf[2 * 256 + tid] = w2;
+    wbuf[3 * 256 + tid] = w3;
+    float4 a_cur[KG][J];
+    bool act[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      act[g] = act_next[g];
+#pragma unroll
+      for (int j = 0; j < J; ++j) a_cur[g][j] = a_next[g][j];
+    }
+    __syncthreads();   // stage n visible; every wave is past its reads of this buffer (stage n-2)
+    if (n + 1 < n_macro) IMF_PREFETCH(n + 1)
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      if (act[g]) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+#pragma unroll
+          for (int cb = 0; cb < CO_BLK; ++cb) {
+            const float4 b = wbuf[g * SUB_F4 + (j * CO_BLK + cb) * 64 + lane];
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].x, b.x, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].y, b.y, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].z, b.z, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].w, b.w, acc[cb], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#undef IMF_PREFETCH
+
+  if (S == 1) {
+    conv_epilogue<CO_BLK>(p, acc, tile, y, wave, r16, q4);
+  } else {   // raw partial sums, slot-major
+    const int CW = 16 * CO_BLK;
+#pragma unroll
+    for (int cb = 0; cb < CO_BLK; ++cb) {
+      const int col = y * CW + cb * 16 + r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long slot = tile_slot0 + wave * 16 + q4 * 4 + r;
+        p.partial[((long long)z * p.n_slots + slot) * p.cout + col] = acc[cb][r];
+      }
+    }
+  }
+}
+
+// Adds the split-K partial sums in ascending partition order and applies the epilogue.
+// One thread per (slot, 4 output channels).
+__global__ void __launch_bounds__(256)
+k_spconv_reduce(const ConvParams p, int S) {
+  const int c4n = p.cout / 4;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long slot = idx / c4n;
+  const int c4 = (int)(idx - slot * c4n);
+  const bool in_range = slot < p.n_slots;
+  const int orow = in_range ? row_of_slot(p, slot) : -1;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (orow >= 0) {
+    for (int zz = 0; zz < S; ++zz) {
+      const float4 v = *reinterpret_cast<const float4 *>(
+          p.partial + ((long long)zz * p.n_slots + slot) * p.cout + 4 * c4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float x[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = 4 * c4 + e;
+      float v = x[e] * (p.scale ? p.scale[col] : 1.f) + (p.shift ? p.shift[col] : 0.f);
+      if (p.residual) v += p.residual[(long long)orow * p.cout + col];
+      if (p.relu) v = fmaxf(v, 0.f);
+      x[e] = v;
+    }
+    s = make_float4(x[0], x[1], x[2], x[3]);
+  }
+  if (p.l2norm) {   // cout in {32, 64}: a row = 8 or 16 consecutive lanes (all lanes take part)
+    float ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+    for (int o = 1; o < c4n; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    const float nrm = sqrtf(ss);
+    s.x /= nrm; s.y /= nrm; s.z /= nrm; s.w /= nrm;
+  }
+  if (orow >= 0) *reinterpret_cast<float4 *>(p.out + (long long)orow * p.cout + 4 * c4) = s;
 }
 
 // ---- first layer: tiny Cin (all-ones occupancy feature), one thread per output row -------------
@@ -242,31 +433,65 @@ int imf_pack_weights(const float *w, int kvol, int cin, int cout, float *packed,
   return IMF_OK;
 }
 
+int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol) {
+  if (kvol <= 1 || kvol >= kKCache) return 1;
+  const int64_t blocks = (n_slots / IMF_TILE_ROWS) * (cout / (16 * co_blk_of(cout)));
+  if (blocks >= 512) return 1;
+  int64_t s = div_up(768, blocks);
+  if (s > 8) s = 8;
+  if (s > kvol / 2) s = kvol / 2;
+  return s < 1 ? 1 : (int)s;
+}
+
+size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split) {
+  return split <= 1 ? 0 : (size_t)split * (size_t)n_slots * (size_t)cout * sizeof(float);
+}
+
 int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   IMF_REQUIRE(a, "imf_spconv_fwd: null args");
-  IMF_REQUIRE(a->in_a && a->w_packed && a->tile_rows && a->tile_mask && a->out,
-              "imf_spconv_fwd: null pointer");
+  IMF_REQUIRE(a->in_a && a->w_packed && a->out, "imf_spconv_fwd: null pointer");
   IMF_REQUIRE(a->kvol >= 1 && a->kvol <= IMF_MAX_KVOL, "imf_spconv_fwd: kvol=%d", a->kvol);
-  IMF_REQUIRE(a->nbr || a->kvol == 1, "imf_spconv_fwd: nbr may be NULL only when kvol == 1");
+  IMF_REQUIRE((a->nbr && a->tile_mask) || a->kvol == 1,
+              "imf_spconv_fwd: nbr / tile_mask may be NULL only when kvol == 1");
   IMF_REQUIRE(a->c_a > 0 && a->c_a % 32 == 0 && a->c_b >= 0 && a->c_b % 32 == 0,
               "imf_spconv_fwd: c_a=%d c_b=%d must be multiples of 32", a->c_a, a->c_b);
   IMF_REQUIRE((a->c_b == 0) == (a->in_b == nullptr), "imf_spconv_fwd: in_b / c_b mismatch");
   IMF_REQUIRE(a->cout > 0 && a->cout % 32 == 0, "imf_spconv_fwd: cout=%d", a->cout);
   IMF_REQUIRE(a->n_slots > 0 && a->n_slots % IMF_TILE_ROWS == 0, "imf_spconv_fwd: n_slots");
-  IMF_REQUIRE(a->n_out > 0, "imf_spconv_fwd: n_out");
+  IMF_REQUIRE(a->n_out > 0 && (a->tile_rows || a->n_out <= a->n_slots), "imf_spconv_fwd: n_out");
   const int cin = a->c_a + a->c_b;
   const int J = ci_chunk_of(cin) / 16, CB = co_blk_of(a->cout);
   IMF_REQUIRE(!a->l2norm || a->cout == 16 * CB, "imf_spconv_fwd: l2norm needs cout in {32, 64}");
+  IMF_REQUIRE(a->variant == 0 || a->variant == 1, "imf_spconv_fwd: variant=%d", a->variant);
+  const bool simple = a->variant == 1 || a->kvol >= kKCache;
+  int split = simple ? 1 : (a->split_k > 0 ? a->split_k : imf_spconv_auto_split(a->n_slots, a->cout, a->kvol));
+  IMF_REQUIRE(split >= 1 && split <= 32, "imf_spconv_fwd: split_k=%d", split);
+  if (split > 1)
+    IMF_REQUIRE(a->workspace && a->workspace_bytes >= imf_spconv_workspace_bytes(a->n_slots, a->cout, split),
+                "imf_spconv_fwd: split_k=%d needs %zu workspace bytes", split,
+                imf_spconv_workspace_bytes(a->n_slots, a->cout, split));
   ConvParams p{a->in_a, a->in_b, a->c_a, a->c_b, a->w_packed, a->kvol, a->cout, a->tile_rows,
-               a->nbr, a->tile_mask, (long long)a->n_slots, a->scale, a->shift, a->residual,
-               a->relu, a->l2norm, a->out};
-  dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)));
+               a->nbr, a->tile_mask, (long long)a->n_slots, (long long)a->n_out, a->scale, a->shift,
+               a->residual, a->relu, a->l2norm, a->out, (float *)a->workspace};
+  dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
-  if (CB == 4 && J == 4)      k_spconv_mfma<4, 4><<<grid, 256, 0, st>>>(p);
-  else if (CB == 4 && J == 2) k_spconv_mfma<4, 2><<<grid, 256, 0, st>>>(p);
-  else if (CB == 2 && J == 4) k_spconv_mfma<2, 4><<<grid, 256, 0, st>>>(p);
-  else                        k_spconv_mfma<2, 2><<<grid, 256, 0, st>>>(p);
+  if (simple) {
+    if (CB == 4 && J == 4)      k_spconv_mfma_simple<4, 4><<<grid, 256, 0, st>>>(p);
+    else if (CB == 4 && J == 2) k_spconv_mfma_simple<4, 2><<<grid, 256, 0, st>>>(p);
+    else if (CB == 2 && J == 4) k_spconv_mfma_simple<2, 4><<<grid, 256, 0, st>>>(p);
+    else                        k_spconv_mfma_simple<2, 2><<<grid, 256, 0, st>>>(p);
+  } else {
+    if (CB == 4 && J == 4)      k_spconv_mfma<4, 4><<<grid, 256, 0, st>>>(p);
+    else if (CB == 4 && J == 2) k_spconv_mfma<4, 2><<<grid, 256, 0, st>>>(p);
+    else if (CB == 2 && J == 4) k_spconv_mfma<2, 4><<<grid, 256, 0, st>>>(p);
+    else                        k_spconv_mfma<2, 2><<<grid, 256, 0, st>>>(p);
+  }
   IMF_CHECK_LAUNCH("k_spconv_mfma");
+  if (split > 1) {
+    const long long total = (long long)a->n_slots * (a->cout / 4);
+    k_spconv_reduce<<<(unsigned)div_up(total, 256), 256, 0, st>>>(p, split);
+    IMF_CHECK_LAUNCH("k_spconv_reduce");
+  }
   return IMF_OK;
 }
 

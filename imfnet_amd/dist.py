@@ -1,0 +1,96 @@
+"""Multi-GPU layer: one process per GPU, fragments sharded across ranks, ONE exchange at the end
+(SURVEY §8e).  The reference has no distributed code at all (scripts/generate_desc.py:8 pins
+CUDA_VISIBLE_DEVICES="0"); fragments are independent units (eval-mode BatchNorm, no cross-fragment
+state), so the path shards embarrassingly and the only collective is the final variable-length
+gather of [M_i, 32] descriptor blocks to rank 0 -- `torch.distributed` send/recv, which is RCCL
+over xGMI with backend "nccl" (each peer reaches the root over its own direct link) and gloo on CPU
+for the tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  Returns
+    (rank, world_size, local_rank); a single process without the env vars is (0, 1, 0)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_fragments(costs, world_size):
+    """Longest-processing-time-first assignment of fragments to ranks.  costs[i] ~ work of fragment
+    i (point or voxel count).  Returns world_size lists of fragment indices (each ascending);
+    deterministic, every fragment assigned exactly once."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda q: (loads[q], q))
+        shards[r].append(i)
+        loads[r] += costs[i]
+    return [sorted(s) for s in shards]
+
+
+def gather_blocks(block, dst=0, group=None):
+    """Variable-length gather of 2-D row blocks (same dtype / column count, different row counts)
+    to rank `dst`.  Returns the list of per-rank tensors on `dst` (rank order), None elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [block]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    block = block.contiguous()
+    n = torch.tensor([block.shape[0]], dtype=torch.int64, device=block.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    if rank != dst:
+        if block.shape[0]:
+            dist.send(block, dst=dst, group=group)
+        return None
+    out = []
+    for r in range(world):
+        if r == dst:
+            out.append(block)
+            continue
+        buf = torch.empty((counts[r],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        if counts[r]:
+            dist.recv(buf, src=r, group=group)
+        out.append(buf)
+    return out
+
+
+def gather_fragment_descriptors(results, n_fragments, shards, dst=0):
+    """results: {fragment index: F [M_i, D]} computed by this rank (its shard).  Gathers every
+    rank's blocks to `dst` and returns {fragment index: F} for ALL fragments there (None elsewhere).
+    One count exchange + one block exchange per rank, independent of the number of fragments."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = shards[rank]
+    dev = next(iter(results.values())).device if results else torch.device("cpu")
+    D = next(iter(results.values())).shape[1] if results else 0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        d = torch.tensor([D], dtype=torch.int64, device=dev)
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        D = int(d.item())
+    rows = torch.tensor([[results[i].shape[0]] for i in mine], dtype=torch.int64, device=dev).reshape(-1, 1)
+    feats = torch.cat([results[i] for i in mine], 0) if mine else torch.empty((0, D), device=dev)
+    all_rows = gather_blocks(rows, dst)
+    all_feats = gather_blocks(feats, dst)
+    if all_rows is None:
+        return None
+    out = {}
+    for r, (rr, ff) in enumerate(zip(all_rows, all_feats)):
+        start = 0
+        for i, m in zip(shards[r], rr.reshape(-1).tolist()):
+            out[i] = ff[start:start + m]
+            start += m
+    assert len(out) == n_fragments
+    return out

@@ -8,6 +8,26 @@ from . import _lib
 from ._lib import ConvArgs, ImfError, TILE_ROWS, MASK_WORDS, check
 
 
+# When set to a list, every sparse-conv launch is bracketed by HIP events on the launch stream and
+# appended as a dict (bench.py's live roofline measurement).  None in normal operation.
+TRACE = None
+
+
+def _trace_begin():
+    if TRACE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _trace_end(e0, **info):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        TRACE.append(dict(info, start=e0, end=e1))
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -49,11 +69,12 @@ class Level:
 
 class Rulebook:
     """Tiled kernel map (see include/imfnet_hip.h)."""
-    __slots__ = ("tile_rows", "nbr", "tile_mask", "n_slots", "n_out", "kvol")
+    __slots__ = ("tile_rows", "nbr", "tile_mask", "n_slots", "n_out", "kvol", "max_active")
 
-    def __init__(self, tile_rows, nbr, tile_mask, n_slots, n_out, kvol):
+    def __init__(self, tile_rows, nbr, tile_mask, n_slots, n_out, kvol, max_active=None):
         self.tile_rows, self.nbr, self.tile_mask = tile_rows, nbr, tile_mask
         self.n_slots, self.n_out, self.kvol = n_slots, n_out, kvol
+        self.max_active = kvol if max_active is None else max_active   # active offsets per tile
 
 
 def _new_table(n, device):
@@ -152,17 +173,12 @@ def rulebook_transpose(coarse_level, fine_level, ksize=3):
                                    fine_level.ts, ksize, tile_rows.data_ptr(), nbr.data_ptr(),
                                    mask.data_ptr(), n_slots, counters.data_ptr(), _stream()),
           "imf_rulebook_transpose")
-    return Rulebook(tile_rows, nbr, mask, n_slots, n_fine, kvol)
+    return Rulebook(tile_rows, nbr, mask, n_slots, n_fine, kvol, max_active=8)
 
 
 def rulebook_identity(n_out, device):
-    """kvol == 1 (pointwise) 'rulebook': slot == row, every tile active at offset 0."""
-    n_slots = _lib.lib().imf_rulebook_slots(n_out)
-    tile_rows = torch.arange(n_slots, dtype=torch.int32, device=device)
-    tile_rows[n_out:] = -1
-    mask = torch.zeros(n_slots // TILE_ROWS, MASK_WORDS, dtype=torch.int32, device=device)
-    mask[:, 0] = 1
-    return Rulebook(tile_rows, None, mask.reshape(-1), n_slots, n_out, 1)
+    """kvol == 1 (pointwise) 'rulebook': slot == row, one active offset; nothing to build."""
+    return Rulebook(None, None, None, _lib.lib().imf_rulebook_slots(n_out), n_out, 1)
 
 
 def pack_weights(kernel):
@@ -179,7 +195,7 @@ def pack_weights(kernel):
 
 
 def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual=None,
-           relu=False, l2norm=False, out=None):
+           relu=False, l2norm=False, out=None, split_k=0, variant=0):
     """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd."""
     _req(in_a, torch.float32, "in_a", 2)
     if in_b is not None:
@@ -190,15 +206,27 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     a.in_a, a.in_b = in_a.data_ptr(), _ptr(in_b)
     a.c_a, a.c_b = in_a.shape[1], (0 if in_b is None else in_b.shape[1])
     a.w_packed, a.kvol, a.cout = w_packed.data_ptr(), rb.kvol, cout
-    a.tile_rows, a.nbr, a.tile_mask = rb.tile_rows.data_ptr(), _ptr(rb.nbr), rb.tile_mask.data_ptr()
+    a.tile_rows, a.nbr, a.tile_mask = _ptr(rb.tile_rows), _ptr(rb.nbr), _ptr(rb.tile_mask)
     a.n_slots, a.n_out = rb.n_slots, rb.n_out
     a.scale, a.shift, a.residual = _ptr(scale), _ptr(shift), _ptr(residual)
     a.relu, a.l2norm = int(bool(relu)), int(bool(l2norm))
     a.out = out.data_ptr()
+    L = _lib.lib()
+    split = 1 if variant == 1 else (int(split_k) if split_k else L.imf_spconv_auto_split(rb.n_slots, cout, rb.max_active))
+    a.split_k, a.variant = split, int(variant)
+    ws = None
+    if split > 1:
+        nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=in_a.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     if w_packed.numel() != rb.kvol * (a.c_a + a.c_b) * cout:
         raise ImfError(f"packed weight has {w_packed.numel()} floats, expected "
                        f"{rb.kvol}x{a.c_a + a.c_b}x{cout}")
-    check(_lib.lib().imf_spconv_fwd(C.byref(a), _stream()), "imf_spconv_fwd")
+    e0 = _trace_begin()
+    check(L.imf_spconv_fwd(C.byref(a), _stream()), "imf_spconv_fwd")
+    cin = a.c_a + a.c_b
+    _trace_end(e0, kernel=f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>",
+               kvol=rb.kvol, cin=cin, cout=cout, rb=rb, split=split)
     return out
 
 
@@ -210,8 +238,10 @@ def spconv_small_cin(feat, kernel, rb, scale=None, shift=None, relu=False):
     if feat.shape[1] != cin or kvol != rb.kvol:
         raise ImfError("spconv_small_cin: feature / kernel / rulebook mismatch")
     out = torch.empty((rb.n_out, cout), dtype=torch.float32, device=feat.device)
+    e0 = _trace_begin()
     check(_lib.lib().imf_spconv_small_cin(feat.data_ptr(), cin, k.data_ptr(), kvol, cout,
                                           rb.nbr.data_ptr(), rb.n_slots, rb.n_out, _ptr(scale),
                                           _ptr(shift), int(bool(relu)), out.data_ptr(), _stream()),
           "imf_spconv_small_cin")
+    _trace_end(e0, kernel=f"k_spconv_small_cin<{cout}>", kvol=kvol, cin=cin, cout=cout, rb=rb)
     return out

@@ -134,8 +134,9 @@ typedef struct imf_conv_args {
   int32_t c_a, c_b;       /* cin = c_a + c_b; c_a % 32 == 0, c_b % 32 == 0                    */
   const float *w_packed;  /* imf_pack_weights image                                           */
   int32_t kvol, cout;
-  const int32_t *tile_rows, *nbr;   /* rulebook (nbr may be NULL when kvol == 1: in row == out row) */
-  const uint32_t *tile_mask;
+  const int32_t *tile_rows;         /* NULL = identity (slot == row)                                  */
+  const int32_t *nbr;               /* NULL allowed when kvol == 1: input row == output row           */
+  const uint32_t *tile_mask;        /* NULL allowed when kvol == 1: every tile active at offset 0     */
   int64_t n_slots, n_out;
   const float *scale;     /* [cout] or NULL   y = acc * scale + shift  (folded eval BatchNorm /   */
   const float *shift;     /* [cout] or NULL                             bias)                     */
@@ -143,7 +144,18 @@ typedef struct imf_conv_args {
   int32_t relu;           /* y = max(y, 0)                                                        */
   int32_t l2norm;         /* y /= ||y||_2 over the row (requires cout <= 64)                      */
   float *out;             /* [n_out, cout]                                                        */
+  int32_t split_k;        /* 0 = choose automatically; >= 1 = number of kernel-offset partitions  */
+  int32_t variant;        /* 0 = pipelined kernel (default); 1 = simple reference kernel (A/B)     */
+  void *workspace;        /* split-K partial sums; NULL allowed iff split_k resolves to 1          */
+  size_t workspace_bytes; /* >= imf_spconv_workspace_bytes(n_slots, cout, split)                  */
 } imf_conv_args;
+
+/* Kernel-offset partitions imf_spconv_fwd will use for this shape when args.split_k == 0: small
+ * levels (few tiles) are latency-bound, so their offsets are spread over several workgroups whose
+ * partial sums are combined -- in a fixed order, hence still bit-reproducible -- by a second
+ * kernel that also applies the epilogue. */
+int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol);
+size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split);
 
 /* Replaces: ME.MinkowskiConvolution / ME.MinkowskiConvolutionTranspose forward
  *           (model/resunet.py:168-226, model/residual_block.py:40-48) with the following
