@@ -44,13 +44,15 @@ def algorithmic_bytes(rec):
     return pairs * (rec["cin"] + rec["cout"]) * 4 + pairs * 8 + rec["kvol"] * rec["cin"] * rec["cout"] * 4, pairs
 
 
-def cpu_baseline(xyz, img, voxel, sd, seconds_budget=20.0):
-    """The oracle (C geometry + torch-CPU convolutions = MinkowskiEngine's CPU algorithm restated)
-    timed on this box's host cores over a bounded sample of the same workload."""
+def cpu_baseline(xyz, img, voxel, sd, seconds_budget=15.0):
+    """The oracle (C hash-map geometry + torch-CPU gather-GEMM-scatter convolutions =
+    MinkowskiEngine's CPU algorithm restated; dense parts are the torch-CPU ops the reference itself
+    would run) timed on this box's host cores over a bounded sample of the same workload.  torch's
+    intra-op pool does not scale to all cores of a large host on these small GEMMs (256 threads are
+    6x SLOWER than 16 on the EPYC 9575F GPU box), so the thread count is picked by a short probe and
+    reported as `cores`."""
     import imf_oracle as O
     import imf_oracle_cbind as OC
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
 
     def once():
         t0 = time.perf_counter()
@@ -59,17 +61,27 @@ def cpu_baseline(xyz, img, voxel, sd, seconds_budget=20.0):
         F = O.resunet_forward(sd, coords, img, geometry=geom)
         return time.perf_counter() - t0, F.shape[0]
 
-    once()                                             # warm-up (page-in, thread pools)
+    ncpu = os.cpu_count() or 1
+    best_nt, best_t = 1, float("inf")
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32)}):
+        torch.set_num_threads(nt)
+        os.environ["OMP_NUM_THREADS"] = str(nt)
+        once()                                         # warm-up (page-in, thread pools)
+        dt, _ = once()
+        if dt < best_t:
+            best_nt, best_t = nt, dt
+    torch.set_num_threads(best_nt)
     times, m, spent = [], 0, 0.0
     while spent < seconds_budget and len(times) < 12:
         dt, m = once()
         times.append(dt)
         spent += dt
     med = statistics.median(times)
-    return {"value": m / med, "unit": "descriptors/s", "cores": cores, "kind": "port",
-            "sample": f"same fragment (M={m}), full path on the host, median of {len(times)} runs "
-                      f"({med * 1e3:.0f} ms each): C hash-map voxelise/pyramid/rulebooks (OpenMP) + "
-                      f"torch-CPU gather-GEMM-scatter convolutions, image encoder and attention"}
+    return {"value": round(m / med, 1), "unit": "descriptors/s", "cores": best_nt, "kind": "port",
+            "sample": f"the same fragment (M={m}) end to end on the host, median of {len(times)} runs "
+                      f"({med * 1e3:.0f} ms each), {best_nt} threads (best of 8/16/32 on a {ncpu}-cpu host): "
+                      f"C hash-map voxelise/pyramid/rulebooks (OpenMP) + torch-CPU per-offset "
+                      f"gather-GEMM-scatter convolutions, image encoder and attention"}
 
 
 def main():
@@ -140,7 +152,8 @@ def main():
         groups = {}
         bytes_cache = {}
         for rec in trace:
-            ms = rec["start"].elapsed_time(rec["end"])
+            ms = rec["ev"].elapsed_ms()
+            assert ms >= 0.0
             key = id(rec["rb"]), rec["cin"], rec["cout"]
             if key not in bytes_cache:
                 bytes_cache[key] = algorithmic_bytes(rec)
@@ -165,8 +178,7 @@ def main():
             cpu = cpu_baseline(xyz, img, voxel, sd)
         out = {
             "metric": "descriptors/sec (32-D) on 3DMatch fragments",
-            "value": round(total_m * args.steps / elapsed, 1) if world == 1
-            else round(total_m * args.steps / elapsed, 1),
+            "value": round(total_m * args.steps / elapsed, 1),
             "unit": "descriptors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",

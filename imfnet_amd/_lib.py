@@ -32,6 +32,7 @@ class ConvArgs(C.Structure):
         ("out", C.c_void_p),
         ("split_k", C.c_int32), ("variant", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p),
     ]
 
 
@@ -41,6 +42,9 @@ _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
 SIGNATURES = {
     "imf_version": (_I, []),
     "imf_last_error": (C.c_char_p, []),
+    "imf_event_create": (_P, []),
+    "imf_event_destroy": (None, [_P]),
+    "imf_event_elapsed_ms": (C.c_float, [_P, _P]),
     "imf_hash_capacity": (_L, [_L]),
     "imf_unique_workspace_bytes": (_Z, [_L]),
     "imf_voxelize": (_I, [_P, _I, _L, _D, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),

@@ -17,4 +17,17 @@ void set_error(const char *fmt, ...) {
 extern "C" {
 int imf_version(void) { return 100; }   /* 0.1.0 */
 const char *imf_last_error(void) { return imf::g_err; }
+
+void *imf_event_create(void) {
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? (void *)e : nullptr;
+}
+void imf_event_destroy(void *ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+float imf_event_elapsed_ms(void *b, void *e) {
+  float ms = -1.f;
+  if (!b || !e || hipEventElapsedTime(&ms, (hipEvent_t)b, (hipEvent_t)e) != hipSuccess) return -1.f;
+  return ms;
+}
 }

@@ -475,6 +475,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
                a->residual, a->relu, a->l2norm, a->out, (float *)a->workspace};
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
+  if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
   if (simple) {
     if (CB == 4 && J == 4)      k_spconv_mfma_simple<4, 4><<<grid, 256, 0, st>>>(p);
     else if (CB == 4 && J == 2) k_spconv_mfma_simple<4, 2><<<grid, 256, 0, st>>>(p);
@@ -487,6 +488,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
     else                        k_spconv_mfma<2, 2><<<grid, 256, 0, st>>>(p);
   }
   IMF_CHECK_LAUNCH("k_spconv_mfma");
+  if (a->ev_end) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_end, st));
   if (split > 1) {
     const long long total = (long long)a->n_slots * (a->cout / 4);
     k_spconv_reduce<<<(unsigned)div_up(total, 256), 256, 0, st>>>(p, split);

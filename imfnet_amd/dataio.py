@@ -1,0 +1,93 @@
+"""Host-side codecs of the batch path: PLY points in, image in, NPZ out.
+
+The reference uses Open3D (`o3d.io.read_point_cloud`, scripts/generate_desc.py:83), matplotlib
+(`image.imread`, :92), OpenCV (`cv2.resize`, util/uio.py:33-40) and `np.savez_compressed`
+(:118-123).  None of the first three is needed: the fixture PLYs are plain binary-little-endian
+vertex lists, PIL decodes the images, and INTER_LINEAR resize is the half-pixel bilinear formula.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4",
+              "float": "f4", "double": "f8", "int8": "i1", "uint8": "u1", "int16": "i2", "uint16": "u2",
+              "int32": "i4", "uint32": "u4", "float32": "f4", "float64": "f8"}
+
+
+def read_ply_points(path):
+    """Vertex x,y,z of a PLY file as float64 [N,3] (what np.array(pcd.points) is in the reference:
+    Open3D widens float32 vertices to float64)."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, n, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated PLY header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok:
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                in_vertex = tok[1] == "vertex"
+                if in_vertex:
+                    n = int(tok[2])
+            elif tok[0] == "property" and in_vertex:
+                if tok[1] == "list":
+                    raise ValueError(f"{path}: list property in vertex element")
+                props.append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        names = [p[0] for p in props]
+        if not all(a in names for a in "xyz"):
+            raise ValueError(f"{path}: vertex element has no x/y/z")
+        if fmt == "ascii":
+            a = np.loadtxt(f, max_rows=n, ndmin=2)
+            return np.stack([a[:, names.index(c)] for c in "xyz"], 1).astype(np.float64)
+        end = "<" if fmt == "binary_little_endian" else ">"
+        dt = np.dtype([(nm, end + t) for nm, t in props])
+        a = np.frombuffer(f.read(n * dt.itemsize), dtype=dt, count=n)
+    return np.stack([a["x"], a["y"], a["z"]], 1).astype(np.float64)
+
+
+def read_image(path):
+    """matplotlib.image.imread semantics (generate_desc.py:92): PNG -> float32 in [0,1] (HWC, alpha
+    dropped is NOT done by the reference; fixtures are RGB); any other format -> uint8 0..255, which the
+    reference then feeds to the network un-normalised (SURVEY App. D.5 -- kept for parity)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        arr = np.asarray(im)
+    if os.path.splitext(path)[1].lower() == ".png":
+        return np.divide(arr, 255 if arr.dtype == np.uint8 else 65535, dtype=np.float32)
+    return arr
+
+
+def process_image(image, aim_H=480, aim_W=640, mode="resize", clip_mode="center"):
+    """util/uio.py:18-99, `resize` branch (the only one on the path, generate_desc.py:94-95):
+    cv2.resize(image, (aim_W, aim_H), INTER_LINEAR) == bilinear with half-pixel centres and no
+    anti-aliasing; returns float32 HWC.  Already-sized images are returned unchanged."""
+    img = np.asarray(image)
+    H, W, _ = img.shape
+    if H == aim_H and W == aim_W:
+        return img
+    if mode != "resize":
+        raise NotImplementedError("only mode='resize' is on the descriptor-generation path (SURVEY §8a H2)")
+    t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).permute(2, 0, 1)[None]
+    out = F.interpolate(t, size=(aim_H, aim_W), mode="bilinear", align_corners=False)
+    return out[0].permute(1, 2, 0).contiguous().numpy()
+
+
+def image_to_nchw(image):
+    """generate_desc.py:96-97: HWC -> [1,C,H,W]."""
+    return np.expand_dims(np.transpose(image, (2, 0, 1)), 0)
+
+
+def save_descriptors(path, points, xyz_down, feature):
+    """generate_desc.py:118-123 -- keys and dtypes consumed by scripts/evaluation_3dmatch.py:129-132."""
+    if torch.is_tensor(feature):
+        feature = feature.detach().cpu().numpy()
+    np.savez_compressed(path, points=np.asarray(points), xyz=np.asarray(xyz_down), feature=feature)

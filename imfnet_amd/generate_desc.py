@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Batch descriptor generation over a 3DMatch-layout tree -- the reference's
+scripts/generate_desc.py with the same flags, directory contract and NPZ layout:
+
+    python -m imfnet_amd.generate_desc --source <3DMatch_test> --target <desc_dir> -m <checkpoint.pth>
+
+    <source>/<scene>/seq-01/cloud_bin_K.ply + cloud_bin_K_0.png|jpg
+ -> <target>/<scene>/seq-01/cloud_bin_K.npz  {points f64[N,3], xyz f64[M,3], feature f32[M,32]}
+
+Differences, on purpose: the per-fragment timer synchronises the device (the
+reference's does not, so it under-reports); `--voxel_size` is still ignored in favour of the
+checkpoint's config (kept: generate_desc.py:146,186); list.txt is not written-then-deleted.
+Launched under torchrun (one process per GPU) the fragments are sharded across ranks
+longest-first; every rank writes its own NPZ files, and with --gather the descriptors are first
+collected on rank 0 over RCCL and written there.
+"""
+import argparse
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import dist as idist
+from .checkpoint import Config, load_checkpoint
+from .dataio import image_to_nchw, process_image, read_image, read_ply_points, save_descriptors
+from .extract import extract_features
+from .files import ensure_dir, get_file_list, get_folder_list
+from .model import load_model
+
+
+def list_fragments(source_path):
+    """[(scene_dir, ply_path)] in the reference's order (generate_desc.py:65-80)."""
+    folders = get_folder_list(source_path)
+    assert len(folders) > 0, f"Could not find 3DMatch folders under {source_path}"
+    frags = []
+    for scene in folders:
+        if "evaluation" in scene:
+            continue
+        for fi in get_file_list(os.path.join(scene, "seq-01"), ".ply"):
+            frags.append((scene, fi))
+    return frags
+
+
+def load_fragment(ply_path, config):
+    xyz = read_ply_points(ply_path)
+    image_file = ply_path.replace(".ply", "_0.png")
+    if not os.path.exists(image_file):
+        image_file = ply_path.replace(".ply", "_0.jpg")
+    img = read_image(image_file)
+    if img.shape[0] != config.image_H or img.shape[1] != config.image_W:
+        img = process_image(image=img, aim_H=config.image_H, aim_W=config.image_W)
+    return xyz, image_to_nchw(img)
+
+
+def extract_features_batch(model, config, source_path, target_path, voxel_size, device, gather=False):
+    rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) \
+        if torch.distributed.is_initialized() else (0, 1)
+    frags = list_fragments(source_path)
+    shards = idist.shard_fragments([os.path.getsize(f) for _, f in frags], world)
+    model.eval()
+    times, results, meta = [], {}, {}
+    for i in shards[rank]:
+        scene, fi = frags[i]
+        xyz, image = load_fragment(fi, config)
+        torch.cuda.synchronize(device)
+        t0 = time.time()
+        xyz_down, feature = extract_features(model, xyz=xyz, rgb=None, normal=None, voxel_size=voxel_size,
+                                             device=device, skip_check=True, image=image)
+        torch.cuda.synchronize(device)
+        times.append(time.time() - t0)
+        out_dir = os.path.join(target_path, os.path.basename(scene), "seq-01")
+        out_file = os.path.join(out_dir, os.path.basename(fi).replace(".ply", ".npz"))
+        if gather and world > 1:
+            results[i], meta[i] = feature, (out_dir, out_file, xyz, xyz_down)
+        else:
+            ensure_dir(out_dir)
+            save_descriptors(out_file, xyz, xyz_down, feature)
+    if gather and world > 1:
+        # one exchange: descriptors to rank 0 (coordinates are re-derived there from the files' points)
+        all_feats = idist.gather_fragment_descriptors(results, len(frags), shards, dst=0)
+        if rank == 0:
+            for i, (scene, fi) in enumerate(frags):
+                out_dir = os.path.join(target_path, os.path.basename(scene), "seq-01")
+                ensure_dir(out_dir)
+                if i in meta:
+                    _, out_file, xyz, xyz_down = meta[i]
+                else:
+                    from . import sparse as ME
+                    xyz = read_ply_points(fi)
+                    _, inds = ME.utils.sparse_quantize(np.floor(xyz / voxel_size), return_index=True)
+                    xyz_down = xyz[inds]
+                    out_file = os.path.join(out_dir, os.path.basename(fi).replace(".ply", ".npz"))
+                save_descriptors(out_file, xyz, xyz_down, all_feats[i])
+    return times, len(frags)
+
+
+def main(argv=None):
+    logging.basicConfig(format="%(asctime)s %(message)s", datefmt="%m/%d %H:%M:%S", level=logging.INFO,
+                        stream=sys.stdout)
+    p = argparse.ArgumentParser()
+    p.add_argument("--source", required=True, type=str, help="the path of 3DMatch testing")
+    p.add_argument("--target", required=True, type=str, help="the path of generating descriptor")
+    p.add_argument("-m", "--model", default=None, type=str, help="the path of checkpoints.pth")
+    p.add_argument("--voxel_size", default=0.05, type=float,
+                   help="ignored, as in the reference: the checkpoint's config.voxel_size is used")
+    p.add_argument("--extract_features", default=True, action="store_true")
+    p.add_argument("--with_cuda", default=True, action="store_true")
+    p.add_argument("--gather", action="store_true", help="multi-GPU: gather descriptors on rank 0 (RCCL)")
+    p.add_argument("--seeded_weights", type=int, default=None,
+                   help="no checkpoint: random weights from this seed (plumbing / benchmarking)")
+    args = p.parse_args(argv)
+
+    rank, world, local = idist.init_from_env("nccl")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    ensure_dir(args.target)
+    if args.model is not None:
+        state_dict, config = load_checkpoint(args.model)
+    else:
+        assert args.seeded_weights is not None, "give --model or --seeded_weights"
+        state_dict, config = None, Config()
+    Model = load_model(config.model)
+    model = Model(1, config.model_n_out, bn_momentum=0.05, normalize_feature=config.normalize_feature,
+                  conv1_kernel_size=config.conv1_kernel_size, D=3, config=config)
+    if state_dict is not None:
+        model.load_state_dict(state_dict)
+    else:
+        torch.manual_seed(args.seeded_weights)
+        for m in model.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.normal_(0, 0.1)
+    model = model.eval().to(device)
+    with torch.no_grad():
+        times, n = extract_features_batch(model, config, args.source, args.target, config.voxel_size, device,
+                                          gather=args.gather)
+    if times:
+        print(f"[rank {rank}] All Time:{np.sum(times)},AVG:{np.sum(times) / len(times)} "
+              f"({len(times)} of {n} fragments)")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

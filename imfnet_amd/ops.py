@@ -8,24 +8,29 @@ from . import _lib
 from ._lib import ConvArgs, ImfError, TILE_ROWS, MASK_WORDS, check
 
 
-# When set to a list, every sparse-conv launch is bracketed by HIP events on the launch stream and
-# appended as a dict (bench.py's live roofline measurement).  None in normal operation.
+# When set to a list, every sparse-conv launch is bracketed by HIP events recorded on the launch
+# stream right around the main kernel and appended as a dict (bench.py's live roofline
+# measurement).  None in normal operation.
 TRACE = None
 
 
-def _trace_begin():
-    if TRACE is None:
-        return None
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    return e
+class _Ev:
+    """A raw hipEvent_t pair owned by the library side of the C ABI."""
 
+    def __init__(self):
+        L = _lib.lib()
+        self.begin, self.end = L.imf_event_create(), L.imf_event_create()
 
-def _trace_end(e0, **info):
-    if e0 is not None:
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        TRACE.append(dict(info, start=e0, end=e1))
+    def elapsed_ms(self):
+        return _lib.lib().imf_event_elapsed_ms(self.begin, self.end)
+
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            L.imf_event_destroy(self.begin)
+            L.imf_event_destroy(self.end)
+        except Exception:
+            pass
 
 
 def _stream():
@@ -222,11 +227,15 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     if w_packed.numel() != rb.kvol * (a.c_a + a.c_b) * cout:
         raise ImfError(f"packed weight has {w_packed.numel()} floats, expected "
                        f"{rb.kvol}x{a.c_a + a.c_b}x{cout}")
-    e0 = _trace_begin()
+    ev = None
+    if TRACE is not None:
+        ev = _Ev()
+        a.ev_begin, a.ev_end = ev.begin, ev.end
     check(L.imf_spconv_fwd(C.byref(a), _stream()), "imf_spconv_fwd")
-    cin = a.c_a + a.c_b
-    _trace_end(e0, kernel=f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>",
-               kvol=rb.kvol, cin=cin, cout=cout, rb=rb, split=split)
+    if ev is not None:
+        cin = a.c_a + a.c_b
+        TRACE.append(dict(kernel=f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>",
+                          kvol=rb.kvol, cin=cin, cout=cout, rb=rb, split=split, ev=ev))
     return out
 
 
@@ -238,10 +247,8 @@ def spconv_small_cin(feat, kernel, rb, scale=None, shift=None, relu=False):
     if feat.shape[1] != cin or kvol != rb.kvol:
         raise ImfError("spconv_small_cin: feature / kernel / rulebook mismatch")
     out = torch.empty((rb.n_out, cout), dtype=torch.float32, device=feat.device)
-    e0 = _trace_begin()
     check(_lib.lib().imf_spconv_small_cin(feat.data_ptr(), cin, k.data_ptr(), kvol, cout,
                                           rb.nbr.data_ptr(), rb.n_slots, rb.n_out, _ptr(scale),
                                           _ptr(shift), int(bool(relu)), out.data_ptr(), _stream()),
           "imf_spconv_small_cin")
-    _trace_end(e0, kernel=f"k_spconv_small_cin<{cout}>", kvol=kvol, cin=cin, cout=cout, rb=rb)
     return out

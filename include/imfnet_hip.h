@@ -148,6 +148,8 @@ typedef struct imf_conv_args {
   int32_t variant;        /* 0 = pipelined kernel (default); 1 = simple reference kernel (A/B)     */
   void *workspace;        /* split-K partial sums; NULL allowed iff split_k resolves to 1          */
   size_t workspace_bytes; /* >= imf_spconv_workspace_bytes(n_slots, cout, split)                  */
+  void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded on `stream` immediately around the
+                              main MFMA kernel (not the split-K reduce): live roofline timing     */
 } imf_conv_args;
 
 /* Kernel-offset partitions imf_spconv_fwd will use for this shape when args.split_k == 0: small
@@ -173,6 +175,11 @@ int imf_spconv_small_cin(const float *in, int cin, const float *w, int kvol, int
                          const int32_t *nbr, int64_t n_slots, int64_t n_out,
                          const float *scale, const float *shift, int relu,
                          float *out, void *stream);
+
+/* Measurement helpers (bench.py): HIP events on the caller's stream. */
+void *imf_event_create(void);
+void imf_event_destroy(void *ev);
+float imf_event_elapsed_ms(void *ev_begin, void *ev_end);   /* < 0 on error (e.g. not completed) */
 
 #ifdef __cplusplus
 }

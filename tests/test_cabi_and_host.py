@@ -1,0 +1,197 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/imfnet_hip.h
+declares; the host-side mirror of the reference interface (model registry, state_dict schema,
+codecs, file ordering, checkpoint reader); the oracle's C restatement vs its numpy twin."""
+import json
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import imf_oracle as O
+from conftest import GOLDEN, ROOT
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "imfnet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(imf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from imfnet_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    L = _lib.lib()
+    declared = _header_symbols()
+    assert len(declared) >= 17
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(declared)
+    # pure host-side entry points work without a GPU
+    assert L.imf_version() >= 100
+    assert L.imf_hash_capacity(1000) == 2048 and L.imf_hash_capacity(1) == 1024
+    assert L.imf_rulebook_slots(65) == 128
+    assert L.imf_rulebook_transpose_slots(65) == (2 + 8) * 64
+    assert L.imf_packed_weight_floats(27, 64, 64) == 27 * 64 * 64
+    assert L.imf_spconv_auto_split(51264, 64, 27) == 1          # 801 tiles: no split
+    assert L.imf_spconv_auto_split(1088, 256, 27) == 8          # 17 tiles x 4 slabs: split 8
+    assert L.imf_spconv_auto_split(1088, 64, 1) == 1
+    assert L.imf_spconv_workspace_bytes(1088, 256, 8) == 8 * 1088 * 256 * 4
+    assert L.imf_spconv_workspace_bytes(1088, 256, 1) == 0
+
+
+def test_conv_args_struct_matches_header_layout():
+    """ctypes mirror of struct imf_conv_args: field order / count tracks the header."""
+    from imfnet_amd._lib import ConvArgs
+    text = open(os.path.join(ROOT, "include", "imfnet_hip.h")).read()
+    body = text[text.index("typedef struct imf_conv_args {"):text.index("} imf_conv_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [n.strip(" *") for n in re.sub(r"^(const\s+)?\w+\s", "", decl).split(",")]
+    assert names == [f[0] for f in ConvArgs._fields_]
+
+
+def test_errors_are_loud_without_gpu():
+    from imfnet_amd import ImfError, ops
+    with pytest.raises(ImfError):
+        ops.voxelize(torch.zeros(8, 3, dtype=torch.float64), 0.025)       # CPU tensor: no fallback
+    import imfnet_amd.sparse as ME
+    with pytest.raises(ImfError):
+        ME.SparseTensor(torch.ones(4, 1), coordinates=torch.zeros(4, 4, dtype=torch.int32), device="cpu")
+
+
+def test_model_registry_and_schema():
+    from imfnet_amd.model import load_model, MODELS
+    names = {m.__name__ for m in MODELS}
+    assert {"ResUNet2", "ResUNetBN2", "ResUNetBN2B", "ResUNetBN2C", "ResUNetBN2D", "ResUNetBN2E",
+            "ResUNetIN2", "ResUNetIN2B", "ResUNetIN2C", "ResUNetIN2D", "ResUNetIN2E"} <= names
+    assert load_model("NoSuchNet") is None
+    Model = load_model("ResUNetBN2C")
+    m = Model(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3, config=None)
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_schema.json")))
+    sd = m.state_dict()
+    assert len(sd) == 361 and set(sd) == set(ref)
+    assert all(list(sd[k].shape) == ref[k] for k in ref)
+    # strict load of reference-schema weights, and the older 'perceiver_io' prefix
+    seeded = O.seeded_state_dict(0, with_unused_image_layers=True)
+    res = m.load_state_dict(seeded, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert Model.CHANNELS == [None, 32, 64, 128, 256] and Model.TR_CHANNELS == [None, 64, 64, 64, 128]
+    with pytest.raises(ValueError):
+        load_model("ResUNet2")(1, 32, conv1_kernel_size=5, D=3)           # NORM_TYPE None, as upstream
+
+
+def test_dense_submodules_match_reference_goldens(golden, images, seeded_sd):
+    """AttentionFusion / ImageEncoder (torch modules, run here on CPU) vs outputs of the reference's
+    own modules."""
+    from imfnet_amd.model import load_model
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.load_state_dict(seeded_sd, strict=True)
+    m.eval()
+    with torch.no_grad():
+        out = m.attention_fusion(torch.as_tensor(golden["af_ctx"])[None],
+                                 queries_encoder=torch.as_tensor(golden["af_in"])[None])[0]
+        img = m.img_encoder(torch.as_tensor(images[0]))
+    assert np.abs(out.numpy() - golden["af_out"]).max() < 2e-5
+    assert np.abs(img.numpy() - golden["img_out"]).max() < 1e-5
+
+
+def test_bn_folding_is_eval_batchnorm():
+    import imfnet_amd.sparse as ME
+    bn = ME.MinkowskiBatchNorm(8).eval()
+    with torch.no_grad():
+        bn.bn.weight.uniform_(0.5, 1.5); bn.bn.bias.uniform_(-1, 1)
+        bn.bn.running_mean.normal_(); bn.bn.running_var.uniform_(0.5, 2)
+    x = torch.randn(50, 8)
+    sc, sh = bn.folded()
+    assert torch.allclose(x * sc + sh, bn.bn(x), atol=1e-6)
+
+
+def test_ply_reader_and_image_codecs(tmp_path, clouds):
+    from imfnet_amd.dataio import image_to_nchw, process_image, read_image, read_ply_points, save_descriptors
+    pts = clouds[0][:1000]
+    p = tmp_path / "cloud_bin_0.ply"
+    with open(p, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 1000\nproperty float x\n"
+                b"property float y\nproperty float z\nend_header\n")
+        f.write(pts.astype("<f4").tobytes())
+    got = read_ply_points(str(p))
+    assert got.dtype == np.float64 and (got == pts.astype(np.float64)).all()
+    p2 = tmp_path / "d.ply"                                   # double xyz + uchar rgb (3D_head_map layout)
+    with open(p2, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\ncomment x\nelement vertex 3\nproperty double x\n"
+                b"property double y\nproperty double z\nproperty uchar red\nproperty uchar green\n"
+                b"property uchar blue\nend_header\n")
+        for i in range(3):
+            f.write(struct.pack("<dddBBB", i + 0.5, -i, 2.0 * i, 1, 2, 3))
+    assert read_ply_points(str(p2)).tolist() == [[0.5, 0, 0], [1.5, -1, 2], [2.5, -2, 4]]
+    p3 = tmp_path / "a.ply"
+    p3.write_text("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\n"
+                  "property float z\nend_header\n1 2 3\n4 5 6\n")
+    assert read_ply_points(str(p3)).tolist() == [[1, 2, 3], [4, 5, 6]]
+
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    u8 = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    Image.fromarray(u8).save(tmp_path / "i.png")
+    img = read_image(str(tmp_path / "i.png"))
+    assert img.dtype == np.float32 and np.array_equal(img, np.divide(u8, 255, dtype=np.float32))
+    small = process_image(img, aim_H=120, aim_W=160)
+    ref = 0.25 * (img[1::4, 1::4] + img[1::4, 2::4] + img[2::4, 1::4] + img[2::4, 2::4])
+    assert small.shape == (120, 160, 3) and np.abs(small - ref).max() < 1e-6
+    assert process_image(small, aim_H=120, aim_W=160) is small or np.array_equal(process_image(small, 120, 160), small)
+    assert image_to_nchw(small).shape == (1, 3, 120, 160)
+    with pytest.raises(NotImplementedError):
+        process_image(img, 120, 160, mode="clip")
+    out = tmp_path / "o.npz"
+    save_descriptors(str(out), got, got[:10], torch.ones(10, 32))
+    z = np.load(out)
+    assert sorted(z.files) == ["feature", "points", "xyz"] and z["feature"].dtype == np.float32
+    assert z["points"].dtype == np.float64 and z["xyz"].shape == (10, 3)
+
+
+def test_file_ordering_is_natural(tmp_path):
+    from imfnet_amd.files import get_file_list, get_folder_list, sorted_alphanum
+    assert sorted_alphanum(["cloud_bin_10.ply", "cloud_bin_2.ply", "cloud_bin_1.ply"]) == \
+        ["cloud_bin_1.ply", "cloud_bin_2.ply", "cloud_bin_10.ply"]
+    for n in ("cloud_bin_10.ply", "cloud_bin_9.ply", "cloud_bin_9_0.png"):
+        (tmp_path / n).write_text("")
+    (tmp_path / "sub2").mkdir(); (tmp_path / "sub10").mkdir()
+    assert [os.path.basename(f) for f in get_file_list(str(tmp_path), ".ply")] == ["cloud_bin_9.ply", "cloud_bin_10.ply"]
+    assert [os.path.basename(f) for f in get_folder_list(str(tmp_path))] == ["sub2", "sub10"]
+
+
+def test_checkpoint_reader(tmp_path, seeded_sd):
+    from imfnet_amd.checkpoint import Config, load_checkpoint
+    sd = {k.replace("attention_fusion", "perceiver_io"): v for k, v in seeded_sd.items()}
+    cfg = Config(voxel_size=0.025)
+    torch.save({"state_dict": sd, "config": dict(cfg), "epoch": 1}, tmp_path / "c.pth")
+    got, c = load_checkpoint(str(tmp_path / "c.pth"))
+    assert set(got) == set(seeded_sd) and c["voxel_size"] == 0.025
+    assert Config().model == "ResUNetBN2C" and Config().image_W == 160
+
+
+def test_me_utils_host_helpers():
+    import imfnet_amd.sparse as ME
+    bc = ME.utils.batched_coordinates([np.zeros((2, 3), np.int32), np.ones((3, 3), np.int32)])
+    assert bc.dtype == torch.int32 and bc[:, 0].tolist() == [0, 0, 1, 1, 1]
+    a = np.array([[1, 2, 3], [-1, 0, 5]])
+    assert (ME.utils.fnv_hash_vec(a) == O.fnv_hash_vec(a)).all()
+
+
+def test_c_restatement_equals_numpy_oracle(clouds):
+    import imf_oracle_cbind as OC
+    xyz = clouds[1].astype(np.float64)
+    c, i = OC.voxelize(xyz, 0.05)
+    c2, i2 = O.voxelize(xyz, 0.05)
+    assert (c == c2).all() and (i == i2).all()
+    g, g2 = OC.Geometry(c), O.Geometry(c2)
+    for a, b in zip(g.levels + [g.k_first] + g.k3 + g.down + g.up,
+                    g2.levels + [g2.k_first] + g2.k3 + g2.down + g2.up):
+        assert (a == b).all()

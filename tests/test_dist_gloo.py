@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: world_size-2 gloo processes exercise fragment sharding and the single
+variable-length gather of descriptor blocks (imfnet_amd/dist.py) -- the same code that runs over
+RCCL on the GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def test_shard_fragments_lpt():
+    from imfnet_amd.dist import shard_fragments
+    costs = [50, 10, 40, 30, 20, 60, 5, 5]
+    shards = shard_fragments(costs, 3)
+    assert sorted(sum(shards, [])) == list(range(8))
+    loads = [sum(costs[i] for i in s) for s in shards]
+    assert max(loads) - min(loads) <= 20 and max(loads) <= 80
+    assert shard_fragments(costs, 3) == shards                     # deterministic
+    assert shard_fragments([1, 2], 4)[2:] == [[], []]              # more ranks than fragments
+    assert shard_fragments(costs, 1) == [list(range(8))]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from imfnet_amd import dist as idist
+    r, w, _ = idist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    n_frag = 7
+    sizes = [13, 1, 29, 8, 0, 17, 5]                                 # ragged, one empty block
+    shards = idist.shard_fragments([s + 1 for s in sizes], world)
+
+    def desc(i):                                                   # stand-in for the GPU forward
+        g = torch.Generator().manual_seed(100 + i)
+        return torch.randn(sizes[i], 32, generator=g)
+
+    mine = {i: desc(i) for i in shards[rank]}
+    got = idist.gather_fragment_descriptors(mine, n_frag, shards, dst=0)
+    blocks = idist.gather_blocks(torch.full((rank + 2, 3), float(rank)), dst=0)
+    if rank == 0:
+        assert sorted(got) == list(range(n_frag))
+        for i in range(n_frag):
+            assert torch.equal(got[i], desc(i)), i                 # bit-exact, right order, right counts
+        assert [b.shape[0] for b in blocks] == [r + 2 for r in range(world)]
+        assert all(float(b.mean()) == r for r, b in enumerate(blocks))
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([1]))
+    else:
+        assert got is None and blocks is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_over_gloo(tmp_path, world):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert os.path.exists(tmp_path / "ok.npy")
+
+
+def test_single_process_gather_is_identity():
+    from imfnet_amd.dist import gather_blocks, gather_fragment_descriptors
+    x = torch.arange(6.).reshape(3, 2)
+    assert gather_blocks(x)[0] is x
+    out = gather_fragment_descriptors({0: x, 1: x * 2}, 2, [[0, 1]])
+    assert torch.equal(out[1], x * 2)
