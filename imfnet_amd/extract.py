@@ -28,18 +28,23 @@ def _as_device_points(xyz, device):
     return t.to(device, non_blocking=True).contiguous()
 
 
-def sparse_tensor_from_points(xyz, voxel_size, device, feats=None):
+def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=None):
     """Voxelise raw points on the GPU.  Returns (SparseTensor with all-ones / gathered features,
-    inds int64 CUDA tensor of each voxel's first point)."""
+    inds int32 CUDA tensor of each voxel's first point).  `before_sync` (callable) is invoked after
+    the geometry kernels are queued and before the one host synchronisation, so independent work
+    (the image branch) can be put on the GPU while the host waits for the row counts."""
     pts = _as_device_points(xyz, device)
-    lv = ops.voxelize(pts, voxel_size, 0)
-    cm = ME.CoordinateManager(lv)
+    meta = ops.new_meta(4, pts.device)
+    lv = ops.voxelize(pts, voxel_size, 0, meta=meta[0])
+    cm = ME.CoordinateManager(lv, meta=meta)
+    if before_sync is not None:
+        before_sync()
     cm.build_pyramid(8)                               # one host sync for all four row counts
-    inds = lv.first_idx.long()
+    inds = lv.first_idx
     if feats is None:
         f = torch.ones((lv.n, 1), dtype=torch.float32, device=pts.device)        # util/misc.py:76-79
     else:
-        f = torch.as_tensor(feats, dtype=torch.float32).to(pts.device)[inds]      # :89
+        f = torch.as_tensor(feats, dtype=torch.float32).to(pts.device)[inds.long()]   # :89
     st = ME.SparseTensor(f, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm)
     return st, inds
 
@@ -75,11 +80,13 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
         feats.append(np.asarray(normal) / 2)
     feats = np.hstack(feats) if feats else None
 
-    stensor, inds = sparse_tensor_from_points(xyz, voxel_size, device, feats)
     image = torch.as_tensor(image, dtype=torch.float32, device=device)
+    start = getattr(model, "start_image_branch", None)
+    stensor, inds = sparse_tensor_from_points(
+        xyz, voxel_size, device, feats, before_sync=(lambda: start(image)) if start is not None else None)
     F = model(stensor, image).F
 
-    inds_host = inds.cpu().numpy()
+    inds_host = inds.cpu().numpy().astype(np.int64)
     if torch.is_tensor(xyz):
         return_coords = xyz.detach().cpu().numpy().astype(np.float64)[inds_host]
     else:

@@ -15,8 +15,11 @@ Execution is NOT a layer-by-layer walk: in eval mode `forward` runs the fused pl
      the three ME.cat's (two-source gather), the `final` bias and the L2 normalisation.
 `forward_layers` keeps the reference's op-by-op order for tests and training-mode statistics.
 """
+import os
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F_
 
 from .. import sparse as ME
 from .fusion import AttentionFusion
@@ -66,19 +69,87 @@ class ResUNet2(ME.MinkowskiNetwork):
                           dilation=1, bias=True, dimension=D)
         self.img_encoder = ImageEncoder()
         self._folded = None
+        self._pending_image = None        # (image, features, kv, event) queued by start_image_branch
+        self._side = {}                   # device -> side stream
+        self._img_graph = {}              # (device, shape) -> captured image branch
 
     # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
-    def _apply(self, fn, *a, **k):
+    def _invalidate(self):
         self._folded = None
+        self._pending_image = None
+        self._img_graph = {}
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._folded = None
+        self._invalidate()
         return super().load_state_dict(*a, **k)
 
     def train(self, mode=True):
-        self._folded = None
+        self._invalidate()
         return super().train(mode)
+
+    # ---- image branch: independent of the sparse encoder until the bottleneck ------------------
+    def _image_branch(self, image):
+        """Image encoder + the context half of the cross attention (LayerNorm + K/V projection of
+        the image tokens): everything that depends on the image only."""
+        feat = self.img_encoder(image)
+        kv = None
+        blk = self.attention_fusion.cross_attend_blocks[0]
+        if blk.fn.heads == 1 and len(self.attention_fusion.layers) == 0:
+            tokens = feat.flatten(2).transpose(1, 2)                          # [B, H*W, C]
+            kv = blk.fn.to_kv(blk.norm_context(tokens))                       # [B, T, 2*d]
+        return feat, kv
+
+    def start_image_branch(self, image):
+        """Queue the image branch on a side HIP stream (as a captured hipGraph when the shape is
+        static) so it overlaps the geometry build and the sparse encoder.  forward() collects it."""
+        if not self._can_fuse() or not image.is_cuda:
+            return
+        dev = image.device
+        side = self._side.get(dev)
+        if side is None:
+            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            feat, kv = self._run_image_graph(image, side)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        image.record_stream(side)
+        self._pending_image = (image, feat, kv, ev)
+
+    def _run_image_graph(self, image, side):
+        key = (image.device, tuple(image.shape))
+        g = self._img_graph.get(key)
+        if g is None:
+            g = self._img_graph[key] = self._capture_image_graph(image, side)
+        if g is False:                                   # capture unavailable: eager on the side stream
+            return self._image_branch(image)
+        graph, static_in, feat, kv = g
+        static_in.copy_(image)
+        graph.replay()
+        return feat, kv
+
+    def _capture_image_graph(self, image, side):
+        if os.environ.get("IMFNET_NO_GRAPH"):
+            return False
+        try:
+            static_in = image.clone()
+            for _ in range(3):                           # warm-up: MIOpen / hipBLASLt pick their kernels
+                self._image_branch(static_in)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                feat, kv = self._image_branch(static_in)
+            return graph, static_in, feat, kv
+        except Exception as e:                           # noqa: BLE001 -- fall back to eager launches
+            import warnings
+            warnings.warn(f"imfnet_amd: image-branch hipGraph capture failed ({e}); running eagerly")
+            torch.cuda.synchronize()
+            return False
 
     def _bn(self):
         if self._folded is None:
@@ -95,8 +166,15 @@ class ResUNet2(ME.MinkowskiNetwork):
         if not self._can_fuse():
             return self.forward_layers(x, image)
         bn = self._bn()
+        pend, self._pending_image = self._pending_image, None
+        kv = None
+        if pend is not None and pend[0] is image:
+            _, image_feat, kv, ev = pend                  # queued earlier on the side stream
+        else:
+            self.start_image_branch(image)
+            pend, self._pending_image = self._pending_image, None
+            _, image_feat, kv, ev = pend
         x.coordinate_manager.build_pyramid(8)
-        image = self.img_encoder(image)
 
         def down(idx, t):            # conv - norm (no ReLU, resunet.py:168-169) - block
             f, ts = getattr(self, f'conv{idx}').run(t, scale=bn[f'norm{idx}'][0], shift=bn[f'norm{idx}'][1])
@@ -114,7 +192,14 @@ class ResUNet2(ME.MinkowskiNetwork):
         out_s2 = down(2, out_s1)
         out_s4 = down(3, out_s2)
         out = down(4, out_s4)
-        out._F = self.transformer(images=image, F=out.F, xyz=out.C)                   # :189
+        cur = torch.cuda.current_stream(out.F.device)
+        cur.wait_event(ev)                                # join the image branch
+        image_feat.record_stream(cur)
+        if kv is not None and image_feat.shape[0] == 1:
+            kv.record_stream(cur)
+            out._F = self._fusion_fast(out.F, kv[0])                                  # :189
+        else:
+            out._F = self.transformer(images=image_feat, F=out.F, xyz=out.C)
         out = up(4, out, None)
         out = up(3, out, out_s4)                                                     # ME.cat :197
         out = up(2, out, out_s2)                                                     # :208
@@ -145,6 +230,19 @@ class ResUNet2(ME.MinkowskiNetwork):
         if self.normalize_feature:
             return out._like(out.F / torch.norm(out.F, p=2, dim=1, keepdim=True))
         return out
+
+    def _fusion_fast(self, x, kv):
+        """attention_fusion.py:132-154 for one image, single head, depth 0, with the image-only half
+        (K, V) already computed by the image branch.  x [N,256], kv [T,256] -> [N,256]."""
+        blk0, blk1 = self.attention_fusion.cross_attend_blocks
+        att, ff = blk0.fn, blk1.fn.net
+        d = att.dim_head
+        q = F_.linear(blk0.norm(x), att.to_q.weight)
+        p = torch.softmax((q @ kv[:, :d].t()) * att.scale, dim=-1)
+        x = F_.linear(p @ kv[:, d:], att.to_out.weight, att.to_out.bias) + x
+        h = F_.linear(blk1.norm(x), ff[0].weight, ff[0].bias)
+        a, g = h.chunk(2, dim=-1)
+        return F_.linear(a * F_.gelu(g), ff[2].weight, ff[2].bias) + x
 
     def transformer(self, images, F, xyz):
         """Per batch item: the item's stride-8 rows attend over that item's image tokens

@@ -91,7 +91,13 @@ def _new_table(n, device):
     return cap, keys, vals, ws
 
 
-def voxelize(xyz, voxel_size, batch_index=0):
+def new_meta(n_levels, device):
+    """Zeroed [n_levels, 2] int32 block of (row count, error flag) words: ONE D2H copy reads every
+    level's count back."""
+    return torch.zeros((n_levels, 2), dtype=torch.int32, device=device)
+
+
+def voxelize(xyz, voxel_size, batch_index=0, meta=None):
     """util/misc.py:82-87 on the GPU.  xyz: CUDA [N,3] float64 or float32.  Asynchronous: the
     returned Level has n=None until `sync_levels` reads the counts back."""
     if xyz.dtype not in (torch.float64, torch.float32):
@@ -103,7 +109,8 @@ def voxelize(xyz, voxel_size, batch_index=0):
     cap, keys, vals, ws = _new_table(n, dev)
     coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
     first = torch.empty(n, dtype=torch.int32, device=dev)
-    meta = torch.zeros(2, dtype=torch.int32, device=dev)           # [m, err]
+    if meta is None:
+        meta = torch.zeros(2, dtype=torch.int32, device=dev)       # [m, err]
     check(_lib.lib().imf_voxelize(xyz.data_ptr(), int(xyz.dtype == torch.float64), n, float(voxel_size),
                                   int(batch_index), coords.data_ptr(), first.data_ptr(),
                                   meta[0:1].data_ptr(), keys.data_ptr(), vals.data_ptr(), cap,
@@ -112,13 +119,13 @@ def voxelize(xyz, voxel_size, batch_index=0):
     return lv
 
 
-def downsample(level, out_stride, n_in_max=None):
+def downsample(level, out_stride, n_in_max=None, meta=None):
     """coordinate_manager.stride(): level at tensor stride `out_stride` (asynchronous)."""
     n_max = int(n_in_max if n_in_max is not None else level.n)
     dev = level.coords_buf.device
     cap, keys, vals, ws = _new_table(n_max, dev)
     coords = torch.empty((n_max, 4), dtype=torch.int32, device=dev)
-    m = torch.zeros(2, dtype=torch.int32, device=dev)               # [m, unused]
+    m = meta if meta is not None else torch.zeros(2, dtype=torch.int32, device=dev)   # [m, unused]
     check(_lib.lib().imf_downsample(level.coords_buf.data_ptr(), level.n_dev.data_ptr(), n_max,
                                     int(out_stride), coords.data_ptr(), m.data_ptr(), keys.data_ptr(),
                                     vals.data_ptr(), cap, ws.data_ptr(), _stream()), "imf_downsample")
@@ -138,9 +145,13 @@ def level_from_coords(coords):
     return lv
 
 
-def sync_levels(levels):
-    """One host synchronisation: read the row counts of `levels` back."""
-    counts = torch.cat([lv.n_dev for lv in levels]).cpu().tolist()      # [m, err] per level
+def sync_levels(levels, meta_block=None):
+    """One host synchronisation: read the row counts of `levels` back.  `meta_block`: the shared
+    [n,2] count block whose row i belongs to levels[i] (one contiguous D2H copy)."""
+    if meta_block is not None:
+        counts = meta_block[: len(levels)].cpu().reshape(-1).tolist()
+    else:
+        counts = torch.cat([lv.n_dev.reshape(-1)[:2] for lv in levels]).cpu().tolist()   # [m, err] per level
     for i, lv in enumerate(levels):
         if counts[2 * i + 1] != 0:
             raise ImfError("voxelize: a coordinate fell outside [-2^17, 2^17) voxels (or was NaN)")

@@ -45,9 +45,11 @@ class CoordinateMapKey:
 class CoordinateManager:
     """Owns the pyramid levels (coordinates + voxel hash per tensor stride) and the rulebooks."""
 
-    def __init__(self, level0):
+    def __init__(self, level0, meta=None):
         self.levels = {1: level0}
         self._rulebooks = {}
+        self.meta = meta              # optional shared [n_levels,2] count block (row 0 = level0)
+        self.meta_used = 1
 
     # -- levels ---------------------------------------------------------------------------------
     def build_pyramid(self, max_stride=8):
@@ -55,18 +57,29 @@ class CoordinateManager:
         pending = [lv for lv in self.levels.values() if lv.n is None]
         ts = max(self.levels)
         n_bound = None
+        meta, mi = self.meta, self.meta_used
         while ts < max_stride:
             src = self.levels[ts]
             if src.n is not None:
                 n_bound = src.n
             elif n_bound is None:
                 n_bound = src.coords_buf.shape[0]
-            lv = ops.downsample(src, ts * 2, n_in_max=n_bound)
+            row = None
+            if meta is not None and mi < meta.shape[0]:
+                row, mi = meta[mi], mi + 1
+            lv = ops.downsample(src, ts * 2, n_in_max=n_bound, meta=row)
             self.levels[ts * 2] = lv
             pending.append(lv)
             ts *= 2
+        self.meta_used = mi
         if pending:
-            ops.sync_levels(pending)
+            order = [self.levels[t] for t in sorted(self.levels)]
+            shared = meta is not None and len(order) <= meta.shape[0] and \
+                all(lv.n_dev.data_ptr() == meta[i].data_ptr() for i, lv in enumerate(order))
+            if shared:
+                ops.sync_levels(order, meta_block=meta)
+            else:
+                ops.sync_levels(pending)
 
     def level(self, ts):
         if ts not in self.levels or self.levels[ts].n is None:
