@@ -40,7 +40,10 @@ def load_workload(scale, voxel):
 def algorithmic_bytes(rec):
     """pairs*(Cin+Cout)*4 + pairs*8 (rulebook index) + kvol*Cin*Cout*4 (weights)."""
     rb = rec["rb"]
-    pairs = int((rb.nbr >= 0).sum().item()) if rb.nbr is not None else rb.n_out
+    if "arena" in rec:
+        pairs = rb.count_pairs(rec["arena"])
+    else:
+        pairs = int((rb.nbr >= 0).sum().item()) if rb.nbr is not None else rb.n_out
     return pairs * (rec["cin"] + rec["cout"]) * 4 + pairs * 8 + rec["kvol"] * rec["cin"] * rec["cout"] * 4, pairs
 
 

@@ -37,9 +37,7 @@ def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=N
     meta = ops.new_meta(4, pts.device)
     lv = ops.voxelize(pts, voxel_size, 0, meta=meta[0])
     cm = ME.CoordinateManager(lv, meta=meta)
-    if before_sync is not None:
-        before_sync()
-    cm.build_pyramid(8)                               # one host sync for all four row counts
+    cm.build_pyramid(8, before_sync=before_sync)      # one host sync for all four row counts
     inds = lv.first_idx
     if feats is None:
         f = torch.ones((lv.n, 1), dtype=torch.float32, device=pts.device)        # util/misc.py:76-79

@@ -1,0 +1,231 @@
+"""Arena executor for the fused ResUNet forward.
+
+The layer-at-a-time path (`sparse._ConvBase.run` -> `ops.spconv`) allocates a tensor, fills a fresh
+ctypes struct and validates arguments for every launch: ~35 us of Python per convolution, which at
+1-2 ms per fragment made the host the bottleneck.  Here the whole sparse part of one forward is
+planned with integer arithmetic: three device allocations per fragment (rulebook words, feature
+floats, split-K workspace), pre-built `imf_conv_args` structs whose static half (weights, folded
+BatchNorm, epilogue flags) is filled once per model, and raw-pointer updates per fragment.  The
+kernels, their order and their arithmetic are exactly those of the layer-at-a-time path
+(`tests/test_gpu_parity.py::test_fused_equals_layerwise` compares the two).
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib, ops
+from .._lib import ConvArgs, ImfError, MASK_WORDS, TILE_ROWS, check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _RB:
+    """Rulebook living inside the plan's int32 arena (raw device addresses)."""
+    __slots__ = ("tile_rows", "nbr", "tile_mask", "n_slots", "n_out", "kvol", "max_active")
+
+    def count_pairs(self, arena):
+        """Valid (input,output) pairs -- bench.py's algorithmic-bytes accounting, outside timing."""
+        if self.kvol == 1:
+            return self.n_out
+        start = (self.nbr - arena.data_ptr()) // 4
+        return int((arena[start:start + self.kvol * self.n_slots] >= 0).sum().item())
+
+    def __init__(self, n_slots, n_out, kvol, max_active):
+        self.tile_rows = self.nbr = self.tile_mask = 0
+        self.n_slots, self.n_out, self.kvol, self.max_active = n_slots, n_out, kvol, max_active
+
+    def words(self):
+        return self.n_slots + self.kvol * self.n_slots + self.n_slots // TILE_ROWS * MASK_WORDS
+
+    def place(self, base):
+        self.tile_rows = base
+        self.nbr = base + 4 * self.n_slots
+        self.tile_mask = self.nbr + 4 * self.kvol * self.n_slots
+        return base + 4 * self.words()
+
+
+class FusedPlan:
+    """Built once per model (eval mode); `run` executes one fragment."""
+
+    def __init__(self, model):
+        self.model = model
+        self.L = _lib.lib()
+        bn = model._bn()
+        self._keep = []                     # tensors the static struct fields point into
+        self.convs = {}
+
+        def conv_args(name, module, norm=None, relu=False, l2norm=False):
+            a = ConvArgs()
+            a.w_packed = module.packed().data_ptr()
+            a.kvol, a.cout = module.kernel_volume, module.out_channels
+            scale = shift = None
+            if norm is not None:
+                scale, shift = bn[norm]
+            elif module.bias is not None:
+                shift = module.bias.detach().reshape(-1).contiguous()
+            for t in (scale, shift):
+                if t is not None:
+                    self._keep.append(t)
+            a.scale = None if scale is None else scale.data_ptr()
+            a.shift = None if shift is None else shift.data_ptr()
+            a.relu, a.l2norm = int(relu), int(l2norm)
+            self.convs[name] = (a, module)
+
+        m = model
+        self.small_first = m.conv1.in_channels <= 4
+        if self.small_first:
+            self.first_kernel = m.conv1.kernel3().detach().contiguous()
+            self.first_bn = bn["norm1"]
+        else:
+            conv_args("conv1", m.conv1, "norm1")
+        for i in (1, 2, 3, 4):
+            if i > 1:
+                conv_args(f"conv{i}", getattr(m, f"conv{i}"), f"norm{i}")
+            blk = getattr(m, f"block{i}")
+            conv_args(f"block{i}.conv1", blk.conv1, f"block{i}.norm1", relu=True)
+            conv_args(f"block{i}.conv2", blk.conv2, f"block{i}.norm2", relu=True)
+        for i in (4, 3, 2):
+            conv_args(f"conv{i}_tr", getattr(m, f"conv{i}_tr"), f"norm{i}_tr")
+            blk = getattr(m, f"block{i}_tr")
+            conv_args(f"block{i}_tr.conv1", blk.conv1, f"block{i}_tr.norm1", relu=True)
+            conv_args(f"block{i}_tr.conv2", blk.conv2, f"block{i}_tr.norm2", relu=True)
+        conv_args("conv1_tr", m.conv1_tr, relu=True)
+        conv_args("final", m.final, l2norm=bool(m.normalize_feature))
+        self.first_ksize = m.conv1.kernel_size
+        self._trace_arena = None
+
+    # -------------------------------------------------------------------------------------------
+    def _launch(self, name, rb, in_a, c_a, out, in_b=0, c_b=0, residual=0, ws=(0, 0)):
+        a, module = self.convs[name]
+        if c_a + c_b != module.in_channels:
+            raise ImfError(f"{name}: expected {module.in_channels} input channels, got {c_a + c_b}")
+        a.in_a, a.in_b, a.c_a, a.c_b = in_a, (in_b or None), c_a, c_b
+        a.tile_rows, a.nbr, a.tile_mask = (rb.tile_rows or None), (rb.nbr or None), (rb.tile_mask or None)
+        a.n_slots, a.n_out = rb.n_slots, rb.n_out
+        a.residual = residual or None
+        a.out = out
+        split = self.L.imf_spconv_auto_split(rb.n_slots, a.cout, rb.max_active)
+        a.split_k = split
+        a.workspace, a.workspace_bytes = (ws[0] or None, ws[1]) if split > 1 else (None, 0)
+        ev = None
+        if ops.TRACE is not None:
+            ev = ops._Ev()
+            a.ev_begin, a.ev_end = ev.begin, ev.end
+        else:
+            a.ev_begin = a.ev_end = None
+        check(self.L.imf_spconv_fwd(C.byref(a), _stream()), f"imf_spconv_fwd[{name}]")
+        if ev is not None:
+            cin = c_a + c_b
+            ops.TRACE.append(dict(kernel=f"k_spconv_mfma<{4 if a.cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>",
+                                  kvol=rb.kvol, cin=cin, cout=a.cout, rb=rb, split=split, ev=ev, name=name,
+                                  arena=self._trace_arena))
+
+    def run(self, x, fuse):
+        """x: SparseTensor at tensor stride 1 (pyramid built); fuse(F8 [n8,C]) -> [n8,C] is the
+        bottleneck fusion (torch).  Returns the [M, out] descriptor tensor."""
+        m, L = self.model, self.L
+        cm = x.coordinate_manager
+        lv = [cm.level(ts) for ts in (1, 2, 4, 8)]
+        n = [l.n for l in lv]
+        dev = x.F.device
+        st = _stream()
+        Ch, T = m.CHANNELS, m.TR_CHANNELS
+        out_ch = m.final.out_channels
+
+        # ---- rulebooks: one int32 arena ------------------------------------------------------
+        slots = [L.imf_rulebook_slots(k) for k in n]
+        rb_first = _RB(slots[0], n[0], self.first_ksize ** 3, self.first_ksize ** 3)
+        rb_k3 = [_RB(slots[i], n[i], 27, 27) for i in range(4)]
+        rb_dn = [_RB(slots[i + 1], n[i + 1], 27, 27) for i in range(3)]
+        rb_up = [_RB(L.imf_rulebook_transpose_slots(n[i]), n[i], 27, 8) for i in range(3)]
+        rb_id = _RB(slots[0], n[0], 1, 1)
+        all_rb = [rb_first] + rb_k3 + rb_dn + rb_up
+        words = sum(r.words() for r in all_rb) + 16 * 3
+        iarena = torch.empty(words, dtype=torch.int32, device=dev)
+        p = iarena.data_ptr()
+        for r in all_rb:
+            p = r.place(p)
+        counters = [p + 64 * i for i in range(3)]
+        ok = check
+        ok(L.imf_rulebook_conv(lv[0].keys.data_ptr(), lv[0].vals.data_ptr(), lv[0].capacity,
+                               lv[0].coords_buf.data_ptr(), n[0], 1, self.first_ksize, rb_first.tile_rows,
+                               rb_first.nbr, rb_first.tile_mask, st), "imf_rulebook_conv")
+        for i in range(4):
+            ok(L.imf_rulebook_conv(lv[i].keys.data_ptr(), lv[i].vals.data_ptr(), lv[i].capacity,
+                                   lv[i].coords_buf.data_ptr(), n[i], 1 << i, 3, rb_k3[i].tile_rows,
+                                   rb_k3[i].nbr, rb_k3[i].tile_mask, st), "imf_rulebook_conv")
+        for i in range(3):
+            ok(L.imf_rulebook_conv(lv[i].keys.data_ptr(), lv[i].vals.data_ptr(), lv[i].capacity,
+                                   lv[i + 1].coords_buf.data_ptr(), n[i + 1], 1 << i, 3, rb_dn[i].tile_rows,
+                                   rb_dn[i].nbr, rb_dn[i].tile_mask, st), "imf_rulebook_conv")
+            ok(L.imf_rulebook_transpose(lv[i + 1].keys.data_ptr(), lv[i + 1].vals.data_ptr(),
+                                        lv[i + 1].capacity, lv[i].coords_buf.data_ptr(), n[i], 1 << i, 3,
+                                        rb_up[i].tile_rows, rb_up[i].nbr, rb_up[i].tile_mask,
+                                        rb_up[i].n_slots, counters[i], st), "imf_rulebook_transpose")
+
+        # ---- schedule: (conv name, rulebook, in_a, c_a, out, in_b, c_b, residual) ---------------
+        sched = []
+        for i in range(4):
+            c = Ch[i + 1]
+            if i > 0:
+                sched.append((f"conv{i + 1}", rb_dn[i - 1], f"e{i - 1}c", Ch[i], f"e{i}a", None, 0, None))
+            elif not self.small_first:
+                sched.append(("conv1", rb_first, "x", x.F.shape[1], "e0a", None, 0, None))
+            sched.append((f"block{i + 1}.conv1", rb_k3[i], f"e{i}a", c, f"e{i}b", None, 0, None))
+            sched.append((f"block{i + 1}.conv2", rb_k3[i], f"e{i}b", c, f"e{i}c", None, 0, f"e{i}a"))
+        n_enc = len(sched)
+        dec_ch = {2: T[4], 1: T[3], 0: T[2]}
+        for i in (2, 1, 0):                                # output level of conv{i+2}_tr
+            t = dec_ch[i]
+            src, c_src = ("fused", Ch[4]) if i == 2 else (f"d{i + 1}c", dec_ch[i + 1])
+            skip, c_skip = (None, 0) if i == 2 else (f"e{i + 1}c", Ch[i + 2])
+            sched.append((f"conv{i + 2}_tr", rb_up[i], src, c_src, f"d{i}a", skip, c_skip, None))
+            sched.append((f"block{i + 2}_tr.conv1", rb_k3[i], f"d{i}a", t, f"d{i}b", None, 0, None))
+            sched.append((f"block{i + 2}_tr.conv2", rb_k3[i], f"d{i}b", t, f"d{i}c", None, 0, f"d{i}a"))
+        sched.append(("conv1_tr", rb_id, "d0c", T[2], "head", "e0c", Ch[1], None))
+        sched.append(("final", rb_id, "head", T[1], "F", None, 0, None))
+
+        # ---- features: one float arena (+ the largest split-K workspace any launch needs) ------
+        sizes = {}
+        for i in range(4):
+            for sfx in "abc":                              # conv out, block mid, block out
+                sizes[f"e{i}{sfx}"] = n[i] * Ch[i + 1]
+        for i in (2, 1, 0):
+            for sfx in "abc":
+                sizes[f"d{i}{sfx}"] = n[i] * dec_ch[i]
+        sizes["head"] = n[0] * T[1]
+        ws_floats = 0
+        for name, rb, *_ in sched:
+            cout = self.convs[name][0].cout
+            sp = L.imf_spconv_auto_split(rb.n_slots, cout, rb.max_active)
+            if sp > 1:
+                ws_floats = max(ws_floats, sp * rb.n_slots * cout)
+        farena = torch.empty(sum(sizes.values()) + ws_floats, dtype=torch.float32, device=dev)
+        base, off, addr, foff = farena.data_ptr(), 0, {}, {}
+        for name, cnt in sizes.items():
+            addr[name], foff[name] = base + 4 * off, off
+            off += cnt
+        ws = (base + 4 * off, 4 * ws_floats) if ws_floats else (0, 0)
+        F = torch.empty((n[0], out_ch), dtype=torch.float32, device=dev)
+        addr["F"], addr["x"] = F.data_ptr(), x.F.data_ptr()
+        self._trace_arena = iarena
+
+        if self.small_first:
+            sc, sh = self.first_bn
+            check(L.imf_spconv_small_cin(x.F.data_ptr(), x.F.shape[1], self.first_kernel.data_ptr(),
+                                         rb_first.kvol, Ch[1], rb_first.nbr, rb_first.n_slots, n[0],
+                                         sc.data_ptr(), sh.data_ptr(), 0, addr["e0a"], st), "imf_spconv_small_cin")
+
+        def go(entries):
+            for name, rb, a_key, c_a, o_key, b_key, c_b, r_key in entries:
+                self._launch(name, rb, addr[a_key], c_a, addr[o_key], in_b=addr[b_key] if b_key else 0,
+                             c_b=c_b, residual=addr[r_key] if r_key else 0, ws=ws)
+
+        go(sched[:n_enc])                                                       # encoder
+        f8 = farena[foff["e3c"]:foff["e3c"] + sizes["e3c"]].view(n[3], Ch[4])   # bottleneck fusion (torch)
+        fused = fuse(f8).contiguous()
+        addr["fused"] = fused.data_ptr()
+        go(sched[n_enc:])                                                       # decoder + head
+        return F

@@ -69,12 +69,14 @@ class ResUNet2(ME.MinkowskiNetwork):
                           dilation=1, bias=True, dimension=D)
         self.img_encoder = ImageEncoder()
         self._folded = None
+        self._plan = None                 # arena executor (model/plan.py), built lazily in eval mode
         self._pending_image = None        # (image, features, kv, event) queued by start_image_branch
         self._side = {}                   # device -> side stream
         self._img_graph = {}              # (device, shape) -> captured image branch
 
     # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
     def _invalidate(self):
+        self._plan = None
         self._folded = None
         self._pending_image = None
         self._img_graph = {}
@@ -176,36 +178,19 @@ class ResUNet2(ME.MinkowskiNetwork):
             _, image_feat, kv, ev = pend
         x.coordinate_manager.build_pyramid(8)
 
-        def down(idx, t):            # conv - norm (no ReLU, resunet.py:168-169) - block
-            f, ts = getattr(self, f'conv{idx}').run(t, scale=bn[f'norm{idx}'][0], shift=bn[f'norm{idx}'][1])
-            return getattr(self, f'block{idx}').fused(t._like(f, ts), bn[f'block{idx}.norm1'],
-                                                      bn[f'block{idx}.norm2'])
+        def fuse(f8):                                                                 # :189
+            cur = torch.cuda.current_stream(f8.device)
+            cur.wait_event(ev)                            # join the image branch
+            image_feat.record_stream(cur)
+            if kv is not None and image_feat.shape[0] == 1:
+                kv.record_stream(cur)
+                return self._fusion_fast(f8, kv[0])
+            return self.transformer(images=image_feat, F=f8, xyz=x.coordinate_manager.coords(8))
 
-        def up(idx, t, skip):        # [cat] - transposed conv - norm - block
-            n = f'norm{idx}_tr'
-            f, ts = getattr(self, f'conv{idx}_tr').run(t, in_b=None if skip is None else skip.F,
-                                                       scale=bn[n][0], shift=bn[n][1])
-            return getattr(self, f'block{idx}_tr').fused(t._like(f, ts), bn[f'block{idx}_tr.norm1'],
-                                                         bn[f'block{idx}_tr.norm2'])
-
-        out_s1 = down(1, x)          # blocks end in ReLU, so the extra MEF.relu (:171) is the identity
-        out_s2 = down(2, out_s1)
-        out_s4 = down(3, out_s2)
-        out = down(4, out_s4)
-        cur = torch.cuda.current_stream(out.F.device)
-        cur.wait_event(ev)                                # join the image branch
-        image_feat.record_stream(cur)
-        if kv is not None and image_feat.shape[0] == 1:
-            kv.record_stream(cur)
-            out._F = self._fusion_fast(out.F, kv[0])                                  # :189
-        else:
-            out._F = self.transformer(images=image_feat, F=out.F, xyz=out.C)
-        out = up(4, out, None)
-        out = up(3, out, out_s4)                                                     # ME.cat :197
-        out = up(2, out, out_s2)                                                     # :208
-        f, _ = self.conv1_tr.run(out, in_b=out_s1.F, relu=True)                      # :219-225
-        f, _ = self.final.run(out._like(f), l2norm=bool(self.normalize_feature))     # :226-233
-        return out._like(f)
+        if self._plan is None:
+            from .plan import FusedPlan
+            self._plan = FusedPlan(self)
+        return x._like(self._plan.run(x, fuse))
 
     def forward_layers(self, x, image):
         """Op-by-op order of the reference's forward (resunet.py:163-235)."""

@@ -52,8 +52,9 @@ class CoordinateManager:
         self.meta_used = 1
 
     # -- levels ---------------------------------------------------------------------------------
-    def build_pyramid(self, max_stride=8):
-        """Build all missing levels up to `max_stride` with ONE host synchronisation."""
+    def build_pyramid(self, max_stride=8, before_sync=None):
+        """Build all missing levels up to `max_stride` with ONE host synchronisation.  `before_sync`
+        runs after every geometry kernel is queued and right before the host blocks."""
         pending = [lv for lv in self.levels.values() if lv.n is None]
         ts = max(self.levels)
         n_bound = None
@@ -72,6 +73,8 @@ class CoordinateManager:
             pending.append(lv)
             ts *= 2
         self.meta_used = mi
+        if before_sync is not None:
+            before_sync()
         if pending:
             order = [self.levels[t] for t in sorted(self.levels)]
             shared = meta is not None and len(order) <= meta.shape[0] and \
