@@ -413,6 +413,85 @@ k_spconv_small_cin(const float *__restrict__ in, int cin, const float *__restric
   }
 }
 
+
+// ---- first layer, fused with its kernel map: no neighbour table is ever written -----------------
+// One wavefront per output voxel.  Lanes probe the (up to 128) kernel offsets in the input level's
+// hash in two rounds; the hits are then walked with lane = output channel (two half-waves work on
+// the two rounds' hit lists when cout == 32).  Same sum order as the table-driven kernel
+// (k ascending within a round), so results are deterministic.
+template <int COUT>
+__global__ void __launch_bounds__(256)
+k_conv_first_fused(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, uint32_t capmask,
+                   const int32_t *__restrict__ coords, long long n, int ts, int ksize, int kvol,
+                   const float *__restrict__ in, int cin, const float *__restrict__ w,
+                   const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                   float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const int nw = kvol * cin * COUT;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) wl[i] = w[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int HALVES = 64 / COUT;                 // 2 when cout == 32, 1 when cout == 64
+  const int co = lane % COUT, half = lane / COUT;
+  const int r = ksize >> 1;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < n; row += (long long)gridDim.x * 4) {
+    const int4 c = reinterpret_cast<const int4 *>(coords)[row];
+    int res[2];
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      const int k = rnd * 64 + lane;
+      int found = -1;
+      if (k < kvol) {
+        const int dx = k % ksize - r, dy = (k / ksize) % ksize - r, dz = k / (ksize * ksize) - r;
+        const int x = c.y + dx * ts, y = c.z + dy * ts, z = c.w + dz * ts;
+        if (coord_in_range(x, y, z)) found = hash_find(keys, vals, capmask, pack_key(c.x, x, y, z));
+      }
+      res[rnd] = found;
+    }
+    unsigned long long m0 = __ballot(res[0] >= 0), m1 = __ballot(res[1] >= 0);
+    float acc = 0.f;
+    if (HALVES == 2) {
+      // half 0 walks round 0's hits, half 1 walks round 1's (bit b of a round's mask <-> lane b)
+      unsigned long long m = half ? m1 : m0;
+      while (__any(m != 0ull)) {                     // wave-uniform trip count: shuffles stay convergent
+        const bool live = m != 0ull;
+        const int b = live ? __builtin_ctzll(m) : 0;
+        m &= m - 1;
+        const int s0 = __shfl(res[0], b, 64), s1 = __shfl(res[1], b, 64);
+        const int src = half ? s1 : s0;
+        if (live) {
+          const int k = half * 64 + b;
+          for (int ci = 0; ci < cin; ++ci) {
+            const float xv = in ? in[(long long)src * cin + ci] : 1.f;
+            acc = fmaf(xv, wl[(k * cin + ci) * COUT + co], acc);
+          }
+        }
+      }
+      acc += __shfl_xor(acc, 32, 64);
+    } else {
+#pragma unroll
+      for (int rnd = 0; rnd < 2; ++rnd) {
+        unsigned long long m = rnd ? m1 : m0;
+        while (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          const int src = __shfl(res[rnd], b, 64);
+          const int k = rnd * 64 + b;
+          for (int ci = 0; ci < cin; ++ci) {
+            const float xv = in ? in[(long long)src * cin + ci] : 1.f;
+            acc = fmaf(xv, wl[(k * cin + ci) * COUT + co], acc);
+          }
+        }
+      }
+    }
+    if (half == 0) {
+      float v = acc * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+      if (relu) v = fmaxf(v, 0.f);
+      out[row * COUT + co] = v;
+    }
+  }
+}
+
 }  // namespace imf
 
 using namespace imf;
@@ -514,6 +593,32 @@ int imf_spconv_small_cin(const float *in, int cin, const float *w, int kvol, int
   else
     k_spconv_small_cin<64><<<nb, 256, lds, st>>>(in, cin, w, kvol, nbr, n_slots, n_out, scale, shift, relu, out);
   IMF_CHECK_LAUNCH("k_spconv_small_cin");
+  return IMF_OK;
+}
+
+int imf_conv_first_fused(const uint64_t *keys, const int32_t *vals, int64_t capacity,
+                         const int32_t *coords, int64_t n, int ts, int ksize, const float *in, int cin,
+                         const float *w, int cout, const float *scale, const float *shift, int relu,
+                         float *out, void *stream) {
+  IMF_REQUIRE(keys && vals && coords && w && out, "imf_conv_first_fused: null pointer");
+  IMF_REQUIRE(ksize == 3 || ksize == 5, "imf_conv_first_fused: ksize must be 3 or 5");
+  IMF_REQUIRE(cin >= 1 && cin <= 4, "imf_conv_first_fused: cin=%d not in [1,4]", cin);
+  IMF_REQUIRE(cout == 32 || cout == 64, "imf_conv_first_fused: cout=%d not in {32,64}", cout);
+  IMF_REQUIRE(n > 0 && ts >= 1, "imf_conv_first_fused: bad n / ts");
+  IMF_REQUIRE((capacity & (capacity - 1)) == 0, "imf_conv_first_fused: capacity not a power of 2");
+  const int kvol = ksize * ksize * ksize;
+  const size_t lds = (size_t)kvol * cin * cout * sizeof(float);
+  IMF_REQUIRE(lds <= 64 * 1024, "imf_conv_first_fused: kernel does not fit 64 KiB of LDS");
+  hipStream_t st = (hipStream_t)stream;
+  long long nb = div_up(n, 4);
+  if (nb > 2048) nb = 2048;
+  if (cout == 32)
+    k_conv_first_fused<32><<<(unsigned)nb, 256, lds, st>>>(keys, vals, (uint32_t)(capacity - 1), coords, n, ts,
+                                                          ksize, kvol, in, cin, w, scale, shift, relu, out);
+  else
+    k_conv_first_fused<64><<<(unsigned)nb, 256, lds, st>>>(keys, vals, (uint32_t)(capacity - 1), coords, n, ts,
+                                                          ksize, kvol, in, cin, w, scale, shift, relu, out);
+  IMF_CHECK_LAUNCH("k_conv_first_fused");
   return IMF_OK;
 }
 

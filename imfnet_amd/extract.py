@@ -44,6 +44,7 @@ def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=N
     else:
         f = torch.as_tensor(feats, dtype=torch.float32).to(pts.device)[inds.long()]   # :89
     st = ME.SparseTensor(f, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm)
+    st._all_ones = feats is None          # lets the first conv skip the feature gather
     return st, inds
 
 

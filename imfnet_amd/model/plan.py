@@ -95,10 +95,14 @@ class FusedPlan:
         conv_args("final", m.final, l2norm=bool(m.normalize_feature))
         self.first_ksize = m.conv1.kernel_size
         self._trace_arena = None
+        self._side = {}
 
     # -------------------------------------------------------------------------------------------
     def _launch(self, name, rb, in_a, c_a, out, in_b=0, c_b=0, residual=0, ws=(0, 0)):
         a, module = self.convs[name]
+        e = self._ready.pop(id(rb), None)
+        if e is not None:
+            self._main.wait_event(e)            # join the side stream that built this rulebook
         if c_a + c_b != module.in_channels:
             raise ImfError(f"{name}: expected {module.in_channels} input channels, got {c_a + c_b}")
         a.in_a, a.in_b, a.c_a, a.c_b = in_a, (in_b or None), c_a, c_b
@@ -141,29 +145,50 @@ class FusedPlan:
         rb_dn = [_RB(slots[i + 1], n[i + 1], 27, 27) for i in range(3)]
         rb_up = [_RB(L.imf_rulebook_transpose_slots(n[i]), n[i], 27, 8) for i in range(3)]
         rb_id = _RB(slots[0], n[0], 1, 1)
-        all_rb = [rb_first] + rb_k3 + rb_dn + rb_up
+        all_rb = ([] if self.small_first else [rb_first]) + rb_k3 + rb_dn + rb_up
         words = sum(r.words() for r in all_rb) + 16 * 3
         iarena = torch.empty(words, dtype=torch.int32, device=dev)
         p = iarena.data_ptr()
         for r in all_rb:
             p = r.place(p)
         counters = [p + 64 * i for i in range(3)]
-        ok = check
-        ok(L.imf_rulebook_conv(lv[0].keys.data_ptr(), lv[0].vals.data_ptr(), lv[0].capacity,
-                               lv[0].coords_buf.data_ptr(), n[0], 1, self.first_ksize, rb_first.tile_rows,
-                               rb_first.nbr, rb_first.tile_mask, st), "imf_rulebook_conv")
-        for i in range(4):
-            ok(L.imf_rulebook_conv(lv[i].keys.data_ptr(), lv[i].vals.data_ptr(), lv[i].capacity,
-                                   lv[i].coords_buf.data_ptr(), n[i], 1 << i, 3, rb_k3[i].tile_rows,
-                                   rb_k3[i].nbr, rb_k3[i].tile_mask, st), "imf_rulebook_conv")
+        # rb_first and k3@1 are needed at once: main stream.  Everything else is built on a side
+        # stream while conv1 / block1 (MFMA-bound, whole GPU) run; each group is joined by an event
+        # right before its first use.
+        def build_conv(rb, in_lv, out_lv, ksize, stream):
+            check(L.imf_rulebook_conv(in_lv.keys.data_ptr(), in_lv.vals.data_ptr(), in_lv.capacity,
+                                      out_lv.coords_buf.data_ptr(), out_lv.n, in_lv.ts, ksize, rb.tile_rows,
+                                      rb.nbr, rb.tile_mask, stream), "imf_rulebook_conv")
+
+        def build_up(i, stream):
+            check(L.imf_rulebook_transpose(lv[i + 1].keys.data_ptr(), lv[i + 1].vals.data_ptr(),
+                                           lv[i + 1].capacity, lv[i].coords_buf.data_ptr(), n[i], 1 << i, 3,
+                                           rb_up[i].tile_rows, rb_up[i].nbr, rb_up[i].tile_mask,
+                                           rb_up[i].n_slots, counters[i], stream), "imf_rulebook_transpose")
+
+        if not self.small_first:
+            build_conv(rb_first, lv[0], lv[0], self.first_ksize, st)
+        build_conv(rb_k3[0], lv[0], lv[0], 3, st)
+        main = torch.cuda.current_stream(dev)
+        side = self._side.get(dev)
+        if side is None:
+            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)                  # arena allocated / levels built on the main stream
+        iarena.record_stream(side)
+        ss = side.cuda_stream
+        ready = {}                              # rulebook object id -> event
         for i in range(3):
-            ok(L.imf_rulebook_conv(lv[i].keys.data_ptr(), lv[i].vals.data_ptr(), lv[i].capacity,
-                                   lv[i + 1].coords_buf.data_ptr(), n[i + 1], 1 << i, 3, rb_dn[i].tile_rows,
-                                   rb_dn[i].nbr, rb_dn[i].tile_mask, st), "imf_rulebook_conv")
-            ok(L.imf_rulebook_transpose(lv[i + 1].keys.data_ptr(), lv[i + 1].vals.data_ptr(),
-                                        lv[i + 1].capacity, lv[i].coords_buf.data_ptr(), n[i], 1 << i, 3,
-                                        rb_up[i].tile_rows, rb_up[i].nbr, rb_up[i].tile_mask,
-                                        rb_up[i].n_slots, counters[i], st), "imf_rulebook_transpose")
+            build_conv(rb_dn[i], lv[i], lv[i + 1], 3, ss)
+            build_conv(rb_k3[i + 1], lv[i + 1], lv[i + 1], 3, ss)
+            e = torch.cuda.Event()
+            e.record(side)
+            ready[id(rb_dn[i])] = e
+        for i in (2, 1, 0):
+            build_up(i, ss)
+            e = torch.cuda.Event()
+            e.record(side)
+            ready[id(rb_up[i])] = e
+        self._ready, self._main = ready, main
 
         # ---- schedule: (conv name, rulebook, in_a, c_a, out, in_b, c_b, residual) ---------------
         sched = []
@@ -214,9 +239,12 @@ class FusedPlan:
 
         if self.small_first:
             sc, sh = self.first_bn
-            check(L.imf_spconv_small_cin(x.F.data_ptr(), x.F.shape[1], self.first_kernel.data_ptr(),
-                                         rb_first.kvol, Ch[1], rb_first.nbr, rb_first.n_slots, n[0],
-                                         sc.data_ptr(), sh.data_ptr(), 0, addr["e0a"], st), "imf_spconv_small_cin")
+            ones = getattr(x, "_all_ones", False)       # util/misc.py:76-79 occupancy feature
+            check(L.imf_conv_first_fused(lv[0].keys.data_ptr(), lv[0].vals.data_ptr(), lv[0].capacity,
+                                         lv[0].coords_buf.data_ptr(), n[0], 1, self.first_ksize,
+                                         None if ones else x.F.data_ptr(), x.F.shape[1],
+                                         self.first_kernel.data_ptr(), Ch[1], sc.data_ptr(), sh.data_ptr(), 0,
+                                         addr["e0a"], st), "imf_conv_first_fused")
 
         def go(entries):
             for name, rb, a_key, c_a, o_key, b_key, c_b, r_key in entries:

@@ -263,3 +263,19 @@ def spconv_small_cin(feat, kernel, rb, scale=None, shift=None, relu=False):
                                           _ptr(shift), int(bool(relu)), out.data_ptr(), _stream()),
           "imf_spconv_small_cin")
     return out
+
+
+def conv_first_fused(level, feat, kernel, ksize, scale=None, shift=None, relu=False):
+    """First-layer conv fused with its kernel map (imf_conv_first_fused).  feat None = all ones."""
+    k = _req(kernel.detach().contiguous(), torch.float32, "kernel", 3)
+    kvol, cin, cout = k.shape
+    if kvol != ksize ** 3 or (feat is not None and feat.shape[1] != cin):
+        raise ImfError("conv_first_fused: feature / kernel mismatch")
+    if feat is not None:
+        _req(feat, torch.float32, "feat", 2)
+    out = torch.empty((level.n, cout), dtype=torch.float32, device=k.device)
+    check(_lib.lib().imf_conv_first_fused(level.keys.data_ptr(), level.vals.data_ptr(), level.capacity,
+                                          level.coords_buf.data_ptr(), level.n, level.ts, ksize, _ptr(feat),
+                                          cin, k.data_ptr(), cout, _ptr(scale), _ptr(shift), int(bool(relu)),
+                                          out.data_ptr(), _stream()), "imf_conv_first_fused")
+    return out

@@ -176,6 +176,15 @@ int imf_spconv_small_cin(const float *in, int cin, const float *w, int kvol, int
                          const float *scale, const float *shift, int relu,
                          float *out, void *stream);
 
+/* First-layer convolution fused with its own kernel map: probes the input level's voxel hash
+ * directly (one wavefront per output voxel) instead of materialising the 125-column neighbour
+ * table.  in == NULL means the all-ones occupancy feature of util/misc.py:76-79.
+ * Replaces: conv1 + norm1 of model/resunet.py:42-49,168-169 (kernel map included). */
+int imf_conv_first_fused(const uint64_t *keys, const int32_t *vals, int64_t capacity,
+                         const int32_t *coords, int64_t n, int ts, int ksize, const float *in, int cin,
+                         const float *w /* [kvol][cin][cout], unpacked */, int cout,
+                         const float *scale, const float *shift, int relu, float *out, void *stream);
+
 /* Measurement helpers (bench.py): HIP events on the caller's stream. */
 void *imf_event_create(void);
 void imf_event_destroy(void *ev);

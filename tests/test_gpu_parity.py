@@ -244,6 +244,23 @@ def test_spconv_small_cin(ops, geom_s5, cin, cout, ks):
     assert (got - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,ks", [(1, 32, 5), (1, 32, 3), (3, 32, 5), (2, 64, 3), (1, 64, 5)])
+def test_conv_first_fused(ops, geom_s5, cin, cout, ks):
+    """Hash-probing first layer == table-driven small-Cin conv == oracle."""
+    cm, g = geom_s5
+    nbr_ref = g.k_first if ks == 5 else g.k3[0]
+    n = len(g.levels[0])
+    f = torch.ones(n, cin) if cin == 1 else _rand((n, cin), 50)
+    w = _rand((ks ** 3, cin, cout), 51, 0.1)
+    sc, sh = _rand((cout,), 52).abs() + 0.5, _rand((cout,), 53)
+    ref = torch.relu(O.spconv(f, w, nbr_ref) * sc + sh)
+    got = ops.conv_first_fused(cm.level(1), f.to(DEV), w.to(DEV), ks, sc.to(DEV), sh.to(DEV), relu=True).cpu()
+    assert (got - ref).abs().max() < 2e-5
+    if cin == 1:
+        got1 = ops.conv_first_fused(cm.level(1), None, w.to(DEV), ks, sc.to(DEV), sh.to(DEV), relu=True).cpu()
+        assert torch.equal(got, got1)
+
+
 def test_spconv_argument_errors(ops, geom_s5):
     from imfnet_amd import ImfError
     cm, g = geom_s5
