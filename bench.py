@@ -118,8 +118,8 @@ def main():
     img_d = torch.as_tensor(img).to(dev)
 
     def step():
-        st, _ = sparse_tensor_from_points(xyz_d, voxel, dev,
-                                          before_sync=lambda: model.start_image_branch(img_d))
+        st, _ = sparse_tensor_from_points(xyz_d, voxel, dev, inputs_ready=True,
+                                          before_sync=lambda: model.start_image_branch(img_d, inputs_ready=True))
         return model(st, img_d).F
 
     def barrier():

@@ -36,6 +36,13 @@ class ConvArgs(C.Structure):
     ]
 
 
+class LevelDesc(C.Structure):
+    """struct imf_level (include/imfnet_hip.h)."""
+    _fields_ = [("coords", C.c_void_p), ("keys", C.c_void_p), ("vals", C.c_void_p),
+                ("capacity", C.c_int64), ("first_idx", C.c_void_p), ("cap_rows", C.c_int64),
+                ("tensor_stride", C.c_int32)]
+
+
 _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/imfnet_hip.h declares
@@ -49,6 +56,8 @@ SIGNATURES = {
     "imf_unique_workspace_bytes": (_Z, [_L]),
     "imf_voxelize": (_I, [_P, _I, _L, _D, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
     "imf_downsample": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _L, _P, _P]),
+    "imf_pyramid_arena_bytes": (_Z, [_L, _I]),
+    "imf_pyramid_build": (_I, [_P, _I, _L, _D, _I, _I, _P, _Z, _P, C.POINTER(LevelDesc), _P]),
     "imf_rulebook_slots": (_L, [_L]),
     "imf_rulebook_conv": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _P, _P, _P]),
     "imf_rulebook_transpose_slots": (_L, [_L]),

@@ -262,6 +262,19 @@ k_init_transpose(int32_t *counters, int32_t *tile_rows, int64_t n_slots, uint32_
   if (i < n_mask) tile_mask[i] = 0u;
 }
 
+// every level's table (same capacity, level stride in bytes) and the [n_levels,2] count block
+__global__ void __launch_bounds__(256)
+k_init_tables(uint64_t *keys0, int32_t *vals0, int64_t capacity, int n_levels, size_t level_stride,
+              int32_t *meta) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * n_levels) meta[i] = 0;
+  if (i >= capacity) return;
+  for (int l = 0; l < n_levels; ++l) {
+    reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(keys0) + l * level_stride)[i] = kEmptyKey;
+    reinterpret_cast<int32_t *>(reinterpret_cast<char *>(vals0) + l * level_stride)[i] = 0x7FFFFFFF;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_init_table(uint64_t *keys, int32_t *vals, int64_t capacity) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,6 +353,72 @@ int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_
   IMF_CHECK_LAUNCH("k_insert_coords");
   return run_unique_tail(slot_of, block_sums, keys, vals, n_in_max, n_in_dev, coords_out, nullptr,
                          m_out, st);
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t imf_pyramid_arena_bytes(int64_t n, int n_levels) {
+  const size_t cap = (size_t)imf_hash_capacity(n);
+  size_t per_level = align_up((size_t)n * 16, 256) + align_up(cap * 8, 256) + align_up(cap * 4, 256);
+  return (size_t)n_levels * per_level + align_up((size_t)n * 4, 256)          /* first_idx */
+         + align_up(imf_unique_workspace_bytes(n), 256);
+}
+
+int imf_pyramid_build(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
+                      int n_levels, void *arena, size_t arena_bytes, int32_t *meta,
+                      imf_level *levels_out, void *stream) {
+  IMF_REQUIRE(xyz && arena && meta && levels_out, "imf_pyramid_build: null pointer");
+  IMF_REQUIRE(n > 0 && n < (1ll << 31) - 2048, "imf_pyramid_build: n=%lld out of range", (long long)n);
+  IMF_REQUIRE(n_levels >= 1 && n_levels <= 8, "imf_pyramid_build: n_levels=%d", n_levels);
+  IMF_REQUIRE(voxel_size > 0.0, "imf_pyramid_build: voxel_size must be > 0");
+  IMF_REQUIRE(batch_index >= 0 && batch_index < 512, "imf_pyramid_build: batch_index out of [0,512)");
+  IMF_REQUIRE(arena_bytes >= imf_pyramid_arena_bytes(n, n_levels), "imf_pyramid_build: arena too small");
+  IMF_REQUIRE(((uintptr_t)arena & 255) == 0, "imf_pyramid_build: arena must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t cap = imf_hash_capacity(n);
+  char *p = (char *)arena;
+  for (int l = 0; l < n_levels; ++l) {
+    imf_level &L = levels_out[l];
+    L.coords = (int32_t *)p;  p += align_up((size_t)n * 16, 256);
+    L.keys = (uint64_t *)p;   p += align_up((size_t)cap * 8, 256);
+    L.vals = (int32_t *)p;    p += align_up((size_t)cap * 4, 256);
+    L.capacity = cap;
+    L.first_idx = nullptr;
+    L.cap_rows = n;
+    L.tensor_stride = 1 << l;
+  }
+  levels_out[0].first_idx = (int32_t *)p;  p += align_up((size_t)n * 4, 256);
+  int32_t *slot_of = (int32_t *)p;
+  int32_t *block_sums = slot_of + n;
+
+  // all keys / vals regions are contiguous per level; initialise every table + meta in one launch
+  k_init_tables<<<(unsigned)div_up(cap, 256), 256, 0, st>>>(
+      levels_out[0].keys, levels_out[0].vals, cap, n_levels,
+      (size_t)((char *)levels_out[n_levels > 1 ? 1 : 0].keys - (char *)levels_out[0].keys), meta);
+  IMF_CHECK_LAUNCH("k_init_tables");
+  const int nblk = (int)div_up(n, 256);
+  if (xyz_is_f64)
+    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index,
+                                                  levels_out[0].keys, levels_out[0].vals,
+                                                  (uint32_t)(cap - 1), slot_of, meta + 1);
+  else
+    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index,
+                                                 levels_out[0].keys, levels_out[0].vals,
+                                                 (uint32_t)(cap - 1), slot_of, meta + 1);
+  IMF_CHECK_LAUNCH("k_insert_points");
+  int rc = run_unique_tail(slot_of, block_sums, levels_out[0].keys, levels_out[0].vals, n, nullptr,
+                           levels_out[0].coords, levels_out[0].first_idx, meta, st);
+  if (rc) return rc;
+  for (int l = 1; l < n_levels; ++l) {
+    k_insert_coords<<<nblk, 256, 0, st>>>(levels_out[l - 1].coords, meta + 2 * (l - 1), 1 << l,
+                                          levels_out[l].keys, levels_out[l].vals, (uint32_t)(cap - 1),
+                                          slot_of);
+    IMF_CHECK_LAUNCH("k_insert_coords");
+    rc = run_unique_tail(slot_of, block_sums, levels_out[l].keys, levels_out[l].vals, n,
+                         meta + 2 * (l - 1), levels_out[l].coords, nullptr, meta + 2 * l, st);
+    if (rc) return rc;
+  }
+  return IMF_OK;
 }
 
 int64_t imf_rulebook_slots(int64_t n_out) { return div_up(n_out, IMF_TILE_ROWS) * IMF_TILE_ROWS; }

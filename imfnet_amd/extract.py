@@ -28,16 +28,25 @@ def _as_device_points(xyz, device):
     return t.to(device, non_blocking=True).contiguous()
 
 
-def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=None):
+def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=None, inputs_ready=False):
     """Voxelise raw points on the GPU.  Returns (SparseTensor with all-ones / gathered features,
-    inds int32 CUDA tensor of each voxel's first point).  `before_sync` (callable) is invoked after
-    the geometry kernels are queued and before the one host synchronisation, so independent work
-    (the image branch) can be put on the GPU while the host waits for the row counts."""
-    pts = _as_device_points(xyz, device)
-    meta = ops.new_meta(4, pts.device)
-    lv = ops.voxelize(pts, voxel_size, 0, meta=meta[0])
-    cm = ME.CoordinateManager(lv, meta=meta)
-    cm.build_pyramid(8, before_sync=before_sync)      # one host sync for all four row counts
+    inds int32 CUDA tensor of each voxel's first point).
+    The whole geometry (voxel hash + 3 coarser levels) is one library call on a dedicated
+    high-priority stream; `before_sync` (callable) runs after it is queued and before the one host
+    wait, so independent work (the image branch) is put on the GPU while the host waits for the row
+    counts.  `inputs_ready=True` promises that a device-resident `xyz` is already complete (no
+    pending producer on the current stream), which lets the geometry of fragment i+1 overlap the
+    convolutions of fragment i."""
+    on_host = not (torch.is_tensor(xyz) and xyz.is_cuda)
+    if on_host:                                       # upload on the geometry stream itself: in order
+        with torch.cuda.stream(ops.geometry_stream(torch.device(device))):
+            pts = _as_device_points(xyz, device)
+        inputs_ready = True
+    else:
+        pts = _as_device_points(xyz, device)
+    levels = ops.pyramid_from_points(pts, voxel_size, 4, 0, inputs_ready=inputs_ready, before_sync=before_sync)
+    lv = levels[0]
+    cm = ME.CoordinateManager.from_levels(levels)
     inds = lv.first_idx
     if feats is None:
         f = torch.ones((lv.n, 1), dtype=torch.float32, device=pts.device)        # util/misc.py:76-79
@@ -79,11 +88,17 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
         feats.append(np.asarray(normal) / 2)
     feats = np.hstack(feats) if feats else None
 
-    image = torch.as_tensor(image, dtype=torch.float32, device=device)
     start = getattr(model, "start_image_branch", None)
-    stensor, inds = sparse_tensor_from_points(
-        xyz, voxel_size, device, feats, before_sync=(lambda: start(image)) if start is not None else None)
-    F = model(stensor, image).F
+    box = {}
+    if start is not None:
+        hook = lambda: box.setdefault("image", start(image, device=device))   # noqa: E731
+    else:
+        hook = None
+    stensor, inds = sparse_tensor_from_points(xyz, voxel_size, device, feats, before_sync=hook)
+    image_dev = box.get("image")
+    if image_dev is None:
+        image_dev = torch.as_tensor(image, dtype=torch.float32, device=device)
+    F = model(stensor, image_dev).F
 
     inds_host = inds.cpu().numpy().astype(np.int64)
     if torch.is_tensor(xyz):

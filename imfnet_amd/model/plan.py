@@ -147,7 +147,13 @@ class FusedPlan:
         rb_id = _RB(slots[0], n[0], 1, 1)
         all_rb = ([] if self.small_first else [rb_first]) + rb_k3 + rb_dn + rb_up
         words = sum(r.words() for r in all_rb) + 16 * 3
-        iarena = torch.empty(words, dtype=torch.int32, device=dev)
+        main = torch.cuda.current_stream(dev)
+        side = self._side.get(dev)
+        if side is None:
+            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):           # side-stream pool: no need to wait for the main stream
+            iarena = torch.empty(words, dtype=torch.int32, device=dev)
+        iarena.record_stream(main)
         p = iarena.data_ptr()
         for r in all_rb:
             p = r.place(p)
@@ -169,12 +175,6 @@ class FusedPlan:
         if not self.small_first:
             build_conv(rb_first, lv[0], lv[0], self.first_ksize, st)
         build_conv(rb_k3[0], lv[0], lv[0], 3, st)
-        main = torch.cuda.current_stream(dev)
-        side = self._side.get(dev)
-        if side is None:
-            side = self._side[dev] = torch.cuda.Stream(device=dev)
-        side.wait_stream(main)                  # arena allocated / levels built on the main stream
-        iarena.record_stream(side)
         ss = side.cuda_stream
         ready = {}                              # rulebook object id -> event
         for i in range(3):

@@ -71,6 +71,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._folded = None
         self._plan = None                 # arena executor (model/plan.py), built lazily in eval mode
         self._pending_image = None        # (image, features, kv, event) queued by start_image_branch
+        self._fuse_done = None            # event: last fusion finished reading the image branch outputs
         self._side = {}                   # device -> side stream
         self._img_graph = {}              # (device, shape) -> captured image branch
 
@@ -105,23 +106,33 @@ class ResUNet2(ME.MinkowskiNetwork):
             kv = blk.fn.to_kv(blk.norm_context(tokens))                       # [B, T, 2*d]
         return feat, kv
 
-    def start_image_branch(self, image):
+    def start_image_branch(self, image, device=None, inputs_ready=False):
         """Queue the image branch on a side HIP stream (as a captured hipGraph when the shape is
-        static) so it overlaps the geometry build and the sparse encoder.  forward() collects it."""
-        if not self._can_fuse() or not image.is_cuda:
-            return
-        dev = image.device
+        static) so it overlaps the geometry build and the sparse encoder.  forward() collects it.
+        `image`: [B,3,H,W] host array / CPU tensor (uploaded on the side stream itself) or a device
+        tensor; `inputs_ready=True` promises a device tensor is complete, so the branch need not wait
+        for the main stream.  Returns the device tensor to hand to forward()."""
+        if not self._can_fuse():
+            return None
+        on_device = torch.is_tensor(image) and image.is_cuda
+        dev = image.device if on_device else torch.device(device if device is not None else "cuda")
         side = self._side.get(dev)
         if side is None:
             side = self._side[dev] = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
-        side.wait_stream(cur)
+        if on_device and not inputs_ready:
+            side.wait_stream(cur)
+        elif self._fuse_done is not None:
+            side.wait_event(self._fuse_done)              # previous fragment still reads the static outputs
         with torch.cuda.stream(side), torch.no_grad():
+            if not on_device:
+                image = torch.as_tensor(image, dtype=torch.float32).to(dev, non_blocking=True)
             feat, kv = self._run_image_graph(image, side)
             ev = torch.cuda.Event()
             ev.record(side)
         image.record_stream(side)
         self._pending_image = (image, feat, kv, ev)
+        return image
 
     def _run_image_graph(self, image, side):
         key = (image.device, tuple(image.shape))
@@ -176,7 +187,8 @@ class ResUNet2(ME.MinkowskiNetwork):
             self.start_image_branch(image)
             pend, self._pending_image = self._pending_image, None
             _, image_feat, kv, ev = pend
-        x.coordinate_manager.build_pyramid(8)
+        if image_feat.device != x.F.device:
+            raise ME.ImfError("image and sparse tensor live on different devices")
 
         def fuse(f8):                                                                 # :189
             cur = torch.cuda.current_stream(f8.device)
@@ -184,8 +196,12 @@ class ResUNet2(ME.MinkowskiNetwork):
             image_feat.record_stream(cur)
             if kv is not None and image_feat.shape[0] == 1:
                 kv.record_stream(cur)
-                return self._fusion_fast(f8, kv[0])
-            return self.transformer(images=image_feat, F=f8, xyz=x.coordinate_manager.coords(8))
+                out = self._fusion_fast(f8, kv[0])
+            else:
+                out = self.transformer(images=image_feat, F=f8, xyz=x.coordinate_manager.coords(8))
+            self._fuse_done = torch.cuda.Event()
+            self._fuse_done.record(cur)
+            return out
 
         if self._plan is None:
             from .plan import FusedPlan

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, ImfError, TILE_ROWS, MASK_WORDS, check
+from ._lib import ConvArgs, ImfError, LevelDesc, TILE_ROWS, MASK_WORDS, check
 
 
 # When set to a list, every sparse-conv launch is bracketed by HIP events recorded on the launch
@@ -71,6 +71,113 @@ class Level:
     def first_idx(self):
         return self.first_idx_buf[: self.n]
 
+    @property
+    def device(self):
+        return self.coords_buf.device
+
+
+class _Addr:
+    """A raw device address with the `.data_ptr()` face of a tensor (memory owned by an arena)."""
+    __slots__ = ("p",)
+
+    def __init__(self, p):
+        self.p = p
+
+    def data_ptr(self):
+        return self.p
+
+
+class ArenaLevel(Level):
+    """A Level whose buffers live inside one arena built by imf_pyramid_build (raw addresses; the
+    coords / first_idx tensors are materialised as views only when somebody asks for them)."""
+    __slots__ = ("arena", "_desc", "_coords_view", "_first_view")
+
+    def __init__(self, arena, desc, n_dev):
+        Level.__init__(self, _Addr(desc.coords), n_dev, _Addr(desc.keys), _Addr(desc.vals), desc.capacity,
+                       desc.tensor_stride, _Addr(desc.first_idx) if desc.first_idx else None)
+        self.arena, self._desc, self._coords_view, self._first_view = arena, desc, None, None
+
+    def _view(self, addr, count):
+        off = addr - self.arena.data_ptr()
+        return self.arena[off:off + 4 * count].view(torch.int32)
+
+    @property
+    def coords(self):
+        if self._coords_view is None:
+            self._coords_view = self._view(self._desc.coords, 4 * self._desc.cap_rows).view(-1, 4)
+        return self._coords_view[: self.n]
+
+    @property
+    def first_idx(self):
+        if self._first_view is None:
+            self._first_view = self._view(self._desc.first_idx, self._desc.cap_rows)
+        return self._first_view[: self.n]
+
+    @property
+    def device(self):
+        return self.arena.device
+
+
+_GEOM_STREAMS = {}
+_PINNED = {}
+
+
+def geometry_stream(device):
+    """Dedicated high-priority stream for the geometry build: its row-count readback must not queue
+    behind the previous fragment's convolutions on the main stream."""
+    s = _GEOM_STREAMS.get(device)
+    if s is None:
+        s = _GEOM_STREAMS[device] = torch.cuda.Stream(device=device, priority=-1)
+    return s
+
+
+def pyramid_from_points(xyz, voxel_size, n_levels=4, batch_index=0, inputs_ready=False, before_sync=None):
+    """Voxelise + coarse levels in ONE library call on the geometry stream, then one event
+    synchronisation for the row counts.  xyz: CUDA [N,3] f64/f32 tensor.  `inputs_ready`: xyz is
+    known to be complete (e.g. resident data), so the geometry stream need not wait for the main one.
+    Returns the list of levels (n set) -- buffers are safe to use on the current stream."""
+    if xyz.dtype not in (torch.float64, torch.float32):
+        raise ImfError(f"xyz must be float64/float32, got {xyz.dtype}")
+    _req(xyz, xyz.dtype, "xyz", 2)
+    n, dev = xyz.shape[0], xyz.device
+    if n == 0 or xyz.shape[1] != 3:
+        raise ImfError(f"xyz must be [N>0, 3], got {tuple(xyz.shape)}")
+    L = _lib.lib()
+    main = torch.cuda.current_stream(dev)
+    gs = geometry_stream(dev)
+    if not inputs_ready:
+        gs.wait_stream(main)
+    host = _PINNED.get((dev, n_levels))
+    if host is None:
+        host = _PINNED[(dev, n_levels)] = torch.empty((n_levels, 2), dtype=torch.int32).pin_memory()
+    descs = (LevelDesc * n_levels)()
+    with torch.cuda.stream(gs):
+        nbytes = L.imf_pyramid_arena_bytes(n, n_levels)
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        meta = torch.empty((n_levels, 2), dtype=torch.int32, device=dev)
+        check(L.imf_pyramid_build(xyz.data_ptr(), int(xyz.dtype == torch.float64), n, float(voxel_size),
+                                  int(batch_index), n_levels, arena.data_ptr(), nbytes, meta.data_ptr(),
+                                  descs, gs.cuda_stream), "imf_pyramid_build")
+        host.copy_(meta, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(gs)
+    xyz.record_stream(gs)
+    if before_sync is not None:
+        before_sync()
+    ev.synchronize()                                  # the one host wait of the fragment
+    main.wait_event(ev)
+    arena.record_stream(main)
+    meta.record_stream(main)
+    counts = host.tolist()
+    levels = []
+    for i in range(n_levels):
+        if counts[i][1] != 0:
+            raise ImfError("voxelize: a coordinate fell outside [-2^17, 2^17) voxels (or was NaN)")
+        lv = ArenaLevel(arena, descs[i], meta[i])
+        lv.n = int(counts[i][0])
+        levels.append(lv)
+    return levels
+
 
 class Rulebook:
     """Tiled kernel map (see include/imfnet_hip.h)."""
@@ -122,7 +229,7 @@ def voxelize(xyz, voxel_size, batch_index=0, meta=None):
 def downsample(level, out_stride, n_in_max=None, meta=None):
     """coordinate_manager.stride(): level at tensor stride `out_stride` (asynchronous)."""
     n_max = int(n_in_max if n_in_max is not None else level.n)
-    dev = level.coords_buf.device
+    dev = level.device
     cap, keys, vals, ws = _new_table(n_max, dev)
     coords = torch.empty((n_max, 4), dtype=torch.int32, device=dev)
     m = meta if meta is not None else torch.zeros(2, dtype=torch.int32, device=dev)   # [m, unused]
@@ -161,7 +268,7 @@ def sync_levels(levels, meta_block=None):
 def rulebook_conv(in_level, out_level, ksize):
     """Kernel map of ME.MinkowskiConvolution(kernel_size=ksize) from in_level to out_level."""
     L = _lib.lib()
-    n_out, dev = out_level.n, out_level.coords_buf.device
+    n_out, dev = out_level.n, out_level.device
     kvol = ksize ** 3
     n_slots = L.imf_rulebook_slots(n_out)
     tile_rows = torch.empty(n_slots, dtype=torch.int32, device=dev)
@@ -177,7 +284,7 @@ def rulebook_conv(in_level, out_level, ksize):
 def rulebook_transpose(coarse_level, fine_level, ksize=3):
     """Kernel map of ME.MinkowskiConvolutionTranspose(kernel_size=3, stride=2): coarse -> fine."""
     L = _lib.lib()
-    n_fine, dev = fine_level.n, fine_level.coords_buf.device
+    n_fine, dev = fine_level.n, fine_level.device
     kvol = ksize ** 3
     n_slots = L.imf_rulebook_transpose_slots(n_fine)
     tile_rows = torch.empty(n_slots, dtype=torch.int32, device=dev)

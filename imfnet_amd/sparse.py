@@ -45,6 +45,13 @@ class CoordinateMapKey:
 class CoordinateManager:
     """Owns the pyramid levels (coordinates + voxel hash per tensor stride) and the rulebooks."""
 
+    @classmethod
+    def from_levels(cls, levels):
+        cm = cls(levels[0])
+        for lv in levels[1:]:
+            cm.levels[lv.ts] = lv
+        return cm
+
     def __init__(self, level0, meta=None):
         self.levels = {1: level0}
         self._rulebooks = {}
@@ -98,7 +105,7 @@ class CoordinateManager:
         if key not in self._rulebooks:
             if ksize == 1 and stride == 1:
                 lv = self.level(ts_in)
-                rb = ops.rulebook_identity(lv.n, lv.coords_buf.device)
+                rb = ops.rulebook_identity(lv.n, None)
             else:
                 rb = ops.rulebook_conv(self.level(ts_in), self.level(ts_in * stride), ksize)
             self._rulebooks[key] = rb

@@ -80,6 +80,26 @@ int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_
                    uint64_t *keys, int32_t *vals, int64_t capacity,
                    void *workspace, void *stream);
 
+/* One-call geometry: imf_voxelize followed by (n_levels - 1) imf_downsample (tensor strides 2, 4,
+ * ...), all tables and scratch carved out of ONE caller-provided arena, row counts written to
+ * meta[level][0] (meta[level][1] = error flag; the call zeroes meta).  18 kernel launches, no host
+ * synchronisation.  levels_out [host] receives the device addresses inside the arena.
+ * Replaces: util/misc.py:82-95 and the implicit cm.stride() chain of model/resunet.py:54-85. */
+typedef struct imf_level {
+  int32_t *coords;       /* [cap_rows, 4] rows (b,x,y,z), first-occurrence order                 */
+  uint64_t *keys;        /* hash table [capacity]                                                 */
+  int32_t *vals;         /*            [capacity]  row of the voxel                               */
+  int64_t capacity;
+  int32_t *first_idx;    /* level 0: index of each voxel's first point; NULL on coarser levels    */
+  int64_t cap_rows;      /* rows allocated (upper bound = n points)                               */
+  int32_t tensor_stride;
+} imf_level;
+
+size_t imf_pyramid_arena_bytes(int64_t n_points, int n_levels);
+int imf_pyramid_build(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
+                      int n_levels, void *arena, size_t arena_bytes, int32_t *meta,
+                      imf_level *levels_out /* [host] */, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Rulebook (MinkowskiEngine "kernel map"), tiled for the MFMA kernel:
  *   tile_rows int32[n_slots]             output row of every slot, -1 = padding
