@@ -17,6 +17,8 @@
 //   Levels with few tiles are latency-bound, so their offsets are split over gridDim.z workgroups
 //   that write raw partial sums; k_spconv_reduce adds them in a fixed order and applies the
 //   epilogue.  The accumulation order per output element is fixed => bit-reproducible, no atomics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace imf {
@@ -35,6 +37,7 @@ struct ConvParams {
   int relu, l2norm;
   float *out;
   float *partial;   // split-K partial sums [S][n_slots][cout] (S = gridDim.z > 1)
+  int ablate;       // debugging only (env IMF_ABLATE): bit0 no MFMA, bit1 no LDS add, bit2 no A gather, bit3 no B load
 };
 
 // Packed weight image: [y][k][cc][j][cb][lane][t] with
@@ -329,6 +332,185 @@ k_spconv_mfma(const ConvParams p) {
   }
 }
 
+
+// ---- variant 2: wave-autonomous kernel with per-offset compaction ------------------------------
+// One WAVEFRONT (one 64-thread workgroup, no barriers with other waves) owns a 64-row tile x one
+// output slab.  For every active offset k it compacts the rows that actually have an input
+// (ballot + popcount -> LDS list), so the MFMA blocks are full: ~2.6 16-row blocks per offset
+// instead of 4 at 52 % occupancy (-35 % MFMA work).  Because compacted rows no longer line up with
+// fixed accumulator registers, the per-offset products (MFMA with C = 0) are added into an
+// LDS-resident [64 x CW] accumulator tile owned by the wave (distinct addresses per lane, fixed
+// order k ascending => deterministic).  The weight chunk of (k, cc) is held in registers and reused
+// by all row blocks of that offset; A fragments are gathered one block ahead.
+template <int CO_BLK, int J>
+__global__ void __launch_bounds__(64)
+k_spconv_wave(const ConvParams p) {
+  constexpr int CW = 16 * CO_BLK;
+  constexpr int NB = J * CO_BLK;                     // float4 weight fragments per lane per (k, cc)
+  constexpr int SUB_F4 = NB * 64;
+  __shared__ __attribute__((aligned(16))) float acc_l[IMF_TILE_ROWS][CW];
+  __shared__ int list_in[IMF_TILE_ROWS], list_row[IMF_TILE_ROWS];
+  __shared__ int klist[kKCache];
+
+  const int tile = blockIdx.x, y = blockIdx.y, z = blockIdx.z, S = gridDim.z;
+  const int lane = threadIdx.x, r16 = lane & 15, q4 = lane >> 4;
+  const int cin = p.c_a + p.c_b;
+  const int ncc = cin / (16 * J);
+
+  uint32_t mask[IMF_MASK_WORDS] = {1u, 0u, 0u, 0u};
+  if (p.tile_mask) {
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) mask[w] = p.tile_mask[tile * IMF_MASK_WORDS + w];
+  }
+  const int total = __builtin_popcount(mask[0]) + __builtin_popcount(mask[1]) +
+                    __builtin_popcount(mask[2]) + __builtin_popcount(mask[3]);
+  if (total == 0 && S == 1) return;                  // padding tile
+  const int lo = (int)((long long)z * total / S), hi = (int)((long long)(z + 1) * total / S);
+  const int nk = hi - lo;
+  if (lane == 0) {
+    int ord = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) {
+      uint32_t m = mask[w];
+      while (m) {
+        const int k = w * 32 + __builtin_ctz(m);
+        m &= m - 1;
+        if (ord >= lo && ord < hi) klist[n++] = k;
+        ++ord;
+      }
+    }
+  }
+  {   // zero the accumulator tile: CW floats per lane
+    float4 *a4 = reinterpret_cast<float4 *>(&acc_l[0][0]);
+#pragma unroll
+    for (int i = 0; i < CW / 4; ++i) a4[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+
+  const long long slot0 = (long long)tile * IMF_TILE_ROWS;
+  const float4 *wbase = reinterpret_cast<const float4 *>(p.w_packed) +
+                        (long long)y * p.kvol * ncc * SUB_F4 + lane;
+
+  int irow_next = -1;
+  if (nk > 0)
+    irow_next = p.nbr ? p.nbr[(long long)klist[0] * p.n_slots + slot0 + lane] : row_of_slot(p, slot0 + lane);
+
+#pragma unroll 1
+  for (int jk = 0; jk < nk; ++jk) {
+    const int k = klist[jk];
+    const int irow = irow_next;
+    if (jk + 1 < nk)                                  // neighbour column of the next offset: in flight
+      irow_next = p.nbr[(long long)klist[jk + 1] * p.n_slots + slot0 + lane];
+    const bool valid = irow >= 0;
+    const unsigned long long vm = __ballot(valid);
+    const int cnt = __builtin_popcountll(vm);
+    if (cnt == 0) continue;
+    const int pos = __builtin_popcountll(vm & ((1ull << lane) - 1ull));
+    __syncthreads();                                  // previous offset's list fully consumed
+    if (valid) {
+      list_in[pos] = irow;
+      list_row[pos] = lane;
+    }
+    __syncthreads();
+    const int ngroups = (cnt + 15) >> 4;
+#pragma unroll 1
+    for (int cc = 0; cc < ncc; ++cc) {
+      float4 b[NB];
+      const float4 *src = wbase + ((long long)k * ncc + cc) * SUB_F4;
+      if (!(p.ablate & 8)) {
+#pragma unroll
+        for (int e = 0; e < NB; ++e) b[e] = src[e * 64];
+      } else {
+#pragma unroll
+        for (int e = 0; e < NB; ++e) b[e] = make_float4(1.f, 2.f, 3.f, (float)e);
+      }
+      float4 a_next[J];
+      {
+        const int my_in = (r16 < cnt && !(p.ablate & 4)) ? list_in[r16] : -1;
+#pragma unroll
+        for (int j = 0; j < J; ++j) a_next[j] = gather_a(p, my_in, cc * 16 * J + 16 * j + 4 * q4);
+      }
+#pragma unroll 1
+      for (int g = 0; g < ngroups; ++g) {
+        float4 a[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) a[j] = a_next[j];
+        if (g + 1 < ngroups) {
+          const int s = (g + 1) * 16 + r16;
+          const int my_in = (s < cnt && !(p.ablate & 4)) ? list_in[s] : -1;
+#pragma unroll
+          for (int j = 0; j < J; ++j) a_next[j] = gather_a(p, my_in, cc * 16 * J + 16 * j + 4 * q4);
+        }
+        f32x4 d[CO_BLK];
+#pragma unroll
+        for (int cb = 0; cb < CO_BLK; ++cb) d[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(p.ablate & 1)) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+#pragma unroll
+          for (int cb = 0; cb < CO_BLK; ++cb) {
+            const float4 bb = b[j * CO_BLK + cb];
+            d[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, bb.x, d[cb], 0, 0, 0);
+            d[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, bb.y, d[cb], 0, 0, 0);
+            d[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, bb.z, d[cb], 0, 0, 0);
+            d[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, bb.w, d[cb], 0, 0, 0);
+          }
+        }
+        } else {
+#pragma unroll
+          for (int cb = 0; cb < CO_BLK; ++cb) d[cb][0] = a[0].x + b[cb].x + a[J - 1].w + b[NB - 1].w;
+        }
+        // d[cb][r] = product for compacted row g*16 + 4*q4 + r, column 16*cb + r16
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int s2 = g * 16 + 4 * q4 + r;
+          if (s2 < cnt && !(p.ablate & 2)) {
+            const int rho = list_row[s2];
+#pragma unroll
+            for (int cb = 0; cb < CO_BLK; ++cb) atomicAdd(&acc_l[rho][cb * 16 + r16], d[cb][r]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: whole rows out of LDS, float4 per lane -------------------------------------
+  constexpr int LPR = CW / 4;                        // lanes per row
+  constexpr int RPI = 64 / LPR;                      // rows per iteration
+  const int c4 = lane % LPR, rsub = lane / LPR;
+  const int col = y * CW + 4 * c4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (S == 1) {
+    if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + col);
+    if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + col);
+  }
+#pragma unroll 1
+  for (int it = 0; it < IMF_TILE_ROWS / RPI; ++it) {
+    const int row = it * RPI + rsub;
+    float4 v = *reinterpret_cast<const float4 *>(&acc_l[row][4 * c4]);
+    if (S > 1) {
+      *reinterpret_cast<float4 *>(p.partial + ((long long)z * p.n_slots + slot0 + row) * p.cout + col) = v;
+      continue;
+    }
+    const int orow = row_of_slot(p, slot0 + row);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (p.residual && orow >= 0) {
+      const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (long long)orow * p.cout + col);
+      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+    }
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (p.l2norm) {
+      float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      const float nrm = sqrtf(ss);
+      v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
+    }
+    if (orow >= 0) *reinterpret_cast<float4 *>(p.out + (long long)orow * p.cout + col) = v;
+  }
+}
+
 // Adds the split-K partial sums in ascending partition order and applies the epilogue.
 // One thread per (slot, 4 output channels).
 __global__ void __launch_bounds__(256)
@@ -414,11 +596,13 @@ k_spconv_small_cin(const float *__restrict__ in, int cin, const float *__restric
 }
 
 
-// ---- first layer, fused with its kernel map: no neighbour table is ever written -----------------
-// One wavefront per output voxel.  Lanes probe the (up to 128) kernel offsets in the input level's
-// hash in two rounds; the hits are then walked with lane = output channel (two half-waves work on
-// the two rounds' hit lists when cout == 32).  Same sum order as the table-driven kernel
-// (k ascending within a round), so results are deterministic.
+// ---- first layer, fused with its kernel map: no neighbour table is ever written to HBM ----------
+// One workgroup = 32 output voxels.  Phase 1: the 256 threads probe the 32 x kvol kernel offsets in
+// the input level's hash (16 independent probes per thread) into an LDS neighbour tile.  Phase 2:
+// thread = (output channel, row group) walks the offsets in ascending k -- the same sum order as the
+// table-driven kernel and the oracle -- with the weights in LDS.  in == nullptr: all-ones input.
+constexpr int kFirstRows = 32;
+
 template <int COUT>
 __global__ void __launch_bounds__(256)
 k_conv_first_fused(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, uint32_t capmask,
@@ -426,66 +610,55 @@ k_conv_first_fused(const uint64_t *__restrict__ keys, const int32_t *__restrict_
                    const float *__restrict__ in, int cin, const float *__restrict__ w,
                    const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                    float *__restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // [kvol*cin*COUT] weights, then nbr tile
   const int nw = kvol * cin * COUT;
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) wl[i] = w[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int HALVES = 64 / COUT;                 // 2 when cout == 32, 1 when cout == 64
-  const int co = lane % COUT, half = lane / COUT;
+  int *nbr_l = reinterpret_cast<int *>(wl + nw);                   // [kFirstRows][128]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nw; i += 256) wl[i] = w[i];
+  const long long row0 = (long long)blockIdx.x * kFirstRows;
   const int r = ksize >> 1;
-  for (long long row = (long long)blockIdx.x * 4 + wave; row < n; row += (long long)gridDim.x * 4) {
-    const int4 c = reinterpret_cast<const int4 *>(coords)[row];
-    int res[2];
-#pragma unroll
-    for (int rnd = 0; rnd < 2; ++rnd) {
-      const int k = rnd * 64 + lane;
-      int found = -1;
-      if (k < kvol) {
-        const int dx = k % ksize - r, dy = (k / ksize) % ksize - r, dz = k / (ksize * ksize) - r;
-        const int x = c.y + dx * ts, y = c.z + dy * ts, z = c.w + dz * ts;
-        if (coord_in_range(x, y, z)) found = hash_find(keys, vals, capmask, pack_key(c.x, x, y, z));
-      }
-      res[rnd] = found;
+#pragma unroll 4
+  for (int j = 0; j < kFirstRows * 128 / 256; ++j) {
+    const int idx = j * 256 + tid, lr = idx >> 7, k = idx & 127;
+    const long long row = row0 + lr;
+    int found = -1;
+    if (k < kvol && row < n) {
+      const int4 c = reinterpret_cast<const int4 *>(coords)[row];
+      const int dx = k % ksize - r, dy = (k / ksize) % ksize - r, dz = k / (ksize * ksize) - r;
+      const int x = c.y + dx * ts, y = c.z + dy * ts, z = c.w + dz * ts;
+      if (coord_in_range(x, y, z)) found = hash_find(keys, vals, capmask, pack_key(c.x, x, y, z));
     }
-    unsigned long long m0 = __ballot(res[0] >= 0), m1 = __ballot(res[1] >= 0);
-    float acc = 0.f;
-    if (HALVES == 2) {
-      // half 0 walks round 0's hits, half 1 walks round 1's (bit b of a round's mask <-> lane b)
-      unsigned long long m = half ? m1 : m0;
-      while (__any(m != 0ull)) {                     // wave-uniform trip count: shuffles stay convergent
-        const bool live = m != 0ull;
-        const int b = live ? __builtin_ctzll(m) : 0;
-        m &= m - 1;
-        const int s0 = __shfl(res[0], b, 64), s1 = __shfl(res[1], b, 64);
-        const int src = half ? s1 : s0;
-        if (live) {
-          const int k = half * 64 + b;
-          for (int ci = 0; ci < cin; ++ci) {
-            const float xv = in ? in[(long long)src * cin + ci] : 1.f;
-            acc = fmaf(xv, wl[(k * cin + ci) * COUT + co], acc);
-          }
-        }
-      }
-      acc += __shfl_xor(acc, 32, 64);
-    } else {
+    nbr_l[idx] = found;
+  }
+  __syncthreads();
+  constexpr int RPT = kFirstRows * COUT / 256;                     // rows per thread: 4 (cout 32) / 8 (64)
+  constexpr int RG = 256 / COUT;                                   // row groups
+  const int co = tid % COUT, rg = tid / COUT;
+  float acc[RPT];
 #pragma unroll
-      for (int rnd = 0; rnd < 2; ++rnd) {
-        unsigned long long m = rnd ? m1 : m0;
-        while (m) {
-          const int b = __builtin_ctzll(m);
-          m &= m - 1;
-          const int src = __shfl(res[rnd], b, 64);
-          const int k = rnd * 64 + b;
-          for (int ci = 0; ci < cin; ++ci) {
-            const float xv = in ? in[(long long)src * cin + ci] : 1.f;
-            acc = fmaf(xv, wl[(k * cin + ci) * COUT + co], acc);
-          }
+  for (int q = 0; q < RPT; ++q) acc[q] = 0.f;
+  for (int k = 0; k < kvol; ++k) {
+    int idx[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) idx[q] = nbr_l[(rg + q * RG) * 128 + k];
+    for (int ci = 0; ci < cin; ++ci) {
+      const float wv = wl[(k * cin + ci) * COUT + co];
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        if (in) {
+          if (idx[q] >= 0) acc[q] = fmaf(in[(long long)idx[q] * cin + ci], wv, acc[q]);
+        } else {
+          acc[q] += idx[q] >= 0 ? wv : 0.f;                        // x == 1: exact, branch-free
         }
       }
     }
-    if (half == 0) {
-      float v = acc * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+  }
+  const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const long long row = row0 + rg + q * RG;
+    if (row < n) {
+      float v = acc[q] * sc + sh;
       if (relu) v = fmaxf(v, 0.f);
       out[row * COUT + co] = v;
     }
@@ -541,7 +714,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   const int cin = a->c_a + a->c_b;
   const int J = ci_chunk_of(cin) / 16, CB = co_blk_of(a->cout);
   IMF_REQUIRE(!a->l2norm || a->cout == 16 * CB, "imf_spconv_fwd: l2norm needs cout in {32, 64}");
-  IMF_REQUIRE(a->variant == 0 || a->variant == 1, "imf_spconv_fwd: variant=%d", a->variant);
+  IMF_REQUIRE(a->variant >= 0 && a->variant <= 2, "imf_spconv_fwd: variant=%d", a->variant);
   const bool simple = a->variant == 1 || a->kvol >= kKCache;
   int split = simple ? 1 : (a->split_k > 0 ? a->split_k : imf_spconv_auto_split(a->n_slots, a->cout, a->kvol));
   IMF_REQUIRE(split >= 1 && split <= 32, "imf_spconv_fwd: split_k=%d", split);
@@ -551,11 +724,17 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
                 imf_spconv_workspace_bytes(a->n_slots, a->cout, split));
   ConvParams p{a->in_a, a->in_b, a->c_a, a->c_b, a->w_packed, a->kvol, a->cout, a->tile_rows,
                a->nbr, a->tile_mask, (long long)a->n_slots, (long long)a->n_out, a->scale, a->shift,
-               a->residual, a->relu, a->l2norm, a->out, (float *)a->workspace};
+               a->residual, a->relu, a->l2norm, a->out, (float *)a->workspace, 0};
+  if (const char *e = getenv("IMF_ABLATE")) p.ablate = atoi(e);
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
-  if (simple) {
+  if (a->variant == 2 && !simple) {
+    if (CB == 4 && J == 4)      k_spconv_wave<4, 4><<<grid, 64, 0, st>>>(p);
+    else if (CB == 4 && J == 2) k_spconv_wave<4, 2><<<grid, 64, 0, st>>>(p);
+    else if (CB == 2 && J == 4) k_spconv_wave<2, 4><<<grid, 64, 0, st>>>(p);
+    else                        k_spconv_wave<2, 2><<<grid, 64, 0, st>>>(p);
+  } else if (simple) {
     if (CB == 4 && J == 4)      k_spconv_mfma_simple<4, 4><<<grid, 256, 0, st>>>(p);
     else if (CB == 4 && J == 2) k_spconv_mfma_simple<4, 2><<<grid, 256, 0, st>>>(p);
     else if (CB == 2 && J == 4) k_spconv_mfma_simple<2, 4><<<grid, 256, 0, st>>>(p);
@@ -607,11 +786,10 @@ int imf_conv_first_fused(const uint64_t *keys, const int32_t *vals, int64_t capa
   IMF_REQUIRE(n > 0 && ts >= 1, "imf_conv_first_fused: bad n / ts");
   IMF_REQUIRE((capacity & (capacity - 1)) == 0, "imf_conv_first_fused: capacity not a power of 2");
   const int kvol = ksize * ksize * ksize;
-  const size_t lds = (size_t)kvol * cin * cout * sizeof(float);
+  const size_t lds = (size_t)kvol * cin * cout * sizeof(float) + (size_t)kFirstRows * 128 * sizeof(int);
   IMF_REQUIRE(lds <= 64 * 1024, "imf_conv_first_fused: kernel does not fit 64 KiB of LDS");
   hipStream_t st = (hipStream_t)stream;
-  long long nb = div_up(n, 4);
-  if (nb > 2048) nb = 2048;
+  const long long nb = div_up(n, kFirstRows);
   if (cout == 32)
     k_conv_first_fused<32><<<(unsigned)nb, 256, lds, st>>>(keys, vals, (uint32_t)(capacity - 1), coords, n, ts,
                                                           ksize, kvol, in, cin, w, scale, shift, relu, out);

@@ -336,6 +336,8 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     a.out = out.data_ptr()
     L = _lib.lib()
     split = 1 if variant == 1 else (int(split_k) if split_k else L.imf_spconv_auto_split(rb.n_slots, cout, rb.max_active))
+    if rb.kvol == 1:
+        split = 1
     a.split_k, a.variant = split, int(variant)
     ws = None
     if split > 1:

@@ -165,7 +165,8 @@ typedef struct imf_conv_args {
   int32_t l2norm;         /* y /= ||y||_2 over the row (requires cout <= 64)                      */
   float *out;             /* [n_out, cout]                                                        */
   int32_t split_k;        /* 0 = choose automatically; >= 1 = number of kernel-offset partitions  */
-  int32_t variant;        /* 0 = pipelined kernel (default); 1 = simple reference kernel (A/B)     */
+  int32_t variant;        /* 0 = pipelined workgroup kernel; 1 = simple reference kernel;
+                             2 = wave-autonomous kernel with per-offset row compaction          */
   void *workspace;        /* split-K partial sums; NULL allowed iff split_k resolves to 1          */
   size_t workspace_bytes; /* >= imf_spconv_workspace_bytes(n_slots, cout, split)                  */
   void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded on `stream` immediately around the
