@@ -65,6 +65,7 @@ SIGNATURES = {
     "imf_packed_weight_floats": (_L, [_I, _I, _I]),
     "imf_pack_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "imf_spconv_auto_split": (_I, [_L, _I, _I]),
+    "imf_spconv_occupancy": (_I, [_I, _I, _I]),
     "imf_spconv_workspace_bytes": (_Z, [_L, _I, _I]),
     "imf_spconv_fwd": (_I, [C.POINTER(ConvArgs), _P]),
     "imf_spconv_small_cin": (_I, [_P, _I, _P, _I, _I, _P, _L, _L, _P, _P, _I, _P, _P]),

@@ -257,7 +257,6 @@ k_spconv_mfma(const ConvParams p) {
   // left in scratch memory by hipcc (ROCm 7.2), which serialises the prefetch behind vmcnt waits.
   float4 w0, w1, w2, w3;
   float4 a_next[KG][J];
-  bool act_next[KG];
   const float4 *sp[KG];
 
   // prefetch of macro stage n: weights -> w0..w3, A fragments -> a_next
@@ -268,10 +267,17 @@ k_spconv_mfma(const ConvParams p) {
       const int tc = t < n_sub ? t : n_sub - 1;   /* tail: reload the last sub-stage, unused */    \
       const int jk = tc / ncc, cc = tc - jk * ncc;                                                 \
       sp[g] = wbase + ((long long)klist[jk] * ncc + cc) * SUB_F4 + tid;                            \
-      const int irow = nbr_lds[jk][wave * 16 + r16];                                               \
-      act_next[g] = (t < n_sub) && __any(irow >= 0);                                               \
-      _Pragma("unroll") for (int j = 0; j < J; ++j)                                                \
-          a_next[g][j] = gather_a(p, irow, cc * 16 * J + 16 * j + 4 * q4);                         \
+      const int irow = (t < n_sub) ? nbr_lds[jk][wave * 16 + r16] : -1;                            \
+      /* a (k, cc) chunk never straddles the two cat sources: c_a % (16 J) == 0 (host-checked) */   \
+      const int ch0 = cc * 16 * J;                                                                 \
+      const float *rowp = (ch0 < p.c_a) ? p.in_a + (long long)irow * p.c_a + ch0                   \
+                                        : p.in_b + (long long)irow * p.c_b + (ch0 - p.c_a);        \
+      if (irow >= 0) {                                                                             \
+        _Pragma("unroll") for (int j = 0; j < J; ++j)                                              \
+            a_next[g][j] = *reinterpret_cast<const float4 *>(rowp + 16 * j + 4 * q4);              \
+      } else {                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < J; ++j) a_next[g][j] = make_float4(0.f, 0.f, 0.f, 0.f); \
+      }                                                                                            \
     }                                                                                              \
     w0 = sp[0 / QPS][(0 % QPS) * 256];                                                             \
     w1 = sp[1 / QPS][(1 % QPS) * 256];                                                             \
@@ -288,28 +294,24 @@ k_spconv_mfma(const ConvParams p) {
     wbuf[2 * 256 + tid] = w2;
     wbuf[3 * 256 + tid] = w3;
     float4 a_cur[KG][J];
-    bool act[KG];
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
-      act[g] = act_next[g];
 #pragma unroll
       for (int j = 0; j < J; ++j) a_cur[g][j] = a_next[g][j];
     }
     __syncthreads();   // stage n visible; every wave is past its reads of this buffer (stage n-2)
     if (n + 1 < n_macro) IMF_PREFETCH(n + 1)
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-      if (act[g]) {
+    for (int g = 0; g < KG; ++g) {     // unconditional: empty rows carry zeros (a skipped tail adds 0)
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
+      for (int j = 0; j < J; ++j) {
 #pragma unroll
-          for (int cb = 0; cb < CO_BLK; ++cb) {
-            const float4 b = wbuf[g * SUB_F4 + (j * CO_BLK + cb) * 64 + lane];
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].x, b.x, acc[cb], 0, 0, 0);
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].y, b.y, acc[cb], 0, 0, 0);
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].z, b.z, acc[cb], 0, 0, 0);
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].w, b.w, acc[cb], 0, 0, 0);
-          }
+        for (int cb = 0; cb < CO_BLK; ++cb) {
+          const float4 b = wbuf[g * SUB_F4 + (j * CO_BLK + cb) * 64 + lane];
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].x, b.x, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].y, b.y, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].z, b.z, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][j].w, b.w, acc[cb], 0, 0, 0);
         }
       }
     }
@@ -511,6 +513,366 @@ k_spconv_wave(const ConvParams p) {
   }
 }
 
+
+// ---- variant 3: 128-row workgroup kernel with per-offset row compaction ------------------------
+// 8 wavefronts (512 threads) own TWO consecutive rulebook tiles (128 output rows) x one output slab.
+// The K walk (offset k, channel chunk cc) is staged through LDS exactly like variant 0 (double
+// buffer, one barrier per stage), but the M dimension is COMPACTED per offset: only the rows that
+// really have an input at offset k (~52 %) are gathered, so a stage issues ~4.6 full 16-row MFMA
+// blocks instead of 8 half-empty ones.  Every wave derives the compaction itself (two coalesced
+// neighbour-column loads, two ballots, popcounts) one stage ahead, so the A gather of stage t+1 is
+// in flight under the MFMAs of stage t and no extra barrier is needed.  Since compacted rows do not
+// line up with fixed accumulator registers, a wave's 16 x CW product block (MFMA with C = 0) is
+// added into an LDS-resident [128 x CW] accumulator tile; rows are distinct within a stage and
+// stages are separated by the barrier, so plain read-add-write is race-free and the sum order
+// (k, cc ascending) is fixed => bit-reproducible.  The epilogue streams whole rows out of LDS.
+constexpr int kRowsC = 128;
+
+template <int CO_BLK, int J>
+__global__ void __launch_bounds__(512)
+k_spconv_c(const ConvParams p) {
+  constexpr int CW = 16 * CO_BLK;
+  constexpr int SUB_F4 = J * CO_BLK * 64;            // float4 per (k, cc) weight stage
+  constexpr int QPT = (SUB_F4 + 511) / 512;          // float4 per thread per stage (1 or 2)
+  __shared__ float4 wlds[2][SUB_F4];
+  __shared__ __attribute__((aligned(16))) float acc_l[kRowsC][CW];
+  __shared__ int scratch[8][2][32];
+  __shared__ int klist[kKCache];
+
+  const int y = blockIdx.y, z = blockIdx.z, S = gridDim.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int cin = p.c_a + p.c_b;
+  const int ncc = cin / (16 * J);
+  const long long slot0 = (long long)blockIdx.x * kRowsC;
+  const bool has2 = slot0 + IMF_TILE_ROWS < p.n_slots;      // second tile exists
+
+  uint32_t mask[IMF_MASK_WORDS] = {1u, 0u, 0u, 0u};
+  if (p.tile_mask) {
+    const long long t0 = blockIdx.x * 2ll;
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w)
+      mask[w] = p.tile_mask[t0 * IMF_MASK_WORDS + w] | (has2 ? p.tile_mask[(t0 + 1) * IMF_MASK_WORDS + w] : 0u);
+  }
+  const int total = __builtin_popcount(mask[0]) + __builtin_popcount(mask[1]) +
+                    __builtin_popcount(mask[2]) + __builtin_popcount(mask[3]);
+  if (total == 0 && S == 1) return;                  // padding tiles
+  const int lo = (int)((long long)z * total / S), hi = (int)((long long)(z + 1) * total / S);
+  const int nk = hi - lo;
+  if (tid == 0) {
+    int ord = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) {
+      uint32_t m = mask[w];
+      while (m) {
+        const int k = w * 32 + __builtin_ctz(m);
+        m &= m - 1;
+        if (ord >= lo && ord < hi) klist[n++] = k;
+        ++ord;
+      }
+    }
+  }
+  {   // zero the accumulator tile
+    float4 *a4 = reinterpret_cast<float4 *>(&acc_l[0][0]);
+    for (int i = tid; i < kRowsC * CW / 4; i += 512) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+
+  const float4 *wbase = reinterpret_cast<const float4 *>(p.w_packed) +
+                        (long long)y * p.kvol * ncc * SUB_F4;
+  const int n_st = nk * ncc;
+
+  float4 w0, w1;                                     // named on purpose (see variant 0)
+  float4 a_next[J];
+  int rho_next[4];
+  bool act_next = false;
+
+  // prefetch of stage t: weights -> w0/w1, compaction of offset k, A fragments of this wave's block
+#define IMF_PREFETCH_C(t)                                                                          \
+  {                                                                                                \
+    const int jk_ = (t) / ncc, cc_ = (t) - jk_ * ncc, k_ = klist[jk_];                             \
+    const float4 *src_ = wbase + ((long long)k_ * ncc + cc_) * SUB_F4;                             \
+    if (QPT == 2 || tid < SUB_F4) w0 = src_[tid];                                                  \
+    if (QPT == 2) w1 = src_[512 + tid];                                                            \
+    int ir0_, ir1_;                                                                                \
+    if (p.nbr) {                                                                                   \
+      const int *col_ = p.nbr + (long long)k_ * p.n_slots + slot0;                                 \
+      ir0_ = col_[lane];                                                                           \
+      ir1_ = has2 ? col_[64 + lane] : -1;                                                          \
+    } else {                                                                                       \
+      ir0_ = row_of_slot(p, slot0 + lane);                                                         \
+      ir1_ = has2 ? row_of_slot(p, slot0 + 64 + lane) : -1;                                        \
+    }                                                                                              \
+    const unsigned long long m0_ = __ballot(ir0_ >= 0), m1_ = __ballot(ir1_ >= 0);                 \
+    const unsigned long long lt_ = (1ull << lane) - 1ull;                                          \
+    const int c0_ = __builtin_popcountll(m0_), cnt_ = c0_ + __builtin_popcountll(m1_);            \
+    const int p0_ = __builtin_popcountll(m0_ & lt_), p1_ = c0_ + __builtin_popcountll(m1_ & lt_); \
+    int *sc_ = scratch[wave][(t) & 1];                                                             \
+    if (ir0_ >= 0 && (p0_ >> 4) == wave) { sc_[p0_ & 15] = ir0_; sc_[16 + (p0_ & 15)] = lane; }    \
+    if (ir1_ >= 0 && (p1_ >> 4) == wave) { sc_[p1_ & 15] = ir1_; sc_[16 + (p1_ & 15)] = 64 + lane; } \
+    __builtin_amdgcn_wave_barrier();                                                               \
+    const int base_ = 16 * wave;                                                                   \
+    act_next = base_ < cnt_;                                                                       \
+    const int my_in_ = (base_ + r16 < cnt_) ? sc_[r16] : -1;                                       \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
+        rho_next[r] = (base_ + 4 * q4 + r < cnt_) ? sc_[16 + 4 * q4 + r] : -1;                     \
+    _Pragma("unroll") for (int j = 0; j < J; ++j)                                                  \
+        a_next[j] = gather_a(p, my_in_, cc_ * 16 * J + 16 * j + 4 * q4);                           \
+  }
+
+  if (n_st > 0) IMF_PREFETCH_C(0)
+#pragma unroll 1
+  for (int t = 0; t < n_st; ++t) {
+    float4 *wbuf = wlds[t & 1];
+    if (QPT == 2 || tid < SUB_F4) wbuf[tid] = w0;
+    if (QPT == 2) wbuf[512 + tid] = w1;
+    float4 a_cur[J];
+    int rho[4];
+#pragma unroll
+    for (int j = 0; j < J; ++j) a_cur[j] = a_next[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rho[r] = rho_next[r];
+    const bool act = act_next;
+    __syncthreads();   // stage t's weights visible; previous stage's accumulator updates complete
+    if (t + 1 < n_st) IMF_PREFETCH_C(t + 1)
+    if (act) {
+      f32x4 d[CO_BLK];
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) d[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int cb = 0; cb < CO_BLK; ++cb) {
+          const float4 b = wbuf[(j * CO_BLK + cb) * 64 + lane];
+          d[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].x, b.x, d[cb], 0, 0, 0);
+          d[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].y, b.y, d[cb], 0, 0, 0);
+          d[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].z, b.z, d[cb], 0, 0, 0);
+          d[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].w, b.w, d[cb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (rho[r] >= 0) {
+          float *dst = &acc_l[rho[r]][r16];
+#pragma unroll
+          for (int cb = 0; cb < CO_BLK; ++cb) dst[cb * 16] += d[cb][r];
+        }
+      }
+    }
+  }
+#undef IMF_PREFETCH_C
+  __syncthreads();
+
+  // ---- epilogue: whole rows out of LDS, float4 per thread -------------------------------------
+  constexpr int LPR = CW / 4;                        // threads per row
+  constexpr int RPI = 512 / LPR;                     // rows per iteration
+  const int c4 = tid % LPR, rsub = tid / LPR;
+  const int col = y * CW + 4 * c4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (S == 1) {
+    if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + col);
+    if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + col);
+  }
+#pragma unroll 1
+  for (int it = 0; it < kRowsC / RPI; ++it) {
+    const int row = it * RPI + rsub;
+    if (slot0 + row >= p.n_slots) continue;          // wave-uniform (rows of a tile stay together)
+    float4 v = *reinterpret_cast<const float4 *>(&acc_l[row][4 * c4]);
+    if (S > 1) {
+      *reinterpret_cast<float4 *>(p.partial + ((long long)z * p.n_slots + slot0 + row) * p.cout + col) = v;
+      continue;
+    }
+    const int orow = row_of_slot(p, slot0 + row);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (p.residual && orow >= 0) {
+      const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (long long)orow * p.cout + col);
+      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+    }
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (p.l2norm) {
+      float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      const float nrm = sqrtf(ss);
+      v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
+    }
+    if (orow >= 0) *reinterpret_cast<float4 *>(p.out + (long long)orow * p.cout + col) = v;
+  }
+}
+
+
+// ---- variant 4: barrier-free register kernel ---------------------------------------------------
+// Measured (tools/conv_tiles.py, conv_ablate.py): in the LDS-staged kernels the co-resident
+// workgroups of a CU run in lock-step, so the per-stage barrier phase idles the matrix pipe on all
+// four SIMDs at once (46-50 cycles per MFMA instead of the 32 the pipe sustains).  Here every
+// wavefront is autonomous: it owns RB 16-row blocks x one output slab, keeps the accumulators in
+// registers, and streams BOTH operands straight from L1/L2 -- A rows gathered as before, B
+// fragments as coalesced 1 KiB loads of the fragment-major weight image (all waves of a CU walk
+// the offsets at the same pace, so the 16 KiB of an offset's weights are L1 hits after the first
+// touch).  The (offset, 16-channel step) space is walked as one flat software pipeline with a
+// look-ahead of one step; no LDS, no barriers, no atomics; sum order fixed (k, channel ascending).
+template <int CO_BLK, int RB>
+__global__ void __launch_bounds__(256)
+k_spconv_reg(const ConvParams p) {
+  const int y = blockIdx.y, z = blockIdx.z, S = gridDim.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int cin = p.c_a + p.c_b;
+  const int U = cin / 16;                                     // 16-channel steps per offset
+  const long long gw = (long long)blockIdx.x * 4 + wave;      // global wave = RB consecutive row blocks
+  const long long slot_w = gw * 16 * RB;
+  if (slot_w >= p.n_slots) return;
+  const long long tile = slot_w / IMF_TILE_ROWS;
+
+  uint32_t mask[IMF_MASK_WORDS] = {1u, 0u, 0u, 0u};
+  if (p.tile_mask) {
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) mask[w] = p.tile_mask[tile * IMF_MASK_WORDS + w];
+  }
+  const int total = __builtin_popcount(mask[0]) + __builtin_popcount(mask[1]) +
+                    __builtin_popcount(mask[2]) + __builtin_popcount(mask[3]);
+  if (total == 0 && S == 1) return;
+  const int lo = (int)((long long)z * total / S), hi = (int)((long long)(z + 1) * total / S);
+  const int nk = hi - lo;
+  unsigned long long kp0 = 0ull, kp1 = 0ull, kp2 = 0ull;      // offsets of this partition, 7 bits each
+  {
+    int ord = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) {
+      uint32_t m = mask[w];
+      while (m) {
+        const unsigned long long k = (unsigned long long)(w * 32 + __builtin_ctz(m));
+        m &= m - 1;
+        if (ord >= lo && ord < hi) {
+          if (n < 9) kp0 |= k << (7 * n);
+          else if (n < 18) kp1 |= k << (7 * (n - 9));
+          else kp2 |= k << (7 * (n - 18));
+          ++n;
+        }
+        ++ord;
+      }
+    }
+  }
+#define IMF_KGET(jk) ((int)(((jk) < 9 ? kp0 >> (7 * (jk)) : ((jk) < 18 ? kp1 >> (7 * ((jk)-9)) : kp2 >> (7 * ((jk)-18)))) & 127ull))
+
+  f32x4 acc[RB][CO_BLK];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CO_BLK; ++cb) acc[rb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float4 *wslab = reinterpret_cast<const float4 *>(p.w_packed) +
+                        (long long)y * p.kvol * U * (CO_BLK * 64) + lane;
+
+  // rows of offset jk (lane l holds the input row of output row rb*16 + (l & 15))
+#define IMF_LOAD_ROWS(dst, jk)                                                                     \
+  {                                                                                                \
+    _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) {                                           \
+      const long long sl_ = slot_w + rb * 16 + r16;                                                \
+      dst[rb] = p.nbr ? p.nbr[(long long)IMF_KGET(jk) * p.n_slots + sl_] : row_of_slot(p, sl_);    \
+    }                                                                                              \
+  }
+#define IMF_LOAD_STEP(A, B, rows, kk, u)                                                           \
+  {                                                                                                \
+    const float4 *bp_ = wslab + ((long long)(kk) * U + (u)) * (CO_BLK * 64);                       \
+    _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb) B[cb] = bp_[cb * 64];                    \
+    _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) A[rb] = gather_a(p, rows[rb], 16 * (u) + 4 * q4); \
+  }
+#define IMF_MFMA_STEP(A, B)                                                                        \
+  {                                                                                                \
+    _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                             \
+    _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb) {                                       \
+      acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rb].x, B[cb].x, acc[rb][cb], 0, 0, 0); \
+      acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rb].y, B[cb].y, acc[rb][cb], 0, 0, 0); \
+      acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rb].z, B[cb].z, acc[rb][cb], 0, 0, 0); \
+      acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rb].w, B[cb].w, acc[rb][cb], 0, 0, 0); \
+    }                                                                                              \
+  }
+
+  // flat pipeline over (jk, u): "cur" is being multiplied while "nxt" is in flight
+  int rows_cur[RB], rows_nxt[RB];
+  float4 A0[RB], B0[CO_BLK], A1[RB], B1[CO_BLK];
+  int jk = 0;
+  // find the first offset with any valid row in this wave
+  bool have = false;
+  while (jk < nk) {
+    IMF_LOAD_ROWS(rows_cur, jk)
+    bool any = false;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) any |= rows_cur[rb] >= 0;
+    if (__any(any)) { have = true; break; }
+    ++jk;
+  }
+  if (have) {
+    int k = IMF_KGET(jk), u = 0;
+    IMF_LOAD_STEP(A0, B0, rows_cur, k, 0)
+    bool more = true;
+    int njk = jk;                                              // offset the next step belongs to
+    bool rows_nxt_valid = false;
+#pragma unroll 1
+    while (more) {
+      // ---- issue the loads of the next step -------------------------------------------------
+      int nu = u + 1, nk_ = k;
+      bool next_ok = true;
+      if (nu == U) {                                           // move on to the next non-empty offset
+        nu = 0;
+        next_ok = false;
+        njk = jk + 1;
+        while (njk < nk) {
+          IMF_LOAD_ROWS(rows_nxt, njk)
+          bool any = false;
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) any |= rows_nxt[rb] >= 0;
+          if (__any(any)) { next_ok = true; break; }
+          ++njk;
+        }
+        if (next_ok) nk_ = IMF_KGET(njk);
+        rows_nxt_valid = next_ok;
+      }
+      if (next_ok) {
+        if (nu == 0) { IMF_LOAD_STEP(A1, B1, rows_nxt, nk_, 0) }
+        else { IMF_LOAD_STEP(A1, B1, rows_cur, nk_, nu) }
+      }
+      // ---- multiply the current step --------------------------------------------------------
+      IMF_MFMA_STEP(A0, B0)
+      // ---- rotate ----------------------------------------------------------------------------
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) A0[rb] = A1[rb];
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) B0[cb] = B1[cb];
+      if (nu == 0 && rows_nxt_valid) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) rows_cur[rb] = rows_nxt[rb];
+        jk = njk;
+        rows_nxt_valid = false;
+      }
+      u = nu;
+      k = nk_;
+      more = next_ok;
+    }
+  }
+#undef IMF_LOAD_ROWS
+#undef IMF_LOAD_STEP
+#undef IMF_MFMA_STEP
+#undef IMF_KGET
+
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const long long slot_b = slot_w + rb * 16;                 // this 16-row block
+    const int tl = (int)(slot_b / IMF_TILE_ROWS), wv = (int)((slot_b % IMF_TILE_ROWS) / 16);
+    if (S == 1) {
+      conv_epilogue<CO_BLK>(p, acc[rb], tl, y, wv, r16, q4);
+    } else {
+      const int CW = 16 * CO_BLK;
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) {
+        const int col = y * CW + cb * 16 + r16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          p.partial[((long long)z * p.n_slots + slot_b + q4 * 4 + r) * p.cout + col] = acc[rb][cb][r];
+      }
+    }
+  }
+}
+
 // Adds the split-K partial sums in ascending partition order and applies the epilogue.
 // One thread per (slot, 4 output channels).
 __global__ void __launch_bounds__(256)
@@ -685,6 +1047,28 @@ int imf_pack_weights(const float *w, int kvol, int cin, int cout, float *packed,
   return IMF_OK;
 }
 
+/* Resident workgroups per CU the runtime reports for a sparse-conv kernel instantiation (tuning aid). */
+int imf_spconv_occupancy(int variant, int co_blk, int j) {
+  int n = -1;
+  const void *f = nullptr;
+  int threads = 256;
+#define IMF_PICK(K, T)                                                                    \
+  do {                                                                                    \
+    threads = T;                                                                          \
+    if (co_blk == 4 && j == 4) f = (const void *)K<4, 4>;                                 \
+    else if (co_blk == 4 && j == 2) f = (const void *)K<4, 2>;                            \
+    else if (co_blk == 2 && j == 4) f = (const void *)K<2, 4>;                            \
+    else f = (const void *)K<2, 2>;                                                       \
+  } while (0)
+  if (variant == 0) IMF_PICK(k_spconv_mfma, 256);
+  else if (variant == 1) IMF_PICK(k_spconv_mfma_simple, 256);
+  else if (variant == 2) IMF_PICK(k_spconv_wave, 64);
+  else IMF_PICK(k_spconv_c, 512);
+#undef IMF_PICK
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, threads, 0) != hipSuccess) return -1;
+  return n;
+}
+
 int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol) {
   if (kvol <= 1 || kvol >= kKCache) return 1;
   const int64_t blocks = (n_slots / IMF_TILE_ROWS) * (cout / (16 * co_blk_of(cout)));
@@ -714,8 +1098,8 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   const int cin = a->c_a + a->c_b;
   const int J = ci_chunk_of(cin) / 16, CB = co_blk_of(a->cout);
   IMF_REQUIRE(!a->l2norm || a->cout == 16 * CB, "imf_spconv_fwd: l2norm needs cout in {32, 64}");
-  IMF_REQUIRE(a->variant >= 0 && a->variant <= 2, "imf_spconv_fwd: variant=%d", a->variant);
-  const bool simple = a->variant == 1 || a->kvol >= kKCache;
+  IMF_REQUIRE(a->variant >= 0 && a->variant <= 5, "imf_spconv_fwd: variant=%d", a->variant);
+  const bool simple = a->variant == 1 || a->kvol >= kKCache || (a->c_b > 0 && a->c_a % (16 * J) != 0);
   int split = simple ? 1 : (a->split_k > 0 ? a->split_k : imf_spconv_auto_split(a->n_slots, a->cout, a->kvol));
   IMF_REQUIRE(split >= 1 && split <= 32, "imf_spconv_fwd: split_k=%d", split);
   if (split > 1)
@@ -729,7 +1113,23 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
-  if (a->variant == 2 && !simple) {
+  if ((a->variant == 4 || a->variant == 5) && !simple) {
+    const int RBv = a->variant == 4 ? 2 : 1;
+    dim3 g4((unsigned)div_up(a->n_slots / 16, 4 * RBv), grid.y, grid.z);
+    if (RBv == 2) {
+      if (CB == 4) k_spconv_reg<4, 2><<<g4, 256, 0, st>>>(p);
+      else         k_spconv_reg<2, 2><<<g4, 256, 0, st>>>(p);
+    } else {
+      if (CB == 4) k_spconv_reg<4, 1><<<g4, 256, 0, st>>>(p);
+      else         k_spconv_reg<2, 1><<<g4, 256, 0, st>>>(p);
+    }
+  } else if (a->variant == 3 && !simple) {
+    dim3 g2((unsigned)div_up(a->n_slots / IMF_TILE_ROWS, 2), grid.y, grid.z);
+    if (CB == 4 && J == 4)      k_spconv_c<4, 4><<<g2, 512, 0, st>>>(p);
+    else if (CB == 4 && J == 2) k_spconv_c<4, 2><<<g2, 512, 0, st>>>(p);
+    else if (CB == 2 && J == 4) k_spconv_c<2, 4><<<g2, 512, 0, st>>>(p);
+    else                        k_spconv_c<2, 2><<<g2, 512, 0, st>>>(p);
+  } else if (a->variant == 2 && !simple) {
     if (CB == 4 && J == 4)      k_spconv_wave<4, 4><<<grid, 64, 0, st>>>(p);
     else if (CB == 4 && J == 2) k_spconv_wave<4, 2><<<grid, 64, 0, st>>>(p);
     else if (CB == 2 && J == 4) k_spconv_wave<2, 4><<<grid, 64, 0, st>>>(p);

@@ -166,7 +166,9 @@ typedef struct imf_conv_args {
   float *out;             /* [n_out, cout]                                                        */
   int32_t split_k;        /* 0 = choose automatically; >= 1 = number of kernel-offset partitions  */
   int32_t variant;        /* 0 = pipelined workgroup kernel; 1 = simple reference kernel;
-                             2 = wave-autonomous kernel with per-offset row compaction          */
+                             2 = wave-autonomous kernel with per-offset row compaction;
+                             3 = 128-row workgroup kernel with per-offset row compaction;
+                             4 / 5 = barrier-free register kernel, 32 / 16 rows per wavefront    */
   void *workspace;        /* split-K partial sums; NULL allowed iff split_k resolves to 1          */
   size_t workspace_bytes; /* >= imf_spconv_workspace_bytes(n_slots, cout, split)                  */
   void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded on `stream` immediately around the
@@ -178,6 +180,8 @@ typedef struct imf_conv_args {
  * partial sums are combined -- in a fixed order, hence still bit-reproducible -- by a second
  * kernel that also applies the epilogue. */
 int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol);
+/* Tuning aid: resident workgroups per CU reported by the runtime for kernel `variant`. */
+int imf_spconv_occupancy(int variant, int co_blk, int j);
 size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split);
 
 /* Replaces: ME.MinkowskiConvolution / ME.MinkowskiConvolutionTranspose forward

@@ -17,6 +17,8 @@ print("levels", n)
 cases = [  # name, rulebook, cin, cout, rows_in
     ("k3@1 64->64", cm.conv_rulebook(1, 3, 1), 64, 64, n[0]),
     ("k3@1 32->32", cm.conv_rulebook(1, 3, 1), 32, 32, n[0]),
+    ("k1@1 96->64", cm.conv_rulebook(1, 1, 1), 96, 64, n[0]),
+    ("k1@1 64->32", cm.conv_rulebook(1, 1, 1), 64, 32, n[0]),
     ("up@1 128->64", cm.transpose_rulebook(2, 3, 2), 128, 64, n[1]),
     ("dn 1->2 32->64", cm.conv_rulebook(1, 3, 2), 32, 64, n[0]),
     ("k3@2 64->64", cm.conv_rulebook(2, 3, 1), 64, 64, n[1]),
@@ -24,8 +26,9 @@ cases = [  # name, rulebook, cin, cout, rows_in
     ("k3@8 256->256", cm.conv_rulebook(8, 3, 1), 256, 256, n[3]),
     ("up@4 256->128", cm.transpose_rulebook(8, 3, 2), 256, 128, n[3]),
 ]
-variants = [("v0 auto", dict(variant=0)), ("v2 auto", dict(variant=2)), ("v2 s1", dict(variant=2, split_k=1)),
-            ("v2 s2", dict(variant=2, split_k=2)), ("v2 s4", dict(variant=2, split_k=4)), ("v2 s8", dict(variant=2, split_k=8))]
+variants = [("v0 auto", dict(variant=0)), ("v0 s1", dict(variant=0, split_k=1)), ("v3 auto", dict(variant=3)), ("v4 s1", dict(variant=4, split_k=1)),
+            ("v4 auto", dict(variant=4)), ("v4 s2", dict(variant=4, split_k=2)), ("v5 s1", dict(variant=5, split_k=1)),
+            ("v5 auto", dict(variant=5)), ("v5 s2", dict(variant=5, split_k=2))]
 g = torch.Generator().manual_seed(0)
 for name, rb, cin, cout, rows in cases:
     f = torch.randn(rows, cin, generator=g).to(dev)

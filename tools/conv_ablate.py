@@ -16,7 +16,7 @@ g = torch.Generator().manual_seed(0)
 f = torch.randn(levels[0].n, 64, generator=g).to(dev)
 w = ops.pack_weights((torch.randn(27, 64, 64, generator=g) * 0.05).to(dev))
 out = []
-for kw in (dict(variant=2, split_k=1), dict(variant=2, split_k=4)):
+for kw in (dict(variant=int(os.environ.get("VAR","0")), split_k=1),):
     ts = []
     for r in range(5):
         ops.TRACE = []
@@ -25,7 +25,7 @@ for kw in (dict(variant=2, split_k=1), dict(variant=2, split_k=4)):
     out.append("%%s: %%.1f us" %% (kw, np.median(ts[1:])))
 print("IMF_ABLATE=%%s  " %% os.environ.get("IMF_ABLATE", "0") + "  ".join(out))
 ''' % (ROOT, ROOT)
-for ab in (0, 1, 2, 4, 8, 3, 7, 15):
+for ab in (0, 1, 4, 8, 16, 17, 21, 29, 28):
     env = dict(os.environ, IMF_ABLATE=str(ab))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     print((r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
