@@ -586,6 +586,19 @@ k_spconv_c(const ConvParams p) {
   int rho_next[4];
   bool act_next = false;
 
+  int ir0_pf = -1, ir1_pf = -1;                      // neighbour columns of the next stage to compact
+#define IMF_INDEX_C(t)                                                                             \
+  {                                                                                                \
+    const int kq_ = klist[(t) / ncc];                                                              \
+    if (p.nbr) {                                                                                   \
+      const int *col_ = p.nbr + (long long)kq_ * p.n_slots + slot0;                                \
+      ir0_pf = col_[lane];                                                                         \
+      ir1_pf = has2 ? col_[64 + lane] : -1;                                                        \
+    } else {                                                                                       \
+      ir0_pf = row_of_slot(p, slot0 + lane);                                                       \
+      ir1_pf = has2 ? row_of_slot(p, slot0 + 64 + lane) : -1;                                      \
+    }                                                                                              \
+  }
   // prefetch of stage t: weights -> w0/w1, compaction of offset k, A fragments of this wave's block
 #define IMF_PREFETCH_C(t)                                                                          \
   {                                                                                                \
@@ -593,15 +606,8 @@ k_spconv_c(const ConvParams p) {
     const float4 *src_ = wbase + ((long long)k_ * ncc + cc_) * SUB_F4;                             \
     if (QPT == 2 || tid < SUB_F4) w0 = src_[tid];                                                  \
     if (QPT == 2) w1 = src_[512 + tid];                                                            \
-    int ir0_, ir1_;                                                                                \
-    if (p.nbr) {                                                                                   \
-      const int *col_ = p.nbr + (long long)k_ * p.n_slots + slot0;                                 \
-      ir0_ = col_[lane];                                                                           \
-      ir1_ = has2 ? col_[64 + lane] : -1;                                                          \
-    } else {                                                                                       \
-      ir0_ = row_of_slot(p, slot0 + lane);                                                         \
-      ir1_ = has2 ? row_of_slot(p, slot0 + 64 + lane) : -1;                                        \
-    }                                                                                              \
+    const int ir0_ = ir0_pf, ir1_ = ir1_pf;       /* fetched one stage ago: latency hidden */       \
+    if ((t) + 1 < n_st) IMF_INDEX_C((t) + 1)                                                       \
     const unsigned long long m0_ = __ballot(ir0_ >= 0), m1_ = __ballot(ir1_ >= 0);                 \
     const unsigned long long lt_ = (1ull << lane) - 1ull;                                          \
     const int c0_ = __builtin_popcountll(m0_), cnt_ = c0_ + __builtin_popcountll(m1_);            \
@@ -619,7 +625,10 @@ k_spconv_c(const ConvParams p) {
         a_next[j] = gather_a(p, my_in_, cc_ * 16 * J + 16 * j + 4 * q4);                           \
   }
 
-  if (n_st > 0) IMF_PREFETCH_C(0)
+  if (n_st > 0) {
+    IMF_INDEX_C(0)
+    IMF_PREFETCH_C(0)
+  }
 #pragma unroll 1
   for (int t = 0; t < n_st; ++t) {
     float4 *wbuf = wlds[t & 1];
@@ -660,6 +669,7 @@ k_spconv_c(const ConvParams p) {
     }
   }
 #undef IMF_PREFETCH_C
+#undef IMF_INDEX_C
   __syncthreads();
 
   // ---- epilogue: whole rows out of LDS, float4 per thread -------------------------------------

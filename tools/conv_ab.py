@@ -26,9 +26,8 @@ cases = [  # name, rulebook, cin, cout, rows_in
     ("k3@8 256->256", cm.conv_rulebook(8, 3, 1), 256, 256, n[3]),
     ("up@4 256->128", cm.transpose_rulebook(8, 3, 2), 256, 128, n[3]),
 ]
-variants = [("v0 auto", dict(variant=0)), ("v0 s1", dict(variant=0, split_k=1)), ("v3 auto", dict(variant=3)), ("v4 s1", dict(variant=4, split_k=1)),
-            ("v4 auto", dict(variant=4)), ("v4 s2", dict(variant=4, split_k=2)), ("v5 s1", dict(variant=5, split_k=1)),
-            ("v5 auto", dict(variant=5)), ("v5 s2", dict(variant=5, split_k=2))]
+variants = [("v0 auto", dict(variant=0)), ("v0 s1", dict(variant=0, split_k=1)), ("v3 auto", dict(variant=3)), ("v3 s1", dict(variant=3, split_k=1)),
+            ("v3 s2", dict(variant=3, split_k=2)), ("v3 s4", dict(variant=3, split_k=4))]
 g = torch.Generator().manual_seed(0)
 for name, rb, cin, cout, rows in cases:
     f = torch.randn(rows, cin, generator=g).to(dev)

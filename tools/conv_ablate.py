@@ -25,7 +25,7 @@ for kw in (dict(variant=int(os.environ.get("VAR","0")), split_k=1),):
     out.append("%%s: %%.1f us" %% (kw, np.median(ts[1:])))
 print("IMF_ABLATE=%%s  " %% os.environ.get("IMF_ABLATE", "0") + "  ".join(out))
 ''' % (ROOT, ROOT)
-for ab in (0, 1, 4, 8, 16, 17, 21, 29, 28):
+for ab in (0, 256, 512, 768, 1024, 1536, 2048):
     env = dict(os.environ, IMF_ABLATE=str(ab))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     print((r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)

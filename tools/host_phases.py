@@ -7,6 +7,7 @@ import imf_oracle as O
 from imfnet_amd import ops
 from imfnet_amd import sparse as ME
 from imfnet_amd.model import load_model
+from imfnet_amd.model import plan as planmod
 from bench import load_workload
 
 xyz, img, voxel = load_workload(1.7, 0.025)
@@ -18,23 +19,33 @@ xyz_d = torch.as_tensor(xyz).to(dev); img_d = torch.as_tensor(img).to(dev)
 T = {}
 def tick(name, t0):
     T.setdefault(name, []).append(time.perf_counter() - t0)
+# instrument plan.run phases
+orig_run = planmod.FusedPlan.run
+def timed_fuse_wrapper(fuse):
+    def f(x):
+        t = time.perf_counter(); r = fuse(x); tick("6b  fuse (torch attention) queue", t); return r
+    return f
+def run(self, x, fuse):
+    t = time.perf_counter(); r = orig_run(self, x, timed_fuse_wrapper(fuse)); tick("6a  plan.run total", t); return r
+planmod.FusedPlan.run = run
 with torch.no_grad():
-    for it in range(25):
+    for it in range(30):
         t = time.perf_counter()
-        meta = ops.new_meta(4, dev)
-        lv = ops.voxelize(xyz_d, voxel, 0, meta=meta[0])
-        cm = ME.CoordinateManager(lv, meta=meta)
-        tick("1 voxelize queue", t); t = time.perf_counter()
-        # queue downsamples (copy of build_pyramid without sync)
-        cm.build_pyramid(8, before_sync=lambda: (tick("2 downsample queue", t), T.setdefault("_t", []).append(time.perf_counter()),
-                                                  model.start_image_branch(img_d),
-                                                  tick("3 image graph launch", T["_t"][-1]), T["_t"].append(time.perf_counter())))
-        tick("4 sync wait", T["_t"][-1]); t = time.perf_counter()
-        f = torch.ones((lv.n, 1), dtype=torch.float32, device=dev)
-        st = ME.SparseTensor(f, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm); st._all_ones = True
-        tick("5 tensor", t); t = time.perf_counter()
-        F = model(st, img_d).F
-        tick("6 forward queue", t)
+        st = {}
+        def hook():
+            tick("1 geometry queue (pyramid_build)", t)
+            t1 = time.perf_counter()
+            model.start_image_branch(img_d, inputs_ready=True)
+            tick("2 image graph launch", t1)
+            st["t"] = time.perf_counter()
+        levels = ops.pyramid_from_points(xyz_d, voxel, 4, 0, inputs_ready=True, before_sync=hook)
+        tick("3 event wait + level objects", st["t"]); t = time.perf_counter()
+        cm = ME.CoordinateManager.from_levels(levels)
+        f = torch.ones((levels[0].n, 1), dtype=torch.float32, device=dev)
+        s = ME.SparseTensor(f, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm); s._all_ones = True
+        tick("4 tensor objects", t); t = time.perf_counter()
+        F = model(s, img_d).F
+        tick("5 forward queue (total)", t)
     torch.cuda.synchronize()
 for k in sorted(T):
-    if k != "_t": print(f"{k:28s} median {np.median(T[k][5:])*1e6:8.1f} us")
+    print(f"{k:36s} median {np.median(T[k][8:])*1e6:8.1f} us")
