@@ -47,6 +47,24 @@ def algorithmic_bytes(rec):
     return pairs * (rec["cin"] + rec["cout"]) * 4 + pairs * 8 + rec["kvol"] * rec["cin"] * rec["cout"] * 4, pairs
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
+    separate runs; read side doubled per the gfx950 FETCH_SIZE correction).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "no PMC profile committed"
+    ks = json.load(open(path))["kernels"]
+    key = "imf::" + kernel.replace(",", ", ")
+    if key not in ks:
+        return None, f"{key} not in {os.path.basename(path)}"
+    v = ks[key]
+    return v["hbm_bytes_fetch_x2"], (f"bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (raw FETCH {v['fetch_bytes_raw']} B, "
+                                     f"WRITE {v['write_bytes']} B, L2 hit {v['l2_hit_rate']}) from "
+                                     f"profiles/{os.path.basename(path)}; below the algorithmic bytes because "
+                                     f"feature rows are re-gathered from L2 / Infinity Cache, not HBM")
+
+
 def cpu_baseline(xyz, img, voxel, sd, seconds_budget=15.0):
     """The oracle (C hash-map geometry + torch-CPU gather-GEMM-scatter convolutions =
     MinkowskiEngine's CPU algorithm restated; dense parts are the torch-CPU ops the reference itself
@@ -170,8 +188,10 @@ def main():
         g = groups[dom]
         achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
         conv_ms = sum(v["ms"] for v in groups.values()) / args.steps
+        traffic, traffic_note = pmc_traffic(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_note": traffic_note,
                     "launches_per_step": g["n"] // args.steps,
                     "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),
                     "algorithmic_bytes_per_launch": g["bytes"] // g["n"],

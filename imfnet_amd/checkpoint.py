@@ -46,4 +46,6 @@ def load_checkpoint(path, map_location="cpu"):
     cfg = ckpt.get("config", None) if isinstance(ckpt, dict) else None
     if cfg is None:
         cfg = Config()
+    elif not hasattr(cfg, "model"):                    # plain dict / Namespace -> attribute access
+        cfg = Config(**(cfg if isinstance(cfg, dict) else vars(cfg)))
     return sd, cfg
