@@ -111,7 +111,8 @@ k_scan_block_sums(int32_t *block_sums, int nb, int32_t *m_out) {
 __global__ void __launch_bounds__(kScanThreads)
 k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ keys, int32_t *vals,
               int64_t n_static, const int32_t *__restrict__ n_dev,
-              const int32_t *__restrict__ block_offs, int32_t *coords_out, int32_t *first_idx) {
+              const int32_t *__restrict__ block_offs, int32_t *coords_out, int32_t *first_idx,
+              int32_t *bbox) {
   __shared__ int wsum[4];
   const int64_t n = n_dev ? (int64_t)*n_dev : n_static;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -135,6 +136,8 @@ k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ 
   int woff = 0;
   for (int q = 0; q < w; ++q) woff += wsum[q];
   int r = block_offs[blockIdx.x] + woff + inc - cnt;
+  int4 lo = make_int4(0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF);
+  int4 hi = make_int4(-0x7FFFFFFF - 1, -0x7FFFFFFF - 1, -0x7FFFFFFF - 1, -0x7FFFFFFF - 1);
 #pragma unroll
   for (int e = 0; e < kScanItems; ++e) {
     if (s[e] >= 0) {
@@ -148,18 +151,32 @@ k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ 
       if (first_idx) first_idx[r] = (int32_t)(base + e);
       vals[s[e]] = r;   // the table now maps voxel -> row
       ++r;
+      lo.x = min(lo.x, c.x); lo.y = min(lo.y, c.y); lo.z = min(lo.z, c.z); lo.w = min(lo.w, c.w);
+      hi.x = max(hi.x, c.x); hi.y = max(hi.y, c.y); hi.z = max(hi.z, c.z); hi.w = max(hi.w, c.w);
+    }
+  }
+  if (bbox) {   // bounding box of the level (b,x,y,z): wave reduction, then 8 atomics per wave
+    for (int o = 32; o > 0; o >>= 1) {
+      lo.x = min(lo.x, __shfl_down(lo.x, o, 64)); lo.y = min(lo.y, __shfl_down(lo.y, o, 64));
+      lo.z = min(lo.z, __shfl_down(lo.z, o, 64)); lo.w = min(lo.w, __shfl_down(lo.w, o, 64));
+      hi.x = max(hi.x, __shfl_down(hi.x, o, 64)); hi.y = max(hi.y, __shfl_down(hi.y, o, 64));
+      hi.z = max(hi.z, __shfl_down(hi.z, o, 64)); hi.w = max(hi.w, __shfl_down(hi.w, o, 64));
+    }
+    if (lane == 0 && lo.x != 0x7FFFFFFF) {
+      atomicMin(bbox + 0, lo.x); atomicMin(bbox + 1, lo.y); atomicMin(bbox + 2, lo.z); atomicMin(bbox + 3, lo.w);
+      atomicMax(bbox + 4, hi.x); atomicMax(bbox + 5, hi.y); atomicMax(bbox + 6, hi.z); atomicMax(bbox + 7, hi.w);
     }
   }
 }
 
 static int run_unique_tail(int32_t *slot_of, int32_t *block_sums, uint64_t *keys, int32_t *vals,
                            int64_t n_max, const int32_t *n_dev, int32_t *coords_out,
-                           int32_t *first_idx, int32_t *m_out, hipStream_t st) {
+                           int32_t *first_idx, int32_t *m_out, hipStream_t st, int32_t *bbox = nullptr) {
   const int nb = (int)div_up(n_max, kScanTile);
   k_flag_first<<<nb, kScanThreads, 0, st>>>(slot_of, vals, n_max, n_dev, block_sums);
   k_scan_block_sums<<<1, 256, 0, st>>>(block_sums, nb, m_out);
   k_emit_unique<<<nb, kScanThreads, 0, st>>>(slot_of, keys, vals, n_max, n_dev, block_sums,
-                                             coords_out, first_idx);
+                                             coords_out, first_idx, bbox);
   IMF_CHECK_LAUNCH("unique pipeline");
   return IMF_OK;
 }
@@ -268,6 +285,7 @@ k_init_tables(uint64_t *keys0, int32_t *vals0, int64_t capacity, int n_levels, s
               int32_t *meta) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 2 * n_levels) meta[i] = 0;
+  if (i < 8) meta[2 * n_levels + i] = i < 4 ? 0x7FFFFFFF : -0x7FFFFFFF - 1;   // level-0 bounding box
   if (i >= capacity) return;
   for (int l = 0; l < n_levels; ++l) {
     reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(keys0) + l * level_stride)[i] = kEmptyKey;
@@ -407,7 +425,7 @@ int imf_pyramid_build(const void *xyz, int xyz_is_f64, int64_t n, double voxel_s
                                                  (uint32_t)(cap - 1), slot_of, meta + 1);
   IMF_CHECK_LAUNCH("k_insert_points");
   int rc = run_unique_tail(slot_of, block_sums, levels_out[0].keys, levels_out[0].vals, n, nullptr,
-                           levels_out[0].coords, levels_out[0].first_idx, meta, st);
+                           levels_out[0].coords, levels_out[0].first_idx, meta, st, meta + 2 * n_levels);
   if (rc) return rc;
   for (int l = 1; l < n_levels; ++l) {
     k_insert_coords<<<nblk, 256, 0, st>>>(levels_out[l - 1].coords, meta + 2 * (l - 1), 1 << l,

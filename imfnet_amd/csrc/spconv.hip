@@ -989,18 +989,37 @@ k_conv_first_fused(const uint64_t *__restrict__ keys, const int32_t *__restrict_
   for (int i = tid; i < nw; i += 256) wl[i] = w[i];
   const long long row0 = (long long)blockIdx.x * kFirstRows;
   const int r = ksize >> 1;
-#pragma unroll 4
-  for (int j = 0; j < kFirstRows * 128 / 256; ++j) {
+  // 16 probes per thread, issued as independent batches: all first-slot key loads, then all value
+  // loads; only a collision (rare: the level-0 table is <= 25 % full) falls back to the probe loop.
+  constexpr int NP = kFirstRows * 128 / 256;
+  uint64_t want[NP], got[NP];
+  uint32_t hs[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
     const int idx = j * 256 + tid, lr = idx >> 7, k = idx & 127;
     const long long row = row0 + lr;
-    int found = -1;
+    want[j] = kEmptyKey;                               // "no probe": resolves to -1 below
+    hs[j] = 0;
     if (k < kvol && row < n) {
       const int4 c = reinterpret_cast<const int4 *>(coords)[row];
       const int dx = k % ksize - r, dy = (k / ksize) % ksize - r, dz = k / (ksize * ksize) - r;
       const int x = c.y + dx * ts, y = c.z + dy * ts, z = c.w + dz * ts;
-      if (coord_in_range(x, y, z)) found = hash_find(keys, vals, capmask, pack_key(c.x, x, y, z));
+      if (coord_in_range(x, y, z)) {
+        want[j] = pack_key(c.x, x, y, z);
+        hs[j] = hash64(want[j]) & capmask;
+      }
     }
-    nbr_l[idx] = found;
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) got[j] = keys[hs[j]];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    int found = -1;
+    if (want[j] != kEmptyKey) {
+      if (got[j] == want[j]) found = vals[hs[j]];
+      else if (got[j] != kEmptyKey) found = hash_find(keys, vals, capmask, want[j]);   // collision: slow path
+    }
+    nbr_l[j * 256 + tid] = found;
   }
   __syncthreads();
   constexpr int RPT = kFirstRows * COUT / 256;                     // rows per thread: 4 (cout 32) / 8 (64)
@@ -1033,6 +1052,96 @@ k_conv_first_fused(const uint64_t *__restrict__ keys, const int32_t *__restrict_
       float v = acc[q] * sc + sh;
       if (relu) v = fmaxf(v, 0.f);
       out[row * COUT + co] = v;
+    }
+  }
+}
+
+
+// ---- first layer on an occupancy bit grid (all-ones input feature) -----------------------------
+// util/misc.py:76-79 feeds the network a column of ones, so conv1 is "sum of the weight rows of the
+// occupied offsets".  Occupancy of a 5x5x5 neighbourhood is 25 five-bit windows of a dense bit grid
+// over the fragment's bounding box (0.7 MB for a 3DMatch fragment, L2-resident) instead of 125
+// dependent probes into a multi-MB hash table.  Per workgroup (64 voxels): the windows are expanded
+// into a 0/1 matrix A[64 x 128] in LDS and out = A . W runs on fp32 MFMA (exact: the products are
+// 1*w or 0*w, summed in ascending k) with the folded BatchNorm epilogue.
+struct GridDesc {
+  int b0, x0, y0, z0;      // origin (bounding-box min minus the kernel radius)
+  int nb, nx, ny, nz;      // extent in voxels (margins included)
+  int row_words;           // 32-bit words per x-row (>= nx/32 + 2: an unaligned window never leaves the row)
+};
+
+__device__ __forceinline__ long long grid_row(const GridDesc &g, int b, int y, int z) {
+  return ((((long long)(b - g.b0) * g.nz + (z - g.z0)) * g.ny + (y - g.y0)) * g.row_words);
+}
+
+__global__ void __launch_bounds__(256)
+k_bitgrid_fill(const int32_t *__restrict__ coords, long long n, uint32_t *grid, const GridDesc g) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+  const int bit = c.y - g.x0;
+  atomicOr(grid + grid_row(g, c.x, c.z, c.w) + (bit >> 5), 1u << (bit & 31));
+}
+
+constexpr int kBitsRows = 64;
+constexpr int kBitsLda = 130;    // 2*row + kslot distinct mod 32 => conflict-free A-fragment reads
+
+template <int COUT>
+__global__ void __launch_bounds__(256)
+k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_t *__restrict__ grid,
+                  const GridDesc g, int ksize, int kvol, const float *__restrict__ w,
+                  const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                  float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  float *A_l = lds_f;                                    // [64][kBitsLda]
+  float *W_l = lds_f + kBitsRows * kBitsLda;             // [128][COUT], rows >= kvol are zero
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const long long v0 = (long long)blockIdx.x * kBitsRows;
+  for (int i = tid; i < 128 * COUT; i += 256) W_l[i] = i < kvol * COUT ? w[i] : 0.f;
+  for (int i = tid; i < kBitsRows * kBitsLda; i += 256) A_l[i] = 0.f;
+  __syncthreads();
+  const int r = ksize >> 1, nyz = ksize * ksize;
+  for (int it = tid; it < kBitsRows * nyz; it += 256) {
+    const int v = it / nyz, yz = it - v * nyz;
+    if (v0 + v >= n) continue;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[v0 + v];
+    const int dy = yz % ksize - r, dz = yz / ksize - r;
+    const uint32_t *row = grid + grid_row(g, c.x, c.z + dy, c.w + dz);
+    const int bx = c.y - r - g.x0;                       // first bit of the window, >= 0 by construction
+    const int wi = bx >> 5, sh = bx & 31;
+    uint32_t bits = row[wi] >> sh;
+    if (sh + ksize > 32) bits |= row[wi + 1] << (32 - sh);
+    float *dst = A_l + v * kBitsLda + yz * ksize;
+    for (int dx = 0; dx < ksize; ++dx) dst[dx] = (bits >> dx) & 1u ? 1.f : 0.f;
+  }
+  __syncthreads();
+
+  constexpr int CBN = COUT / 16;                         // column blocks; wave w owns row block w
+  const int r16 = lane & 15, q4 = lane >> 4;
+  f32x4 acc[CBN];
+#pragma unroll
+  for (int cb = 0; cb < CBN; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float *arow = A_l + (wave * 16 + r16) * kBitsLda + q4;
+  const float *wcol = W_l + q4 * COUT + r16;
+#pragma unroll 4
+  for (int s = 0; s < 32; ++s) {
+    const float a = arow[4 * s];
+#pragma unroll
+    for (int cb = 0; cb < CBN; ++cb)
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wcol[4 * s * COUT + cb * 16], acc[cb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int cb = 0; cb < CBN; ++cb) {
+    const int col = cb * 16 + r16;
+    const float sc = scale ? scale[col] : 1.f, sh = shift ? shift[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long row = v0 + wave * 16 + q4 * 4 + e;
+      if (row < n) {
+        float v = acc[cb][e] * sc + sh;
+        if (relu) v = fmaxf(v, 0.f);
+        out[row * COUT + col] = v;
+      }
     }
   }
 }
@@ -1207,6 +1316,54 @@ int imf_conv_first_fused(const uint64_t *keys, const int32_t *vals, int64_t capa
     k_conv_first_fused<64><<<(unsigned)nb, 256, lds, st>>>(keys, vals, (uint32_t)(capacity - 1), coords, n, ts,
                                                           ksize, kvol, in, cin, w, scale, shift, relu, out);
   IMF_CHECK_LAUNCH("k_conv_first_fused");
+  return IMF_OK;
+}
+
+static bool grid_desc_from_bbox(const int32_t *bbox, int ksize, GridDesc &g, size_t &words) {
+  const int r = ksize >> 1;
+  g.b0 = bbox[0]; g.x0 = bbox[1] - r; g.y0 = bbox[2] - r; g.z0 = bbox[3] - r;
+  g.nb = bbox[4] - bbox[0] + 1;
+  g.nx = bbox[5] - bbox[1] + 1 + 2 * r; g.ny = bbox[6] - bbox[2] + 1 + 2 * r; g.nz = bbox[7] - bbox[3] + 1 + 2 * r;
+  if (g.nb <= 0 || g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
+  g.row_words = g.nx / 32 + 2;
+  const double w = (double)g.nb * g.nz * g.ny * g.row_words;
+  if (w > (double)(1ull << 28)) return false;            // > 1 GiB of grid: use the hash path
+  words = (size_t)w;
+  return true;
+}
+
+size_t imf_bitgrid_words(const int32_t *bbox, int ksize) {
+  GridDesc g;
+  size_t words = 0;
+  if (!bbox || (ksize != 3 && ksize != 5)) return 0;
+  return grid_desc_from_bbox(bbox, ksize, g, words) ? words : 0;
+}
+
+int imf_conv_first_bitgrid(const int32_t *coords, int64_t n, const int32_t *bbox, int ksize,
+                           uint32_t *grid, size_t grid_words, const float *w, int cout,
+                           const float *scale, const float *shift, int relu, float *out, void *stream) {
+  IMF_REQUIRE(coords && bbox && grid && w && out, "imf_conv_first_bitgrid: null pointer");
+  IMF_REQUIRE(ksize == 3 || ksize == 5, "imf_conv_first_bitgrid: ksize must be 3 or 5");
+  IMF_REQUIRE(cout == 32 || cout == 64, "imf_conv_first_bitgrid: cout=%d not in {32,64}", cout);
+  IMF_REQUIRE(n > 0, "imf_conv_first_bitgrid: n");
+  GridDesc g;
+  size_t words = 0;
+  IMF_REQUIRE(grid_desc_from_bbox(bbox, ksize, g, words) && words <= grid_words,
+              "imf_conv_first_bitgrid: bounding box too large for the provided grid");
+  hipStream_t st = (hipStream_t)stream;
+  IMF_CHECK_HIP(hipMemsetAsync(grid, 0, words * sizeof(uint32_t), st));
+  k_bitgrid_fill<<<(unsigned)div_up(n, 256), 256, 0, st>>>(coords, n, grid, g);
+  const int kvol = ksize * ksize * ksize;
+  const size_t lds = ((size_t)kBitsRows * kBitsLda + 128 * (size_t)cout) * sizeof(float);
+  const unsigned nb = (unsigned)div_up(n, kBitsRows);
+  if (cout == 32) {
+    k_conv_first_bits<32><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out);
+  } else {
+    IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_first_bits<64>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_conv_first_bits<64><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out);
+  }
+  IMF_CHECK_LAUNCH("k_conv_first_bits");
   return IMF_OK;
 }
 

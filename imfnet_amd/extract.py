@@ -28,7 +28,22 @@ def _as_device_points(xyz, device):
     return t.to(device, non_blocking=True).contiguous()
 
 
-def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=None, inputs_ready=False):
+def start_geometry(xyz, voxel_size, device, inputs_ready=False):
+    """Queue the geometry build of a fragment (upload included when xyz is a host array) and return
+    at once.  Handing the result to `sparse_tensor_from_points(geometry=...)` later lets the harness
+    build fragment i+1's voxel pyramid while fragment i's decoder is still running."""
+    on_host = not (torch.is_tensor(xyz) and xyz.is_cuda)
+    if on_host:                                       # upload on the geometry stream itself: in order
+        with torch.cuda.stream(ops.geometry_stream(torch.device(device))):
+            pts = _as_device_points(xyz, device)
+        inputs_ready = True
+    else:
+        pts = _as_device_points(xyz, device)
+    return ops.PyramidFuture(pts, voxel_size, 4, 0, inputs_ready=inputs_ready)
+
+
+def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=None, inputs_ready=False,
+                              geometry=None):
     """Voxelise raw points on the GPU.  Returns (SparseTensor with all-ones / gathered features,
     inds int32 CUDA tensor of each voxel's first point).
     The whole geometry (voxel hash + 3 coarser levels) is one library call on a dedicated
@@ -37,14 +52,11 @@ def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=N
     counts.  `inputs_ready=True` promises that a device-resident `xyz` is already complete (no
     pending producer on the current stream), which lets the geometry of fragment i+1 overlap the
     convolutions of fragment i."""
-    on_host = not (torch.is_tensor(xyz) and xyz.is_cuda)
-    if on_host:                                       # upload on the geometry stream itself: in order
-        with torch.cuda.stream(ops.geometry_stream(torch.device(device))):
-            pts = _as_device_points(xyz, device)
-        inputs_ready = True
-    else:
-        pts = _as_device_points(xyz, device)
-    levels = ops.pyramid_from_points(pts, voxel_size, 4, 0, inputs_ready=inputs_ready, before_sync=before_sync)
+    fut = geometry if geometry is not None else start_geometry(xyz, voxel_size, device, inputs_ready)
+    if before_sync is not None:
+        before_sync()
+    levels = fut.result()
+    pts = fut.xyz
     lv = levels[0]
     cm = ME.CoordinateManager.from_levels(levels)
     inds = lv.first_idx

@@ -126,7 +126,7 @@ class FusedPlan:
                                   kvol=rb.kvol, cin=cin, cout=a.cout, rb=rb, split=split, ev=ev, name=name,
                                   arena=self._trace_arena))
 
-    def run(self, x, fuse):
+    def run(self, x, fuse, after_fuse=None):
         """x: SparseTensor at tensor stride 1 (pyramid built); fuse(F8 [n8,C]) -> [n8,C] is the
         bottleneck fusion (torch).  Returns the [M, out] descriptor tensor."""
         m, L = self.model, self.L
@@ -240,11 +240,23 @@ class FusedPlan:
         if self.small_first:
             sc, sh = self.first_bn
             ones = getattr(x, "_all_ones", False)       # util/misc.py:76-79 occupancy feature
-            check(L.imf_conv_first_fused(lv[0].keys.data_ptr(), lv[0].vals.data_ptr(), lv[0].capacity,
-                                         lv[0].coords_buf.data_ptr(), n[0], 1, self.first_ksize,
-                                         None if ones else x.F.data_ptr(), x.F.shape[1],
-                                         self.first_kernel.data_ptr(), Ch[1], sc.data_ptr(), sh.data_ptr(), 0,
-                                         addr["e0a"], st), "imf_conv_first_fused")
+            bbox = getattr(lv[0], "bbox", None)
+            words = 0
+            if ones and bbox is not None and x.F.shape[1] == 1:
+                box = (C.c_int32 * 8)(*bbox)
+                words = L.imf_bitgrid_words(box, self.first_ksize)
+            if words:
+                grid = torch.empty(words, dtype=torch.int32, device=dev)
+                check(L.imf_conv_first_bitgrid(lv[0].coords_buf.data_ptr(), n[0], box, self.first_ksize,
+                                               grid.data_ptr(), words, self.first_kernel.data_ptr(), Ch[1],
+                                               sc.data_ptr(), sh.data_ptr(), 0, addr["e0a"], st),
+                      "imf_conv_first_bitgrid")
+            else:
+                check(L.imf_conv_first_fused(lv[0].keys.data_ptr(), lv[0].vals.data_ptr(), lv[0].capacity,
+                                             lv[0].coords_buf.data_ptr(), n[0], 1, self.first_ksize,
+                                             None if ones else x.F.data_ptr(), x.F.shape[1],
+                                             self.first_kernel.data_ptr(), Ch[1], sc.data_ptr(), sh.data_ptr(),
+                                             0, addr["e0a"], st), "imf_conv_first_fused")
 
         def go(entries):
             for name, rb, a_key, c_a, o_key, b_key, c_b, r_key in entries:
@@ -255,5 +267,7 @@ class FusedPlan:
         f8 = farena[foff["e3c"]:foff["e3c"] + sizes["e3c"]].view(n[3], Ch[4])   # bottleneck fusion (torch)
         fused = fuse(f8).contiguous()
         addr["fused"] = fused.data_ptr()
+        if after_fuse is not None:      # harness hook: e.g. queue the NEXT fragment's geometry / image branch
+            after_fuse()                # now, so it runs under this fragment's decoder
         go(sched[n_enc:])                                                       # decoder + head
         return F

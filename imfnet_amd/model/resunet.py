@@ -72,6 +72,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._plan = None                 # arena executor (model/plan.py), built lazily in eval mode
         self._pending_image = None        # (image, features, kv, event) queued by start_image_branch
         self._fuse_done = None            # event: last fusion finished reading the image branch outputs
+        self.after_fusion_hook = None     # one-shot callable run once the bottleneck fusion is queued
         self._side = {}                   # device -> side stream
         self._img_graph = {}              # (device, shape) -> captured image branch
 
@@ -206,7 +207,8 @@ class ResUNet2(ME.MinkowskiNetwork):
         if self._plan is None:
             from .plan import FusedPlan
             self._plan = FusedPlan(self)
-        return x._like(self._plan.run(x, fuse))
+        hook, self.after_fusion_hook = self.after_fusion_hook, None      # one-shot
+        return x._like(self._plan.run(x, fuse, hook))
 
     def forward_layers(self, x, image):
         """Op-by-op order of the reference's forward (resunet.py:163-235)."""

@@ -90,12 +90,13 @@ class _Addr:
 class ArenaLevel(Level):
     """A Level whose buffers live inside one arena built by imf_pyramid_build (raw addresses; the
     coords / first_idx tensors are materialised as views only when somebody asks for them)."""
-    __slots__ = ("arena", "_desc", "_coords_view", "_first_view")
+    __slots__ = ("arena", "_desc", "_coords_view", "_first_view", "bbox")
 
     def __init__(self, arena, desc, n_dev):
         Level.__init__(self, _Addr(desc.coords), n_dev, _Addr(desc.keys), _Addr(desc.vals), desc.capacity,
                        desc.tensor_stride, _Addr(desc.first_idx) if desc.first_idx else None)
         self.arena, self._desc, self._coords_view, self._first_view = arena, desc, None, None
+        self.bbox = None              # level 0: [min b,x,y,z, max b,x,y,z] (host ints)
 
     def _view(self, addr, count):
         off = addr - self.arena.data_ptr()
@@ -131,52 +132,74 @@ def geometry_stream(device):
     return s
 
 
+class PyramidFuture:
+    """Geometry of one fragment queued on the geometry stream; `result()` blocks on ITS event only."""
+
+    def __init__(self, xyz, voxel_size, n_levels=4, batch_index=0, inputs_ready=False):
+        if xyz.dtype not in (torch.float64, torch.float32):
+            raise ImfError(f"xyz must be float64/float32, got {xyz.dtype}")
+        _req(xyz, xyz.dtype, "xyz", 2)
+        n, dev = xyz.shape[0], xyz.device
+        if n == 0 or xyz.shape[1] != 3:
+            raise ImfError(f"xyz must be [N>0, 3], got {tuple(xyz.shape)}")
+        L = _lib.lib()
+        self.n_levels, self.dev = n_levels, dev
+        main = torch.cuda.current_stream(dev)
+        gs = geometry_stream(dev)
+        if not inputs_ready:
+            gs.wait_stream(main)
+        pool = _PINNED.setdefault((dev, n_levels), [])
+        self.host = pool.pop() if pool else torch.empty(2 * n_levels + 8, dtype=torch.int32).pin_memory()
+        self.descs = (LevelDesc * n_levels)()
+        with torch.cuda.stream(gs):
+            nbytes = L.imf_pyramid_arena_bytes(n, n_levels)
+            self.arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.meta = torch.empty(2 * n_levels + 8, dtype=torch.int32, device=dev)   # counts/flags + bbox
+            check(L.imf_pyramid_build(xyz.data_ptr(), int(xyz.dtype == torch.float64), n, float(voxel_size),
+                                      int(batch_index), n_levels, self.arena.data_ptr(), nbytes,
+                                      self.meta.data_ptr(), self.descs, gs.cuda_stream), "imf_pyramid_build")
+            self.host.copy_(self.meta, non_blocking=True)
+            self.ev = torch.cuda.Event()
+            self.ev.record(gs)
+        xyz.record_stream(gs)
+        self.xyz = xyz
+        self._levels = None
+
+    def result(self):
+        """Wait for the row counts (the one host wait of the fragment) and hand the levels to the
+        CURRENT stream."""
+        if self._levels is not None:
+            return self._levels
+        n_levels = self.n_levels
+        self.ev.synchronize()
+        main = torch.cuda.current_stream(self.dev)
+        main.wait_event(self.ev)
+        self.arena.record_stream(main)
+        self.meta.record_stream(main)
+        counts = self.host.tolist()
+        _PINNED[(self.dev, n_levels)].append(self.host)
+        self.host = None
+        levels = []
+        for i in range(n_levels):
+            if counts[2 * i + 1] != 0:
+                raise ImfError("voxelize: a coordinate fell outside [-2^17, 2^17) voxels (or was NaN)")
+            lv = ArenaLevel(self.arena, self.descs[i], self.meta[2 * i:2 * i + 2])
+            lv.n = int(counts[2 * i])
+            levels.append(lv)
+        levels[0].bbox = counts[2 * n_levels:2 * n_levels + 8]
+        self._levels = levels
+        return levels
+
+
 def pyramid_from_points(xyz, voxel_size, n_levels=4, batch_index=0, inputs_ready=False, before_sync=None):
     """Voxelise + coarse levels in ONE library call on the geometry stream, then one event
     synchronisation for the row counts.  xyz: CUDA [N,3] f64/f32 tensor.  `inputs_ready`: xyz is
     known to be complete (e.g. resident data), so the geometry stream need not wait for the main one.
     Returns the list of levels (n set) -- buffers are safe to use on the current stream."""
-    if xyz.dtype not in (torch.float64, torch.float32):
-        raise ImfError(f"xyz must be float64/float32, got {xyz.dtype}")
-    _req(xyz, xyz.dtype, "xyz", 2)
-    n, dev = xyz.shape[0], xyz.device
-    if n == 0 or xyz.shape[1] != 3:
-        raise ImfError(f"xyz must be [N>0, 3], got {tuple(xyz.shape)}")
-    L = _lib.lib()
-    main = torch.cuda.current_stream(dev)
-    gs = geometry_stream(dev)
-    if not inputs_ready:
-        gs.wait_stream(main)
-    host = _PINNED.get((dev, n_levels))
-    if host is None:
-        host = _PINNED[(dev, n_levels)] = torch.empty((n_levels, 2), dtype=torch.int32).pin_memory()
-    descs = (LevelDesc * n_levels)()
-    with torch.cuda.stream(gs):
-        nbytes = L.imf_pyramid_arena_bytes(n, n_levels)
-        arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        meta = torch.empty((n_levels, 2), dtype=torch.int32, device=dev)
-        check(L.imf_pyramid_build(xyz.data_ptr(), int(xyz.dtype == torch.float64), n, float(voxel_size),
-                                  int(batch_index), n_levels, arena.data_ptr(), nbytes, meta.data_ptr(),
-                                  descs, gs.cuda_stream), "imf_pyramid_build")
-        host.copy_(meta, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(gs)
-    xyz.record_stream(gs)
+    fut = PyramidFuture(xyz, voxel_size, n_levels, batch_index, inputs_ready)
     if before_sync is not None:
         before_sync()
-    ev.synchronize()                                  # the one host wait of the fragment
-    main.wait_event(ev)
-    arena.record_stream(main)
-    meta.record_stream(main)
-    counts = host.tolist()
-    levels = []
-    for i in range(n_levels):
-        if counts[i][1] != 0:
-            raise ImfError("voxelize: a coordinate fell outside [-2^17, 2^17) voxels (or was NaN)")
-        lv = ArenaLevel(arena, descs[i], meta[i])
-        lv.n = int(counts[i][0])
-        levels.append(lv)
-    return levels
+    return fut.result()
 
 
 class Rulebook:
@@ -387,4 +410,27 @@ def conv_first_fused(level, feat, kernel, ksize, scale=None, shift=None, relu=Fa
                                           level.coords_buf.data_ptr(), level.n, level.ts, ksize, _ptr(feat),
                                           cin, k.data_ptr(), cout, _ptr(scale), _ptr(shift), int(bool(relu)),
                                           out.data_ptr(), _stream()), "imf_conv_first_fused")
+    return out
+
+
+def conv_first_bitgrid(level, kernel, ksize, scale=None, shift=None, relu=False):
+    """First-layer conv of the all-ones feature on an occupancy bit grid (imf_conv_first_bitgrid).
+    Returns None when the level has no bounding box or the box is too large (use conv_first_fused)."""
+    bbox = getattr(level, "bbox", None)
+    if bbox is None:
+        return None
+    k = _req(kernel.detach().contiguous(), torch.float32, "kernel", 3)
+    kvol, cin, cout = k.shape
+    if cin != 1 or kvol != ksize ** 3:
+        raise ImfError("conv_first_bitgrid: needs a [ksize^3, 1, cout] kernel")
+    L = _lib.lib()
+    box = (C.c_int32 * 8)(*bbox)
+    words = L.imf_bitgrid_words(box, ksize)
+    if words == 0:
+        return None
+    grid = torch.empty(words, dtype=torch.int32, device=k.device)
+    out = torch.empty((level.n, cout), dtype=torch.float32, device=k.device)
+    check(L.imf_conv_first_bitgrid(level.coords_buf.data_ptr(), level.n, box, ksize, grid.data_ptr(), words,
+                                   k.data_ptr(), cout, _ptr(scale), _ptr(shift), int(bool(relu)),
+                                   out.data_ptr(), _stream()), "imf_conv_first_bitgrid")
     return out

@@ -82,8 +82,10 @@ int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_
 
 /* One-call geometry: imf_voxelize followed by (n_levels - 1) imf_downsample (tensor strides 2, 4,
  * ...), all tables and scratch carved out of ONE caller-provided arena, row counts written to
- * meta[level][0] (meta[level][1] = error flag; the call zeroes meta).  18 kernel launches, no host
- * synchronisation.  levels_out [host] receives the device addresses inside the arena.
+ * meta[level][0] (meta[level][1] = error flag), followed by the bounding box of level 0:
+ * meta[2*n_levels + 0..3] = min (b,x,y,z), [4..7] = max -- meta is int32[2*n_levels + 8], initialised
+ * by the call.  18 kernel launches, no host synchronisation.  levels_out [host] receives the device
+ * addresses inside the arena.
  * Replaces: util/misc.py:82-95 and the implicit cm.stride() chain of model/resunet.py:54-85. */
 typedef struct imf_level {
   int32_t *coords;       /* [cap_rows, 4] rows (b,x,y,z), first-occurrence order                 */
@@ -209,6 +211,18 @@ int imf_conv_first_fused(const uint64_t *keys, const int32_t *vals, int64_t capa
                          const int32_t *coords, int64_t n, int ts, int ksize, const float *in, int cin,
                          const float *w /* [kvol][cin][cout], unpacked */, int cout,
                          const float *scale, const float *shift, int relu, float *out, void *stream);
+
+/* First-layer convolution for the all-ones occupancy feature (util/misc.py:76-79) on a dense
+ * occupancy BIT GRID over the level's bounding box (bbox [host] = min b,x,y,z, max b,x,y,z as
+ * imf_pyramid_build reports it): 25 five-bit windows per voxel instead of 125 hash probes, then
+ * out = occupancy . W on fp32 MFMA.  grid: caller scratch of >= imf_bitgrid_words(bbox, ksize)
+ * uint32 words (0 = box too large: use imf_conv_first_fused).  Tensor stride 1.
+ * Replaces: conv1 + norm1 of model/resunet.py:42-49,168-169 (kernel map included). */
+size_t imf_bitgrid_words(const int32_t *bbox /* [host] */, int ksize);
+int imf_conv_first_bitgrid(const int32_t *coords, int64_t n, const int32_t *bbox /* [host] */, int ksize,
+                           uint32_t *grid, size_t grid_words, const float *w /* [kvol][1][cout] */,
+                           int cout, const float *scale, const float *shift, int relu, float *out,
+                           void *stream);
 
 /* Measurement helpers (bench.py): HIP events on the caller's stream. */
 void *imf_event_create(void);

@@ -271,6 +271,27 @@ def test_conv_first_fused(ops, geom_s5, cin, cout, ks):
         assert torch.equal(got, got1)
 
 
+@pytest.mark.parametrize("cout,ks,scale,vs", [(32, 5, 1.0, 0.05), (32, 3, 1.0, 0.05), (64, 5, 1.0, 0.05),
+                                               (32, 5, 1.7, 0.025)])
+def test_conv_first_bitgrid(ops, clouds, cout, ks, scale, vs):
+    """Occupancy bit-grid first layer (all-ones input) == oracle sparse conv over the k-offset table;
+    the pyramid build reports the level-0 bounding box it needs."""
+    xyz = clouds[0].astype(np.float64) * scale
+    levels = ops.pyramid_from_points(torch.as_tensor(xyz).to(DEV), vs, 4)
+    c_ref, _ = O.voxelize(xyz, vs)
+    assert levels[0].bbox[:4] == [0] + c_ref[:, 1:].min(0).tolist()
+    assert levels[0].bbox[4:] == [0] + c_ref[:, 1:].max(0).tolist()
+    nbr_ref = O.rulebook(c_ref, c_ref, 1, ks)
+    w = _rand((ks ** 3, 1, cout), 61, 0.1)
+    sc, sh = _rand((cout,), 62).abs() + 0.5, _rand((cout,), 63)
+    got = ops.conv_first_bitgrid(levels[0], w.to(DEV), ks, sc.to(DEV), sh.to(DEV), relu=True)
+    assert got is not None
+    ref = torch.relu(O.spconv(torch.ones(len(c_ref), 1), w, nbr_ref) * sc + sh)
+    assert (got.cpu() - ref).abs().max() < 2e-5
+    fused = ops.conv_first_fused(levels[0], None, w.to(DEV), ks, sc.to(DEV), sh.to(DEV), relu=True)
+    assert (got - fused).abs().max() < 2e-5
+
+
 def test_spconv_argument_errors(ops, geom_s5):
     from imfnet_amd import ImfError
     cm, g = geom_s5

@@ -26,8 +26,9 @@ cases = [  # name, rulebook, cin, cout, rows_in
     ("k3@8 256->256", cm.conv_rulebook(8, 3, 1), 256, 256, n[3]),
     ("up@4 256->128", cm.transpose_rulebook(8, 3, 2), 256, 128, n[3]),
 ]
-variants = [("v0 auto", dict(variant=0)), ("v0 s1", dict(variant=0, split_k=1)), ("v3 auto", dict(variant=3)), ("v3 s1", dict(variant=3, split_k=1)),
-            ("v3 s2", dict(variant=3, split_k=2)), ("v3 s4", dict(variant=3, split_k=4))]
+variants = [("v0 auto", dict(variant=0)), ("v0 s1", dict(variant=0, split_k=1)), ("v0 s2", dict(variant=0, split_k=2)),
+            ("v0 s3", dict(variant=0, split_k=3)), ("v0 s4", dict(variant=0, split_k=4)), ("v0 s6", dict(variant=0, split_k=6)),
+            ("v0 s8", dict(variant=0, split_k=8))]
 g = torch.Generator().manual_seed(0)
 for name, rb, cin, cout, rows in cases:
     f = torch.randn(rows, cin, generator=g).to(dev)
