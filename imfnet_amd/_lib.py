@@ -32,6 +32,7 @@ class ConvArgs(C.Structure):
         ("out", C.c_void_p),
         ("split_k", C.c_int32), ("variant", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("tickets", C.c_void_p),
         ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p),
     ]
 

@@ -95,6 +95,8 @@ class FusedPlan:
         conv_args("final", m.final, l2norm=bool(m.normalize_feature))
         self.first_ksize = m.conv1.kernel_size
         self._trace_arena = None
+        self._tickets = 0
+        self.fused_reduce = False
         self._side = {}
 
     # -------------------------------------------------------------------------------------------
@@ -113,6 +115,7 @@ class FusedPlan:
         split = self.L.imf_spconv_auto_split(rb.n_slots, a.cout, rb.max_active)
         a.split_k = split
         a.workspace, a.workspace_bytes = (ws[0] or None, ws[1]) if split > 1 else (None, 0)
+        a.tickets = (self._tickets or None) if (split > 1 and self.fused_reduce) else None
         ev = None
         if ops.TRACE is not None:
             ev = ops._Ev()
@@ -221,12 +224,19 @@ class FusedPlan:
             for sfx in "abc":
                 sizes[f"d{i}{sfx}"] = n[i] * dec_ch[i]
         sizes["head"] = n[0] * T[1]
-        ws_floats = 0
+        ws_floats, n_tickets = 0, 0
         for name, rb, *_ in sched:
             cout = self.convs[name][0].cout
             sp = L.imf_spconv_auto_split(rb.n_slots, cout, rb.max_active)
             if sp > 1:
                 ws_floats = max(ws_floats, sp * rb.n_slots * cout)
+                n_tickets = max(n_tickets, rb.n_slots // TILE_ROWS * max(1, cout // 32))
+        # arrival counters of the optional in-kernel split-K combine (measured SLOWER on MI355X than
+        # the second launch: every partition pays an agent-scope release = L2 write-back; 1.91 vs
+        # 1.60 ms/fragment), zeroed once per fragment and left zero by every launch
+        if self.fused_reduce:
+            tickets = torch.zeros(max(1, n_tickets), dtype=torch.int32, device=dev)
+            self._tickets = tickets.data_ptr()
         farena = torch.empty(sum(sizes.values()) + ws_floats, dtype=torch.float32, device=dev)
         base, off, addr, foff = farena.data_ptr(), 0, {}, {}
         for name, cnt in sizes.items():

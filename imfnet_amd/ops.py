@@ -341,7 +341,7 @@ def pack_weights(kernel):
 
 
 def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual=None,
-           relu=False, l2norm=False, out=None, split_k=0, variant=0):
+           relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False):
     """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd."""
     _req(in_a, torch.float32, "in_a", 2)
     if in_b is not None:
@@ -367,6 +367,9 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
         nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=in_a.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+        if fused_reduce and variant == 0:
+            tk = torch.zeros(rb.n_slots // TILE_ROWS * max(1, cout // 32), dtype=torch.int32, device=in_a.device)
+            a.tickets = tk.data_ptr()
     if w_packed.numel() != rb.kvol * (a.c_a + a.c_b) * cout:
         raise ImfError(f"packed weight has {w_packed.numel()} floats, expected "
                        f"{rb.kvol}x{a.c_a + a.c_b}x{cout}")

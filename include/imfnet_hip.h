@@ -173,6 +173,9 @@ typedef struct imf_conv_args {
                              4 / 5 = barrier-free register kernel, 32 / 16 rows per wavefront    */
   void *workspace;        /* split-K partial sums; NULL allowed iff split_k resolves to 1          */
   size_t workspace_bytes; /* >= imf_spconv_workspace_bytes(n_slots, cout, split)                  */
+  int32_t *tickets;       /* optional: int32[n_tiles * n_slabs] arrival counters, ZERO on entry (left zero on
+                             exit): with split_k > 1 the last partition to finish a tile reduces it inside
+                             the same launch (agent-scope release/acquire) -- no second kernel            */
   void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded on `stream` immediately around the
                               main MFMA kernel (not the split-K reduce): live roofline timing     */
 } imf_conv_args;

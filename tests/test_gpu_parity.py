@@ -172,7 +172,7 @@ def _rb_and_ref(cm, g, which):
     return cm.conv_rulebook(1, 1, 1), None, len(g.levels[0])
 
 
-@pytest.mark.parametrize("mode", ["auto", "split1", "split5", "simple", "wave", "wave_split3", "c", "c_split3",
+@pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple", "wave", "wave_split3", "c", "c_split3",
                                   "reg2", "reg1", "reg2_split3"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
@@ -184,11 +184,12 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
     fa, fb = _rand((n_in, ca), 10), (_rand((n_in, cb), 11) if cb else None)
     w = _rand((kvol, ca + cb, cout), 12, 1.0 / np.sqrt(kvol * (ca + cb)))
     kw = {"auto": {}, "split1": {"split_k": 1}, "split5": {"split_k": 5}, "simple": {"variant": 1},
+          "split5_fused": {"split_k": 5, "fused_reduce": True},
           "wave": {"variant": 2, "split_k": 1}, "wave_split3": {"variant": 2, "split_k": 3},
           "c": {"variant": 3, "split_k": 1}, "c_split3": {"variant": 3, "split_k": 3},
           "reg2": {"variant": 4, "split_k": 1}, "reg1": {"variant": 5, "split_k": 1},
           "reg2_split3": {"variant": 4, "split_k": 3}}[mode]
-    if mode in ("split5", "wave_split3", "c_split3", "reg2_split3") and kvol == 1:
+    if mode in ("split5", "split5_fused", "wave_split3", "c_split3", "reg2_split3") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")
     out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV)), cout, rb,
                      in_b=None if fb is None else fb.to(DEV), **kw).cpu()
@@ -238,6 +239,10 @@ def test_spconv_deterministic(ops, geom_s5):
         a = ops.spconv(f, wp, 64, rb, **kw)
         b = ops.spconv(f, wp, 64, rb, **kw)
         assert torch.equal(a, b)
+    # in-kernel combine == two-pass combine, bit for bit, and stable over many launches
+    ref = ops.spconv(f, wp, 64, rb, split_k=6, fused_reduce=False)
+    for _ in range(20):
+        assert torch.equal(ops.spconv(f, wp, 64, rb, split_k=6, fused_reduce=True), ref)
 
 
 @pytest.mark.parametrize("cin,cout,ks", [(1, 32, 5), (1, 32, 3), (3, 32, 3), (4, 64, 3)])
