@@ -75,6 +75,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self.after_fusion_hook = None     # one-shot callable run once the bottleneck fusion is queued
         self._side = {}                   # device -> side stream
         self._img_graph = {}              # (device, shape) -> captured image branch
+        self._fusion_graph = {}           # (row bucket, stream, kv buffer) -> captured fusion block
 
     # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
     def _invalidate(self):
@@ -82,6 +83,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._folded = None
         self._pending_image = None
         self._img_graph = {}
+        self._fusion_graph = {}
 
     def _apply(self, fn, *a, **k):
         self._invalidate()
@@ -191,11 +193,23 @@ class ResUNet2(ME.MinkowskiNetwork):
         if image_feat.device != x.F.device:
             raise ME.ImfError("image and sparse tensor live on different devices")
 
+        graph_io = None
+        if kv is not None and image_feat.shape[0] == 1 and not os.environ.get("IMFNET_NO_GRAPH"):
+            # bottleneck fusion as a captured hipGraph per 128-row bucket of stride-8 voxels: the block's
+            # input IS block4's output buffer and its output IS conv4_tr's input (no copies); rows
+            # beyond n8 hold stale finite values and are never read (every op of the block is row-local)
+            graph_io = lambda n8: self._fusion_graph_for(n8, kv)                      # noqa: E731
+
         def fuse(f8):                                                                 # :189
             cur = torch.cuda.current_stream(f8.device)
             cur.wait_event(ev)                            # join the image branch
             image_feat.record_stream(cur)
-            if kv is not None and image_feat.shape[0] == 1:
+            g = self._fusion_graph.get(self._fusion_key(f8.shape[0], kv)) if graph_io is not None else None
+            if g is not None and g[1].data_ptr() == f8.data_ptr():
+                kv.record_stream(cur)
+                g[0].replay()
+                out = g[2][: f8.shape[0]]
+            elif kv is not None and image_feat.shape[0] == 1:
                 kv.record_stream(cur)
                 out = self._fusion_fast(f8, kv[0])
             else:
@@ -208,7 +222,7 @@ class ResUNet2(ME.MinkowskiNetwork):
             from .plan import FusedPlan
             self._plan = FusedPlan(self)
         hook, self.after_fusion_hook = self.after_fusion_hook, None      # one-shot
-        return x._like(self._plan.run(x, fuse, hook))
+        return x._like(self._plan.run(x, fuse, hook, fusion_input=graph_io))
 
     def forward_layers(self, x, image):
         """Op-by-op order of the reference's forward (resunet.py:163-235)."""
@@ -233,6 +247,34 @@ class ResUNet2(ME.MinkowskiNetwork):
         if self.normalize_feature:
             return out._like(out.F / torch.norm(out.F, p=2, dim=1, keepdim=True))
         return out
+
+    def _fusion_key(self, n8, kv):
+        return ((n8 + 127) // 128 * 128, torch.cuda.current_stream(kv.device).cuda_stream, kv.data_ptr())
+
+    def _fusion_graph_for(self, n8, kv):
+        """(graph, static_in [bucket,C], static_out [bucket,C]) for this row bucket on the current
+        stream, captured on first use; None if capture is unavailable."""
+        key = self._fusion_key(n8, kv)
+        g = self._fusion_graph.get(key)
+        if g is None:
+            try:
+                C4 = self.CHANNELS[4]
+                static_in = torch.zeros((key[0], C4), dtype=torch.float32, device=kv.device)
+                with torch.no_grad():
+                    for _ in range(2):
+                        self._fusion_fast(static_in, kv[0])
+                    torch.cuda.current_stream(kv.device).synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        static_out = self._fusion_fast(static_in, kv[0])
+                g = (graph, static_in, static_out)
+            except Exception as e:                       # noqa: BLE001
+                import warnings
+                warnings.warn(f"imfnet_amd: fusion hipGraph capture failed ({e}); running eagerly")
+                torch.cuda.synchronize()
+                g = False
+            self._fusion_graph[key] = g
+        return g or None
 
     def _fusion_fast(self, x, kv):
         """attention_fusion.py:132-154 for one image, single head, depth 0, with the image-only half
