@@ -44,6 +44,12 @@ class LevelDesc(C.Structure):
                 ("tensor_stride", C.c_int32)]
 
 
+class FusionWeights(C.Structure):
+    """struct imf_fusion_weights (include/imfnet_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "wq_p", "wo_p", "bo", "ln2_g", "ln2_b", "w1_p", "b1",
+                                          "w2_p", "b2")]
+
+
 _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/imfnet_hip.h declares
@@ -70,6 +76,7 @@ SIGNATURES = {
     "imf_spconv_workspace_bytes": (_Z, [_L, _I, _I]),
     "imf_spconv_fwd": (_I, [C.POINTER(ConvArgs), _P]),
     "imf_spconv_small_cin": (_I, [_P, _I, _P, _I, _I, _P, _L, _L, _P, _P, _I, _P, _P]),
+    "imf_fusion_attention": (_I, [_P, _L, _P, _P, _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P]),
     "imf_bitgrid_words": (_Z, [_P, _I]),
     "imf_conv_first_bitgrid": (_I, [_P, _L, _P, _I, _P, _Z, _P, _I, _P, _P, _I, _P, _P]),
     "imf_conv_first_fused": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P]),

@@ -1,0 +1,266 @@
+// Bottleneck fusion block (model/attention_fusion.py:132-154 with depth 0, one head):
+//   x  = Attn(LN(x), ctx = LN(img tokens)) + x        q: 256->128, softmax over the image tokens, out 128->256
+//   x  = FF(LN(x)) + x                                 256 -> 2 x 1024 (GEGLU, exact-erf GELU) -> 256
+// as ONE kernel.  In PyTorch this is 15 launches of ~5 us each on 1 k rows (launch-latency bound,
+// 0.12 ms per fragment); here a workgroup of 8 wavefronts owns 16 point rows, keeps every
+// intermediate (LN, q, scores, probabilities, attention output, hidden) in LDS and walks the six
+// GEMMs on fp32 MFMA with the N dimension split over the waves.  All weight matrices -- and the
+// image-dependent K^T / V, packed once per fragment on the image-branch stream -- are in the same
+// fragment-major layout as the convolution weights (imf_pack_weights with kvol = 1), so every B
+// fragment is one coalesced float4 per lane.  Deterministic (fixed summation order), fp32 throughout.
+#include "common.h"
+
+namespace imf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFD = 256;     // point feature dim (CHANNELS[4])
+constexpr int kFQ = 128;     // attention inner dim
+constexpr int kFH = 1024;    // GEGLU hidden (dim * 4)
+constexpr int kFRows = 16;
+
+struct FusionParams {
+  const float *x;
+  long long n;
+  const float *ktp, *vp;     // packed K^T [kFQ x tokp] and V [tokp x kFQ]
+  int ntok, tokp;            // valid tokens, padded to a multiple of 64
+  float scale;
+  const float *ln1g, *ln1b, *wq, *wo, *bo, *ln2g, *ln2b, *w1, *b1, *w2, *b2;
+  float *out;
+};
+
+// float4 holding the B fragments of MFMA steps 4u'..4u'+3 (u = 16-channel step) for column block c
+__device__ __forceinline__ const float4 *bfrag(const float *packed, int ncc, int u, int c, int lane) {
+  const int y = c >> 2, cb = c & 3, cc = u >> 2, j = u & 3;
+  return reinterpret_cast<const float4 *>(packed) + ((((long long)y * ncc + cc) * 4 + j) * 4 + cb) * 64 + lane;
+}
+
+// acc[i] += A[16 x K] . B[K x 16] for NC column blocks cblk[i]; A in LDS (row stride lda, lda % 4 == 0).
+// The B fragments come straight from L2 (each is used by exactly one wave of one workgroup), so the
+// loop is a register software pipeline D steps deep: without it every 16-channel step exposes a full
+// L2 round trip (measured: 110 us for the whole block vs ~35 with the pipeline).  K/16 % D == 0.
+template <int NC, int D>
+__device__ __forceinline__ void gemm16(f32x4 (&acc)[NC], const float *A, int lda, int K, const float *packed,
+                                       const int (&cblk)[NC], int lane) {
+  const int r16 = lane & 15, q4 = lane >> 4, ncc = K / 64, U = K / 16;
+  const float *arow = A + r16 * lda + 4 * q4;
+  float4 bq[D][NC];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int i = 0; i < NC; ++i) bq[d][i] = *bfrag(packed, ncc, d, cblk[i], lane);
+#pragma unroll 1
+  for (int u0 = 0; u0 < U; u0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int u = u0 + d;
+      const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * u);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const float4 b = bq[d][i];
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[i], 0, 0, 0);
+      }
+      if (u + D < U) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) bq[d][i] = *bfrag(packed, ncc, u + D, cblk[i], lane);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// LayerNorm of row `row` (256 wide, eps 1e-5, biased variance) from src to dst; one wave, 4 floats / lane
+__device__ __forceinline__ void layer_norm_row(const float *src, float *dst, const float *g, const float *b, int lane) {
+  const float4 v = *reinterpret_cast<const float4 *>(src + 4 * lane);
+  const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / kFD);
+  const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+  const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / kFD);
+  const float rstd = rsqrtf(var + 1e-5f);
+  const float4 gg = *reinterpret_cast<const float4 *>(g + 4 * lane), bb = *reinterpret_cast<const float4 *>(b + 4 * lane);
+  *reinterpret_cast<float4 *>(dst + 4 * lane) =
+      make_float4(dx * rstd * gg.x + bb.x, dy * rstd * gg.y + bb.y, dz * rstd * gg.z + bb.z, dw * rstd * gg.w + bb.w);
+}
+
+constexpr int kLdX = kFD + 4;       // 260: (row * lda) % 64 == 4 * row -> conflict-free ds_read_b128 of A
+constexpr int kLdQ = kFQ + 4;       // 132
+constexpr int kLdG = kFH + 4;       // 1028
+constexpr int kMaxTokP = 320;
+constexpr int kLdS = kMaxTokP + 4;  // 324
+
+__global__ void __launch_bounds__(512)
+k_fusion_attention(const FusionParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *X = lds;                          // [16][260]  x, later y
+  float *N = X + kFRows * kLdX;            // [16][260]  LN(x), later LN(y)
+  float *S = N + kFRows * kLdX;            // [16][324]  scores -> probabilities
+  float *Q = S + kFRows * kLdS;            // [16][132]  q, later attention output
+  float *G = Q + kFRows * kLdQ;            // [16][1028] GEGLU hidden
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const long long row0 = (long long)blockIdx.x * kFRows;
+
+  // ---- load x, LayerNorm 1 (wave w: rows 2w, 2w+1) ------------------------------------------
+  for (int rr = 0; rr < 2; ++rr) {
+    const int r = 2 * wave + rr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < p.n) v = *reinterpret_cast<const float4 *>(p.x + (row0 + r) * kFD + 4 * lane);
+    *reinterpret_cast<float4 *>(X + r * kLdX + 4 * lane) = v;
+  }
+  __syncthreads();
+  for (int rr = 0; rr < 2; ++rr) layer_norm_row(X + (2 * wave + rr) * kLdX, N + (2 * wave + rr) * kLdX, p.ln1g, p.ln1b, lane);
+  __syncthreads();
+
+  // ---- q = LN(x) Wq^T : N = 128 -> column block = wave -----------------------------------------
+  {
+    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int cb[1] = {wave};
+    gemm16<1, 8>(acc, N, kLdX, kFD, p.wq, cb, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Q[(4 * q4 + r) * kLdQ + wave * 16 + r16] = acc[0][r];
+  }
+  __syncthreads();
+
+  // ---- scores = q K^T * scale : N = tokp (<= 320 -> <= 20 column blocks, round-robin over waves) --
+  const int ncb_s = p.tokp / 16;
+  for (int c = wave; c < ncb_s; c += 8) {
+    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int cb[1] = {c};
+    gemm16<1, 8>(acc, Q, kLdQ, kFQ, p.ktp, cb, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(4 * q4 + r) * kLdS + c * 16 + r16] = acc[0][r] * p.scale;
+  }
+  __syncthreads();
+
+  // ---- softmax over the valid tokens (wave w: rows 2w, 2w+1; 5 columns per lane) ----------------
+  for (int rr = 0; rr < 2; ++rr) {
+    float *srow = S + (2 * wave + rr) * kLdS;
+    float v[5], m = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < p.ntok) ? srow[c] : -3.0e38f;
+      m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < p.ntok) ? expf(v[i] - m) : 0.f;
+      s += v[i];
+    }
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = lane + 64 * i;
+      if (c < p.tokp) srow[c] = v[i] * inv;
+    }
+  }
+  __syncthreads();
+
+  // ---- o = P V : K = tokp, N = 128 -> column block = wave (written over q) -----------------------
+  {
+    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int cb[1] = {wave};
+    gemm16<1, 4>(acc, S, kLdS, p.tokp, p.vp, cb, lane);   // q was last read before the previous barrier
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Q[(4 * q4 + r) * kLdQ + wave * 16 + r16] = acc[0][r];
+  }
+  __syncthreads();
+
+  // ---- y = o Wo^T + bo + x : N = 256 -> 2 column blocks per wave; y replaces x in place -----------
+  {
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int cb[2] = {2 * wave, 2 * wave + 1};
+    gemm16<2, 8>(acc, Q, kLdQ, kFQ, p.wo, cb, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = cb[i] * 16 + r16;
+      const float bias = p.bo[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[(4 * q4 + r) * kLdX + col] += acc[i][r] + bias;   // each element owned by one lane
+    }
+  }
+  __syncthreads();
+  for (int rr = 0; rr < 2; ++rr) layer_norm_row(X + (2 * wave + rr) * kLdX, N + (2 * wave + rr) * kLdX, p.ln2g, p.ln2b, lane);
+  __syncthreads();
+
+  // ---- GEGLU: h = LN(y) W1^T + b1 (2048 wide); g = h[:1024] * gelu(h[1024:]) ---------------------
+  // wave w owns hidden columns [128 w, 128 w + 128): value blocks 8w..8w+7 and gate blocks 64+8w..
+  for (int half = 0; half < 2; ++half) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int c0 = 8 * wave + 4 * half;
+    const int cb[8] = {c0, c0 + 1, c0 + 2, c0 + 3, 64 + c0, 64 + c0 + 1, 64 + c0 + 2, 64 + c0 + 3};
+    gemm16<8, 2>(acc, N, kLdX, kFD, p.w1, cb, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = (c0 + i) * 16 + r16;
+      const float bv = p.b1[col], bg = p.b1[kFH + col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float val = acc[i][r] + bv, gate = acc[4 + i][r] + bg;
+        G[(4 * q4 + r) * kLdG + col] = val * (0.5f * gate * (1.f + erff(gate * 0.70710678118654752f)));
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- z = g W2^T + b2 + y : K = 1024, N = 256 -> 2 column blocks per wave ------------------------
+  {
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int cb[2] = {2 * wave, 2 * wave + 1};
+    gemm16<2, 8>(acc, G, kLdG, kFH, p.w2, cb, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = cb[i] * 16 + r16;
+      const float bias = p.b2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long row = row0 + 4 * q4 + r;
+        if (row < p.n) p.out[row * kFD + col] = acc[i][r] + bias + X[(4 * q4 + r) * kLdX + col];
+      }
+    }
+  }
+}
+
+}  // namespace imf
+
+using namespace imf;
+
+extern "C" {
+
+int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed, int n_tokens,
+                         int tokens_padded, const imf_fusion_weights *w, float scale, float *out, void *stream) {
+  IMF_REQUIRE(x && kt_packed && v_packed && w && out, "imf_fusion_attention: null pointer");
+  IMF_REQUIRE(w->ln1_g && w->ln1_b && w->wq_p && w->wo_p && w->bo && w->ln2_g && w->ln2_b && w->w1_p && w->b1 &&
+                  w->w2_p && w->b2, "imf_fusion_attention: null weight pointer");
+  IMF_REQUIRE(n > 0, "imf_fusion_attention: n");
+  IMF_REQUIRE(tokens_padded % 64 == 0 && tokens_padded <= kMaxTokP && n_tokens > 0 && n_tokens <= tokens_padded,
+              "imf_fusion_attention: tokens=%d padded=%d (padded %% 64 == 0, <= %d)", n_tokens, tokens_padded, kMaxTokP);
+  FusionParams p{x, (long long)n, kt_packed, v_packed, n_tokens, tokens_padded, scale, w->ln1_g, w->ln1_b,
+                 w->wq_p, w->wo_p, w->bo, w->ln2_g, w->ln2_b, w->w1_p, w->b1, w->w2_p, w->b2, out};
+  const size_t lds = (size_t)kFRows * (2 * kLdX + kLdS + kLdQ + kLdG) * sizeof(float);
+  static bool attr_set = false;   // idempotent; a benign race at worst sets it twice
+  if (!attr_set) {
+    IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_fusion_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  k_fusion_attention<<<(unsigned)div_up(n, kFRows), 512, lds, (hipStream_t)stream>>>(p);
+  IMF_CHECK_LAUNCH("k_fusion_attention");
+  return IMF_OK;
+}
+
+}  // extern "C"

@@ -129,7 +129,7 @@ class FusedPlan:
                                   kvol=rb.kvol, cin=cin, cout=a.cout, rb=rb, split=split, ev=ev, name=name,
                                   arena=self._trace_arena))
 
-    def run(self, x, fuse, after_fuse=None, fusion_input=None):
+    def run(self, x, fuse, after_fuse=None):
         """x: SparseTensor at tensor stride 1 (pyramid built); fuse(F8 [n8,C]) -> [n8,C] is the
         bottleneck fusion (torch).  Returns the [M, out] descriptor tensor."""
         m, L = self.model, self.L
@@ -245,12 +245,6 @@ class FusedPlan:
         ws = (base + 4 * off, 4 * ws_floats) if ws_floats else (0, 0)
         F = torch.empty((n[0], out_ch), dtype=torch.float32, device=dev)
         addr["F"], addr["x"] = F.data_ptr(), x.F.data_ptr()
-        f8_static = None
-        if fusion_input is not None:            # the fusion block's own (graph-captured) input buffer
-            g = fusion_input(n[3])
-            if g is not None:
-                f8_static = g[1]
-                addr["e3c"] = f8_static.data_ptr()
         self._trace_arena = iarena
 
         if self.small_first:
@@ -280,10 +274,7 @@ class FusedPlan:
                              c_b=c_b, residual=addr[r_key] if r_key else 0, ws=ws)
 
         go(sched[:n_enc])                                                       # encoder
-        if f8_static is not None:
-            f8 = f8_static[: n[3]]
-        else:
-            f8 = farena[foff["e3c"]:foff["e3c"] + sizes["e3c"]].view(n[3], Ch[4])   # bottleneck fusion (torch)
+        f8 = farena[foff["e3c"]:foff["e3c"] + sizes["e3c"]].view(n[3], Ch[4])   # bottleneck fusion
         fused = fuse(f8).contiguous()
         addr["fused"] = fused.data_ptr()
         if after_fuse is not None:      # harness hook: e.g. queue the NEXT fragment's geometry / image branch

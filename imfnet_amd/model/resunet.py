@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F_
 
+from .. import ops
 from .. import sparse as ME
 from .fusion import AttentionFusion
 from .image_encoder import ImageEncoder
@@ -70,12 +71,13 @@ class ResUNet2(ME.MinkowskiNetwork):
         self.img_encoder = ImageEncoder()
         self._folded = None
         self._plan = None                 # arena executor (model/plan.py), built lazily in eval mode
-        self._pending_image = None        # (image, features, kv, event) queued by start_image_branch
+        self._pending_image = None        # (image, features, kv, event, packed K/V) queued by start_image_branch
+        self._kv_packed = {}              # (device, image shape) -> packed K^T / V buffers
         self._fuse_done = None            # event: last fusion finished reading the image branch outputs
         self.after_fusion_hook = None     # one-shot callable run once the bottleneck fusion is queued
         self._side = {}                   # device -> side stream
         self._img_graph = {}              # (device, shape) -> captured image branch
-        self._fusion_graph = {}           # (row bucket, stream, kv buffer) -> captured fusion block
+        self._fw = None                   # packed weights of the fused fusion kernel
 
     # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
     def _invalidate(self):
@@ -83,7 +85,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._folded = None
         self._pending_image = None
         self._img_graph = {}
-        self._fusion_graph = {}
+        self._fw = None
 
     def _apply(self, fn, *a, **k):
         self._invalidate()
@@ -102,12 +104,20 @@ class ResUNet2(ME.MinkowskiNetwork):
         """Image encoder + the context half of the cross attention (LayerNorm + K/V projection of
         the image tokens): everything that depends on the image only."""
         feat = self.img_encoder(image)
-        kv = None
+        kv = kt = vp = None
         blk = self.attention_fusion.cross_attend_blocks[0]
         if blk.fn.heads == 1 and len(self.attention_fusion.layers) == 0:
             tokens = feat.flatten(2).transpose(1, 2)                          # [B, H*W, C]
             kv = blk.fn.to_kv(blk.norm_context(tokens))                       # [B, T, 2*d]
-        return feat, kv
+            T, d = kv.shape[1], kv.shape[2] // 2
+            tp = (T + 63) // 64 * 64
+            if feat.shape[0] == 1 and tp <= 320:
+                # zero-padded K^T [d, tp] and V [tp, d] for the fused fusion kernel (packed right after)
+                kt = torch.zeros((d, tp), dtype=kv.dtype, device=kv.device)
+                kt[:, :T] = kv[0, :, :d].t()
+                vp = torch.zeros((tp, d), dtype=kv.dtype, device=kv.device)
+                vp[:T] = kv[0, :, d:]
+        return feat, kv, kt, vp
 
     def start_image_branch(self, image, device=None, inputs_ready=False):
         """Queue the image branch on a side HIP stream (as a captured hipGraph when the shape is
@@ -130,11 +140,21 @@ class ResUNet2(ME.MinkowskiNetwork):
         with torch.cuda.stream(side), torch.no_grad():
             if not on_device:
                 image = torch.as_tensor(image, dtype=torch.float32).to(dev, non_blocking=True)
-            feat, kv = self._run_image_graph(image, side)
+            feat, kv, kt, vp = self._run_image_graph(image, side)
+            packed = None
+            if kt is not None and self._fusion_weights().supported:
+                key = (dev, tuple(image.shape))
+                bufs = self._kv_packed.get(key)
+                if bufs is None:
+                    bufs = self._kv_packed[key] = (torch.empty(kt.numel(), dtype=torch.float32, device=dev),
+                                                   torch.empty(vp.numel(), dtype=torch.float32, device=dev))
+                ops.pack_weights(kt, out=bufs[0])          # fragment-major K^T / V, on the side stream
+                ops.pack_weights(vp, out=bufs[1])
+                packed = (bufs[0], bufs[1], kv.shape[1], kt.shape[1])
             ev = torch.cuda.Event()
             ev.record(side)
         image.record_stream(side)
-        self._pending_image = (image, feat, kv, ev)
+        self._pending_image = (image, feat, kv, ev, packed)
         return image
 
     def _run_image_graph(self, image, side):
@@ -144,10 +164,10 @@ class ResUNet2(ME.MinkowskiNetwork):
             g = self._img_graph[key] = self._capture_image_graph(image, side)
         if g is False:                                   # capture unavailable: eager on the side stream
             return self._image_branch(image)
-        graph, static_in, feat, kv = g
+        graph, static_in, outs = g
         static_in.copy_(image)
         graph.replay()
-        return feat, kv
+        return outs
 
     def _capture_image_graph(self, image, side):
         if os.environ.get("IMFNET_NO_GRAPH"):
@@ -159,8 +179,8 @@ class ResUNet2(ME.MinkowskiNetwork):
             side.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                feat, kv = self._image_branch(static_in)
-            return graph, static_in, feat, kv
+                outs = self._image_branch(static_in)
+            return graph, static_in, outs
         except Exception as e:                           # noqa: BLE001 -- fall back to eager launches
             import warnings
             warnings.warn(f"imfnet_amd: image-branch hipGraph capture failed ({e}); running eagerly")
@@ -184,31 +204,21 @@ class ResUNet2(ME.MinkowskiNetwork):
         bn = self._bn()
         pend, self._pending_image = self._pending_image, None
         kv = None
-        if pend is not None and pend[0] is image:
-            _, image_feat, kv, ev = pend                  # queued earlier on the side stream
-        else:
+        if pend is None or pend[0] is not image:
             self.start_image_branch(image)
             pend, self._pending_image = self._pending_image, None
-            _, image_feat, kv, ev = pend
+        _, image_feat, kv, ev, packed = pend               # queued on the side stream
         if image_feat.device != x.F.device:
             raise ME.ImfError("image and sparse tensor live on different devices")
-
-        graph_io = None
-        if kv is not None and image_feat.shape[0] == 1 and not os.environ.get("IMFNET_NO_GRAPH"):
-            # bottleneck fusion as a captured hipGraph per 128-row bucket of stride-8 voxels: the block's
-            # input IS block4's output buffer and its output IS conv4_tr's input (no copies); rows
-            # beyond n8 hold stale finite values and are never read (every op of the block is row-local)
-            graph_io = lambda n8: self._fusion_graph_for(n8, kv)                      # noqa: E731
 
         def fuse(f8):                                                                 # :189
             cur = torch.cuda.current_stream(f8.device)
             cur.wait_event(ev)                            # join the image branch
             image_feat.record_stream(cur)
-            g = self._fusion_graph.get(self._fusion_key(f8.shape[0], kv)) if graph_io is not None else None
-            if g is not None and g[1].data_ptr() == f8.data_ptr():
-                kv.record_stream(cur)
-                g[0].replay()
-                out = g[2][: f8.shape[0]]
+            if packed is not None:                         # one HIP kernel: attention + GEGLU feed-forward
+                for t in packed[:2]:
+                    t.record_stream(cur)
+                out = ops.fusion_attention(f8, packed[0], packed[1], packed[2], packed[3], self._fusion_weights())
             elif kv is not None and image_feat.shape[0] == 1:
                 kv.record_stream(cur)
                 out = self._fusion_fast(f8, kv[0])
@@ -222,7 +232,7 @@ class ResUNet2(ME.MinkowskiNetwork):
             from .plan import FusedPlan
             self._plan = FusedPlan(self)
         hook, self.after_fusion_hook = self.after_fusion_hook, None      # one-shot
-        return x._like(self._plan.run(x, fuse, hook, fusion_input=graph_io))
+        return x._like(self._plan.run(x, fuse, hook))
 
     def forward_layers(self, x, image):
         """Op-by-op order of the reference's forward (resunet.py:163-235)."""
@@ -248,33 +258,10 @@ class ResUNet2(ME.MinkowskiNetwork):
             return out._like(out.F / torch.norm(out.F, p=2, dim=1, keepdim=True))
         return out
 
-    def _fusion_key(self, n8, kv):
-        return ((n8 + 127) // 128 * 128, torch.cuda.current_stream(kv.device).cuda_stream, kv.data_ptr())
-
-    def _fusion_graph_for(self, n8, kv):
-        """(graph, static_in [bucket,C], static_out [bucket,C]) for this row bucket on the current
-        stream, captured on first use; None if capture is unavailable."""
-        key = self._fusion_key(n8, kv)
-        g = self._fusion_graph.get(key)
-        if g is None:
-            try:
-                C4 = self.CHANNELS[4]
-                static_in = torch.zeros((key[0], C4), dtype=torch.float32, device=kv.device)
-                with torch.no_grad():
-                    for _ in range(2):
-                        self._fusion_fast(static_in, kv[0])
-                    torch.cuda.current_stream(kv.device).synchronize()
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        static_out = self._fusion_fast(static_in, kv[0])
-                g = (graph, static_in, static_out)
-            except Exception as e:                       # noqa: BLE001
-                import warnings
-                warnings.warn(f"imfnet_amd: fusion hipGraph capture failed ({e}); running eagerly")
-                torch.cuda.synchronize()
-                g = False
-            self._fusion_graph[key] = g
-        return g or None
+    def _fusion_weights(self):
+        if self._fw is None:
+            self._fw = ops.FusionKernelWeights(self.attention_fusion)
+        return self._fw
 
     def _fusion_fast(self, x, kv):
         """attention_fusion.py:132-154 for one image, single head, depth 0, with the image-only half

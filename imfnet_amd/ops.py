@@ -327,14 +327,14 @@ def rulebook_identity(n_out, device):
     return Rulebook(None, None, None, _lib.lib().imf_rulebook_slots(n_out), n_out, 1)
 
 
-def pack_weights(kernel):
+def pack_weights(kernel, out=None):
     """ME kernel tensor [kvol,cin,cout] (or [cin,cout]) -> MFMA fragment-major image."""
     k = kernel.detach()
     if k.dim() == 2:
         k = k.unsqueeze(0)
     k = _req(k.contiguous().float(), torch.float32, "kernel", 3)
     kvol, cin, cout = k.shape
-    packed = torch.empty(kvol * cin * cout, dtype=torch.float32, device=k.device)
+    packed = out if out is not None else torch.empty(kvol * cin * cout, dtype=torch.float32, device=k.device)
     check(_lib.lib().imf_pack_weights(k.data_ptr(), kvol, cin, cout, packed.data_ptr(), _stream()),
           "imf_pack_weights")
     return packed
@@ -436,4 +436,36 @@ def conv_first_bitgrid(level, kernel, ksize, scale=None, shift=None, relu=False)
     check(L.imf_conv_first_bitgrid(level.coords_buf.data_ptr(), level.n, box, ksize, grid.data_ptr(), words,
                                    k.data_ptr(), cout, _ptr(scale), _ptr(shift), int(bool(relu)),
                                    out.data_ptr(), _stream()), "imf_conv_first_bitgrid")
+    return out
+
+
+class FusionKernelWeights:
+    """Packed weights of the bottleneck fusion block for imf_fusion_attention (built once per model)."""
+
+    def __init__(self, attention_fusion):
+        from ._lib import FusionWeights
+        blk0, blk1 = attention_fusion.cross_attend_blocks
+        att, ff = blk0.fn, blk1.fn.net
+        self.dim, self.inner, self.hidden = att.to_q.in_features, att.to_q.out_features, ff[2].in_features
+        self.scale = float(att.scale)
+        self.supported = (att.heads == 1 and len(attention_fusion.layers) == 0 and self.dim == 256 and
+                          self.inner == 128 and self.hidden == 1024 and att.to_q.weight.is_cuda)
+        if not self.supported:
+            return
+        f = lambda t: t.detach().float().contiguous()                     # noqa: E731
+        self.t = dict(ln1_g=f(blk0.norm.weight), ln1_b=f(blk0.norm.bias), wq_p=pack_weights(f(att.to_q.weight).t()),
+                      wo_p=pack_weights(f(att.to_out.weight).t()), bo=f(att.to_out.bias), ln2_g=f(blk1.norm.weight),
+                      ln2_b=f(blk1.norm.bias), w1_p=pack_weights(f(ff[0].weight).t()), b1=f(ff[0].bias),
+                      w2_p=pack_weights(f(ff[2].weight).t()), b2=f(ff[2].bias))
+        self.c = FusionWeights(**{k: v.data_ptr() for k, v in self.t.items()})
+
+
+def fusion_attention(x, kt_packed, v_packed, n_tokens, tokens_padded, fw, out=None):
+    """x [n,256] -> [n,256]: imf_fusion_attention (one kernel for attention + GEGLU feed-forward)."""
+    _req(x, torch.float32, "x", 2)
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().imf_fusion_attention(x.data_ptr(), x.shape[0], kt_packed.data_ptr(), v_packed.data_ptr(),
+                                          int(n_tokens), int(tokens_padded), C.byref(fw.c), C.c_float(fw.scale),
+                                          out.data_ptr(), _stream()), "imf_fusion_attention")
     return out

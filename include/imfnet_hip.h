@@ -227,6 +227,21 @@ int imf_conv_first_bitgrid(const int32_t *coords, int64_t n, const int32_t *bbox
                            int cout, const float *scale, const float *shift, int relu, float *out,
                            void *stream);
 
+/* Bottleneck fusion block (one image, one attention head, depth 0) as ONE kernel.
+ * Replaces: ResUNet2.transformer + AttentionFusion.forward (model/resunet.py:237-273,
+ *           model/attention_fusion.py:65-95,132-154) for the N stride-8 point rows x [n,256]:
+ *   x = to_out(softmax(to_q(LN(x)) K^T * scale) V) + x ;  x = W2(GEGLU(W1 LN(x))) + x
+ * Every matrix is given in the fragment-major layout of imf_pack_weights(kvol = 1) applied to the
+ * TRANSPOSED torch Linear weight ([in, out]): wq_p [256->128], wo_p [128->256], w1_p [256->2048],
+ * w2_p [1024->256]; kt_packed = pack(K^T [128, tokens_padded]), v_packed = pack(V [tokens_padded, 128])
+ * with K, V = chunks of to_kv(LN(image tokens)), zero-padded to tokens_padded (multiple of 64, <= 320). */
+typedef struct imf_fusion_weights {
+  const float *ln1_g, *ln1_b, *wq_p, *wo_p, *bo, *ln2_g, *ln2_b, *w1_p, *b1, *w2_p, *b2;
+} imf_fusion_weights;
+int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed,
+                         int n_tokens, int tokens_padded, const imf_fusion_weights *w /* [host] */,
+                         float scale, float *out, void *stream);
+
 /* Measurement helpers (bench.py): HIP events on the caller's stream. */
 void *imf_event_create(void);
 void imf_event_destroy(void *ev);

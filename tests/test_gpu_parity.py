@@ -319,6 +319,26 @@ def model(seeded_sd):
     return m.eval().to(DEV)
 
 
+def test_fused_fusion_kernel_matches_reference_module(ops, model, golden):
+    """imf_fusion_attention (one HIP kernel) vs the output of the reference's own AttentionFusion
+    module on the golden inputs (413 point rows -- not a multiple of 16 -- x 300 image tokens)."""
+    fw = model._fusion_weights()
+    assert fw.supported
+    x = torch.as_tensor(golden["af_in"]).to(DEV)
+    ctx = torch.as_tensor(golden["af_ctx"]).to(DEV)
+    blk = model.attention_fusion.cross_attend_blocks[0]
+    with torch.no_grad():
+        kv = blk.fn.to_kv(blk.norm_context(ctx))                       # [300, 256]
+        kt = torch.zeros(128, 320, device=DEV); kt[:, :300] = kv[:, :128].t()
+        vp = torch.zeros(320, 128, device=DEV); vp[:300] = kv[:, 128:]
+        out = ops.fusion_attention(x, ops.pack_weights(kt), ops.pack_weights(vp), 300, 320, fw)
+        ref_torch = model._fusion_fast(x, kv)
+    assert np.abs(out.cpu().numpy() - golden["af_out"]).max() < 5e-5
+    assert (out - ref_torch).abs().max() < 5e-5
+    out2 = ops.fusion_attention(x, ops.pack_weights(kt), ops.pack_weights(vp), 300, 320, fw)
+    assert torch.equal(out, out2)                                       # deterministic
+
+
 def test_forward_matches_reference_golden_S5(model, clouds, images, golden):
     """Config 1: cloud_bin_0 @ 5 cm.  Golden = the reference's own model code (CPU stand-in ops)."""
     from imfnet_amd.extract import extract_features
