@@ -175,11 +175,16 @@ class FusedPlan:
                                            rb_up[i].tile_rows, rb_up[i].nbr, rb_up[i].tile_mask,
                                            rb_up[i].n_slots, counters[i], stream), "imf_rulebook_transpose")
 
-        if not self.small_first:
-            build_conv(rb_first, lv[0], lv[0], self.first_ksize, st)
-        build_conv(rb_k3[0], lv[0], lv[0], 3, st)
         ss = side.cuda_stream
         ready = {}                              # rulebook object id -> event
+        if not self.small_first:
+            build_conv(rb_first, lv[0], lv[0], self.first_ksize, st)
+            build_conv(rb_k3[0], lv[0], lv[0], 3, st)
+        else:                                   # conv1 needs no rulebook: k3@1 is built under it
+            build_conv(rb_k3[0], lv[0], lv[0], 3, ss)
+            e = torch.cuda.Event()
+            e.record(side)
+            ready[id(rb_k3[0])] = e
         for i in range(3):
             build_conv(rb_dn[i], lv[i], lv[i + 1], 3, ss)
             build_conv(rb_k3[i + 1], lv[i + 1], lv[i + 1], 3, ss)
