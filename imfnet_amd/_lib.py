@@ -59,6 +59,9 @@ SIGNATURES = {
     "imf_event_create": (_P, []),
     "imf_event_destroy": (None, [_P]),
     "imf_event_elapsed_ms": (C.c_float, [_P, _P]),
+    "imf_nn_workspace_bytes": (_Z, [_L, _L]),
+    "imf_nn_search": (_I, [_P, _L, _P, _L, _I, _P, _P, _P, _Z, _P]),
+    "imf_mutual_inliers": (_I, [_P, _L, _P, _L, _P, _P, _P, _D, _P, _P, _P]),
     "imf_hash_capacity": (_L, [_L]),
     "imf_unique_workspace_bytes": (_Z, [_L]),
     "imf_voxelize": (_I, [_P, _I, _L, _D, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),

@@ -1,0 +1,91 @@
+"""Descriptor matching for the feature-match-recall evaluation, host side.
+
+Mirrors the reference's names: `knn_search` is util/uio.py:245-258, the mutual check and the inlier
+ratio are scripts/evaluation_3dmatch.py:207-234.  Everything runs in libimfnet_hip.so
+(`imf_nn_search`, `imf_mutual_inliers`); there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ImfError, check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _descs(x, device, name):
+    t = torch.as_tensor(x)
+    if t.dim() != 2:
+        raise ImfError(f"{name} must be [n, dim], got {tuple(t.shape)}")
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def nn_search(query, db, return_dist2=False):
+    """Device tensors in, device tensors out: nn int32 [n_query] (and squared fp64 distances)."""
+    if query.shape[1] != db.shape[1]:
+        raise ImfError(f"descriptor widths differ: {query.shape[1]} vs {db.shape[1]}")
+    if db.shape[0] == 0:
+        raise ImfError("knn_search on an empty destination set")
+    nq, nd, dim = query.shape[0], db.shape[0], query.shape[1]
+    dev = query.device
+    L = _lib.lib()
+    ws_bytes = L.imf_nn_workspace_bytes(nq, nd)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    nn = torch.empty(nq, dtype=torch.int32, device=dev)
+    d2 = torch.empty(nq, dtype=torch.float64, device=dev) if return_dist2 else None
+    check(L.imf_nn_search(query.data_ptr(), nq, db.data_ptr(), nd, dim, nn.data_ptr(),
+                          d2.data_ptr() if return_dist2 else None, ws.data_ptr(), ws_bytes, _stream()),
+          "imf_nn_search")
+    return (nn, d2) if return_dist2 else nn
+
+
+def knn_search(points_src, points_dst, k=1, device="cuda"):
+    """util/uio.py:245-258: for every row of points_src the index of its nearest row of points_dst
+    (exact, fp64 distances).  Returns int32 numpy [len(points_src)]; only k=1 (the only value the
+    evaluation uses, scripts/evaluation_3dmatch.py:207-210)."""
+    if k != 1:
+        raise NotImplementedError("knn_search: the evaluation path uses k=1 only")
+    nn = nn_search(_descs(points_src, device, "points_src"), _descs(points_dst, device, "points_dst"))
+    return nn.cpu().numpy()
+
+
+def mutual_inliers(nn21, nn12, kpts1=None, kpts2=None, pose=None, inlier_thresh=0.1):
+    """scripts/evaluation_3dmatch.py:212-233 on device tensors.  Returns (frag2_match_indices int32
+    device tensor, n_matches, n_inliers); n_inliers is 0 when no geometry is given."""
+    dev = nn21.device
+    n2, n1 = nn21.shape[0], nn12.shape[0]
+    match2 = torch.empty(max(n2, 1), dtype=torch.int32, device=dev)
+    meta = torch.zeros(2, dtype=torch.int32, device=dev)
+    geo = kpts1 is not None and kpts2 is not None and pose is not None
+    if geo:
+        kpts1 = torch.as_tensor(kpts1).to(device=dev, dtype=torch.float64).contiguous()
+        kpts2 = torch.as_tensor(kpts2).to(device=dev, dtype=torch.float64).contiguous()
+        if kpts1.shape != (n1, 3) or kpts2.shape != (n2, 3):
+            raise ImfError(f"keypoints must be [{n1},3] and [{n2},3], got {tuple(kpts1.shape)}, {tuple(kpts2.shape)}")
+        T = np.ascontiguousarray(np.asarray(pose, dtype=np.float64).reshape(4, 4))
+        pose_p = T.ctypes.data_as(C.c_void_p)
+    check(_lib.lib().imf_mutual_inliers(nn21.data_ptr(), n2, nn12.data_ptr(), n1,
+                                        kpts1.data_ptr() if geo else None, kpts2.data_ptr() if geo else None,
+                                        pose_p if geo else None, float(inlier_thresh), match2.data_ptr(),
+                                        meta.data_ptr(), _stream()), "imf_mutual_inliers")
+    n_matches, n_inliers = meta.tolist()
+    return match2[:n_matches], n_matches, n_inliers
+
+
+def feature_match(frag1_kpts, frag1_descs, frag2_kpts, frag2_descs, gt_pose, inlier_thresh=0.1,
+                  device="cuda"):
+    """The FMR part of `register_fragment_pair` (scripts/evaluation_3dmatch.py:207-234): both
+    nearest-neighbour searches, the mutual check, the ground-truth transform and the inlier count.
+    Returns (num_inliers, inlier_ratio, frag2_match_indices, frag21_nnindices); inlier_ratio is nan
+    when there is no mutual match (the reference divides 0 by 0)."""
+    d1 = _descs(frag1_descs, device, "frag1_descs")
+    d2 = _descs(frag2_descs, device, "frag2_descs")
+    nn21 = nn_search(d2, d1)
+    nn12 = nn_search(d1, d2)
+    match2, n_matches, n_inliers = mutual_inliers(nn21, nn12, frag1_kpts, frag2_kpts, gt_pose, inlier_thresh)
+    ratio = n_inliers / n_matches if n_matches else float("nan")
+    return n_inliers, ratio, match2.cpu().numpy(), nn21.cpu().numpy()

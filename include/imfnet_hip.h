@@ -242,6 +242,27 @@ int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, cons
                          int n_tokens, int tokens_padded, const imf_fusion_weights *w /* [host] */,
                          float scale, float *out, void *stream);
 
+/* ---- Descriptor matching for feature-match recall ---------------------------------
+ * imf_nn_search replaces util/uio.py:245-258 `knn_search(points_src, points_dst, k=1)` (one Open3D
+ * KD-tree query per row, fp64) as called twice at scripts/evaluation_3dmatch.py:207-210: for every
+ * row of `query` [n_query, dim] the index of the row of `db` [n_db, dim] with the smallest squared L2
+ * distance.  Exact: scores are formed in fp64 (f64 matrix pipe); ties go to the lowest index.
+ * dim in {16, 32, 64}.  nn_dist2 (optional, may be null) receives the squared distance in fp64.
+ * workspace: imf_nn_workspace_bytes(n_query, n_db) bytes of device memory. */
+size_t imf_nn_workspace_bytes(int64_t n_query, int64_t n_db);
+int imf_nn_search(const float *query, int64_t n_query, const float *db, int64_t n_db, int dim,
+                  int32_t *nn_index, double *nn_dist2, void *workspace, size_t workspace_bytes,
+                  void *stream);
+/* imf_mutual_inliers replaces scripts/evaluation_3dmatch.py:212-234: frag2 index j survives iff
+ * nn12[nn21[j]] == j; survivors are written ascending to match_idx2 (capacity n2).  When kpts1
+ * [n1,3], kpts2 [n2,3] (device fp64) and pose_host (HOST pointer, 16 doubles, row-major 4x4) are all
+ * non-null, each surviving frag2 keypoint is transformed by the pose (homogeneous multiply and
+ * divide by w, as Open3D's PointCloud::transform) and counted as an inlier when its distance to
+ * kpts1[nn21[j]] is < inlier_thresh.  meta (device int32[2]) = {n_matches, n_inliers}. */
+int imf_mutual_inliers(const int32_t *nn21, int64_t n2, const int32_t *nn12, int64_t n1,
+                       const double *kpts1, const double *kpts2, const double *pose_host,
+                       double inlier_thresh, int32_t *match_idx2, int32_t *meta, void *stream);
+
 /* Measurement helpers (bench.py): HIP events on the caller's stream. */
 void *imf_event_create(void);
 void imf_event_destroy(void *ev);

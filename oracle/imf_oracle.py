@@ -427,3 +427,50 @@ def seeded_state_dict(seed=0, conv1_kernel_size=5, in_channels=1, out_channels=3
     if with_unused_image_layers:
         lin(ip + "fc", 1000, 512)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------
+# Descriptor matching for feature-match recall -- test infrastructure like the rest
+# of this file.  Parity status: the reference's KD-tree (Open3D 0.12 KDTreeFlann) is absent here; an
+# exact 1-NN is uniquely defined up to exact ties, and this restatement is cross-checked against
+# scipy's independent exact KD-tree in tests/test_oracle_golden.py.
+# ---------------------------------------------------------------------------------------------
+def knn_search(points_src, points_dst, k=1, chunk=256):
+    """util/uio.py:245-258: exact nearest row of points_dst for every row of points_src, fp64
+    `sum((a-b)^2)` distances; on exact ties the lowest index (first minimum)."""
+    assert k == 1
+    src = np.asarray(points_src, dtype=np.float64)
+    dst = np.asarray(points_dst, dtype=np.float64)
+    out = np.empty(len(src), dtype=np.int32)
+    for s in range(0, len(src), chunk):
+        d = ((src[s:s + chunk, None, :] - dst[None, :, :]) ** 2).sum(-1)
+        out[s:s + chunk] = d.argmin(1)
+    return out
+
+
+def mutual_match_indices(frag21_nnindices, frag12_nnindices):
+    """scripts/evaluation_3dmatch.py:212-217."""
+    return np.flatnonzero(np.equal(np.arange(len(frag21_nnindices)), frag12_nnindices[frag21_nnindices]))
+
+
+def transform_points(points, T):
+    """Open3D PointCloud::transform (scripts/evaluation_3dmatch.py:223-225): homogeneous 4x4
+    multiply, then divide by w."""
+    p = np.asarray(points, dtype=np.float64)
+    T = np.asarray(T, dtype=np.float64)
+    h = np.concatenate([p, np.ones((len(p), 1))], 1) @ T.T
+    return h[:, :3] / h[:, 3:4]
+
+
+def feature_match(frag1_kpts, frag1_descs, frag2_kpts, frag2_descs, gt_pose, inlier_thresh=0.1):
+    """scripts/evaluation_3dmatch.py:207-234 -> (num_inliers, inlier_ratio, frag2_match_indices,
+    frag21_nnindices)."""
+    nn21 = knn_search(frag2_descs, frag1_descs)
+    nn12 = knn_search(frag1_descs, frag2_descs)
+    m2 = mutual_match_indices(nn21, nn12)
+    k2 = transform_points(np.asarray(frag2_kpts)[m2], gt_pose)
+    k1 = np.asarray(frag1_kpts, dtype=np.float64)[nn21[m2]]
+    distances = np.sqrt(np.sum(np.square(k1 - k2), axis=1))
+    num_inliers = int(np.sum(distances < inlier_thresh))
+    ratio = num_inliers / len(distances) if len(distances) else float("nan")
+    return num_inliers, ratio, m2.astype(np.int32), nn21

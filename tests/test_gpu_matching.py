@@ -1,0 +1,161 @@
+"""GPU parity of the descriptor-matching row: imf_nn_search / imf_mutual_inliers
+through the C ABI against the oracle's restatement of util/uio.py:245-258 and
+scripts/evaluation_3dmatch.py:207-234.  Index work: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import imf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _descs(rng, n, dim=32):
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)          # L2-normalised like the model's output
+
+
+def _rigid(rng):
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    T = np.eye(4)
+    T[:3, :3] = q
+    T[:3, 3] = rng.uniform(-2, 2, 3)
+    return T
+
+
+@pytest.mark.parametrize("nq,nd,dim", [(1, 1, 32), (5, 3, 32), (16, 16, 32), (17, 63, 32), (64, 65, 32),
+                                       (129, 4097, 32), (1000, 777, 32), (333, 500, 16), (200, 321, 64)])
+def test_nn_search_matches_oracle(nq, nd, dim):
+    from imfnet_amd.matching import knn_search, nn_search
+    rng = np.random.default_rng(nq * 131 + nd)
+    q, d = _descs(rng, nq, dim), _descs(rng, nd, dim)
+    ref = O.knn_search(q, d)
+    got = knn_search(q, d)
+    assert got.dtype == np.int32 and got.shape == (nq,)
+    assert (got == ref).all()
+    nn, d2 = nn_search(torch.as_tensor(q).cuda(), torch.as_tensor(d).cuda(), return_dist2=True)
+    exact = ((q.astype(np.float64) - d.astype(np.float64)[ref]) ** 2).sum(1)
+    assert np.abs(d2.cpu().numpy() - exact).max() < 1e-12
+
+
+def test_nn_search_unnormalised_and_scipy_kdtree():
+    """Arbitrary (not unit-length) descriptors; cross-check with an independent exact KD-tree."""
+    from scipy.spatial import cKDTree
+    from imfnet_amd.matching import knn_search
+    rng = np.random.default_rng(5)
+    q = (rng.standard_normal((700, 32)) * rng.uniform(0.1, 30, (700, 1))).astype(np.float32)
+    d = (rng.standard_normal((900, 32)) * rng.uniform(0.1, 30, (900, 1))).astype(np.float32)
+    got = knn_search(q, d)
+    assert (got == cKDTree(d.astype(np.float64)).query(q.astype(np.float64), k=1)[1]).all()
+    assert (got == O.knn_search(q, d)).all()
+
+
+def test_nn_search_ties_take_lowest_index():
+    from imfnet_amd.matching import knn_search
+    rng = np.random.default_rng(9)
+    base = _descs(rng, 150)
+    d = np.concatenate([base, base[::-1], base[:40]], 0)         # every row appears 2-3 times
+    q = np.concatenate([base[10:90], _descs(rng, 33)], 0)
+    got = knn_search(q, d)
+    assert (got == O.knn_search(q, d)).all()
+    assert (got[:80] == np.arange(10, 90)).all()                 # exact duplicates: first occurrence
+
+
+def test_nn_search_rejects_bad_arguments():
+    from imfnet_amd.matching import knn_search, nn_search
+    from imfnet_amd._lib import ImfError
+    with pytest.raises(ImfError):
+        knn_search(np.zeros((4, 32), np.float32), np.zeros((0, 32), np.float32))
+    with pytest.raises(ImfError):
+        knn_search(np.zeros((4, 32), np.float32), np.zeros((4, 16), np.float32))
+    with pytest.raises(ImfError):
+        knn_search(np.zeros((4, 24), np.float32), np.zeros((4, 24), np.float32))   # width not in {16,32,64}
+    with pytest.raises(NotImplementedError):
+        knn_search(np.zeros((4, 32), np.float32), np.zeros((4, 32), np.float32), k=2)
+    empty = nn_search(torch.zeros((0, 32), device="cuda"), torch.zeros((3, 32), device="cuda"))
+    assert empty.shape == (0,)
+
+
+@pytest.mark.parametrize("n1,n2,noise", [(400, 300, 0.02), (1500, 2100, 0.05), (5000, 5000, 0.08)])
+def test_feature_match_matches_oracle(n1, n2, noise):
+    """A synthetic overlapping pair: frag2's descriptors / keypoints are noisy, transformed copies of
+    part of frag1's plus distractors; ground-truth pose known."""
+    from imfnet_amd.matching import feature_match
+    rng = np.random.default_rng(n1 + n2)
+    T = _rigid(rng)
+    k1 = rng.uniform(-1.5, 1.5, (n1, 3))
+    d1 = _descs(rng, n1)
+    n_shared = min(n1, n2) * 2 // 3
+    pick = rng.permutation(n1)[:n_shared]
+    d2 = np.concatenate([d1[pick] + noise * rng.standard_normal((n_shared, 32)).astype(np.float32),
+                         _descs(rng, n2 - n_shared)], 0).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    k2_in_1 = np.concatenate([k1[pick] + rng.normal(0, 0.06, (n_shared, 3)), rng.uniform(-1.5, 1.5, (n2 - n_shared, 3))], 0)
+    Tinv = np.linalg.inv(T)
+    k2 = k2_in_1 @ Tinv[:3, :3].T + Tinv[:3, 3]
+    perm = rng.permutation(n2)
+    d2, k2 = d2[perm], k2[perm]
+    ref = O.feature_match(k1, d1, k2, d2, T, 0.1)
+    got = feature_match(k1, d1, k2, d2, T, 0.1)
+    assert (got[3] == ref[3]).all()                              # frag21_nnindices
+    assert (got[2] == ref[2]).all() and got[2].dtype == np.int32  # frag2_match_indices, ascending
+    assert got[0] == ref[0] and got[1] == ref[1]
+    assert 0 < got[0] < len(got[2])                              # the case exercises both outcomes
+
+
+def test_mutual_inliers_edge_cases():
+    from imfnet_amd.matching import feature_match, mutual_inliers
+    # no mutual match at all: a 3-cycle nn21 = [1,2,0], nn12 = [1,2,0]
+    nn21 = torch.tensor([1, 2, 0], dtype=torch.int32, device="cuda")
+    nn12 = torch.tensor([1, 2, 0], dtype=torch.int32, device="cuda")
+    m, n_matches, n_inl = mutual_inliers(nn21, nn12)
+    assert n_matches == 0 and n_inl == 0 and m.shape == (0,)
+    # single keypoint each side: always mutual; inlier iff within the threshold after the pose
+    T = np.eye(4)
+    T[:3, 3] = [0.05, 0, 0]
+    one = np.ones((1, 32), np.float32)
+    n_inl, ratio, m2, nn = feature_match(np.zeros((1, 3)), one, np.zeros((1, 3)), one, T, 0.1)
+    assert (n_inl, ratio, list(m2), list(nn)) == (1, 1.0, [0], [0])
+    n_inl, ratio, _, _ = feature_match(np.zeros((1, 3)), one, np.zeros((1, 3)), one, T, 0.05)   # strict <
+    assert (n_inl, ratio) == (0, 0.0)
+    # projective row is honoured (divide by w), as Open3D's transform does
+    T2 = np.eye(4)
+    T2[3, 3] = 2.0
+    k = np.array([[0.3, 0.0, 0.0]])
+    assert feature_match(k / 2, one, k, one, T2, 1e-9)[0] == 1
+
+
+def test_self_match_properties_full_size():
+    """Size-independent properties at the evaluation's full size (5 000 keypoints): matching a set
+    against itself is the identity, every keypoint is mutual, distances are ~0."""
+    from imfnet_amd.matching import mutual_inliers, nn_search
+    rng = np.random.default_rng(77)
+    d = torch.as_tensor(_descs(rng, 5000)).cuda()
+    nn, d2 = nn_search(d, d, return_dist2=True)
+    assert torch.equal(nn.cpu(), torch.arange(5000, dtype=torch.int32))
+    assert float(d2.max()) < 1e-12
+    m, n_matches, _ = mutual_inliers(nn, nn)
+    assert n_matches == 5000 and torch.equal(m.cpu(), torch.arange(5000, dtype=torch.int32))
+
+
+def test_fixture_pair_descriptors_match(clouds, images, seeded_sd):
+    """End to end on the in-tree pair: descriptors of both fixture fragments from the HIP path
+    (5 cm), then matching on the GPU vs the oracle on the same descriptors."""
+    from imfnet_amd.extract import extract_features
+    from imfnet_amd.matching import feature_match
+    from imfnet_amd.model import load_model
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.eval().cuda()
+    out = []
+    for i in (0, 1):
+        xyz, F = extract_features(m, xyz=clouds[i].astype(np.float64), voxel_size=0.05, device="cuda",
+                                  skip_check=True, image=torch.as_tensor(images[i]))
+        out.append((xyz, F.cpu().numpy()))
+    (k1, d1), (k2, d2) = out
+    T = np.eye(4)                                               # both fragments share the scene frame here
+    ref = O.feature_match(k1, d1, k2, d2, T, 0.1)
+    got = feature_match(k1, d1, k2, d2, T, 0.1)
+    assert (got[3] == ref[3]).all() and (got[2] == ref[2]).all() and got[:2] == ref[:2]

@@ -104,3 +104,33 @@ def test_fnv_hash_known_answer():
     assert int(O.fnv_hash_vec(np.array([[1, 2, 3]]))[0]) == h
     neg = O.fnv_hash_vec(np.array([[-1, 0, 5]]))
     assert neg.dtype == np.uint64
+
+
+# ---- descriptor matching ----------------------------------------------------------
+def test_knn_restatement_equals_independent_kdtree():
+    """The reference's KD-tree (Open3D) is absent; an exact 1-NN is unique up to exact ties, so the
+    oracle's brute force must equal scipy's exact KD-tree."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((700, 32)).astype(np.float32)
+    b = rng.standard_normal((900, 32)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    assert (O.knn_search(b, a) == cKDTree(a.astype(np.float64)).query(b.astype(np.float64), k=1)[1]).all()
+    assert O.knn_search(b, a).dtype == np.int32
+
+
+def test_mutual_match_and_inlier_ratio_hand_case():
+    nn21 = np.array([2, 0, 0, 1], dtype=np.int32)                # frag2 -> frag1
+    nn12 = np.array([1, 3, 0], dtype=np.int32)                   # frag1 -> frag2
+    assert list(O.mutual_match_indices(nn21, nn12)) == [0, 1, 3]
+    T = np.eye(4)
+    T[:3, 3] = [1.0, 0.0, 0.0]
+    assert np.allclose(O.transform_points(np.array([[0.0, 2.0, 3.0]]), T), [[1.0, 2.0, 3.0]])
+    T[3, 3] = 2.0
+    assert np.allclose(O.transform_points(np.array([[0.0, 2.0, 3.0]]), T), [[0.5, 1.0, 1.5]])
+    d = np.eye(32, dtype=np.float32)[:3]
+    k1 = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0]], dtype=np.float64)
+    k2 = k1 + np.array([[0.0, 0.05, 0], [0.0, 0.2, 0], [0.0, 0.099, 0]])
+    n_inl, ratio, m2, nn = O.feature_match(k1, d, k2, d, np.eye(4), 0.1)
+    assert (n_inl, list(m2), list(nn)) == (2, [0, 1, 2], [0, 1, 2]) and abs(ratio - 2 / 3) < 1e-15
