@@ -62,6 +62,8 @@ SIGNATURES = {
     "imf_nn_workspace_bytes": (_Z, [_L, _L]),
     "imf_nn_search": (_I, [_P, _L, _P, _L, _I, _P, _P, _P, _Z, _P]),
     "imf_mutual_inliers": (_I, [_P, _L, _P, _L, _P, _P, _P, _D, _P, _P, _P]),
+    "imf_keypoint_workspace_bytes": (_Z, [_L, _L]),
+    "imf_select_keypoints": (_I, [_P, _L, _P, _L, _D, _P, _P, _P, _Z, _P]),
     "imf_hash_capacity": (_L, [_L]),
     "imf_unique_workspace_bytes": (_Z, [_L]),
     "imf_voxelize": (_I, [_P, _I, _L, _D, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),

@@ -53,6 +53,25 @@ def knn_search(points_src, points_dst, k=1, device="cuda"):
     return nn.cpu().numpy()
 
 
+def select_keypoints(sample_points, coords, voxel_size, device="cuda"):
+    """scripts/evaluation_3dmatch.py:162-171: indices (ascending, int64 numpy like `np.where`) of the
+    rows of `coords` (the descriptor file's `xyz`) whose voxel key occurs among the voxel keys of
+    `sample_points` (the randomly drawn raw points)."""
+    s = torch.as_tensor(sample_points).to(device=device, dtype=torch.float64).contiguous()
+    c = torch.as_tensor(coords).to(device=device, dtype=torch.float64).contiguous()
+    if s.dim() != 2 or c.dim() != 2 or s.shape[1] != 3 or c.shape[1] != 3:
+        raise ImfError(f"expected [n,3] arrays, got {tuple(s.shape)} and {tuple(c.shape)}")
+    ns, m = s.shape[0], c.shape[0]
+    L = _lib.lib()
+    ws_bytes = L.imf_keypoint_workspace_bytes(ns, m)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=s.device)
+    inds = torch.empty(max(m, 1), dtype=torch.int32, device=s.device)
+    count = torch.zeros(1, dtype=torch.int32, device=s.device)
+    check(L.imf_select_keypoints(s.data_ptr(), ns, c.data_ptr(), m, float(voxel_size), inds.data_ptr(),
+                                 count.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "imf_select_keypoints")
+    return inds[:int(count.item())].cpu().numpy().astype(np.int64)
+
+
 def mutual_inliers(nn21, nn12, kpts1=None, kpts2=None, pose=None, inlier_thresh=0.1):
     """scripts/evaluation_3dmatch.py:212-233 on device tensors.  Returns (frag2_match_indices int32
     device tensor, n_matches, n_inliers); n_inliers is 0 when no geometry is given."""

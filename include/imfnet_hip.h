@@ -263,6 +263,18 @@ int imf_mutual_inliers(const int32_t *nn21, int64_t n2, const int32_t *nn12, int
                        const double *kpts1, const double *kpts2, const double *pose_host,
                        double inlier_thresh, int32_t *match_idx2, int32_t *meta, void *stream);
 
+/* ---- Keypoint -> voxel selection of the evaluator ----------------------------------
+ * Replaces scripts/evaluation_3dmatch.py:162-171: the ascending indices i of the rows of `coords`
+ * [n_voxels,3] (the `xyz` array of a descriptor file, device fp64) whose key
+ * ME.utils.fnv_hash_vec(floor(coords[i] / voxel_size)) occurs among the keys of `samples`
+ * [n_samples,3] (the sampled raw points, device fp64) -- np.where(np.isin(key_coords, key_points))[0].
+ * inds: device int32, capacity n_voxels; count: device int32[1].  Same FNV-1a-64 key as the
+ * reference, so the selected set is identical even under a key collision. */
+size_t imf_keypoint_workspace_bytes(int64_t n_samples, int64_t n_voxels);
+int imf_select_keypoints(const double *samples, int64_t n_samples, const double *coords, int64_t n_voxels,
+                         double voxel_size, int32_t *inds, int32_t *count, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 /* Measurement helpers (bench.py): HIP events on the caller's stream. */
 void *imf_event_create(void);
 void imf_event_destroy(void *ev);

@@ -474,3 +474,11 @@ def feature_match(frag1_kpts, frag1_descs, frag2_kpts, frag2_descs, gt_pose, inl
     num_inliers = int(np.sum(distances < inlier_thresh))
     ratio = num_inliers / len(distances) if len(distances) else float("nan")
     return num_inliers, ratio, m2.astype(np.int32), nn21
+
+
+def select_keypoints(sample_points, coords, voxel_size):
+    """scripts/evaluation_3dmatch.py:162-171: rows of `coords` whose FNV key is among
+    the keys of the sampled points."""
+    key_points = fnv_hash_vec(np.floor(np.asarray(sample_points, dtype=np.float64) / voxel_size))
+    key_coords = fnv_hash_vec(np.floor(np.asarray(coords, dtype=np.float64) / voxel_size))
+    return np.where(np.isin(key_coords, key_points))[0]

@@ -159,3 +159,37 @@ def test_fixture_pair_descriptors_match(clouds, images, seeded_sd):
     ref = O.feature_match(k1, d1, k2, d2, T, 0.1)
     got = feature_match(k1, d1, k2, d2, T, 0.1)
     assert (got[3] == ref[3]).all() and (got[2] == ref[2]).all() and got[:2] == ref[:2]
+
+
+# ---- keypoint -> voxel selection --------------------------------------------------
+@pytest.mark.parametrize("voxel,n_keypoints", [(0.05, 5000), (0.025, 5000), (0.025, 300), (0.1, 100000)])
+def test_select_keypoints_matches_oracle(clouds, voxel, n_keypoints):
+    """The evaluator's selection on the fixture fragment: xyz_down from the voxeliser, 5 000 random raw
+    points (scripts/evaluation_3dmatch.py:154-171)."""
+    from imfnet_amd.matching import select_keypoints
+    pts = clouds[0].astype(np.float64)
+    _, inds = O.voxelize(pts, voxel)
+    xyz_down = pts[inds]
+    rng = np.random.RandomState(3)
+    pick = rng.choice(len(pts), min(len(pts), n_keypoints), replace=False)
+    ref = O.select_keypoints(pts[pick], xyz_down, voxel)
+    got = select_keypoints(pts[pick], xyz_down, voxel)
+    assert got.dtype == np.int64 and (got == ref).all()
+    assert 0 < len(got) <= min(n_keypoints, len(xyz_down))
+
+
+def test_select_keypoints_edge_cases():
+    from imfnet_amd.matching import select_keypoints
+    rng = np.random.default_rng(0)
+    coords = rng.uniform(-3, 3, (1500, 3))
+    assert len(select_keypoints(np.zeros((0, 3)), coords, 0.05)) == 0          # no samples
+    assert len(select_keypoints(coords[:5], np.zeros((0, 3)), 0.05)) == 0      # no voxels
+    got = select_keypoints(coords, coords, 0.05)                               # everything selected
+    assert (got == np.arange(1500)).all()
+    far = coords + 100.0
+    assert len(select_keypoints(far, coords, 0.05)) == 0                       # disjoint
+    # negative coordinates and exact voxel boundaries hash like numpy's float -> uint64 cast
+    c = np.array([[-0.05, 0.0, 0.05], [-1e-9, -0.05 - 1e-9, 0.1], [0.049999, -0.1, 0.0]])
+    s = np.array([[-0.01, 0.01, 0.09], [-0.04, -0.09, 0.14]])
+    assert (select_keypoints(s, c, 0.05) == O.select_keypoints(s, c, 0.05)).all()
+    assert list(O.select_keypoints(s, c, 0.05)) == [0, 1]

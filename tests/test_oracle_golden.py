@@ -134,3 +134,11 @@ def test_mutual_match_and_inlier_ratio_hand_case():
     k2 = k1 + np.array([[0.0, 0.05, 0], [0.0, 0.2, 0], [0.0, 0.099, 0]])
     n_inl, ratio, m2, nn = O.feature_match(k1, d, k2, d, np.eye(4), 0.1)
     assert (n_inl, list(m2), list(nn)) == (2, [0, 1, 2], [0, 1, 2]) and abs(ratio - 2 / 3) < 1e-15
+
+
+def test_select_keypoints_restatement_hand_case():
+    """scripts/evaluation_3dmatch.py:162-171 -- FNV keys of floor(p / voxel), membership, ascending."""
+    c = np.array([[-0.05, 0.0, 0.05], [-1e-9, -0.05 - 1e-9, 0.1], [0.049999, -0.1, 0.0]])
+    s = np.array([[-0.04, -0.09, 0.14], [-0.01, 0.01, 0.09]])
+    assert list(O.select_keypoints(s, c, 0.05)) == [0, 1]
+    assert O.fnv_hash_vec(np.array([[-1.0, 0.0, 1.0]]))[0] == O.fnv_hash_vec(np.array([[2 ** 64 - 1, 0, 1]], dtype=np.uint64))[0]
