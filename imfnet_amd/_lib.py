@@ -76,6 +76,7 @@ SIGNATURES = {
     "imf_rulebook_transpose": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P]),
     "imf_packed_weight_floats": (_L, [_I, _I, _I]),
     "imf_pack_weights": (_I, [_P, _I, _I, _I, _P, _P]),
+    "imf_pack_weights_split16": (_I, [_P, _I, _I, _I, _P, _P]),
     "imf_spconv_auto_split": (_I, [_L, _I, _I]),
     "imf_spconv_occupancy": (_I, [_I, _I, _I]),
     "imf_spconv_workspace_bytes": (_Z, [_L, _I, _I]),

@@ -19,34 +19,9 @@
 //   epilogue.  The accumulation order per output element is fixed => bit-reproducible, no atomics.
 #include <stdlib.h>
 
-#include "common.h"
+#include "spconv_shared.h"
 
 namespace imf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvParams {
-  const float *in_a, *in_b;
-  int c_a, c_b;
-  const float *w_packed;
-  int kvol, cout;
-  const int32_t *tile_rows, *nbr;
-  const uint32_t *tile_mask;
-  long long n_slots, n_out;
-  const float *scale, *shift, *residual;
-  int relu, l2norm;
-  float *out;
-  float *partial;   // split-K partial sums [S][n_slots][cout] (S = gridDim.z > 1)
-  int *tickets;     // optional arrival counters [n_tiles][n_slabs] (zero on entry, left zero): the last
-                    // partition to arrive reduces the tile in-kernel instead of a second launch
-  int ablate;       // debugging only (env IMF_ABLATE): bit0 no MFMA, bit1 no LDS add, bit2 no A gather, bit3 no B load
-};
-
-// Packed weight image: [y][k][cc][j][cb][lane][t] with
-//   ci = cc*CI_CHUNK + 16 j + 4 (lane>>4) + t,  co = y*CW + 16 cb + (lane&15)
-// i.e. one "stage" (y,k,cc) is J*CO_BLK B-fragment quads, each 64 lanes x float4, contiguous.
-__host__ __device__ inline int ci_chunk_of(int cin) { return (cin % 64 == 0) ? 64 : 32; }
-__host__ __device__ inline int co_blk_of(int cout) { return (cout % 64 == 0) ? 4 : 2; }
 
 __global__ void __launch_bounds__(256)
 k_pack_weights(const float *__restrict__ w, int kvol, int cin, int cout, float *__restrict__ packed) {
@@ -66,66 +41,6 @@ k_pack_weights(const float *__restrict__ w, int kvol, int cin, int cout, float *
   const int ci = cc * CI + 16 * j + 4 * (lane >> 4) + t;
   const int co = y * CW + 16 * cb + (lane & 15);
   packed[idx] = w[((long long)k * cin + ci) * cout + co];
-}
-
-__device__ __forceinline__ int row_of_slot(const ConvParams &p, long long slot) {
-  if (p.tile_rows) return p.tile_rows[slot];
-  return slot < p.n_out ? (int)slot : -1;
-}
-
-__device__ __forceinline__ float4 gather_a(const ConvParams &p, int irow, int ci) {
-  if (irow < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
-  const float *src = (ci < p.c_a) ? p.in_a + (long long)irow * p.c_a + ci
-                                  : p.in_b + (long long)irow * p.c_b + (ci - p.c_a);
-  return *reinterpret_cast<const float4 *>(src);
-}
-
-// acc[cb][r] = out[row 4*q4 + r of the wavefront's 16][col 16*cb + r16]
-template <int CO_BLK>
-__device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (&acc)[CO_BLK], int tile,
-                                              int y, int wave, int r16, int q4) {
-  const int CW = 16 * CO_BLK;
-  int orow[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    orow[r] = row_of_slot(p, (long long)tile * IMF_TILE_ROWS + wave * 16 + q4 * 4 + r);
-
-  float v[CO_BLK][4];
-#pragma unroll
-  for (int cb = 0; cb < CO_BLK; ++cb) {
-    const int col = y * CW + cb * 16 + r16;
-    const float sc = p.scale ? p.scale[col] : 1.f;
-    const float sh = p.shift ? p.shift[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float x = acc[cb][r] * sc + sh;
-      if (p.residual && orow[r] >= 0) x += p.residual[(long long)orow[r] * p.cout + col];
-      if (p.relu) x = fmaxf(x, 0.f);
-      v[cb][r] = x;
-    }
-  }
-  if (p.l2norm) {   // whole row lives in this workgroup slab (cout == CW): reduce over 16 lanes
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float ss = 0.f;
-#pragma unroll
-      for (int cb = 0; cb < CO_BLK; ++cb) ss += v[cb][r] * v[cb][r];
-      ss += __shfl_xor(ss, 1, 64);
-      ss += __shfl_xor(ss, 2, 64);
-      ss += __shfl_xor(ss, 4, 64);
-      ss += __shfl_xor(ss, 8, 64);
-      const float nrm = sqrtf(ss);
-#pragma unroll
-      for (int cb = 0; cb < CO_BLK; ++cb) v[cb][r] = v[cb][r] / nrm;   // no eps: resunet.py:230
-    }
-  }
-#pragma unroll
-  for (int cb = 0; cb < CO_BLK; ++cb) {
-    const int col = y * CW + cb * 16 + r16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (orow[r] >= 0) p.out[(long long)orow[r] * p.cout + col] = v[cb][r];
-  }
 }
 
 // ---- variant 1: simple reference kernel (single LDS buffer, two barriers per stage) -----------
@@ -236,7 +151,6 @@ __device__ __forceinline__ void fused_reduce_tile(const ConvParams &p, int S, lo
 }
 
 // ---- variant 0: pipelined kernel ------------------------------------------------------------
-constexpr int kKCache = 28;   // active offsets cached per workgroup (kvol <= 27 uses this kernel)
 
 template <int CO_BLK, int J>
 __global__ void __launch_bounds__(256)
@@ -1279,8 +1193,10 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   const int cin = a->c_a + a->c_b;
   const int J = ci_chunk_of(cin) / 16, CB = co_blk_of(a->cout);
   IMF_REQUIRE(!a->l2norm || a->cout == 16 * CB, "imf_spconv_fwd: l2norm needs cout in {32, 64}");
-  IMF_REQUIRE(a->variant >= 0 && a->variant <= 5, "imf_spconv_fwd: variant=%d", a->variant);
-  const bool simple = a->variant == 1 || a->kvol >= kKCache || (a->c_b > 0 && a->c_a % (16 * J) != 0);
+  IMF_REQUIRE(a->variant >= 0 && a->variant <= 6, "imf_spconv_fwd: variant=%d", a->variant);
+  const bool simple = a->variant != 6 && (a->variant == 1 || a->kvol >= kKCache || (a->c_b > 0 && a->c_a % (16 * J) != 0));
+  IMF_REQUIRE(a->variant != 6 || a->kvol < kKCache,
+              "imf_spconv_fwd: variant 6 (split-f16 weights) needs kvol <= %d", kKCache - 1);
   int split = simple ? 1 : (a->split_k > 0 ? a->split_k : imf_spconv_auto_split(a->n_slots, a->cout, a->kvol));
   IMF_REQUIRE(split >= 1 && split <= 32, "imf_spconv_fwd: split_k=%d", split);
   if (split > 1)
@@ -1295,7 +1211,9 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
-  if ((a->variant == 4 || a->variant == 5) && !simple) {
+  if (a->variant == 6) {
+    launch_spconv_h3(p, grid, CB, st);
+  } else if ((a->variant == 4 || a->variant == 5) && !simple) {
     const int RBv = a->variant == 4 ? 2 : 1;
     dim3 g4((unsigned)div_up(a->n_slots / 16, 4 * RBv), grid.y, grid.z);
     if (RBv == 2) {

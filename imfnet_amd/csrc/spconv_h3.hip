@@ -1,0 +1,215 @@
+// Sparse convolution, variant 6: fp32 arithmetic emulated on the f16 matrix pipe ("split-f16").
+//
+// The fp32 MFMA (v_mfma_f32_16x16x4_f32) issues once per 32 cycles for 2 048 FLOP; the f16 MFMA
+// (v_mfma_f32_16x16x32_f16) once per ~17 cycles for 16 384 FLOP.  Every fp32 operand is written as
+// x = hi + lo with hi = f16(x), lo = f16(x - hi) (22-23 significant bits; f16 subnormals are kept by
+// the converts and by the MFMA on gfx950, tools/ubench/mfma_f16_denorm.hip), and the product is
+// formed as lo_a*hi_w + hi_a*lo_w + hi_a*hi_w with fp32 accumulation inside the MFMA: three f16
+// MFMAs per 32 input channels instead of eight fp32 ones (~5x fewer matrix-pipe cycles) at fp32-class
+// accuracy (the dropped lo*lo term is 2^-22 relative; measured end to end: max |dF| 3e-7 against an
+// fp64-accumulated network, plain fp32 is 2e-7).  Inputs must stay below the f16 range (65 504) --
+// true for BatchNorm'ed activations; the weights are split once at pack time.
+//
+// Work decomposition is the one of variant 0 (spconv.hip): 64-row rulebook tile x 32/64-wide output
+// slab x a partition of the tile's active offsets; 16 KiB weight stages double-buffered in LDS with
+// register prefetch; A gathered straight from the input rows (lane l: 8 consecutive channels
+// 32cc + 8(l>>4).. of row nbr[k][l&15], split to hi/lo in registers).
+#include "spconv_shared.h"
+
+namespace imf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// Packed image (same size as the fp32 one: two halves per weight):
+//   [y][k][cc][q = 2 cb + h][lane][t],  ci = 32 cc + 8 (lane>>4) + t,  co = y CW + 16 cb + (lane&15),
+//   h = 0: hi halves, h = 1: lo halves; one (q, lane) entry = 8 halves = one float4.
+__global__ void __launch_bounds__(256)
+k_pack_weights_h3(const float *__restrict__ w, int kvol, int cin, int cout, _Float16 *__restrict__ packed) {
+  const long long total = (long long)kvol * cin * cout;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int CB = co_blk_of(cout), CW = 16 * CB, ncc = cin / 32;
+  long long r = idx;
+  const int t = r & 7; r >>= 3;
+  const int lane = r & 63; r >>= 6;
+  const int cb = r % CB; r /= CB;
+  const int cc = r % ncc; r /= ncc;
+  const int k = r % kvol; r /= kvol;
+  const int y = (int)r;
+  const int ci = cc * 32 + 8 * (lane >> 4) + t;
+  const int co = y * CW + 16 * cb + (lane & 15);
+  const float v = w[((long long)k * cin + ci) * cout + co];
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  const long long q0 = ((((long long)y * kvol + k) * ncc + cc) * (2 * CB) + 2 * cb) * 64 + lane;
+  packed[q0 * 8 + t] = hi;
+  packed[(q0 + 64) * 8 + t] = lo;
+}
+
+__device__ __forceinline__ void split8(const float4 &x0, const float4 &x1, f16x8 &hi, f16x8 &lo) {
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const _Float16 h = (_Float16)v[t];
+    hi[t] = h;
+    lo[t] = (_Float16)(v[t] - (float)h);
+  }
+}
+
+template <int CO_BLK>
+__global__ void __launch_bounds__(256)
+k_spconv_h3(const ConvParams p) {
+  constexpr int SUB_F4 = 2 * CO_BLK * 64;            // float4 per (k, cc) sub-stage: 512 or 256
+  constexpr int KG = 1024 / SUB_F4;                  // sub-stages per 16 KiB macro stage: 2 or 4
+  constexpr int QPS = SUB_F4 / 256;                  // float4 per thread per sub-stage: 2 or 1
+  __shared__ float4 wlds[2][1024];
+  __shared__ int nbr_lds[kKCache][IMF_TILE_ROWS];
+  __shared__ int klist[kKCache];
+
+  const int tile = blockIdx.x, y = blockIdx.y, z = blockIdx.z, S = gridDim.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int cin = p.c_a + p.c_b;
+  const int ncc = cin / 32;
+
+  uint32_t mask[IMF_MASK_WORDS] = {1u, 0u, 0u, 0u};
+  if (p.tile_mask) {
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) mask[w] = p.tile_mask[tile * IMF_MASK_WORDS + w];
+  }
+  const int total = __builtin_popcount(mask[0]) + __builtin_popcount(mask[1]) +
+                    __builtin_popcount(mask[2]) + __builtin_popcount(mask[3]);
+  if (total == 0 && S == 1) return;                  // padding tile
+  const int lo = (int)((long long)z * total / S), hi = (int)((long long)(z + 1) * total / S);
+  const int nk = hi - lo;
+
+  if (tid == 0) {
+    int ord = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) {
+      uint32_t m = mask[w];
+      while (m) {
+        const int k = w * 32 + __builtin_ctz(m);
+        m &= m - 1;
+        if (ord >= lo && ord < hi) klist[n++] = k;
+        ++ord;
+      }
+    }
+  }
+  __syncthreads();
+  const long long tile_slot0 = (long long)tile * IMF_TILE_ROWS;
+  for (int j = wave; j < nk; j += 4)
+    nbr_lds[j][lane] = p.nbr ? p.nbr[(long long)klist[j] * p.n_slots + tile_slot0 + lane]
+                             : row_of_slot(p, tile_slot0 + lane);
+  __syncthreads();
+
+  f32x4 acc[CO_BLK];
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float4 *wbase = reinterpret_cast<const float4 *>(p.w_packed) +
+                        (long long)y * p.kvol * ncc * SUB_F4;
+  const int n_sub = nk * ncc;
+  const int n_macro = (n_sub + KG - 1) / KG;
+
+  // prefetch registers: named scalars for the weight quads (an array would land in scratch)
+  float4 w0, w1, w2, w3;
+  float4 a_next[KG][2];
+  const float4 *sp[KG];
+
+#define IMF_PREFETCH(n)                                                                           \
+  {                                                                                                \
+    _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                              \
+      const int t = (n) * KG + g;                                                                  \
+      const int tc = t < n_sub ? t : n_sub - 1;   /* tail: reload the last sub-stage, unused */    \
+      const int jk = tc / ncc, cc = tc - jk * ncc;                                                 \
+      sp[g] = wbase + ((long long)klist[jk] * ncc + cc) * SUB_F4 + tid;                            \
+      const int irow = (t < n_sub) ? nbr_lds[jk][wave * 16 + r16] : -1;                            \
+      const int ch0 = cc * 32;   /* c_a % 32 == 0: a chunk never straddles the two cat sources */   \
+      const float *rowp = (ch0 < p.c_a) ? p.in_a + (long long)irow * p.c_a + ch0                   \
+                                        : p.in_b + (long long)irow * p.c_b + (ch0 - p.c_a);        \
+      if (irow >= 0) {                                                                             \
+        a_next[g][0] = *reinterpret_cast<const float4 *>(rowp + 8 * q4);                           \
+        a_next[g][1] = *reinterpret_cast<const float4 *>(rowp + 8 * q4 + 4);                       \
+      } else {                                                                                     \
+        a_next[g][0] = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
+        a_next[g][1] = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
+      }                                                                                            \
+    }                                                                                              \
+    w0 = sp[0 / QPS][(0 % QPS) * 256];                                                             \
+    w1 = sp[1 / QPS][(1 % QPS) * 256];                                                             \
+    w2 = sp[2 / QPS][(2 % QPS) * 256];                                                             \
+    w3 = sp[3 / QPS][(3 % QPS) * 256];                                                             \
+  }
+
+  if (n_macro > 0) IMF_PREFETCH(0)
+#pragma unroll 1
+  for (int n = 0; n < n_macro; ++n) {
+    float4 *wbuf = wlds[n & 1];
+    wbuf[0 * 256 + tid] = w0;
+    wbuf[1 * 256 + tid] = w1;
+    wbuf[2 * 256 + tid] = w2;
+    wbuf[3 * 256 + tid] = w3;
+    f16x8 ah[KG], al[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) split8(a_next[g][0], a_next[g][1], ah[g], al[g]);
+    __syncthreads();   // stage n visible; every wave is past its reads of this buffer (stage n-2)
+    if (n + 1 < n_macro) IMF_PREFETCH(n + 1)
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      f16x8 bh[CO_BLK], bl[CO_BLK];
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) {
+        bh[cb] = *reinterpret_cast<const f16x8 *>(&wbuf[g * SUB_F4 + (2 * cb) * 64 + lane]);
+        bl[cb] = *reinterpret_cast<const f16x8 *>(&wbuf[g * SUB_F4 + (2 * cb + 1) * 64 + lane]);
+      }
+      // small terms first; consecutive MFMAs use different accumulators
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g], bh[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g], bl[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g], bh[cb], acc[cb], 0, 0, 0);
+    }
+  }
+#undef IMF_PREFETCH
+
+  if (S == 1) {
+    conv_epilogue<CO_BLK>(p, acc, tile, y, wave, r16, q4);
+  } else {   // raw partial sums, slot-major (k_spconv_reduce finishes)
+    const int CW = 16 * CO_BLK;
+#pragma unroll
+    for (int cb = 0; cb < CO_BLK; ++cb) {
+      const int col = y * CW + cb * 16 + r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long slot = tile_slot0 + wave * 16 + q4 * 4 + r;
+        p.partial[((long long)z * p.n_slots + slot) * p.cout + col] = acc[cb][r];
+      }
+    }
+  }
+}
+
+void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st) {
+  if (co_blk == 4) k_spconv_h3<4><<<grid, 256, 0, st>>>(p);
+  else             k_spconv_h3<2><<<grid, 256, 0, st>>>(p);
+}
+
+}  // namespace imf
+
+using namespace imf;
+
+extern "C" int imf_pack_weights_split16(const float *w, int kvol, int cin, int cout, float *packed,
+                                        void *stream) {
+  IMF_REQUIRE(w && packed, "imf_pack_weights_split16: null pointer");
+  IMF_REQUIRE(kvol >= 1 && kvol <= IMF_MAX_KVOL, "imf_pack_weights_split16: kvol=%d", kvol);
+  IMF_REQUIRE(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0,
+              "imf_pack_weights_split16: cin=%d cout=%d must be multiples of 32", cin, cout);
+  const long long total = (long long)kvol * cin * cout;
+  k_pack_weights_h3<<<(unsigned)div_up(total, 256), 256, 0, (hipStream_t)stream>>>(
+      w, kvol, cin, cout, reinterpret_cast<_Float16 *>(packed));
+  IMF_CHECK_LAUNCH("k_pack_weights_h3");
+  return IMF_OK;
+}

@@ -1,0 +1,97 @@
+// Pieces shared by the sparse-convolution kernels (spconv.hip, spconv_h3.hip).
+#pragma once
+#include "common.h"
+
+namespace imf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+  const float *in_a, *in_b;
+  int c_a, c_b;
+  const float *w_packed;
+  int kvol, cout;
+  const int32_t *tile_rows, *nbr;
+  const uint32_t *tile_mask;
+  long long n_slots, n_out;
+  const float *scale, *shift, *residual;
+  int relu, l2norm;
+  float *out;
+  float *partial;   // split-K partial sums [S][n_slots][cout] (S = gridDim.z > 1)
+  int *tickets;     // optional arrival counters [n_tiles][n_slabs] (zero on entry, left zero): the last
+                    // partition to arrive reduces the tile in-kernel instead of a second launch
+  int ablate;       // debugging only (env IMF_ABLATE): bit0 no MFMA, bit1 no LDS add, bit2 no A gather, bit3 no B load
+};
+
+// Packed weight image: [y][k][cc][j][cb][lane][t] with
+//   ci = cc*CI_CHUNK + 16 j + 4 (lane>>4) + t,  co = y*CW + 16 cb + (lane&15)
+// i.e. one "stage" (y,k,cc) is J*CO_BLK B-fragment quads, each 64 lanes x float4, contiguous.
+__host__ __device__ inline int ci_chunk_of(int cin) { return (cin % 64 == 0) ? 64 : 32; }
+__host__ __device__ inline int co_blk_of(int cout) { return (cout % 64 == 0) ? 4 : 2; }
+
+__device__ __forceinline__ int row_of_slot(const ConvParams &p, long long slot) {
+  if (p.tile_rows) return p.tile_rows[slot];
+  return slot < p.n_out ? (int)slot : -1;
+}
+
+__device__ __forceinline__ float4 gather_a(const ConvParams &p, int irow, int ci) {
+  if (irow < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float *src = (ci < p.c_a) ? p.in_a + (long long)irow * p.c_a + ci
+                                  : p.in_b + (long long)irow * p.c_b + (ci - p.c_a);
+  return *reinterpret_cast<const float4 *>(src);
+}
+
+// acc[cb][r] = out[row 4*q4 + r of the wavefront's 16][col 16*cb + r16]
+template <int CO_BLK>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (&acc)[CO_BLK], int tile,
+                                              int y, int wave, int r16, int q4) {
+  const int CW = 16 * CO_BLK;
+  int orow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    orow[r] = row_of_slot(p, (long long)tile * IMF_TILE_ROWS + wave * 16 + q4 * 4 + r);
+
+  float v[CO_BLK][4];
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb) {
+    const int col = y * CW + cb * 16 + r16;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = acc[cb][r] * sc + sh;
+      if (p.residual && orow[r] >= 0) x += p.residual[(long long)orow[r] * p.cout + col];
+      if (p.relu) x = fmaxf(x, 0.f);
+      v[cb][r] = x;
+    }
+  }
+  if (p.l2norm) {   // whole row lives in this workgroup slab (cout == CW): reduce over 16 lanes
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float ss = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) ss += v[cb][r] * v[cb][r];
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
+      ss += __shfl_xor(ss, 8, 64);
+      const float nrm = sqrtf(ss);
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) v[cb][r] = v[cb][r] / nrm;   // no eps: resunet.py:230
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb) {
+    const int col = y * CW + cb * 16 + r16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (orow[r] >= 0) p.out[(long long)orow[r] * p.cout + col] = v[cb][r];
+  }
+}
+
+constexpr int kKCache = 28;   // active offsets cached per workgroup (kvol <= 27 uses the pipelined kernels)
+
+// spconv_h3.hip: variant 6 (split-f16 MFMA); grid = (tiles, cout / (16 CB), split)
+void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st);
+
+}  // namespace imf

@@ -59,6 +59,7 @@ class FusedPlan:
         def conv_args(name, module, norm=None, relu=False, l2norm=False):
             a = ConvArgs()
             a.w_packed = module.packed().data_ptr()
+            a.variant = ops.conv_variant_for(module.kernel_volume)
             a.kvol, a.cout = module.kernel_volume, module.out_channels
             scale = shift = None
             if norm is not None:
@@ -125,7 +126,7 @@ class FusedPlan:
         check(self.L.imf_spconv_fwd(C.byref(a), _stream()), f"imf_spconv_fwd[{name}]")
         if ev is not None:
             cin = c_a + c_b
-            ops.TRACE.append(dict(kernel=f"k_spconv_mfma<{4 if a.cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>",
+            ops.TRACE.append(dict(kernel=ops.conv_kernel_name(a.variant, cin, a.cout),
                                   kvol=rb.kvol, cin=cin, cout=a.cout, rb=rb, split=split, ev=ev, name=name,
                                   arena=self._trace_arena))
 

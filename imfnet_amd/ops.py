@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/imfnet_hip.h).  torch is used only for device
 memory and streams; every computation below happens in libimfnet_hip.so on the GPU."""
 import ctypes as C
+import os
 
 import torch
 
@@ -327,17 +328,35 @@ def rulebook_identity(n_out, device):
     return Rulebook(None, None, None, _lib.lib().imf_rulebook_slots(n_out), n_out, 1)
 
 
-def pack_weights(kernel, out=None):
-    """ME kernel tensor [kvol,cin,cout] (or [cin,cout]) -> MFMA fragment-major image."""
+# Sparse-conv kernel variant used by the model layers (include/imfnet_hip.h, imf_conv_args.variant):
+# 6 = split-f16 MFMA (fp32-class accuracy, ~5x fewer matrix-pipe cycles), 0 = fp32 MFMA.
+CONV_VARIANT = int(os.environ.get("IMF_CONV_VARIANT", "6"))
+MAX_PIPELINED_KVOL = 27
+
+
+def conv_variant_for(kvol):
+    """Variant 6 needs kvol <= 27 (its split-f16 weight image is only read by the pipelined kernel)."""
+    return CONV_VARIANT if (CONV_VARIANT != 6 or kvol <= MAX_PIPELINED_KVOL) else 0
+
+
+def pack_weights(kernel, out=None, split16=False):
+    """ME kernel tensor [kvol,cin,cout] (or [cin,cout]) -> MFMA fragment-major image: fp32 B
+    fragments (variants 0-5) or, with split16, the hi/lo f16 fragments of variant 6 (same size)."""
     k = kernel.detach()
     if k.dim() == 2:
         k = k.unsqueeze(0)
     k = _req(k.contiguous().float(), torch.float32, "kernel", 3)
     kvol, cin, cout = k.shape
     packed = out if out is not None else torch.empty(kvol * cin * cout, dtype=torch.float32, device=k.device)
-    check(_lib.lib().imf_pack_weights(k.data_ptr(), kvol, cin, cout, packed.data_ptr(), _stream()),
-          "imf_pack_weights")
+    fn = _lib.lib().imf_pack_weights_split16 if split16 else _lib.lib().imf_pack_weights
+    check(fn(k.data_ptr(), kvol, cin, cout, packed.data_ptr(), _stream()), "imf_pack_weights")
     return packed
+
+
+def conv_kernel_name(variant, cin, cout):
+    if variant == 6:
+        return f"k_spconv_h3<{4 if cout % 64 == 0 else 2}>"
+    return f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>"
 
 
 def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual=None,
@@ -380,7 +399,7 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     check(L.imf_spconv_fwd(C.byref(a), _stream()), "imf_spconv_fwd")
     if ev is not None:
         cin = a.c_a + a.c_b
-        TRACE.append(dict(kernel=f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>",
+        TRACE.append(dict(kernel=conv_kernel_name(variant, cin, cout),
                           kvol=rb.kvol, cin=cin, cout=cout, rb=rb, split=split, ev=ev))
     return out
 

@@ -249,9 +249,10 @@ class _ConvBase(nn.Module):
         return k.unsqueeze(0) if k.dim() == 2 else k
 
     def packed(self):
-        tag = (self.kernel.data_ptr(), self.kernel._version)
+        variant = ops.conv_variant_for(self.kernel_volume)
+        tag = (self.kernel.data_ptr(), self.kernel._version, variant == 6)
         if self._packed is None or self._packed[0] != tag:
-            self._packed = (tag, ops.pack_weights(self.kernel))
+            self._packed = (tag, ops.pack_weights(self.kernel, split16=(variant == 6)))
         return self._packed[1]
 
     def rulebook(self, x):
@@ -277,7 +278,8 @@ class _ConvBase(nn.Module):
             out = ops.spconv_small_cin(feat, self.kernel3(), rb, scale, shift, relu)
         else:
             out = ops.spconv(feat, self.packed(), self.out_channels, rb, in_b=in_b, scale=scale,
-                             shift=shift, residual=residual, relu=relu, l2norm=l2norm)
+                             shift=shift, residual=residual, relu=relu, l2norm=l2norm,
+                             variant=ops.conv_variant_for(self.kernel_volume))
         return out, ts_out
 
     def forward(self, x):

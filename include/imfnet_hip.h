@@ -149,6 +149,10 @@ int64_t imf_packed_weight_floats(int kvol, int cin, int cout);
  * [cin][cout] when kvol == 1) into the order the MFMA kernel streams it.  Done once per model
  * load.  cin % 32 == 0, cout % 32 == 0. */
 int imf_pack_weights(const float *w, int kvol, int cin, int cout, float *packed, void *stream);
+/* The same weights as hi/lo f16 B fragments for imf_conv_args.variant == 6 (split-f16 MFMA: every
+ * fp32 operand x = f16(x) + f16(x - f16(x)); products hi*hi + hi*lo + lo*hi accumulate in fp32).  The
+ * image has the size of the fp32 one (imf_packed_weight_floats). */
+int imf_pack_weights_split16(const float *w, int kvol, int cin, int cout, float *packed, void *stream);
 
 typedef struct imf_conv_args {
   const float *in_a;      /* [n_in, c_a]                                                      */
@@ -170,7 +174,9 @@ typedef struct imf_conv_args {
   int32_t variant;        /* 0 = pipelined workgroup kernel; 1 = simple reference kernel;
                              2 = wave-autonomous kernel with per-offset row compaction;
                              3 = 128-row workgroup kernel with per-offset row compaction;
-                             4 / 5 = barrier-free register kernel, 32 / 16 rows per wavefront    */
+                             4 / 5 = barrier-free register kernel, 32 / 16 rows per wavefront;
+                             6 = variant 0's pipeline on the f16 matrix pipe with split operands
+                                 (w_packed from imf_pack_weights_split16; kvol <= 27; |input| < 65504) */
   void *workspace;        /* split-K partial sums; NULL allowed iff split_k resolves to 1          */
   size_t workspace_bytes; /* >= imf_spconv_workspace_bytes(n_slots, cout, split)                  */
   int32_t *tickets;       /* optional: int32[n_tiles * n_slabs] arrival counters, ZERO on entry (left zero on

@@ -173,7 +173,7 @@ def _rb_and_ref(cm, g, which):
 
 
 @pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple", "wave", "wave_split3", "c", "c_split3",
-                                  "reg2", "reg1", "reg2_split3"])
+                                  "reg2", "reg1", "reg2_split3", "h3", "h3_split1", "h3_split5"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
     """Plain convolution (no epilogue) vs the oracle; error measured against an fp64 evaluation and
@@ -188,10 +188,11 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
           "wave": {"variant": 2, "split_k": 1}, "wave_split3": {"variant": 2, "split_k": 3},
           "c": {"variant": 3, "split_k": 1}, "c_split3": {"variant": 3, "split_k": 3},
           "reg2": {"variant": 4, "split_k": 1}, "reg1": {"variant": 5, "split_k": 1},
-          "reg2_split3": {"variant": 4, "split_k": 3}}[mode]
-    if mode in ("split5", "split5_fused", "wave_split3", "c_split3", "reg2_split3") and kvol == 1:
+          "reg2_split3": {"variant": 4, "split_k": 3}, "h3": {"variant": 6},
+          "h3_split1": {"variant": 6, "split_k": 1}, "h3_split5": {"variant": 6, "split_k": 5}}[mode]
+    if mode in ("split5", "split5_fused", "wave_split3", "c_split3", "reg2_split3", "h3_split5") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")
-    out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV)), cout, rb,
+    out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV), split16=mode.startswith("h3")), cout, rb,
                      in_b=None if fb is None else fb.to(DEV), **kw).cpu()
     fin = fa if fb is None else torch.cat([fa, fb], 1)
     wk = w if kvol > 1 else w[0]
@@ -227,6 +228,44 @@ def test_spconv_epilogues(ops, geom_s5):
         got = ops.spconv(f.to(DEV), wp, 32, rb, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV),
                          relu=True, **kw).cpu()
         assert (got - torch.relu(base * sc + sh + res)).abs().max() < 5e-5
+
+
+def test_spconv_split16_variant(ops, geom_s5):
+    """Variant 6 (split-f16 MFMA): the packed image decodes to hi + lo == w within 2^-21, epilogues and
+    determinism as the fp32 kernels, and fp32-class error on inputs spanning seven decades."""
+    cm, g = geom_s5
+    rb, nbr_ref = cm.conv_rulebook(1, 3, 1), g.k3[0]
+    n = len(g.levels[0])
+    w = _rand((27, 64, 32), 40, 0.05)
+    img = ops.pack_weights(w.to(DEV), split16=True).cpu().view(torch.float16)
+    # [y][k][cc][q = 2 cb + h][lane][t]: ci = 32 cc + 8 (lane >> 4) + t, co = 16 cb + (lane & 15)
+    v = img.view(1, 27, 2, 2, 2, 4, 16, 8).float()              # y k cc cb h g c t
+    rec = (v[:, :, :, :, 0] + v[:, :, :, :, 1])[0]              # k cc cb g c t
+    rec = rec.permute(0, 1, 3, 5, 2, 4).reshape(27, 64, 32)     # k (cc g t) (cb c)
+    assert ((rec - w).abs() <= w.abs() * 2.0 ** -21 + 2.0 ** -24).all()
+    f = _rand((n, 64), 41)
+    sc, sh, res = _rand((32,), 42).abs() + 0.5, _rand((32,), 43), _rand((n, 32), 44)
+    wp = ops.pack_weights(w.to(DEV), split16=True)
+    base = O.spconv_f64(f, w, nbr_ref)
+    for kw in ({}, {"split_k": 1}, {"split_k": 3}):
+        got = ops.spconv(f.to(DEV), wp, 32, rb, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV),
+                         relu=True, variant=6, **kw)
+        assert (got.cpu().double() - torch.relu(base * sc + sh + res)).abs().max() < 2e-5
+        assert torch.equal(got, ops.spconv(f.to(DEV), wp, 32, rb, scale=sc.to(DEV), shift=sh.to(DEV),
+                                           residual=res.to(DEV), relu=True, variant=6, **kw))
+        ref = (base + sh)
+        ref = ref / ref.norm(dim=1, keepdim=True)
+        got = ops.spconv(f.to(DEV), wp, 32, rb, shift=sh.to(DEV), l2norm=True, variant=6, **kw).cpu()
+        assert (got.double() - ref).abs().max() < 2e-6
+    # wide dynamic range: |x| from 1e-4 to 1e3 (f16 subnormal lo parts on the small ones)
+    mag = torch.pow(10.0, torch.empty(n, 64).uniform_(-4, 3, generator=torch.Generator().manual_seed(45)))
+    fw = f.sign() * mag
+    got = ops.spconv(fw.to(DEV), wp, 32, rb, variant=6).cpu().double()
+    ref64 = O.spconv_f64(fw, w, nbr_ref)
+    bound = O.spconv_f64(fw.abs(), w.abs(), nbr_ref) * 2e-6 + 1e-7
+    assert ((got - ref64).abs() <= bound).all()
+    with pytest.raises(Exception):                             # k5 (125 offsets) is not served by variant 6
+        ops.spconv(f.to(DEV), wp, 32, cm.conv_rulebook(1, 5, 1), variant=6)
 
 
 def test_spconv_deterministic(ops, geom_s5):

@@ -26,19 +26,20 @@ cases = [  # name, rulebook, cin, cout, rows_in
     ("k3@8 256->256", cm.conv_rulebook(8, 3, 1), 256, 256, n[3]),
     ("up@4 256->128", cm.transpose_rulebook(8, 3, 2), 256, 128, n[3]),
 ]
-variants = [("v0 auto", dict(variant=0)), ("v0 s1", dict(variant=0, split_k=1)), ("v0 s2", dict(variant=0, split_k=2)),
-            ("v0 s3", dict(variant=0, split_k=3)), ("v0 s4", dict(variant=0, split_k=4)), ("v0 s6", dict(variant=0, split_k=6)),
-            ("v0 s8", dict(variant=0, split_k=8))]
+variants = [("v0 auto", dict(variant=0)), ("v0 s1", dict(variant=0, split_k=1)),
+            ("v6 auto", dict(variant=6)), ("v6 s1", dict(variant=6, split_k=1)), ("v6 s2", dict(variant=6, split_k=2)),
+            ("v6 s4", dict(variant=6, split_k=4)), ("v6 s8", dict(variant=6, split_k=8))]
 g = torch.Generator().manual_seed(0)
 for name, rb, cin, cout, rows in cases:
     f = torch.randn(rows, cin, generator=g).to(dev)
-    w = ops.pack_weights((torch.randn(rb.kvol, cin, cout, generator=g) * 0.05).to(dev))
+    wt = (torch.randn(rb.kvol, cin, cout, generator=g) * 0.05).to(dev)
+    wp = {0: ops.pack_weights(wt), 6: ops.pack_weights(wt, split16=True)}
     res = {}
     outs = {}
     for rnd in range(6):
         for vn, kw in variants:
             ops.TRACE = []
-            outs[vn] = ops.spconv(f, w, cout, rb, **kw)
+            outs[vn] = ops.spconv(f, wp[kw['variant']], cout, rb, **kw)
             torch.cuda.synchronize()
             ms = ops.TRACE[0]["ev"].elapsed_ms(); ops.TRACE = None
             if rnd: res.setdefault(vn, []).append(ms * 1e3)
