@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libimfnet_hip.so")
+LIB_PATH = os.environ.get("IMF_LIB") or os.path.join(_HERE, "libimfnet_hip.so")   # IMF_LIB: diagnostic builds
 
 TILE_ROWS = 64
 MASK_WORDS = 4

@@ -82,24 +82,38 @@ k_spconv_h3(const ConvParams p) {
   const int lo = (int)((long long)z * total / S), hi = (int)((long long)(z + 1) * total / S);
   const int nk = hi - lo;
 
-  if (tid == 0) {
-    int ord = 0, n = 0;
+  // offset list of this partition, built by 128 lanes in parallel: lane k owns offset k, its rank
+  // among the active offsets is a popcount of the mask bits below it
+  if (tid < 32 * IMF_MASK_WORDS) {
+    const int w = tid >> 5, b = tid & 31;
+    const uint32_t mw = w == 0 ? mask[0] : (w == 1 ? mask[1] : (w == 2 ? mask[2] : mask[3]));
+    if ((mw >> b) & 1u) {
+      int ord = __builtin_popcount(mw & ((1u << b) - 1u));
 #pragma unroll
-    for (int w = 0; w < IMF_MASK_WORDS; ++w) {
-      uint32_t m = mask[w];
-      while (m) {
-        const int k = w * 32 + __builtin_ctz(m);
-        m &= m - 1;
-        if (ord >= lo && ord < hi) klist[n++] = k;
-        ++ord;
-      }
+      for (int v = 0; v < IMF_MASK_WORDS; ++v)
+        if (v < w) ord += __builtin_popcount(mask[v]);
+      if (ord >= lo && ord < hi) klist[ord - lo] = tid;
     }
   }
   __syncthreads();
+  // the tile's slice of the neighbour table: all loads in flight together, then the LDS stores
   const long long tile_slot0 = (long long)tile * IMF_TILE_ROWS;
-  for (int j = wave; j < nk; j += 4)
-    nbr_lds[j][lane] = p.nbr ? p.nbr[(long long)klist[j] * p.n_slots + tile_slot0 + lane]
-                             : row_of_slot(p, tile_slot0 + lane);
+  {
+    constexpr int kPer = (kKCache * IMF_TILE_ROWS + 255) / 256;   // 7
+    int v[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = tid + 256 * i, j = e >> 6, r = e & 63;
+      v[i] = -1;
+      if (j < nk)
+        v[i] = p.nbr ? p.nbr[(long long)klist[j] * p.n_slots + tile_slot0 + r] : row_of_slot(p, tile_slot0 + r);
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = tid + 256 * i, j = e >> 6, r = e & 63;
+      if (j < nk) nbr_lds[j][r] = v[i];
+    }
+  }
   __syncthreads();
 
   f32x4 acc[CO_BLK];

@@ -14,7 +14,8 @@ cm = ME.CoordinateManager.from_levels(levels)
 rb = cm.conv_rulebook(1, 3, 1)
 g = torch.Generator().manual_seed(0)
 f = torch.randn(levels[0].n, 64, generator=g).to(dev)
-w = ops.pack_weights((torch.randn(27, 64, 64, generator=g) * 0.05).to(dev))
+VAR = int(os.environ.get("VAR","0"))
+w = ops.pack_weights((torch.randn(27, 64, 64, generator=g) * 0.05).to(dev), split16=(VAR == 6))
 out = []
 for kw in (dict(variant=int(os.environ.get("VAR","0")), split_k=1),):
     ts = []
@@ -25,7 +26,7 @@ for kw in (dict(variant=int(os.environ.get("VAR","0")), split_k=1),):
     out.append("%%s: %%.1f us" %% (kw, np.median(ts[1:])))
 print("IMF_ABLATE=%%s  " %% os.environ.get("IMF_ABLATE", "0") + "  ".join(out))
 ''' % (ROOT, ROOT)
-for ab in (0, 256, 512, 768, 1024, 1536, 2048):
+for ab in [int(x) for x in os.environ.get("ABLATIONS", "0,1,2,4,8,3,5,6,7,12,15").split(",")]:
     env = dict(os.environ, IMF_ABLATE=str(ab))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     print((r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)

@@ -16,7 +16,7 @@ cm = ME.CoordinateManager.from_levels(levels)
 rb = cm.conv_rulebook(1 << lvl, 3, 1)
 g = torch.Generator().manual_seed(0)
 f = torch.randn(levels[lvl].n, cin, generator=g).to(dev)
-w = ops.pack_weights((torch.randn(27, cin, cout, generator=g) * 0.05).to(dev))
+w = ops.pack_weights((torch.randn(27, cin, cout, generator=g) * 0.05).to(dev), split16=(variant == 6))
 for _ in range(10):
     ops.spconv(f, w, cout, rb, variant=variant, split_k=split)
 torch.cuda.synchronize()
