@@ -82,7 +82,8 @@ SIGNATURES = {
     "imf_spconv_workspace_bytes": (_Z, [_L, _I, _I]),
     "imf_spconv_fwd": (_I, [C.POINTER(ConvArgs), _P]),
     "imf_spconv_small_cin": (_I, [_P, _I, _P, _I, _I, _P, _L, _L, _P, _P, _I, _P, _P]),
-    "imf_fusion_attention": (_I, [_P, _L, _P, _P, _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P]),
+    "imf_fusion_workspace_bytes": (_Z, [_L]),
+    "imf_fusion_attention": (_I, [_P, _L, _P, _P, _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P, _Z, _P]),
     "imf_bitgrid_words": (_Z, [_P, _I]),
     "imf_conv_first_bitgrid": (_I, [_P, _L, _P, _I, _P, _Z, _P, _I, _P, _P, _I, _P, _P]),
     "imf_conv_first_fused": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P]),

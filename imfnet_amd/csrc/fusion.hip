@@ -8,6 +8,8 @@
 // image-dependent K^T / V, packed once per fragment on the image-branch stream -- are in the same
 // fragment-major layout as the convolution weights (imf_pack_weights with kvol = 1), so every B
 // fragment is one coalesced float4 per lane.  Deterministic (fixed summation order), fp32 throughout.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace imf {
@@ -27,6 +29,7 @@ struct FusionParams {
   float scale;
   const float *ln1g, *ln1b, *wq, *wo, *bo, *ln2g, *ln2b, *w1, *b1, *w2, *b2;
   float *out;
+  float *partial;   // [HS][n][256] when the GEGLU hidden dimension is split over gridDim.y (HS > 1)
 };
 
 // float4 holding the B fragments of MFMA steps 4u'..4u'+3 (u = 16-channel step) for column block c
@@ -39,16 +42,17 @@ __device__ __forceinline__ const float4 *bfrag(const float *packed, int ncc, int
 // The B fragments come straight from L2 (each is used by exactly one wave of one workgroup), so the
 // loop is a register software pipeline D steps deep: without it every 16-channel step exposes a full
 // L2 round trip (measured: 110 us for the whole block vs ~35 with the pipeline).  K/16 % D == 0.
+// (kfull, ub): the packed matrix has kfull rows and the A slice covers its 16-row steps ub .. ub + K/16.
 template <int NC, int D>
 __device__ __forceinline__ void gemm16(f32x4 (&acc)[NC], const float *A, int lda, int K, const float *packed,
-                                       const int (&cblk)[NC], int lane) {
-  const int r16 = lane & 15, q4 = lane >> 4, ncc = K / 64, U = K / 16;
+                                       const int (&cblk)[NC], int lane, int kfull = 0, int ub = 0) {
+  const int r16 = lane & 15, q4 = lane >> 4, ncc = (kfull ? kfull : K) / 64, U = K / 16;
   const float *arow = A + r16 * lda + 4 * q4;
   float4 bq[D][NC];
 #pragma unroll
   for (int d = 0; d < D; ++d)
 #pragma unroll
-    for (int i = 0; i < NC; ++i) bq[d][i] = *bfrag(packed, ncc, d, cblk[i], lane);
+    for (int i = 0; i < NC; ++i) bq[d][i] = *bfrag(packed, ncc, ub + d, cblk[i], lane);
 #pragma unroll 1
   for (int u0 = 0; u0 < U; u0 += D) {
 #pragma unroll
@@ -65,7 +69,7 @@ __device__ __forceinline__ void gemm16(f32x4 (&acc)[NC], const float *A, int lda
       }
       if (u + D < U) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i) bq[d][i] = *bfrag(packed, ncc, u + D, cblk[i], lane);
+        for (int i = 0; i < NC; ++i) bq[d][i] = *bfrag(packed, ncc, ub + u + D, cblk[i], lane);
       }
     }
   }
@@ -94,12 +98,19 @@ __device__ __forceinline__ void layer_norm_row(const float *src, float *dst, con
 
 constexpr int kLdX = kFD + 4;       // 260: (row * lda) % 64 == 4 * row -> conflict-free ds_read_b128 of A
 constexpr int kLdQ = kFQ + 4;       // 132
-constexpr int kLdG = kFH + 4;       // 1028
+template <int HS> constexpr int ld_g() { return kFH / HS + 4; }   // 1028 / 516 / 260
 constexpr int kMaxTokP = 320;
 constexpr int kLdS = kMaxTokP + 4;  // 324
 
+// HS = number of slices of the GEGLU hidden dimension (gridDim.y): with ~1 k rows a 16-row workgroup
+// per row block fills only 68 of 256 CUs and each one streams all 3.6 MB of weights; with HS = 4 every
+// workgroup repeats the (cheap) attention part, takes a quarter of W1 / W2 and writes a partial z that
+// k_fusion_reduce sums in a fixed order.
+template <int HS>
 __global__ void __launch_bounds__(512)
 k_fusion_attention(const FusionParams p) {
+  constexpr int kLdG = ld_g<HS>();
+  const int hs = blockIdx.y;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *X = lds;                          // [16][260]  x, later y
   float *N = X + kFRows * kLdX;            // [16][260]  LN(x), later LN(y)
@@ -197,32 +208,43 @@ k_fusion_attention(const FusionParams p) {
   __syncthreads();
 
   // ---- GEGLU: h = LN(y) W1^T + b1 (2048 wide); g = h[:1024] * gelu(h[1024:]) ---------------------
-  // wave w owns hidden columns [128 w, 128 w + 128): value blocks 8w..8w+7 and gate blocks 64+8w..
-  for (int half = 0; half < 2; ++half) {
-    f32x4 acc[8];
+  // this workgroup's hidden slice is [hs * 1024/HS, +1024/HS); wave w owns 128/HS of its columns:
+  // value blocks vb0 .. and gate blocks 64 + vb0 ..
+  constexpr int VB = 8 / HS;                 // value blocks per wave: 8, 4 or 2
+  constexpr int PASS = VB > 4 ? 2 : 1;       // at most 4 value + 4 gate accumulators at a time
+  constexpr int VP = VB / PASS;
+  for (int half = 0; half < PASS; ++half) {
+    f32x4 acc[2 * VP];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int c0 = 8 * wave + 4 * half;
-    const int cb[8] = {c0, c0 + 1, c0 + 2, c0 + 3, 64 + c0, 64 + c0 + 1, 64 + c0 + 2, 64 + c0 + 3};
-    gemm16<8, 2>(acc, N, kLdX, kFD, p.w1, cb, lane);
+    for (int i = 0; i < 2 * VP; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lb0 = VB * wave + VP * half;                  // first local value block
+    const int c0 = hs * (64 / HS) + lb0;                    // ... and its global index
+    int cb[2 * VP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = (c0 + i) * 16 + r16;
+    for (int i = 0; i < VP; ++i) {
+      cb[i] = c0 + i;
+      cb[VP + i] = 64 + c0 + i;
+    }
+    gemm16<2 * VP, (VP == 4 ? 2 : 4)>(acc, N, kLdX, kFD, p.w1, cb, lane);
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+      const int col = (c0 + i) * 16 + r16, lcol = (lb0 + i) * 16 + r16;
       const float bv = p.b1[col], bg = p.b1[kFH + col];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float val = acc[i][r] + bv, gate = acc[4 + i][r] + bg;
-        G[(4 * q4 + r) * kLdG + col] = val * (0.5f * gate * (1.f + erff(gate * 0.70710678118654752f)));
+        const float val = acc[i][r] + bv, gate = acc[VP + i][r] + bg;
+        G[(4 * q4 + r) * kLdG + lcol] = val * (0.5f * gate * (1.f + erff(gate * 0.70710678118654752f)));
       }
     }
   }
   __syncthreads();
 
-  // ---- z = g W2^T + b2 + y : K = 1024, N = 256 -> 2 column blocks per wave ------------------------
+  // ---- z = g W2^T + b2 + y : K = 1024 / HS of this slice, N = 256 -> 2 column blocks per wave ---------
   {
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     const int cb[2] = {2 * wave, 2 * wave + 1};
-    gemm16<2, 8>(acc, G, kLdG, kFH, p.w2, cb, lane);
+    gemm16<2, 8>(acc, G, kLdG, kFH / HS, p.w2, cb, lane, kFH, hs * (kFH / HS / 16));
+    float *dst = HS == 1 ? p.out : p.partial + (long long)hs * p.n * kFD;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int col = cb[i] * 16 + r16;
@@ -230,10 +252,52 @@ k_fusion_attention(const FusionParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long row = row0 + 4 * q4 + r;
-        if (row < p.n) p.out[row * kFD + col] = acc[i][r] + bias + X[(4 * q4 + r) * kLdX + col];
+        if (row < p.n) {
+          float v = acc[i][r];
+          if (hs == 0) v += bias + X[(4 * q4 + r) * kLdX + col];   // bias and residual enter once
+          dst[row * kFD + col] = v;
+        }
       }
     }
   }
+}
+
+// out = sum over the HS partial slices, ascending (deterministic)
+__global__ void __launch_bounds__(256) k_fusion_reduce(const float *__restrict__ partial, long long n4, int hs,
+                                                       float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = reinterpret_cast<const float4 *>(partial)[i];
+  for (int h = 1; h < hs; ++h) {
+    const float4 v = reinterpret_cast<const float4 *>(partial)[(long long)h * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4 *>(out)[i] = s;
+}
+
+template <int HS>
+static int launch_fusion(const FusionParams &p, hipStream_t st) {
+  const size_t lds = (size_t)kFRows * (2 * kLdX + kLdS + kLdQ + ld_g<HS>()) * sizeof(float);
+  static bool attr_set = false;   // idempotent; a benign race at worst sets it twice
+  if (!attr_set) {
+    IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_fusion_attention<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  k_fusion_attention<HS><<<dim3((unsigned)div_up(p.n, kFRows), HS), 512, lds, st>>>(p);
+  IMF_CHECK_LAUNCH("k_fusion_attention");
+  if (HS > 1) {
+    const long long n4 = p.n * kFD / 4;
+    k_fusion_reduce<<<(unsigned)div_up(n4, 256), 256, 0, st>>>(p.partial, n4, HS, p.out);
+    IMF_CHECK_LAUNCH("k_fusion_reduce");
+  }
+  return IMF_OK;
+}
+
+// slices of the hidden dimension: fill ~256 CUs, one workgroup each
+static int fusion_slices(int64_t n) {
+  const int64_t blocks = div_up(n, kFRows);
+  if (const char *e = getenv("IMF_FUSION_SLICES")) return atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
+  return blocks <= 64 ? 4 : (blocks <= 128 ? 2 : 1);   // measured: 272 workgroups on 256 CUs lose to 136
 }
 
 }  // namespace imf
@@ -242,25 +306,29 @@ using namespace imf;
 
 extern "C" {
 
+size_t imf_fusion_workspace_bytes(int64_t n) {
+  const int hs = fusion_slices(n);
+  return hs > 1 ? (size_t)hs * (size_t)n * kFD * sizeof(float) : 0;
+}
+
 int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed, int n_tokens,
-                         int tokens_padded, const imf_fusion_weights *w, float scale, float *out, void *stream) {
+                         int tokens_padded, const imf_fusion_weights *w, float scale, float *out, void *workspace,
+                         size_t workspace_bytes, void *stream) {
   IMF_REQUIRE(x && kt_packed && v_packed && w && out, "imf_fusion_attention: null pointer");
   IMF_REQUIRE(w->ln1_g && w->ln1_b && w->wq_p && w->wo_p && w->bo && w->ln2_g && w->ln2_b && w->w1_p && w->b1 &&
                   w->w2_p && w->b2, "imf_fusion_attention: null weight pointer");
   IMF_REQUIRE(n > 0, "imf_fusion_attention: n");
   IMF_REQUIRE(tokens_padded % 64 == 0 && tokens_padded <= kMaxTokP && n_tokens > 0 && n_tokens <= tokens_padded,
               "imf_fusion_attention: tokens=%d padded=%d (padded %% 64 == 0, <= %d)", n_tokens, tokens_padded, kMaxTokP);
+  const int hs = fusion_slices(n);
+  IMF_REQUIRE(hs == 1 || (workspace && workspace_bytes >= imf_fusion_workspace_bytes(n)),
+              "imf_fusion_attention: needs %zu workspace bytes", imf_fusion_workspace_bytes(n));
   FusionParams p{x, (long long)n, kt_packed, v_packed, n_tokens, tokens_padded, scale, w->ln1_g, w->ln1_b,
-                 w->wq_p, w->wo_p, w->bo, w->ln2_g, w->ln2_b, w->w1_p, w->b1, w->w2_p, w->b2, out};
-  const size_t lds = (size_t)kFRows * (2 * kLdX + kLdS + kLdQ + kLdG) * sizeof(float);
-  static bool attr_set = false;   // idempotent; a benign race at worst sets it twice
-  if (!attr_set) {
-    IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_fusion_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  k_fusion_attention<<<(unsigned)div_up(n, kFRows), 512, lds, (hipStream_t)stream>>>(p);
-  IMF_CHECK_LAUNCH("k_fusion_attention");
-  return IMF_OK;
+                 w->wq_p, w->wo_p, w->bo, w->ln2_g, w->ln2_b, w->w1_p, w->b1, w->w2_p, w->b2, out, (float *)workspace};
+  hipStream_t st = (hipStream_t)stream;
+  if (hs == 4) return launch_fusion<4>(p, st);
+  if (hs == 2) return launch_fusion<2>(p, st);
+  return launch_fusion<1>(p, st);
 }
 
 }  // extern "C"

@@ -484,7 +484,10 @@ def fusion_attention(x, kt_packed, v_packed, n_tokens, tokens_padded, fw, out=No
     _req(x, torch.float32, "x", 2)
     if out is None:
         out = torch.empty_like(x)
-    check(_lib.lib().imf_fusion_attention(x.data_ptr(), x.shape[0], kt_packed.data_ptr(), v_packed.data_ptr(),
-                                          int(n_tokens), int(tokens_padded), C.byref(fw.c), C.c_float(fw.scale),
-                                          out.data_ptr(), _stream()), "imf_fusion_attention")
+    L = _lib.lib()
+    nbytes = L.imf_fusion_workspace_bytes(x.shape[0])
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+    check(L.imf_fusion_attention(x.data_ptr(), x.shape[0], kt_packed.data_ptr(), v_packed.data_ptr(),
+                                 int(n_tokens), int(tokens_padded), C.byref(fw.c), C.c_float(fw.scale),
+                                 out.data_ptr(), ws.data_ptr(), nbytes, _stream()), "imf_fusion_attention")
     return out

@@ -244,9 +244,12 @@ int imf_conv_first_bitgrid(const int32_t *coords, int64_t n, const int32_t *bbox
 typedef struct imf_fusion_weights {
   const float *ln1_g, *ln1_b, *wq_p, *wo_p, *bo, *ln2_g, *ln2_b, *w1_p, *b1, *w2_p, *b2;
 } imf_fusion_weights;
+/* Workspace for the hidden-dimension split the library applies to small n (so that ~1 k rows still fill
+ * the chip): imf_fusion_workspace_bytes(n) bytes of device memory (0 when no split is used). */
+size_t imf_fusion_workspace_bytes(int64_t n);
 int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed,
                          int n_tokens, int tokens_padded, const imf_fusion_weights *w /* [host] */,
-                         float scale, float *out, void *stream);
+                         float scale, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Descriptor matching for feature-match recall ---------------------------------
  * imf_nn_search replaces util/uio.py:245-258 `knn_search(points_src, points_dst, k=1)` (one Open3D
