@@ -25,8 +25,8 @@ def timed_fuse_wrapper(fuse):
     def f(x):
         t = time.perf_counter(); r = fuse(x); tick("6b  fuse (torch attention) queue", t); return r
     return f
-def run(self, x, fuse):
-    t = time.perf_counter(); r = orig_run(self, x, timed_fuse_wrapper(fuse)); tick("6a  plan.run total", t); return r
+def run(self, x, fuse, after_fuse=None):
+    t = time.perf_counter(); r = orig_run(self, x, timed_fuse_wrapper(fuse), after_fuse); tick("6a  plan.run total", t); return r
 planmod.FusedPlan.run = run
 with torch.no_grad():
     for it in range(30):
@@ -47,5 +47,17 @@ with torch.no_grad():
         F = model(s, img_d).F
         tick("5 forward queue (total)", t)
     torch.cuda.synchronize()
+    # whole-step host enqueue time vs wall time per step
+    t = time.perf_counter(); n = 30
+    for it in range(n):
+        levels = ops.pyramid_from_points(xyz_d, voxel, 4, 0, inputs_ready=True, before_sync=lambda: model.start_image_branch(img_d, inputs_ready=True))
+        cm = ME.CoordinateManager.from_levels(levels)
+        f = torch.ones((levels[0].n, 1), dtype=torch.float32, device=dev)
+        s = ME.SparseTensor(f, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm); s._all_ones = True
+        F = model(s, img_d).F
+    t_host = time.perf_counter() - t
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t
+    print(f"host enqueue {t_host / n * 1e6:.1f} us/step, wall {t_all / n * 1e6:.1f} us/step")
 for k in sorted(T):
     print(f"{k:36s} median {np.median(T[k][8:])*1e6:8.1f} us")
