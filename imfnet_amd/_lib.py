@@ -50,6 +50,39 @@ class FusionWeights(C.Structure):
                                           "w2_p", "b2")]
 
 
+class NetConv(C.Structure):
+    """struct imf_net_conv."""
+    _fields_ = [("w_packed", C.c_void_p), ("kvol", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int32), ("l2norm", C.c_int32),
+                ("variant", C.c_int32)]
+
+
+class ResunetDesc(C.Structure):
+    """struct imf_resunet_desc."""
+    _fields_ = [("channels", C.c_int32 * 5), ("tr_channels", C.c_int32 * 5), ("in_channels", C.c_int32),
+                ("out_channels", C.c_int32), ("first_ksize", C.c_int32), ("small_first", C.c_int32),
+                ("conv", NetConv * 23), ("first_kernel", C.c_void_p), ("first_scale", C.c_void_p),
+                ("first_shift", C.c_void_p), ("fusion", FusionWeights), ("fusion_scale", C.c_float)]
+
+
+class NetTrace(C.Structure):
+    """struct imf_net_trace."""
+    _fields_ = [("ev_begin", C.c_void_p), ("ev_end", C.c_void_p), ("nbr", C.c_void_p), ("kvol", C.c_int32),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("split", C.c_int32), ("n_slots", C.c_int64),
+                ("n_out", C.c_int64), ("launched", C.c_int32)]
+
+
+class ResunetIO(C.Structure):
+    """struct imf_resunet_io."""
+    _fields_ = [("level", LevelDesc * 4), ("n", C.c_int64 * 4), ("bbox", C.c_void_p), ("x", C.c_void_p),
+                ("x_all_ones", C.c_int32), ("kt_packed", C.c_void_p), ("v_packed", C.c_void_p),
+                ("n_tokens", C.c_int32), ("tokens_padded", C.c_int32), ("image_ready", C.c_void_p),
+                ("fusion_done", C.c_void_p), ("int_arena", C.c_void_p), ("int_arena_bytes", C.c_size_t),
+                ("float_arena", C.c_void_p), ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p),
+                ("events", C.c_void_p * 8), ("side_stream", C.c_void_p), ("main_stream", C.c_void_p),
+                ("trace", C.POINTER(NetTrace))]
+
+
 _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/imfnet_hip.h declares
@@ -64,6 +97,9 @@ SIGNATURES = {
     "imf_mutual_inliers": (_I, [_P, _L, _P, _L, _P, _P, _P, _D, _P, _P, _P]),
     "imf_keypoint_workspace_bytes": (_Z, [_L, _L]),
     "imf_select_keypoints": (_I, [_P, _L, _P, _L, _D, _P, _P, _P, _Z, _P]),
+    "imf_resunet_int_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64), _P]),
+    "imf_resunet_float_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64)]),
+    "imf_resunet_forward": (_I, [C.POINTER(ResunetDesc), C.POINTER(ResunetIO)]),
     "imf_hash_capacity": (_L, [_L]),
     "imf_unique_workspace_bytes": (_Z, [_L]),
     "imf_voxelize": (_I, [_P, _I, _L, _D, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),

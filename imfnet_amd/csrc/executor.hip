@@ -1,0 +1,316 @@
+// Native executor for the ResUNet layer schedule (host code only: no kernels here).
+//
+// The reference runs one fragment as ~100 Python-level MinkowskiEngine calls
+// (model/resunet.py:163-235).  The Python arena executor (imfnet_amd/model/plan.py) already reduced
+// that to one ctypes call per launch, but at 0.88 ms per fragment its 0.5 ms of interpreter time per
+// forward is as long as the GPU work.  imf_resunet_forward walks the same schedule natively: rulebook
+// builds on a side stream joined by events, the first convolution, the encoder, the fused bottleneck
+// attention (after the image branch's event), the decoder and the head -- one call per fragment,
+// ~100 launches at C++ cost.  Arithmetic, launch order and buffers are those of plan.py
+// (tests/test_gpu_parity.py::test_native_executor_equals_python_plan).
+#include <string.h>
+
+#include "common.h"
+
+namespace imf {
+namespace {
+
+struct Rb {   // rulebook inside the int arena
+  int32_t *tile_rows = nullptr, *nbr = nullptr;
+  uint32_t *tile_mask = nullptr;
+  int64_t n_slots = 0, n_out = 0;
+  int kvol = 1, max_active = 1;
+  int ready_event = -1;   // index into io->events that the main stream must wait on before first use
+  size_t words() const { return (size_t)n_slots + (size_t)kvol * n_slots + (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS; }
+  int32_t *place(int32_t *p) {
+    tile_rows = p;
+    nbr = p + n_slots;
+    tile_mask = (uint32_t *)(nbr + (size_t)kvol * n_slots);
+    return p + words();
+  }
+};
+
+struct Sizes {
+  int64_t n[4];
+  int64_t slots[4], up_slots[3];
+  int ch[5], tr[5], dec[3];
+  int first_kvol;
+  bool small_first;
+};
+
+Sizes sizes_of(const imf_resunet_desc *net, const int64_t *n) {
+  Sizes s;
+  for (int i = 0; i < 4; ++i) {
+    s.n[i] = n[i];
+    s.slots[i] = imf_rulebook_slots(n[i]);
+  }
+  for (int i = 0; i < 3; ++i) s.up_slots[i] = imf_rulebook_transpose_slots(n[i]);
+  for (int i = 0; i < 5; ++i) {
+    s.ch[i] = net->channels[i];
+    s.tr[i] = net->tr_channels[i];
+  }
+  s.dec[2] = s.tr[4];
+  s.dec[1] = s.tr[3];
+  s.dec[0] = s.tr[2];
+  s.first_kvol = net->first_ksize * net->first_ksize * net->first_ksize;
+  s.small_first = net->small_first != 0;
+  return s;
+}
+
+size_t rb_words(int64_t n_slots, int kvol) {
+  return (size_t)n_slots + (size_t)kvol * n_slots + (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS;
+}
+
+size_t int_words(const Sizes &s) {
+  size_t w = 0;
+  if (!s.small_first) w += rb_words(s.slots[0], s.first_kvol);
+  for (int i = 0; i < 4; ++i) w += rb_words(s.slots[i], 27);
+  for (int i = 0; i < 3; ++i) w += rb_words(s.slots[i + 1], 27);
+  for (int i = 0; i < 3; ++i) w += rb_words(s.up_slots[i], 27);
+  return w + 16 * 3;
+}
+
+// feature buffers: e{i}{a,b,c} (encoder level i: conv out, block mid, block out), d{i}{a,b,c}, head, fused
+enum { E0A = 0, D0A = 12, HEAD = 21, FUSED = 22, NBUF = 23 };
+inline int ebuf(int i, int s) { return E0A + 3 * i + s; }
+inline int dbuf(int i, int s) { return D0A + 3 * i + s; }
+
+void buffer_floats(const Sizes &s, size_t (&cnt)[NBUF]) {
+  for (int i = 0; i < 4; ++i)
+    for (int k = 0; k < 3; ++k) cnt[ebuf(i, k)] = (size_t)s.n[i] * s.ch[i + 1];
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k) cnt[dbuf(i, k)] = (size_t)s.n[i] * s.dec[i];
+  cnt[HEAD] = (size_t)s.n[0] * s.tr[1];
+  cnt[FUSED] = (size_t)s.n[3] * s.ch[4];
+}
+
+struct Step {   // one fused convolution of the schedule
+  int conv;     // index into imf_resunet_desc::conv
+  Rb *rb;
+  int in_a, c_a, out, in_b, c_b, residual;   // buffer ids (-1 none; -2 = io->x; -3 = io->out)
+};
+
+}  // namespace
+}  // namespace imf
+
+using namespace imf;
+
+extern "C" {
+
+size_t imf_resunet_int_arena_bytes(const imf_resunet_desc *net, const int64_t *n, const int32_t *bbox) {
+  if (!net || !n) return 0;
+  const Sizes s = sizes_of(net, n);
+  size_t words = int_words(s);
+  if (s.small_first && bbox) words += imf_bitgrid_words(bbox, net->first_ksize);
+  return words * 4 + 256;
+}
+
+size_t imf_resunet_float_arena_bytes(const imf_resunet_desc *net, const int64_t *n) {
+  if (!net || !n) return 0;
+  const Sizes s = sizes_of(net, n);
+  size_t cnt[NBUF];
+  buffer_floats(s, cnt);
+  size_t total = 0;
+  for (int i = 0; i < NBUF; ++i) total += (cnt[i] + 63) / 64 * 64;
+  // largest split-K workspace of any launch (same rule as imf_spconv_fwd's automatic split)
+  size_t ws = 0;
+  auto consider = [&](int64_t n_slots, int cout, int max_active) {
+    const int sp = imf_spconv_auto_split(n_slots, cout, max_active);
+    if (sp > 1) ws = ws > (size_t)sp * n_slots * cout ? ws : (size_t)sp * n_slots * cout;
+  };
+  for (int i = 0; i < 4; ++i) {
+    consider(s.slots[i], s.ch[i + 1], 27);
+    if (i < 3) consider(s.slots[i], s.dec[i], 27);
+    if (i > 0) consider(s.slots[i], s.ch[i + 1], 27);   // strided conv into level i
+  }
+  for (int i = 0; i < 3; ++i) consider(s.up_slots[i], s.dec[i], 8);
+  if (!s.small_first) consider(s.slots[0], s.ch[1], s.first_kvol);
+  total += ws;
+  total += imf_fusion_workspace_bytes(s.n[3]) / 4;
+  return total * 4 + 2048;   // alignment slack of the three carved regions
+}
+
+int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
+  IMF_REQUIRE(net && io, "imf_resunet_forward: null pointer");
+  IMF_REQUIRE(io->int_arena && io->float_arena && io->out, "imf_resunet_forward: null arena / out");
+  for (int i = 0; i < 4; ++i)
+    IMF_REQUIRE(io->n[i] > 0 && io->level[i].coords && io->level[i].keys && io->level[i].vals,
+                "imf_resunet_forward: level %d missing", i);
+  IMF_REQUIRE(net->small_first || io->x, "imf_resunet_forward: input features required");
+  const Sizes s = sizes_of(net, io->n);
+  IMF_REQUIRE(io->int_arena_bytes >= imf_resunet_int_arena_bytes(net, io->n, io->bbox),
+              "imf_resunet_forward: int arena %zu < %zu bytes", io->int_arena_bytes,
+              imf_resunet_int_arena_bytes(net, io->n, io->bbox));
+  IMF_REQUIRE(io->float_arena_bytes >= imf_resunet_float_arena_bytes(net, io->n),
+              "imf_resunet_forward: float arena %zu < %zu bytes", io->float_arena_bytes,
+              imf_resunet_float_arena_bytes(net, io->n));
+  hipStream_t main = (hipStream_t)io->main_stream, side = (hipStream_t)io->side_stream;
+  for (int i = 0; i < 7; ++i) IMF_REQUIRE(io->events[i], "imf_resunet_forward: events[%d] missing", i);
+
+  // ---- rulebooks in the int arena --------------------------------------------------------------
+  Rb rb_first, rb_k3[4], rb_dn[3], rb_up[3], rb_id;
+  int32_t *p = (int32_t *)(((uintptr_t)io->int_arena + 255) & ~(uintptr_t)255);
+  if (!s.small_first) {
+    rb_first.n_slots = s.slots[0]; rb_first.n_out = s.n[0]; rb_first.kvol = rb_first.max_active = s.first_kvol;
+    p = rb_first.place(p);
+  }
+  for (int i = 0; i < 4; ++i) {
+    rb_k3[i].n_slots = s.slots[i]; rb_k3[i].n_out = s.n[i]; rb_k3[i].kvol = rb_k3[i].max_active = 27;
+    p = rb_k3[i].place(p);
+  }
+  for (int i = 0; i < 3; ++i) {
+    rb_dn[i].n_slots = s.slots[i + 1]; rb_dn[i].n_out = s.n[i + 1]; rb_dn[i].kvol = rb_dn[i].max_active = 27;
+    p = rb_dn[i].place(p);
+  }
+  for (int i = 0; i < 3; ++i) {
+    rb_up[i].n_slots = s.up_slots[i]; rb_up[i].n_out = s.n[i]; rb_up[i].kvol = 27; rb_up[i].max_active = 8;
+    p = rb_up[i].place(p);
+  }
+  int32_t *counters = p;
+  p += 16 * 3;
+  uint32_t *bitgrid = (uint32_t *)p;
+  rb_id.n_slots = s.slots[0]; rb_id.n_out = s.n[0]; rb_id.kvol = rb_id.max_active = 1;   // no tables: identity
+
+  auto build_conv = [&](Rb &rb, const imf_level &in, const imf_level &out, int64_t n_out, int ksize,
+                        hipStream_t st) -> int {
+    return imf_rulebook_conv(in.keys, in.vals, in.capacity, out.coords, n_out, in.tensor_stride, ksize,
+                             rb.tile_rows, rb.nbr, rb.tile_mask, st);
+  };
+  int ev = 0;
+  auto mark = [&](Rb &rb) -> int {   // record on the side stream; the main stream waits before first use
+    IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[ev], side));
+    rb.ready_event = ev++;
+    return IMF_OK;
+  };
+  int rc;
+  if (!s.small_first) {
+    if ((rc = build_conv(rb_first, io->level[0], io->level[0], s.n[0], net->first_ksize, main))) return rc;
+    if ((rc = build_conv(rb_k3[0], io->level[0], io->level[0], s.n[0], 3, main))) return rc;
+  } else {   // conv1 needs no rulebook: k3@1 is built under it
+    if ((rc = build_conv(rb_k3[0], io->level[0], io->level[0], s.n[0], 3, side))) return rc;
+    if ((rc = mark(rb_k3[0]))) return rc;
+  }
+  for (int i = 0; i < 3; ++i) {
+    if ((rc = build_conv(rb_dn[i], io->level[i], io->level[i + 1], s.n[i + 1], 3, side))) return rc;
+    if ((rc = build_conv(rb_k3[i + 1], io->level[i + 1], io->level[i + 1], s.n[i + 1], 3, side))) return rc;
+    if ((rc = mark(rb_dn[i]))) return rc;
+  }
+  for (int i = 2; i >= 0; --i) {
+    rc = imf_rulebook_transpose(io->level[i + 1].keys, io->level[i + 1].vals, io->level[i + 1].capacity,
+                                io->level[i].coords, s.n[i], 1 << i, 3, rb_up[i].tile_rows, rb_up[i].nbr,
+                                rb_up[i].tile_mask, rb_up[i].n_slots, counters + 16 * i, side);
+    if (rc) return rc;
+    if ((rc = mark(rb_up[i]))) return rc;
+  }
+
+  // ---- feature buffers in the float arena ------------------------------------------------------
+  size_t cnt[NBUF];
+  buffer_floats(s, cnt);
+  float *buf[NBUF];
+  float *fp = (float *)(((uintptr_t)io->float_arena + 255) & ~(uintptr_t)255);
+  for (int i = 0; i < NBUF; ++i) {
+    buf[i] = fp;
+    fp += (cnt[i] + 63) / 64 * 64;
+  }
+  float *ws = fp;
+  const size_t total_floats = (io->float_arena_bytes - ((char *)fp - (char *)io->float_arena)) / 4;
+  const size_t fusion_ws_floats = imf_fusion_workspace_bytes(s.n[3]) / 4;
+  float *fusion_ws = (float *)io->float_arena + (io->float_arena_bytes / 4) - fusion_ws_floats - 64;
+  fusion_ws = (float *)((uintptr_t)fusion_ws & ~(uintptr_t)255);
+  const size_t ws_bytes = ((char *)fusion_ws - (char *)ws);
+  (void)total_floats;
+
+  // ---- schedule (model/resunet.py:168-226) ---------------------------------------------------------
+  Step sched[24];
+  int n_steps = 0, n_enc = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int c = s.ch[i + 1];
+    if (i > 0) sched[n_steps++] = Step{3 * i, &rb_dn[i - 1], ebuf(i - 1, 2), s.ch[i], ebuf(i, 0), -1, 0, -1};
+    else if (!s.small_first) sched[n_steps++] = Step{0, &rb_first, -2, net->in_channels, ebuf(0, 0), -1, 0, -1};
+    sched[n_steps++] = Step{3 * i + 1, &rb_k3[i], ebuf(i, 0), c, ebuf(i, 1), -1, 0, -1};
+    sched[n_steps++] = Step{3 * i + 2, &rb_k3[i], ebuf(i, 1), c, ebuf(i, 2), -1, 0, ebuf(i, 0)};
+  }
+  n_enc = n_steps;
+  for (int i = 2; i >= 0; --i) {   // output level of conv{i+2}_tr
+    const int t = s.dec[i];
+    const int conv0 = 12 + 3 * (2 - i);
+    const int src = i == 2 ? FUSED : dbuf(i + 1, 2), c_src = i == 2 ? s.ch[4] : s.dec[i + 1];
+    const int skip = i == 2 ? -1 : ebuf(i + 1, 2), c_skip = i == 2 ? 0 : s.ch[i + 2];
+    sched[n_steps++] = Step{conv0, &rb_up[i], src, c_src, dbuf(i, 0), skip, c_skip, -1};
+    sched[n_steps++] = Step{conv0 + 1, &rb_k3[i], dbuf(i, 0), t, dbuf(i, 1), -1, 0, -1};
+    sched[n_steps++] = Step{conv0 + 2, &rb_k3[i], dbuf(i, 1), t, dbuf(i, 2), -1, 0, dbuf(i, 0)};
+  }
+  sched[n_steps++] = Step{21, &rb_id, dbuf(0, 2), s.tr[2], HEAD, ebuf(0, 2), s.ch[1], -1};
+  sched[n_steps++] = Step{22, &rb_id, HEAD, s.tr[1], -3, -1, 0, -1};
+
+  auto addr = [&](int id) -> float * {
+    if (id == -1) return nullptr;
+    if (id == -2) return const_cast<float *>(io->x);
+    if (id == -3) return io->out;
+    return buf[id];
+  };
+
+  // ---- first convolution (Cin <= 4): occupancy bit grid for the all-ones feature, else hash probing --
+  if (s.small_first) {
+    size_t words = 0;
+    if (io->x_all_ones && io->bbox && net->in_channels == 1) words = imf_bitgrid_words(io->bbox, net->first_ksize);
+    if (words) {
+      rc = imf_conv_first_bitgrid(io->level[0].coords, s.n[0], io->bbox, net->first_ksize, bitgrid, words,
+                                  net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
+                                  buf[ebuf(0, 0)], main);
+    } else {
+      rc = imf_conv_first_fused(io->level[0].keys, io->level[0].vals, io->level[0].capacity, io->level[0].coords,
+                                s.n[0], 1, net->first_ksize, io->x_all_ones ? nullptr : io->x, net->in_channels,
+                                net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
+                                buf[ebuf(0, 0)], main);
+    }
+    if (rc) return rc;
+  }
+
+  auto launch = [&](const Step &st) -> int {
+    const imf_net_conv &c = net->conv[st.conv];
+    IMF_REQUIRE(c.w_packed, "imf_resunet_forward: conv %d has no weights", st.conv);
+    IMF_REQUIRE(st.c_a + st.c_b == c.cin, "imf_resunet_forward: conv %d expects %d input channels, got %d",
+                st.conv, c.cin, st.c_a + st.c_b);
+    Rb &rb = *st.rb;
+    if (rb.ready_event >= 0) {
+      IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->events[rb.ready_event], 0));
+      rb.ready_event = -1;
+    }
+    imf_conv_args a;
+    memset(&a, 0, sizeof(a));
+    a.in_a = addr(st.in_a); a.in_b = addr(st.in_b); a.c_a = st.c_a; a.c_b = st.c_b;
+    a.w_packed = c.w_packed; a.kvol = c.kvol; a.cout = c.cout;
+    a.tile_rows = rb.tile_rows; a.nbr = rb.nbr; a.tile_mask = rb.tile_mask;
+    a.n_slots = rb.n_slots; a.n_out = rb.n_out;
+    a.scale = c.scale; a.shift = c.shift; a.residual = addr(st.residual);
+    a.relu = c.relu; a.l2norm = c.l2norm; a.out = addr(st.out);
+    const int split = imf_spconv_auto_split(rb.n_slots, c.cout, rb.max_active);
+    a.split_k = c.kvol == 1 ? 1 : split;
+    a.variant = c.variant;
+    if (a.split_k > 1) { a.workspace = ws; a.workspace_bytes = ws_bytes; }
+    if (io->trace) {
+      imf_net_trace &t = io->trace[st.conv];
+      a.ev_begin = t.ev_begin; a.ev_end = t.ev_end;
+      t.nbr = rb.nbr; t.kvol = c.kvol; t.cin = c.cin; t.cout = c.cout; t.split = a.split_k;
+      t.n_slots = rb.n_slots; t.n_out = rb.n_out; t.launched = 1;
+    }
+    return imf_spconv_fwd(&a, main);
+  };
+
+  for (int i = 0; i < n_enc; ++i)
+    if ((rc = launch(sched[i]))) return rc;
+
+  // ---- bottleneck fusion (model/resunet.py:237-273) ----------------------------------------------------
+  if (io->image_ready) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
+  rc = imf_fusion_attention(buf[ebuf(3, 2)], s.n[3], io->kt_packed, io->v_packed, io->n_tokens, io->tokens_padded,
+                            &net->fusion, net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4, main);
+  if (rc) return rc;
+  if (io->fusion_done) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->fusion_done, main));
+
+  for (int i = n_enc; i < n_steps; ++i)
+    if ((rc = launch(sched[i]))) return rc;
+  return IMF_OK;
+}
+
+}  // extern "C"

@@ -71,6 +71,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self.img_encoder = ImageEncoder()
         self._folded = None
         self._plan = None                 # arena executor (model/plan.py), built lazily in eval mode
+        self._native_plan = None          # its native twin: one C call per fragment (csrc/executor.hip)
         self._pending_image = None        # (image, features, kv, event, packed K/V) queued by start_image_branch
         self._kv_packed = {}              # (device, image shape) -> packed K^T / V buffers
         self._fuse_done = None            # event: last fusion finished reading the image branch outputs
@@ -82,6 +83,7 @@ class ResUNet2(ME.MinkowskiNetwork):
     # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
     def _invalidate(self):
         self._plan = None
+        self._native_plan = None
         self._folded = None
         self._pending_image = None
         self._img_graph = {}
@@ -232,6 +234,18 @@ class ResUNet2(ME.MinkowskiNetwork):
             from .plan import FusedPlan
             self._plan = FusedPlan(self)
         hook, self.after_fusion_hook = self.after_fusion_hook, None      # one-shot
+        native = (packed is not None and hook is None and x.F.is_cuda and
+                  not os.environ.get("IMFNET_PYTHON_EXECUTOR"))
+        if native:                                      # one C call: csrc/executor.hip
+            if self._native_plan is None:
+                from .plan import NativePlan
+                self._native_plan = NativePlan(self, self._plan)
+            cur = torch.cuda.current_stream(x.F.device)
+            image_feat.record_stream(cur)
+            for t in packed[:2]:
+                t.record_stream(cur)
+            self._fuse_done = torch.cuda.Event()
+            return x._like(self._native_plan.run(x, packed, ev, self._fuse_done))
         return x._like(self._plan.run(x, fuse, hook))
 
     def forward_layers(self, x, image):

@@ -251,6 +251,64 @@ int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, cons
                          int n_tokens, int tokens_padded, const imf_fusion_weights *w /* [host] */,
                          float scale, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Native executor for the ResUNet layer schedule -----------------------------------------------
+ * One call per fragment replaces the ~100 per-layer calls of model/resunet.py:163-235 (rulebook builds
+ * on a side stream, first convolution, encoder, bottleneck fusion, decoder, head), in the launch order
+ * and with the arithmetic of the per-layer entry points above.  Configuration: batch 1, one attention
+ * head, fusion depth 0 (IMFNet's).  All pointers inside the structs are device pointers except where
+ * noted; the structs themselves live on the host. */
+typedef struct imf_net_conv {          /* static half of one fused convolution */
+  const float *w_packed;               /* imf_pack_weights / imf_pack_weights_split16 image (see variant) */
+  int32_t kvol, cin, cout;
+  const float *scale, *shift;          /* folded BatchNorm or bias; NULL = identity */
+  int32_t relu, l2norm, variant;
+} imf_net_conv;
+
+typedef struct imf_resunet_desc {
+  int32_t channels[5], tr_channels[5]; /* CHANNELS / TR_CHANNELS of model/resunet.py:22-23 (index 0 unused) */
+  int32_t in_channels, out_channels, first_ksize;
+  int32_t small_first;                 /* in_channels <= 4: conv1 runs as imf_conv_first_* (first_* below) */
+  /* 0 conv1 | 1,2 block1 | 3 conv2 | 4,5 block2 | 6 conv3 | 7,8 block3 | 9 conv4 | 10,11 block4 |
+   * 12 conv4_tr | 13,14 block4_tr | 15 conv3_tr | 16,17 block3_tr | 18 conv2_tr | 19,20 block2_tr |
+   * 21 conv1_tr | 22 final */
+  imf_net_conv conv[23];
+  const float *first_kernel, *first_scale, *first_shift;   /* conv1 [kvol][cin][cout] unpacked + norm1 */
+  imf_fusion_weights fusion;
+  float fusion_scale;
+} imf_resunet_desc;
+
+typedef struct imf_net_trace {         /* optional per-convolution measurement record (index = conv id) */
+  void *ev_begin, *ev_end;             /* in: hipEvent_t pair recorded around the main kernel */
+  const int32_t *nbr;                  /* out: the launch's neighbour table (NULL for 1x1x1) */
+  int32_t kvol, cin, cout, split;
+  int64_t n_slots, n_out;
+  int32_t launched;
+} imf_net_trace;
+
+typedef struct imf_resunet_io {        /* per fragment */
+  imf_level level[4];                  /* tensor strides 1, 2, 4, 8 (imf_pyramid_build) */
+  int64_t n[4];                        /* rows per level */
+  const int32_t *bbox;                 /* [host] level-0 bounding box (8 ints) or NULL */
+  const float *x;                      /* [n0, in_channels] input features (may be NULL when x_all_ones) */
+  int32_t x_all_ones;                  /* util/misc.py:76-79 occupancy feature */
+  const float *kt_packed, *v_packed;   /* image tokens' K^T / V, packed (imf_fusion_attention) */
+  int32_t n_tokens, tokens_padded;
+  void *image_ready;                   /* hipEvent_t the main stream waits on before the fusion, or NULL */
+  void *fusion_done;                   /* hipEvent_t recorded on the main stream right after the fusion
+                                          (the image tokens' K/V may be overwritten after it), or NULL */
+  void *int_arena;  size_t int_arena_bytes;     /* >= imf_resunet_int_arena_bytes   */
+  void *float_arena; size_t float_arena_bytes;  /* >= imf_resunet_float_arena_bytes */
+  float *out;                          /* [n0, out_channels] descriptors */
+  void *events[8];                     /* caller-owned hipEvent_t (imf_event_create): side-stream joins */
+  void *side_stream, *main_stream;
+  imf_net_trace *trace;                /* [host] 23 records or NULL */
+} imf_resunet_io;
+
+size_t imf_resunet_int_arena_bytes(const imf_resunet_desc *net, const int64_t *n /* [4] */,
+                                   const int32_t *bbox /* [host] or NULL */);
+size_t imf_resunet_float_arena_bytes(const imf_resunet_desc *net, const int64_t *n /* [4] */);
+int imf_resunet_forward(const imf_resunet_desc *net /* [host] */, const imf_resunet_io *io /* [host] */);
+
 /* ---- Descriptor matching for feature-match recall ---------------------------------
  * imf_nn_search replaces util/uio.py:245-258 `knn_search(points_src, points_dst, k=1)` (one Open3D
  * KD-tree query per row, fp64) as called twice at scripts/evaluation_3dmatch.py:207-210: for every

@@ -426,6 +426,32 @@ def test_fused_equals_layerwise(model, clouds, images):
     assert (a - b).abs().max() < 2e-5
 
 
+def test_native_executor_equals_python_plan(model, clouds, images, monkeypatch):
+    """imf_resunet_forward (one C call per fragment) issues the launches of the Python arena executor:
+    descriptors must be bit-identical, for both fragments and two voxel sizes, also when traced."""
+    from imfnet_amd import ops as O_
+    from imfnet_amd.extract import sparse_tensor_from_points
+    for k, voxel in ((0, 0.05), (1, 0.05), (0, 0.025)):
+        xyz = clouds[k].astype(np.float64)
+        img = torch.as_tensor(images[k]).to(DEV)
+        with torch.no_grad():
+            monkeypatch.setenv("IMFNET_PYTHON_EXECUTOR", "1")
+            st, _ = sparse_tensor_from_points(xyz, voxel, torch.device(DEV))
+            a = model(st, img).F.clone()
+            monkeypatch.delenv("IMFNET_PYTHON_EXECUTOR")
+            st2, _ = sparse_tensor_from_points(xyz, voxel, torch.device(DEV))
+            b = model(st2, img).F.clone()
+            O_.TRACE = []
+            st3, _ = sparse_tensor_from_points(xyz, voxel, torch.device(DEV))
+            c = model(st3, img).F.clone()
+            torch.cuda.synchronize()
+            trace, O_.TRACE = O_.TRACE, None
+        assert model._native_plan is not None
+        assert torch.equal(a, b) and torch.equal(a, c)
+        assert len(trace) == 22 and all(r["ev"].elapsed_ms() > 0 for r in trace)
+        assert sorted(r["name"] for r in trace)[0] == "block1.conv1"
+
+
 def test_forward_from_coordinates_api(model, clouds, images, golden):
     """The reference's call shape: ME.SparseTensor(feats, coordinates=coords, device) -> model(...)."""
     import imfnet_amd.sparse as ME
