@@ -56,8 +56,19 @@ __device__ __forceinline__ void split8(const float4 &x0, const float4 &x1, f16x8
   }
 }
 
+#ifdef IMF_H3_STAMPS   // diagnostic build only (make stamps; tools/conv_stamps.py): s_memtime stamps -> p.partial
+#define IMF_STAMP(i)                                                                             \
+  do {                                                                                           \
+    if (lane == 0 && (i) < 128)                                                                  \
+      reinterpret_cast<long long *>(p.partial)[((long long)blockIdx.x * 4 + wave) * 128 + (i)] = \
+          (long long)__builtin_readcyclecounter();                                               \
+  } while (0)
+#else
+#define IMF_STAMP(i) do { } while (0)
+#endif
+
 template <int CO_BLK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)   // 4 workgroups per CU: <= 128 registers per lane
 k_spconv_h3(const ConvParams p) {
   constexpr int SUB_F4 = 2 * CO_BLK * 64;            // float4 per (k, cc) sub-stage: 512 or 256
   constexpr int KG = 1024 / SUB_F4;                  // sub-stages per 16 KiB macro stage: 2 or 4
@@ -71,6 +82,7 @@ k_spconv_h3(const ConvParams p) {
   const int cin = p.c_a + p.c_b;
   const int ncc = cin / 32;
 
+  IMF_STAMP(0);
   uint32_t mask[IMF_MASK_WORDS] = {1u, 0u, 0u, 0u};
   if (p.tile_mask) {
 #pragma unroll
@@ -96,6 +108,7 @@ k_spconv_h3(const ConvParams p) {
     }
   }
   __syncthreads();
+  IMF_STAMP(1);
   // the tile's slice of the neighbour table: all loads in flight together, then the LDS stores
   const long long tile_slot0 = (long long)tile * IMF_TILE_ROWS;
   {
@@ -115,49 +128,79 @@ k_spconv_h3(const ConvParams p) {
     }
   }
   __syncthreads();
+  IMF_STAMP(2);
 
   f32x4 acc[CO_BLK];
 #pragma unroll
   for (int cb = 0; cb < CO_BLK; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const float4 *wbase = reinterpret_cast<const float4 *>(p.w_packed) +
-                        (long long)y * p.kvol * ncc * SUB_F4;
   const int n_sub = nk * ncc;
   const int n_macro = (n_sub + KG - 1) / KG;
 
   // prefetch registers: named scalars for the weight quads (an array would land in scratch)
   float4 w0, w1, w2, w3;
   float4 a_next[KG][2];
-  const float4 *sp[KG];
 
-#define IMF_PREFETCH(n)                                                                           \
+  // The (offset, input row) of a sub-stage come from LDS; they are looked up one macro stage before
+  // the loads that use them are issued, so the prefetch never waits on an LDS round trip, and the
+  // (offset ordinal, channel chunk) pair is advanced incrementally (no division in the loop).
+  int lk_t = 0, lk_jk = 0, lk_cc = 0;
+  int k_nx[KG], irow_nx[KG], cc_nx[KG];
+#define IMF_LOOKUP()                                                                               \
   {                                                                                                \
     _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                              \
-      const int t = (n) * KG + g;                                                                  \
-      const int tc = t < n_sub ? t : n_sub - 1;   /* tail: reload the last sub-stage, unused */    \
-      const int jk = tc / ncc, cc = tc - jk * ncc;                                                 \
-      sp[g] = wbase + ((long long)klist[jk] * ncc + cc) * SUB_F4 + tid;                            \
-      const int irow = (t < n_sub) ? nbr_lds[jk][wave * 16 + r16] : -1;                            \
-      const int ch0 = cc * 32;   /* c_a % 32 == 0: a chunk never straddles the two cat sources */   \
-      const float *rowp = (ch0 < p.c_a) ? p.in_a + (long long)irow * p.c_a + ch0                   \
-                                        : p.in_b + (long long)irow * p.c_b + (ch0 - p.c_a);        \
-      if (irow >= 0) {                                                                             \
-        a_next[g][0] = *reinterpret_cast<const float4 *>(rowp + 8 * q4);                           \
-        a_next[g][1] = *reinterpret_cast<const float4 *>(rowp + 8 * q4 + 4);                       \
-      } else {                                                                                     \
-        a_next[g][0] = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
-        a_next[g][1] = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
-      }                                                                                            \
+      const bool live = lk_t < n_sub;                                                              \
+      const int jk = live ? lk_jk : 0;                                                             \
+      k_nx[g] = klist[jk];                                                                         \
+      irow_nx[g] = live ? nbr_lds[jk][wave * 16 + r16] : -1;                                       \
+      cc_nx[g] = live ? lk_cc : 0;                                                                 \
+      ++lk_t;                                                                                      \
+      if (++lk_cc == ncc) { lk_cc = 0; ++lk_jk; }                                                  \
     }                                                                                              \
-    w0 = sp[0 / QPS][(0 % QPS) * 256];                                                             \
-    w1 = sp[1 / QPS][(1 % QPS) * 256];                                                             \
-    w2 = sp[2 / QPS][(2 % QPS) * 256];                                                             \
-    w3 = sp[3 / QPS][(3 % QPS) * 256];                                                             \
   }
 
-  if (n_macro > 0) IMF_PREFETCH(0)
+  // prefetch of the macro stage looked up last: weights -> w0..w3, A fragments -> a_next.
+  // Raw buffer loads (SGPR base + 32-bit offsets): no 64-bit address arithmetic, and a row without an
+  // input at this offset gets an offset beyond the 2 GiB window, which the hardware reads as zeros --
+  // no branch, no zero fill.  The loop was issue-bound on exactly that scalar/vector bookkeeping.
+  const unsigned woff0 = (unsigned)tid * 16u;
+  const long long wslab = (long long)y * p.kvol * ncc * SUB_F4 * 16;     // bytes
+#define IMF_PREFETCH(n)                                                                           \
+  {                                                                                                \
+    unsigned wso[KG];                                                                              \
+    _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                              \
+      const int k = __builtin_amdgcn_readfirstlane(k_nx[g]);                                       \
+      const int cc = cc_nx[g];                                                                     \
+      wso[g] = (unsigned)(wslab + ((long long)k * ncc + cc) * (SUB_F4 * 16));                      \
+      const int irow = irow_nx[g];                                                                 \
+      /* a chunk never straddles the two cat sources: c_a % 32 == 0 (host-checked) */               \
+      const int ch0 = cc * 32;                                                                     \
+      const bool first = ch0 < p.c_a;                                                              \
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(                         \
+          const_cast<float *>(first ? p.in_a : p.in_b), (short)0, 0x7FFFFFFF, 0x00020000);         \
+      const unsigned stride = (unsigned)(first ? p.c_a : p.c_b) * 4u;                              \
+      const unsigned voff = irow >= 0 ? (unsigned)irow * stride + 32u * q4 : 0x80000000u;          \
+      const int soff = (first ? ch0 : ch0 - p.c_a) * 4;                                            \
+      a_next[g][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));      \
+      a_next[g][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16u, soff, 0)); \
+    }                                                                                              \
+    w0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff0 + (0 % QPS) * 4096u, wso[0 / QPS], 0)); \
+    w1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff0 + (1 % QPS) * 4096u, wso[1 / QPS], 0)); \
+    w2 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff0 + (2 % QPS) * 4096u, wso[2 / QPS], 0)); \
+    w3 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff0 + (3 % QPS) * 4096u, wso[3 / QPS], 0)); \
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.w_packed), (short)0, 0x7FFFFFFF, 0x00020000);
+
+  IMF_LOOKUP()
+  if (n_macro > 0) {
+    IMF_PREFETCH(0)
+    IMF_LOOKUP()
+  }
+  IMF_STAMP(3);
 #pragma unroll 1
   for (int n = 0; n < n_macro; ++n) {
+    IMF_STAMP(8 + 4 * n);
     float4 *wbuf = wlds[n & 1];
     wbuf[0 * 256 + tid] = w0;
     wbuf[1 * 256 + tid] = w1;
@@ -166,8 +209,14 @@ k_spconv_h3(const ConvParams p) {
     f16x8 ah[KG], al[KG];
 #pragma unroll
     for (int g = 0; g < KG; ++g) split8(a_next[g][0], a_next[g][1], ah[g], al[g]);
+    IMF_STAMP(9 + 4 * n);
     __syncthreads();   // stage n visible; every wave is past its reads of this buffer (stage n-2)
-    if (n + 1 < n_macro) IMF_PREFETCH(n + 1)
+    IMF_STAMP(10 + 4 * n);
+    if (n + 1 < n_macro) {
+      IMF_PREFETCH(n + 1)
+      IMF_LOOKUP()
+    }
+    IMF_STAMP(11 + 4 * n);
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       f16x8 bh[CO_BLK], bl[CO_BLK];
@@ -189,9 +238,12 @@ k_spconv_h3(const ConvParams p) {
     }
   }
 #undef IMF_PREFETCH
+#undef IMF_LOOKUP
+  IMF_STAMP(4);
 
   if (S == 1) {
     conv_epilogue<CO_BLK>(p, acc, tile, y, wave, r16, q4);
+    IMF_STAMP(5);
   } else {   // raw partial sums, slot-major (k_spconv_reduce finishes)
     const int CW = 16 * CO_BLK;
 #pragma unroll
