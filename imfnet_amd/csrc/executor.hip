@@ -116,7 +116,8 @@ size_t imf_resunet_float_arena_bytes(const imf_resunet_desc *net, const int64_t 
   size_t ws = 0;
   auto consider = [&](int64_t n_slots, int cout, int max_active) {
     const int sp = imf_spconv_auto_split(n_slots, cout, max_active);
-    if (sp > 1) ws = ws > (size_t)sp * n_slots * cout ? ws : (size_t)sp * n_slots * cout;
+    const size_t need = imf_spconv_workspace_bytes(n_slots, cout, sp) / 4;
+    ws = ws > need ? ws : need;
   };
   for (int i = 0; i < 4; ++i) {
     consider(s.slots[i], s.ch[i + 1], 27);
@@ -288,7 +289,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     const int split = imf_spconv_auto_split(rb.n_slots, c.cout, rb.max_active);
     a.split_k = c.kvol == 1 ? 1 : split;
     a.variant = c.variant;
-    if (a.split_k > 1) { a.workspace = ws; a.workspace_bytes = ws_bytes; }
+    a.workspace = ws; a.workspace_bytes = ws_bytes;   // split-K partials or the balanced tail's
     if (io->trace) {
       imf_net_trace &t = io->trace[st.conv];
       a.ev_begin = t.ev_begin; a.ev_end = t.ev_end;

@@ -862,18 +862,19 @@ k_spconv_reg(const ConvParams p) {
 // Adds the split-K partial sums in ascending partition order and applies the epilogue.
 // One thread per (slot, 4 output channels).
 __global__ void __launch_bounds__(256)
-k_spconv_reduce(const ConvParams p, int S) {
+k_spconv_reduce(const ConvParams p, int S, long long slot0) {
+  // slots [slot0, n_slots): the whole table for split-K, the balanced tail's tiles otherwise
   const int c4n = p.cout / 4;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long slot = idx / c4n;
-  const int c4 = (int)(idx - slot * c4n);
+  const long long rel = idx / c4n, slot = slot0 + rel, nrel = p.n_slots - slot0;
+  const int c4 = (int)(idx - rel * c4n);
   const bool in_range = slot < p.n_slots;
   const int orow = in_range ? row_of_slot(p, slot) : -1;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (orow >= 0) {
     for (int zz = 0; zz < S; ++zz) {
       const float4 v = *reinterpret_cast<const float4 *>(
-          p.partial + ((long long)zz * p.n_slots + slot) * p.cout + 4 * c4);
+          p.partial + ((long long)zz * nrel + rel) * p.cout + 4 * c4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     float x[4] = {s.x, s.y, s.z, s.w};
@@ -1175,7 +1176,11 @@ int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol) {
 }
 
 size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split) {
-  return split <= 1 ? 0 : (size_t)split * (size_t)n_slots * (size_t)cout * sizeof(float);
+  if (split > 1) return (size_t)split * (size_t)n_slots * (size_t)cout * sizeof(float);
+  // unsplit launches of >= 512 tiles may balance their last partial round of workgroups (variant 6)
+  const int64_t n_tiles = n_slots / IMF_TILE_ROWS;
+  if (n_tiles < 512 || n_tiles % 256 == 0) return 0;
+  return (size_t)8 * (size_t)(n_tiles % 256) * IMF_TILE_ROWS * (size_t)cout * sizeof(float);
 }
 
 int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
@@ -1208,10 +1213,29 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
                a->residual, a->relu, a->l2norm, a->out, (float *)a->workspace,
                (a->variant == 0 && !simple) ? a->tickets : nullptr, 0};
   if (const char *e = getenv("IMF_ABLATE")) p.ablate = atoi(e);
+  p.tail_begin = p.tail_split = 0;
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
   if (a->variant == 6) {
+    // Balanced tail: with >= 2 full rounds of workgroups per CU and a partial last round (801 tiles on
+    // 256 CUs: 33 CUs get a 4th tile and set the kernel time), the tail tiles are split over their
+    // offsets so every CU receives the same work.  Needs a little workspace; skipped without it.
+    // Measured (S50k): the two 64->64 layers drop 61 -> 56 us, but the extra reduce launch takes the
+    // step-level gain back (0.886 vs 0.884 ms), so it is opt-in: IMF_CONV_TAIL=1.
+    static const int tail_env = getenv("IMF_CONV_TAIL") ? atoi(getenv("IMF_CONV_TAIL")) : 0;
+    const long long n_tiles = grid.x;
+    const int tail_tiles = (int)(n_tiles % 256);
+    const int ts = a->kvol >= 16 ? 8 : 4;
+    // (not for parity-grouped transposed rulebooks: their slot order comes from atomics, and splitting
+    // only SOME tiles would make a row's rounding depend on where it landed -- bit-reproducibility)
+    const bool fixed_order = a->n_slots == imf_rulebook_slots(a->n_out);
+    if (tail_env && fixed_order && split == 1 && grid.y == 1 && a->kvol >= 8 && n_tiles >= 512 && tail_tiles > 0 &&
+        a->workspace && a->workspace_bytes >= (size_t)ts * tail_tiles * IMF_TILE_ROWS * a->cout * sizeof(float)) {
+      p.tail_begin = (int)(n_tiles - tail_tiles);
+      p.tail_split = ts;
+      grid.x = (unsigned)(p.tail_begin + tail_tiles * ts);
+    }
     launch_spconv_h3(p, grid, CB, st);
   } else if ((a->variant == 4 || a->variant == 5) && !simple) {
     const int RBv = a->variant == 4 ? 2 : 1;
@@ -1247,9 +1271,15 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   }
   IMF_CHECK_LAUNCH("k_spconv_mfma");
   if (a->ev_end) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_end, st));
+  if (p.tail_split > 1) {
+    const long long slot0 = (long long)p.tail_begin * IMF_TILE_ROWS;
+    const long long total = (a->n_slots - slot0) * (a->cout / 4);
+    k_spconv_reduce<<<(unsigned)div_up(total, 256), 256, 0, st>>>(p, p.tail_split, slot0);
+    IMF_CHECK_LAUNCH("k_spconv_reduce");
+  }
   if (split > 1 && !p.tickets) {
     const long long total = (long long)a->n_slots * (a->cout / 4);
-    k_spconv_reduce<<<(unsigned)div_up(total, 256), 256, 0, st>>>(p, split);
+    k_spconv_reduce<<<(unsigned)div_up(total, 256), 256, 0, st>>>(p, split, 0);
     IMF_CHECK_LAUNCH("k_spconv_reduce");
   }
   return IMF_OK;

@@ -77,7 +77,17 @@ k_spconv_h3(const ConvParams p) {
   __shared__ int nbr_lds[kKCache][IMF_TILE_ROWS];
   __shared__ int klist[kKCache];
 
-  const int tile = blockIdx.x, y = blockIdx.y, z = blockIdx.z, S = gridDim.z;
+  int tile = blockIdx.x, z = blockIdx.z, S = gridDim.z;
+  long long part_slot0 = 0, part_slots = p.n_slots;
+  if (p.tail_split > 1 && tile >= p.tail_begin) {   // balanced tail: see ConvParams
+    const int r = tile - p.tail_begin;
+    tile = p.tail_begin + r / p.tail_split;
+    z = r % p.tail_split;
+    S = p.tail_split;
+    part_slot0 = (long long)p.tail_begin * IMF_TILE_ROWS;
+    part_slots = p.n_slots - part_slot0;
+  }
+  const int y = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
   const int cin = p.c_a + p.c_b;
   const int ncc = cin / 32;
@@ -252,7 +262,7 @@ k_spconv_h3(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long slot = tile_slot0 + wave * 16 + q4 * 4 + r;
-        p.partial[((long long)z * p.n_slots + slot) * p.cout + col] = acc[cb][r];
+        p.partial[((long long)z * part_slots + (slot - part_slot0)) * p.cout + col] = acc[cb][r];
       }
     }
   }

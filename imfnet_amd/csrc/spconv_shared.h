@@ -21,6 +21,10 @@ struct ConvParams {
   int *tickets;     // optional arrival counters [n_tiles][n_slabs] (zero on entry, left zero): the last
                     // partition to arrive reduces the tile in-kernel instead of a second launch
   int ablate;       // debugging only (env IMF_ABLATE): bit0 no MFMA, bit1 no LDS add, bit2 no A gather, bit3 no B load
+  // Tail balancing (variant 6, gridDim.z == 1): tiles >= tail_begin are split tail_split ways over their
+  // active offsets so that the last, partial round of workgroups per CU is made of small pieces; their
+  // partial sums live in `partial` as [tail_split][n_slots - 64 tail_begin][cout].  0 = off.
+  int tail_begin, tail_split;
 };
 
 // Packed weight image: [y][k][cc][j][cb][lane][t] with

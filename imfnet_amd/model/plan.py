@@ -115,7 +115,7 @@ class FusedPlan:
         a.out = out
         split = self.L.imf_spconv_auto_split(rb.n_slots, a.cout, rb.max_active)
         a.split_k = split
-        a.workspace, a.workspace_bytes = (ws[0] or None, ws[1]) if split > 1 else (None, 0)
+        a.workspace, a.workspace_bytes = (ws[0] or None, ws[1])
         a.tickets = (self._tickets or None) if (split > 1 and self.fused_reduce) else None
         ev = None
         if ops.TRACE is not None:
@@ -234,8 +234,8 @@ class FusedPlan:
         for name, rb, *_ in sched:
             cout = self.convs[name][0].cout
             sp = L.imf_spconv_auto_split(rb.n_slots, cout, rb.max_active)
+            ws_floats = max(ws_floats, L.imf_spconv_workspace_bytes(rb.n_slots, cout, sp) // 4)
             if sp > 1:
-                ws_floats = max(ws_floats, sp * rb.n_slots * cout)
                 n_tickets = max(n_tickets, rb.n_slots // TILE_ROWS * max(1, cout // 32))
         # arrival counters of the optional in-kernel split-K combine (measured SLOWER on MI355X than
         # the second launch: every partition pays an agent-scope release = L2 write-back; 1.91 vs

@@ -382,10 +382,11 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
         split = 1
     a.split_k, a.variant = split, int(variant)
     ws = None
-    if split > 1:
-        nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)
+    nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)   # split-K partials / balanced-tail partials
+    if nbytes:
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=in_a.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    if split > 1:
         if fused_reduce and variant == 0:
             tk = torch.zeros(rb.n_slots // TILE_ROWS * max(1, cout // 32), dtype=torch.int32, device=in_a.device)
             a.tickets = tk.data_ptr()

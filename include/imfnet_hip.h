@@ -177,7 +177,9 @@ typedef struct imf_conv_args {
                              4 / 5 = barrier-free register kernel, 32 / 16 rows per wavefront;
                              6 = variant 0's pipeline on the f16 matrix pipe with split operands
                                  (w_packed from imf_pack_weights_split16; kvol <= 27; |input| < 65504) */
-  void *workspace;        /* split-K partial sums; NULL allowed iff split_k resolves to 1          */
+  void *workspace;        /* split-K partial sums (NULL allowed iff split_k resolves to 1); with split 1 and
+                             variant 6 an optional scratch that lets launches of >= 512 tiles balance
+                             their last round of workgroups (imf_spconv_workspace_bytes says how much) */
   size_t workspace_bytes; /* >= imf_spconv_workspace_bytes(n_slots, cout, split)                  */
   int32_t *tickets;       /* optional: int32[n_tiles * n_slabs] arrival counters, ZERO on entry (left zero on
                              exit): with split_k > 1 the last partition to finish a tile reduces it inside
