@@ -100,6 +100,8 @@ SIGNATURES = {
     "imf_resunet_int_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64), _P]),
     "imf_resunet_float_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64)]),
     "imf_resunet_forward": (_I, [C.POINTER(ResunetDesc), C.POINTER(ResunetIO)]),
+    "imf_ransac_workspace_bytes": (_Z, [_I]),
+    "imf_ransac_registration": (_I, [_P, _L, _P, _L, _P, _I, _D, _D, _I, C.c_uint64, _P, _P, _P, _P, _Z, _P]),
     "imf_hash_capacity": (_L, [_L]),
     "imf_unique_workspace_bytes": (_Z, [_L]),
     "imf_voxelize": (_I, [_P, _I, _L, _D, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),

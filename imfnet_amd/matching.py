@@ -108,3 +108,37 @@ def feature_match(frag1_kpts, frag1_descs, frag2_kpts, frag2_descs, gt_pose, inl
     match2, n_matches, n_inliers = mutual_inliers(nn21, nn12, frag1_kpts, frag2_kpts, gt_pose, inlier_thresh)
     ratio = n_inliers / n_matches if n_matches else float("nan")
     return n_inliers, ratio, match2.cpu().numpy(), nn21.cpu().numpy()
+
+
+def ransac_registration(src, dst, corres, ransac_n=3, max_corr_dist=0.075, edge_similarity=0.9, max_iter=50000,
+                        seed=0, device="cuda"):
+    """Device RANSAC on given correspondences (imf_ransac_registration).  Returns (T 4x4 numpy
+    source->target, winning iteration, inliers, hypotheses that passed the checkers, fitness, rmse)."""
+    s = torch.as_tensor(src).to(device=device, dtype=torch.float64).contiguous()
+    d = torch.as_tensor(dst).to(device=device, dtype=torch.float64).contiguous()
+    c = torch.as_tensor(corres).to(device=s.device, dtype=torch.int32).contiguous()
+    if s.dim() != 2 or s.shape[1] != 3 or d.dim() != 2 or d.shape[1] != 3 or c.shape != (s.shape[0],):
+        raise ImfError("ransac_registration: src [n,3], dst [m,3], corres [n]")
+    L = _lib.lib()
+    nbytes = L.imf_ransac_workspace_bytes(int(max_iter))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
+    T = torch.empty(16, dtype=torch.float64, device=s.device)
+    meta = torch.empty(3, dtype=torch.int32, device=s.device)
+    stats = torch.empty(2, dtype=torch.float64, device=s.device)
+    check(L.imf_ransac_registration(s.data_ptr(), s.shape[0], d.data_ptr(), d.shape[0], c.data_ptr(), int(ransac_n),
+                                    float(max_corr_dist), float(edge_similarity), int(max_iter), int(seed),
+                                    T.data_ptr(), meta.data_ptr(), stats.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+          "imf_ransac_registration")
+    it, inl, nvalid = meta.tolist()
+    fit, rmse = stats.tolist()
+    return T.cpu().numpy().reshape(4, 4), it, inl, nvalid, fit, rmse
+
+
+def run_ransac(xyz0, xyz1, feat0, feat1, voxel_size, ransac_n=4, seed=0, device="cuda"):
+    """scripts/benchmark_util.py:16-34: feature correspondences (nearest xyz1 feature of every xyz0
+    point), then RANSAC with the edge-length (0.9) and distance (1.5 voxel) checkers, 50 000
+    hypotheses.  Returns the 4x4 transformation xyz0 -> xyz1 like `result_ransac.transformation`."""
+    f0, f1 = _descs(feat0, device, "feat0"), _descs(feat1, device, "feat1")
+    corres = nn_search(f0, f1)
+    return ransac_registration(xyz0, xyz1, corres, ransac_n=ransac_n, max_corr_dist=voxel_size * 1.5,
+                               edge_similarity=0.9, max_iter=50000, seed=seed, device=device)[0]

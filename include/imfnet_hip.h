@@ -344,6 +344,23 @@ int imf_select_keypoints(const double *samples, int64_t n_samples, const double 
                          double voxel_size, int32_t *inds, int32_t *count, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* ---- RANSAC registration on feature correspondences -------------------------------
+ * Replaces scripts/benchmark_util.py:16-34 run_ransac = Open3D 0.12
+ * registration_ransac_based_on_feature_matching(..., TransformationEstimationPointToPoint(False),
+ * ransac_n, [EdgeLength(edge_similarity), Distance(max_corr_dist)], RANSACConvergenceCriteria(max_iter,
+ * 1000), mutual_filter=False) given the correspondences corres[i] = nearest target feature of source
+ * point i (imf_nn_search(src_feat, dst_feat)).  src [n_src,3], dst [n_dst,3] device fp64.  All
+ * max_iter hypotheses are drawn (the reference's second criterion never fires); the draw sequence is a
+ * counter-based generator of `seed` (Open3D's clock-seeded one cannot be reproduced), identical in
+ * the oracle.  out_T: device 16 doubles, row-major 4x4 source->target (identity if nothing survives);
+ * out_meta: device int32[3] = {winning iteration or -1, its inlier count, hypotheses that passed the
+ * checkers}; out_stats: device double[2] = {fitness, inlier RMSE}. */
+size_t imf_ransac_workspace_bytes(int max_iter);
+int imf_ransac_registration(const double *src, int64_t n_src, const double *dst, int64_t n_dst,
+                            const int32_t *corres, int ransac_n, double max_corr_dist, double edge_similarity,
+                            int max_iter, uint64_t seed, double *out_T, int32_t *out_meta, double *out_stats,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 /* Measurement helpers (bench.py): HIP events on the caller's stream. */
 void *imf_event_create(void);
 void imf_event_destroy(void *ev);

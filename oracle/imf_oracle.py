@@ -482,3 +482,98 @@ def select_keypoints(sample_points, coords, voxel_size):
     key_points = fnv_hash_vec(np.floor(np.asarray(sample_points, dtype=np.float64) / voxel_size))
     key_coords = fnv_hash_vec(np.floor(np.asarray(coords, dtype=np.float64) / voxel_size))
     return np.where(np.isin(key_coords, key_points))[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# RANSAC registration.  Parity status: UNPINNED against the reference -- Open3D 0.12 is
+# absent here and seeds its generator from std::random_device, so not even the reference reproduces its
+# own draws.  The published algorithm (Open3D 0.12 Registration.cpp, RegistrationRANSACBasedOnCorrespondence;
+# CorrespondenceChecker.cpp; Eigen::umeyama) is restated over a counter-based generator shared with the
+# HIP path.  The rigid fit is cross-checked against a closed-form construction in the tests.
+# ---------------------------------------------------------------------------------------------
+def _splitmix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def rigid_fit(src, dst):
+    """TransformationEstimationPointToPoint(False) = Eigen::umeyama without scale, batched:
+    src, dst [..., n, 3] -> [..., 4, 4] with dst ~ R src + t."""
+    src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+    ms, md = src.mean(-2, keepdims=True), dst.mean(-2, keepdims=True)
+    H = np.swapaxes(src - ms, -1, -2) @ (dst - md)
+    U, _, Vt = np.linalg.svd(H)
+    V = np.swapaxes(Vt, -1, -2)
+    d = np.sign(np.linalg.det(V @ np.swapaxes(U, -1, -2)))
+    D = np.zeros(H.shape)
+    D[..., 0, 0] = D[..., 1, 1] = 1.0
+    D[..., 2, 2] = d
+    R = V @ D @ np.swapaxes(U, -1, -2)
+    T = np.zeros(H.shape[:-2] + (4, 4))
+    T[..., :3, :3] = R
+    T[..., :3, 3] = md[..., 0, :] - (R @ ms[..., 0, :, None])[..., 0]
+    T[..., 3, 3] = 1.0
+    return T
+
+
+def ransac_registration(src, dst, corres, ransac_n=3, max_corr_dist=0.075, edge_similarity=0.9,
+                        max_iter=50000, seed=0):
+    """scripts/benchmark_util.py:16-34 with the correspondences given (corres[i] = nearest target
+    feature of source point i).  Returns (T 4x4 source->target, winning iteration or -1, inlier count,
+    hypotheses that passed the checkers, fitness, inlier_rmse)."""
+    src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+    corres = np.asarray(corres)
+    n = len(src)
+    it = np.arange(max_iter, dtype=np.uint64)
+    picks = np.stack([(_splitmix64(np.uint64(seed) ^ (it * np.uint64(4) + np.uint64(j))) % np.uint64(n)).astype(np.int64)
+                      for j in range(ransac_n)], 1)                       # [iter, ransac_n]
+    S, D = src[picks], dst[corres[picks]]
+    ok = np.ones(max_iter, bool)
+    for i in range(ransac_n):                                             # CorrespondenceCheckerBasedOnEdgeLength
+        for j in range(i + 1, ransac_n):
+            ds = np.linalg.norm(S[:, i] - S[:, j], axis=1)
+            dd = np.linalg.norm(D[:, i] - D[:, j], axis=1)
+            ok &= ~((ds < dd * edge_similarity) | (dd < ds * edge_similarity))
+    T = rigid_fit(S, D)
+    moved = S @ np.swapaxes(T[:, :3, :3], 1, 2) + T[:, None, :3, 3]
+    ok &= ~(np.linalg.norm(moved - D, axis=2) > max_corr_dist).any(1)     # CorrespondenceCheckerBasedOnDistance
+    best = (-1, 0, 0.0)
+    tgt = dst[corres]
+    for h in np.flatnonzero(ok):                                          # ascending: ties keep the earliest
+        dis = np.linalg.norm(src @ T[h, :3, :3].T + T[h, :3, 3] - tgt, axis=1)
+        inl = dis < max_corr_dist
+        c = int(inl.sum())
+        if c == 0:
+            continue
+        rm = float(np.sqrt((dis[inl] ** 2).sum() / c))
+        if c > best[1] or (c == best[1] and rm < best[2]):
+            best = (int(h), c, rm)
+    Tb = T[best[0]] if best[0] >= 0 else np.eye(4)
+    return Tb, best[0], best[1], int(ok.sum()), best[1] / n, best[2]
+
+
+def compute_transform_error(transform, covariance, estimated_transform):
+    """util/uio.py:191-197 (nibabel's mat2quat restated: w-first quaternion of the relative rotation)."""
+    rel = np.linalg.inv(transform) @ estimated_transform
+    R, t = rel[:3, :3], rel[:3, 3]
+    K = np.array([[R[0, 0] - R[1, 1] - R[2, 2], 0, 0, 0],
+                  [R[0, 1] + R[1, 0], R[1, 1] - R[0, 0] - R[2, 2], 0, 0],
+                  [R[0, 2] + R[2, 0], R[1, 2] + R[2, 1], R[2, 2] - R[0, 0] - R[1, 1], 0],
+                  [R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1], R[0, 0] + R[1, 1] + R[2, 2]]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    if q[0] < 0:
+        q = -q
+    er = np.concatenate([t, q[1:]], axis=0)
+    return (er.reshape(1, 6) @ covariance @ er.reshape(6, 1) / covariance[0, 0]).item()
+
+
+def compute_registration_error(gt_transform, est_transform):
+    """util/uio.py:143-176: (RRE in degrees, RTE)."""
+    x = 0.5 * (np.trace(est_transform[:3, :3].T @ gt_transform[:3, :3]) - 1.0)
+    rre = 180.0 * np.arccos(np.clip(x, -1.0, 1.0)) / np.pi
+    return rre, float(np.linalg.norm(gt_transform[:3, 3] - est_transform[:3, 3]))

@@ -193,3 +193,54 @@ def test_select_keypoints_edge_cases():
     s = np.array([[-0.01, 0.01, 0.09], [-0.04, -0.09, 0.14]])
     assert (select_keypoints(s, c, 0.05) == O.select_keypoints(s, c, 0.05)).all()
     assert list(O.select_keypoints(s, c, 0.05)) == [0, 1]
+
+
+# ---- RANSAC registration ------------------------------------------------------------
+def _ransac_case(rng, n, outlier_frac, noise):
+    T = _rigid(rng)
+    src = rng.uniform(-1.5, 1.5, (n, 3))
+    dst = (src @ T[:3, :3].T + T[:3, 3] + rng.normal(0, noise, (n, 3)))
+    perm = rng.permutation(n)
+    dst = dst[perm]
+    corres = np.argsort(perm).astype(np.int32)
+    bad = rng.random(n) < outlier_frac
+    corres[bad] = rng.integers(0, n, bad.sum())
+    return src, dst, corres, T
+
+
+@pytest.mark.parametrize("n,ransac_n,iters,seed", [(300, 3, 4000, 0), (2000, 3, 50000, 1), (5000, 3, 50000, 7),
+                                                   (1200, 4, 20000, 2)])
+def test_ransac_matches_oracle(n, ransac_n, iters, seed):
+    """Same draws, same checkers, same scoring as the restatement: the winning hypothesis, its inlier
+    count and the number of hypotheses that pass the checkers are exact; the transformation to 1e-9."""
+    from imfnet_amd.matching import ransac_registration
+    rng = np.random.default_rng(100 + n)
+    src, dst, corres, Tg = _ransac_case(rng, n, 0.65, 0.01)
+    ref = O.ransac_registration(src, dst, corres, ransac_n, 0.075, 0.9, iters, seed)
+    got = ransac_registration(src, dst, corres, ransac_n, 0.075, 0.9, iters, seed)
+    assert got[1] == ref[1] and got[2] == ref[2] and got[3] == ref[3]
+    assert np.abs(got[0] - ref[0]).max() < 1e-9
+    assert abs(got[4] - ref[4]) < 1e-15 and abs(got[5] - ref[5]) < 1e-12
+    rre, rte = O.compute_registration_error(Tg, got[0])
+    assert rre < 3.0 and rte < 0.06
+
+
+def test_ransac_edge_cases_and_run_ransac():
+    from imfnet_amd.matching import ransac_registration, run_ransac
+    rng = np.random.default_rng(5)
+    src, dst, corres, Tg = _ransac_case(rng, 800, 0.5, 0.005)
+    # nothing survives: identity, iteration -1 (Open3D's default RegistrationResult)
+    T, it, inl, nvalid, fit, rmse = ransac_registration(src, dst + 100.0 * rng.standard_normal(dst.shape), corres,
+                                                        3, 0.075, 0.9, 3000, 0)
+    assert it == -1 and inl == 0 and fit == 0.0 and (T == np.eye(4)).all()
+    # determinism, and a different seed is a different draw sequence
+    a = ransac_registration(src, dst, corres, 3, 0.075, 0.9, 8000, 11)
+    b = ransac_registration(src, dst, corres, 3, 0.075, 0.9, 8000, 11)
+    c = ransac_registration(src, dst, corres, 3, 0.075, 0.9, 8000, 12)
+    assert a[1:] == b[1:] and (a[0] == b[0]).all() and a[1] != c[1]
+    # the reference's call shape: features in, transformation out (benchmark_util.py:16-34)
+    feat1 = _descs(rng, 800)
+    feat0 = feat1[corres] + 0.01 * rng.standard_normal((800, 32)).astype(np.float32)
+    T = run_ransac(src, dst, feat0, feat1, 0.05, ransac_n=3)
+    rre, rte = O.compute_registration_error(Tg, T)
+    assert T.shape == (4, 4) and rre < 3.0 and rte < 0.06

@@ -142,3 +142,47 @@ def test_select_keypoints_restatement_hand_case():
     s = np.array([[-0.04, -0.09, 0.14], [-0.01, 0.01, 0.09]])
     assert list(O.select_keypoints(s, c, 0.05)) == [0, 1]
     assert O.fnv_hash_vec(np.array([[-1.0, 0.0, 1.0]]))[0] == O.fnv_hash_vec(np.array([[2 ** 64 - 1, 0, 1]], dtype=np.uint64))[0]
+
+
+# ---- RANSAC registration ----------------------------------------------------------
+def test_ransac_restatement_pieces():
+    """Known-answer for the shared generator (published splitmix64 vector), the rigid fit against a
+    constructed motion (also a reflection-prone planar sample), and the error metrics of util/uio.py."""
+    assert int(O._splitmix64(0)) == 0xE220A8397B1DCDAF and int(O._splitmix64(0x9E3779B97F4A7C15)) == 0x6E789E6AA1B965F4
+    rng = np.random.default_rng(0)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    t = np.array([0.3, -0.2, 0.5])
+    s = rng.standard_normal((6, 3, 3))
+    T = O.rigid_fit(s, s @ q.T + t)
+    assert np.abs(T[:, :3, :3] - q).max() < 1e-12 and np.abs(T[:, :3, 3] - t).max() < 1e-12
+    assert np.allclose(np.linalg.det(T[:, :3, :3]), 1.0)
+    Tg = np.eye(4)
+    Tg[:3, :3], Tg[:3, 3] = q, t
+    rre0, rte0 = O.compute_registration_error(Tg, Tg)
+    assert rre0 < 1e-4 and rte0 == 0.0                     # arccos of 1 - 1e-16
+    assert abs(O.compute_transform_error(Tg, np.eye(6), Tg)) < 1e-24
+    Te = Tg.copy()
+    Te[:3, 3] += [0.03, 0.0, 0.04]
+    rre, rte = O.compute_registration_error(Tg, Te)
+    assert rre < 1e-4 and abs(rte - 0.05) < 1e-12
+
+
+def test_ransac_restatement_recovers_known_motion():
+    rng = np.random.default_rng(1)
+    n = 1500
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    Tg = np.eye(4)
+    Tg[:3, :3], Tg[:3, 3] = q, [0.4, -0.1, 0.2]
+    src = rng.uniform(-1.5, 1.5, (n, 3))
+    dst = src @ q.T + Tg[:3, 3] + rng.normal(0, 0.005, (n, 3))
+    corres = np.arange(n)
+    bad = rng.random(n) < 0.6
+    corres[bad] = rng.integers(0, n, bad.sum())
+    T, it, inl, nvalid, fit, rmse = O.ransac_registration(src, dst, corres, 3, 0.075, 0.9, 20000, seed=3)
+    rre, rte = O.compute_registration_error(Tg, T)
+    assert it >= 0 and inl >= 0.35 * n and nvalid > 50 and rre < 3.0 and rte < 0.05 and rmse < 0.075
+    # no hypothesis can survive when every correspondence is wrong by metres
+    T0, it0, inl0, *_ = O.ransac_registration(src, dst + 50 * rng.standard_normal((n, 3)), corres, 3, 0.075, 0.9, 2000, seed=3)
+    assert it0 == -1 and inl0 == 0 and (T0 == np.eye(4)).all()
