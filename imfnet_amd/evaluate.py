@@ -1,0 +1,231 @@
+"""Scene-level registration evaluation on the GPU rows of SURVEY §8f -- the flow of
+scripts/evaluation_3dmatch.py:86-330 (`register_fragment_pair`, `run_scene_matching`, the FMR part of
+`compute_metrics`) over descriptor files written by imfnet_amd.generate_desc.
+
+Per pair: keypoint -> voxel selection (`select_keypoints`), RANSAC registration (`run_ransac`, RR / RRE /
+RTE against gt.log + gt.info), mutual nearest-neighbour matching and the inlier ratio under the
+ground-truth pose (`feature_match`).  File formats are the reference's: `<desc_root>/<scene>/<seq>/
+cloud_bin_K.npz` (points, xyz, feature), `<benchmark_root>/<scene>/gt.log|gt.info`, one result line per
+pair `frag1 frag2 num_inliers inlier_ratio gt_flag rr rre rte ir`.  Two documented differences: the
+keypoint draw uses a seeded `numpy.random.RandomState` (the reference draws unseeded and caches the
+indices in `<out_root>/<desc_type>_keypoints/`; those files are honoured when present), and RANSAC's
+hypotheses come from the seeded counter-based generator of imf_ransac_registration.
+"""
+import argparse
+import json
+import os
+from collections import namedtuple
+
+import numpy as np
+
+from . import dist as idist
+from .matching import feature_match, run_ransac, select_keypoints
+
+INLIER_RATIO_THRESHES = [0.05, 0.20]                      # scripts/evaluation_3dmatch.py:32
+Pose = namedtuple("Pose", ["indices", "transformation"])
+
+
+def read_log(filepath):
+    """util/uio.py:202-215: blocks of `i j n` + a 4x4 matrix."""
+    lines = [l for l in open(filepath).read().splitlines() if l.strip()]
+    poses = []
+    for i in range(len(lines) // 5):
+        ids = [int(v) for v in lines[5 * i].split()[:3]]
+        mat = np.array([[float(v) for v in lines[5 * i + 1 + r].split()[:4]] for r in range(4)], dtype=np.float64)
+        poses.append(Pose(indices=ids, transformation=mat))
+    return poses
+
+
+def read_info_file(filepath):
+    """util/uio.py:217-233: blocks of `i j n` + a 6x6 covariance (float32 like the reference)."""
+    lines = [l.strip() for l in open(filepath).read().splitlines() if l.strip()]
+    out = []
+    for i in range(len(lines) // 7):
+        head = lines[7 * i].split()
+        cov = np.array([lines[7 * i + r].split() for r in range(1, 7)], dtype=np.float32)
+        out.append(dict(test_pair=[int(head[0]), int(head[1])], num_fragments=int(head[2]), covariance=cov))
+    return out
+
+
+def compute_transform_error(transform, covariance, estimated_transform):
+    """util/uio.py:191-198 (nibabel.quaternions.mat2quat restated: w-first unit quaternion)."""
+    rel = np.linalg.inv(transform) @ estimated_transform
+    R, t = rel[:3, :3], rel[:3, 3]
+    K = np.array([[R[0, 0] - R[1, 1] - R[2, 2], 0, 0, 0],
+                  [R[0, 1] + R[1, 0], R[1, 1] - R[0, 0] - R[2, 2], 0, 0],
+                  [R[0, 2] + R[2, 0], R[1, 2] + R[2, 1], R[2, 2] - R[0, 0] - R[1, 1], 0],
+                  [R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1], R[0, 0] + R[1, 1] + R[2, 2]]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    if q[0] < 0:
+        q = -q
+    er = np.concatenate([t, q[1:]], axis=0)
+    return (er.reshape(1, 6) @ covariance @ er.reshape(6, 1) / covariance[0, 0]).item()
+
+
+def compute_registration_error(gt_transform, est_transform):
+    """util/uio.py:143-176: (RRE degrees, RTE)."""
+    x = 0.5 * (np.trace(est_transform[:3, :3].T @ gt_transform[:3, :3]) - 1.0)
+    rre = 180.0 * np.arccos(np.clip(x, -1.0, 1.0)) / np.pi
+    return float(rre), float(np.linalg.norm(gt_transform[:3, 3] - est_transform[:3, 3]))
+
+
+def compute_inlier_ratio(ref_corr_points, src_corr_points, transform, positive_radius=0.1):
+    """util/uio.py:110-121."""
+    moved = src_corr_points @ transform[:3, :3].T + transform[:3, 3]
+    return float(np.mean(np.sqrt(((ref_corr_points - moved) ** 2).sum(1)) < positive_radius))
+
+
+def register_fragment_pair(data_i, data_j, gt_pose, covariance, voxel_size, num_rand_keypoints=5000,
+                           inlier_thresh=0.1, keypoint_inds=None, seed=0, device="cuda"):
+    """scripts/evaluation_3dmatch.py:86-235 for one pair.  data_*: dicts with `points`, `xyz`,
+    `feature`.  Returns (num_inliers, inlier_ratio, gt_flag, [rr, rre, rte, ir], keypoint_inds)."""
+    coord_i, points_i, feat_i = data_i["xyz"], data_i["points"], data_i["feature"]
+    coord_j, points_j, feat_j = data_j["xyz"], data_j["points"], data_j["feature"]
+    if num_rand_keypoints > 0:
+        if keypoint_inds is None:                                               # :154-156
+            rs = np.random.RandomState(seed)
+            keypoint_inds = (rs.choice(len(points_i), min(len(points_i), num_rand_keypoints), replace=False),
+                             rs.choice(len(points_j), min(len(points_j), num_rand_keypoints), replace=False))
+        inds_i = select_keypoints(points_i[keypoint_inds[0]], coord_i, voxel_size, device=device)   # :162-171
+        inds_j = select_keypoints(points_j[keypoint_inds[1]], coord_j, voxel_size, device=device)
+        frag1_kpts, frag1_descs = coord_i[inds_i], feat_i[inds_i]
+        frag2_kpts, frag2_descs = coord_j[inds_j], feat_j[inds_j]
+    else:
+        frag1_kpts, frag1_descs, frag2_kpts, frag2_descs = coord_i, feat_i, coord_j, feat_j
+    # ---- RR (:176-205): the smaller set is the RANSAC source ---------------------------------------
+    if len(frag1_kpts) < len(frag2_kpts):
+        trans = run_ransac(frag1_kpts, frag2_kpts, frag1_descs, frag2_descs, voxel_size, ransac_n=3, seed=seed,
+                           device=device)
+    else:
+        trans = np.linalg.inv(run_ransac(frag2_kpts, frag1_kpts, frag2_descs, frag1_descs, voxel_size, ransac_n=3,
+                                         seed=seed, device=device))
+    es_T = np.linalg.inv(trans)
+    accepted = compute_transform_error(gt_pose, covariance, es_T) < 0.2 ** 2
+    rr, rre, rte = 0, 0, 0
+    if accepted:
+        rre, rte = compute_registration_error(gt_pose, es_T)
+        rr = 1
+    frag2_es = frag2_kpts @ es_T[:3, :3].T + es_T[:3, 3]
+    ir = compute_inlier_ratio(frag2_es, frag2_kpts, gt_pose, positive_radius=0.1)              # :200-203
+    # ---- FMR (:207-234) -----------------------------------------------------------------------------
+    num_inliers, inlier_ratio, _, _ = feature_match(frag1_kpts, frag1_descs, frag2_kpts, frag2_descs, gt_pose,
+                                                    inlier_thresh, device=device)
+    return num_inliers, inlier_ratio, 1, [rr, rre, rte, ir], keypoint_inds
+
+
+def run_scene_matching(scene_name, seq_name, desc_root, benchmark_root, out_root, desc_type="IMFNet", voxel_size=0.025,
+                       num_rand_keypoints=5000, inlier_thresh=0.1, seed=0, device="cuda", rank=0, world=1):
+    """scripts/evaluation_3dmatch.py:239-329.  With world > 1 the pairs are sharded over the ranks
+    (independent units) and every rank writes its own part file; rank 0's caller merges them."""
+    seq_dir = os.path.join(desc_root, scene_name, seq_name)
+    fragment_names = sorted((f[:-4] for f in os.listdir(seq_dir) if f.endswith(".npz")),
+                            key=lambda s: int(s.split("_")[-1]))
+    poses = read_log(os.path.join(benchmark_root, scene_name, "gt.log"))
+    infos = read_info_file(os.path.join(benchmark_root, scene_name, "gt.info"))
+    out_folder = os.path.join(out_root, desc_type)
+    kp_folder = os.path.join(out_root, desc_type + "_keypoints")
+    os.makedirs(out_folder, exist_ok=True)
+    os.makedirs(kp_folder, exist_ok=True)
+    cache, lines = {}, []
+
+    def load(name):
+        if name not in cache:
+            if len(cache) > 8:
+                cache.pop(next(iter(cache)))
+            z = np.load(os.path.join(seq_dir, name + ".npz"))
+            cache[name] = {k: z[k] for k in ("points", "xyz", "feature")}
+        return cache[name]
+
+    for k, pose in enumerate(poses):
+        if k % world != rank:
+            continue
+        i, j = pose.indices[0], pose.indices[1]
+        assert i < j
+        f1, f2 = fragment_names[i], fragment_names[j]
+        kp_path = os.path.join(kp_folder, f"{scene_name}_{seq_name}_{i}_{j}_keypoints.npz")
+        kp = None
+        if os.path.isfile(kp_path):
+            z = np.load(kp_path)
+            kp = (z["inds_i"], z["inds_j"])
+        n_inl, ratio, gt_flag, (rr, rre, rte, ir), kp_used = register_fragment_pair(
+            load(f1), load(f2), pose.transformation, infos[k]["covariance"], voxel_size, num_rand_keypoints,
+            inlier_thresh, keypoint_inds=kp, seed=seed + k, device=device)
+        if kp is None and kp_used is not None:
+            np.savez(kp_path, inds_i=kp_used[0], inds_j=kp_used[1])
+        lines.append((k, f"{f1} {f2} {n_inl} {ratio:.8f} {gt_flag} {rr} {rre} {rte} {ir}"))
+    base = os.path.join(out_folder, "{}-{}-{:.2f}".format(scene_name, seq_name, inlier_thresh))
+    part = base + (f".part{rank}" if world > 1 else "") + ".txt"
+    with open(part, "w") as fh:
+        for _, line in lines:
+            fh.write(line + "\n")
+    return base, lines
+
+
+def compute_metrics(result_files, out_path=None):
+    """FMR / RR summary of the per-scene result files (scripts/evaluation_3dmatch.py:331-470): per scene
+    and averaged recall at the inlier-ratio thresholds, mean inlier count, registration recall."""
+    rows = {}
+    for path in result_files:
+        scene = os.path.basename(path).split("-seq")[0]
+        rec = [l.split() for l in open(path).read().splitlines() if l.strip()]
+        ratios = np.array([float(r[3]) for r in rec], dtype=np.float32)
+        flags = np.array([int(r[4]) for r in rec]) == 1
+        rows[scene] = {
+            "pairs": len(rec),
+            **{f"recall@{t:.2f}": float(np.sum(ratios[flags] > t) / max(1, flags.sum())) for t in INLIER_RATIO_THRESHES},
+            "avg_matches": float(np.mean([int(r[2]) for r in rec])) if rec else 0.0,
+            "registration_recall": float(np.mean([float(r[5]) for r in rec])) if rec else 0.0,
+        }
+    summary = {"scenes": rows}
+    for key in ([f"recall@{t:.2f}" for t in INLIER_RATIO_THRESHES] + ["registration_recall"]):
+        summary["mean_" + key] = float(np.mean([v[key] for v in rows.values()])) if rows else 0.0
+    if out_path:
+        with open(out_path, "w") as fh:
+            json.dump(summary, fh, indent=1)
+    return summary
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="3DMatch-style registration evaluation on the GPU")
+    ap.add_argument("--desc_root", required=True, help="output tree of imfnet_amd.generate_desc")
+    ap.add_argument("--benchmark_root", required=True, help="<root>/<scene>/gt.log and gt.info")
+    ap.add_argument("--out_root", required=True)
+    ap.add_argument("--desc_type", default="IMFNet")
+    ap.add_argument("--seq", default="seq-01")
+    ap.add_argument("--voxel_size", type=float, default=0.025)
+    ap.add_argument("--num_rand_keypoints", type=int, default=5000)
+    ap.add_argument("--inlier_thresh", type=float, default=0.1)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+    rank, world, local = idist.init_from_env()
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    scenes = sorted(d for d in os.listdir(args.desc_root) if os.path.isdir(os.path.join(args.benchmark_root, d)))
+    files = []
+    for scene in scenes:
+        base, _ = run_scene_matching(scene, args.seq, args.desc_root, args.benchmark_root, args.out_root, args.desc_type,
+                                     args.voxel_size, args.num_rand_keypoints, args.inlier_thresh, args.seed,
+                                     device=f"cuda:{local}", rank=rank, world=world)
+        files.append(base)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    if rank == 0:
+        merged = []
+        for base in files:
+            if world > 1:                                  # merge the ranks' parts in pair order
+                parts = [open(f"{base}.part{r}.txt").read().splitlines() for r in range(world)]
+                n = sum(len(p) for p in parts)
+                lines = [parts[k % world][k // world] for k in range(n)]
+                with open(base + ".txt", "w") as fh:
+                    fh.write("\n".join(lines) + "\n")
+            merged.append(base + ".txt")
+        summary = compute_metrics(merged, os.path.join(args.out_root, f"{args.desc_type}-metrics-{args.inlier_thresh:.2f}.json"))
+        print(json.dumps({k: v for k, v in summary.items() if k != "scenes"}))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -150,3 +150,17 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def write_pair_ground_truth():
+    """tests/golden/redkitchen_pair_0_1_gt.npz: ground-truth pose and covariance of the in-tree fragment pair
+    (files/cloud_bin_0.ply, cloud_bin_1.ply are 7-scenes-redkitchen fragments 0 and 1): the first block of
+    benchmarks/3DMatch/7-scenes-redkitchen/gt.log and gt.info -- data, used by the evaluator tests."""
+    import numpy as np
+    root = "/root/reference/benchmarks/3DMatch/7-scenes-redkitchen/"
+    log = open(root + "gt.log").read().splitlines()[:5]
+    info = open(root + "gt.info").read().splitlines()[:7]
+    pose = np.array([[float(v) for v in l.split()] for l in log[1:5]])
+    cov = np.array([[float(v) for v in l.split()] for l in info[1:7]])
+    np.savez(os.path.join(os.path.dirname(os.path.abspath(__file__)), "redkitchen_pair_0_1_gt.npz"), pose=pose,
+             covariance=cov, indices=np.array([0, 1, 60]))

@@ -1,6 +1,8 @@
 """GPU parity of the descriptor-matching row: imf_nn_search / imf_mutual_inliers
 through the C ABI against the oracle's restatement of util/uio.py:245-258 and
 scripts/evaluation_3dmatch.py:207-234.  Index work: bit-exact."""
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -244,3 +246,59 @@ def test_ransac_edge_cases_and_run_ransac():
     T = run_ransac(src, dst, feat0, feat1, 0.05, ransac_n=3)
     rre, rte = O.compute_registration_error(Tg, T)
     assert T.shape == (4, 4) and rre < 3.0 and rte < 0.06
+
+
+# ---- scene-level evaluator on the in-tree pair (scripts/evaluation_3dmatch.py flow) ---------------------
+def test_evaluator_on_the_redkitchen_pair(tmp_path, clouds, images, seeded_sd):
+    """Descriptor files of the two in-tree fragments (7-scenes-redkitchen 0 and 1) + their ground-truth pose
+    and covariance from the benchmark -> `imfnet_amd.evaluate`; every number of the result line is
+    re-derived with the oracle from the same files."""
+    import os
+    from imfnet_amd import evaluate as E
+    from imfnet_amd.extract import extract_features
+    from imfnet_amd.model import load_model
+    gt = np.load(os.path.join(os.path.dirname(__file__), "golden", "redkitchen_pair_0_1_gt.npz"))
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.eval().cuda()
+    desc = tmp_path / "desc" / "7-scenes-redkitchen" / "seq-01"
+    bench = tmp_path / "bench" / "7-scenes-redkitchen"
+    desc.mkdir(parents=True)
+    bench.mkdir(parents=True)
+    data = {}
+    for k in (0, 1):
+        pts = clouds[k].astype(np.float64)
+        xyz, F = extract_features(m, xyz=pts, voxel_size=0.05, device="cuda", skip_check=True,
+                                  image=torch.as_tensor(images[k]))
+        data[k] = dict(points=pts, xyz=xyz, feature=F.cpu().numpy())
+        np.savez(desc / f"cloud_bin_{k}.npz", **data[k])
+    with open(bench / "gt.log", "w") as fh:
+        fh.write("0\t 1\t 60\t\n" + "".join("\t".join(f"{v:.8e}" for v in row) + "\n" for row in gt["pose"]))
+    with open(bench / "gt.info", "w") as fh:
+        fh.write("0\t 1\t 60\t\n" + "".join("\t".join(f"{v:.8e}" for v in row) + "\n" for row in gt["covariance"]))
+    out = tmp_path / "out"
+    assert E.main(["--desc_root", str(tmp_path / "desc"), "--benchmark_root", str(tmp_path / "bench"),
+                   "--out_root", str(out), "--voxel_size", "0.05", "--num_rand_keypoints", "2000", "--seed", "4"]) == 0
+    line = open(out / "IMFNet" / "7-scenes-redkitchen-seq-01-0.10.txt").read().split()
+    assert line[:2] == ["cloud_bin_0", "cloud_bin_1"] and line[4] == "1"
+    # oracle re-derivation from the same files and the cached keypoint draw
+    kp = np.load(out / "IMFNet_keypoints" / "7-scenes-redkitchen_seq-01_0_1_keypoints.npz")
+    pose = E.read_log(bench / "gt.log")[0].transformation
+    cov = E.read_info_file(bench / "gt.info")[0]["covariance"]
+    sel = [O.select_keypoints(data[k]["points"][kp["inds_i" if k == 0 else "inds_j"]], data[k]["xyz"], 0.05) for k in (0, 1)]
+    k1, d1 = data[0]["xyz"][sel[0]], data[0]["feature"][sel[0]]
+    k2, d2 = data[1]["xyz"][sel[1]], data[1]["feature"][sel[1]]
+    n_inl, ratio, _, _ = O.feature_match(k1, d1, k2, d2, pose, 0.1)
+    assert int(line[2]) == n_inl and abs(float(line[3]) - ratio) < 1e-8
+    if len(k1) < len(k2):
+        trans = O.ransac_registration(k1, k2, O.knn_search(d1, d2), 3, 0.075, 0.9, 50000, 4)[0]
+    else:
+        trans = np.linalg.inv(O.ransac_registration(k2, k1, O.knn_search(d2, d1), 3, 0.075, 0.9, 50000, 4)[0])
+    es_T = np.linalg.inv(trans)
+    accepted = O.compute_transform_error(pose, cov, es_T) < 0.04
+    assert int(line[5]) == int(accepted)
+    if accepted:
+        rre, rte = O.compute_registration_error(pose, es_T)
+        assert abs(float(line[6]) - rre) < 1e-6 and abs(float(line[7]) - rte) < 1e-8
+    summary = json.load(open(out / "IMFNet-metrics-0.10.json"))
+    assert summary["scenes"]["7-scenes-redkitchen"]["pairs"] == 1
