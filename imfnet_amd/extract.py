@@ -74,7 +74,7 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
     """xyz: [N,3] points (numpy float64/float32, or a tensor already on the device).
     rgb in [0,1] / normal in [-1,1] are optional per-point inputs (concatenated as rgb-0.5, normal/2);
     with neither, the input feature is a column of ones.  image: [1,3,H,W] float32."""
-    if is_eval:
+    if is_eval and model.training:                   # (walking ~190 modules per fragment costs 0.7 ms)
         model.eval()
     if not skip_check:
         assert xyz.shape[1] == 3
@@ -112,9 +112,10 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
         image_dev = torch.as_tensor(image, dtype=torch.float32, device=device)
     F = model(stensor, image_dev).F
 
-    inds_host = inds.cpu().numpy().astype(np.int64)
-    if torch.is_tensor(xyz):
-        return_coords = xyz.detach().cpu().numpy().astype(np.float64)[inds_host]
+    if torch.is_tensor(xyz) and xyz.is_cuda:          # gather on the device, copy only the M selected rows
+        return_coords = xyz.detach()[inds.long()].cpu().numpy().astype(np.float64)
     else:
-        return_coords = np.asarray(xyz)[inds_host]
+        inds_host = inds.cpu().numpy().astype(np.int64)
+        host = xyz.detach().numpy() if torch.is_tensor(xyz) else np.asarray(xyz)
+        return_coords = host[inds_host].astype(np.float64, copy=False)
     return return_coords, F

@@ -55,16 +55,44 @@ def load_fragment(ply_path, config):
     return xyz, image_to_nchw(img)
 
 
-def extract_features_batch(model, config, source_path, target_path, voxel_size, device, gather=False):
+def extract_features_batch(model, config, source_path, target_path, voxel_size, device, gather=False, workers=4):
+    """scripts/generate_desc.py:44-133.  The reference decodes, computes and writes one fragment at a
+    time; at ~1 ms of GPU work per fragment the PLY/PNG decode (tens of ms) and the zlib write
+    (~0.1 s) would leave the GPU idle, so `workers` loader threads run ahead of the GPU and as many
+    writer threads take the device-to-host copy + `savez_compressed` behind it (numpy / PIL / zlib
+    release the GIL).  workers=0 is the reference's sequential order; outputs are identical."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
     rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) \
         if torch.distributed.is_initialized() else (0, 1)
     frags = list_fragments(source_path)
     shards = idist.shard_fragments([os.path.getsize(f) for _, f in frags], world)
     model.eval()
     times, results, meta = [], {}, {}
-    for i in shards[rank]:
+    mine = list(shards[rank])
+    loader = ThreadPoolExecutor(max_workers=workers) if workers > 0 else None
+    writer = ThreadPoolExecutor(max_workers=workers) if workers > 0 else None
+    pending, writes, nxt = deque(), [], 0
+
+    def submit_loads():
+        nonlocal nxt
+        while loader is not None and nxt < len(mine) and len(pending) < 2 * workers:
+            pending.append(loader.submit(load_fragment, frags[mine[nxt]][1], config))
+            nxt += 1
+
+    def write(out_dir, out_file, xyz, xyz_down, feature, done):
+        done.synchronize()                               # the descriptors of THIS fragment are complete
+        ensure_dir(out_dir)
+        save_descriptors(out_file, xyz, xyz_down, feature)
+
+    submit_loads()
+    for n_done, i in enumerate(mine):
         scene, fi = frags[i]
-        xyz, image = load_fragment(fi, config)
+        if loader is not None:
+            xyz, image = pending.popleft().result()
+            submit_loads()
+        else:
+            xyz, image = load_fragment(fi, config)
         torch.cuda.synchronize(device)
         t0 = time.time()
         xyz_down, feature = extract_features(model, xyz=xyz, rgb=None, normal=None, voxel_size=voxel_size,
@@ -75,9 +103,20 @@ def extract_features_batch(model, config, source_path, target_path, voxel_size, 
         out_file = os.path.join(out_dir, os.path.basename(fi).replace(".ply", ".npz"))
         if gather and world > 1:
             results[i], meta[i] = feature, (out_dir, out_file, xyz, xyz_down)
+        elif writer is not None:
+            done = torch.cuda.Event()
+            done.record()
+            writes.append(writer.submit(write, out_dir, out_file, xyz, xyz_down, feature, done))
+            while len(writes) > 4 * workers:             # bound the host memory held by queued writes
+                writes.pop(0).result()
         else:
             ensure_dir(out_dir)
             save_descriptors(out_file, xyz, xyz_down, feature)
+    for w in writes:
+        w.result()
+    for pool in (loader, writer):
+        if pool is not None:
+            pool.shutdown()
     if gather and world > 1:
         # one exchange: descriptors to rank 0 (coordinates are re-derived there from the files' points)
         all_feats = idist.gather_fragment_descriptors(results, len(frags), shards, dst=0)
@@ -109,6 +148,8 @@ def main(argv=None):
     p.add_argument("--extract_features", default=True, action="store_true")
     p.add_argument("--with_cuda", default=True, action="store_true")
     p.add_argument("--gather", action="store_true", help="multi-GPU: gather descriptors on rank 0 (RCCL)")
+    p.add_argument("--workers", type=int, default=4,
+                   help="loader / writer threads around the GPU (0 = the reference's sequential order)")
     p.add_argument("--seeded_weights", type=int, default=None,
                    help="no checkpoint: random weights from this seed (plumbing / benchmarking)")
     args = p.parse_args(argv)
@@ -136,7 +177,7 @@ def main(argv=None):
     model = model.eval().to(device)
     with torch.no_grad():
         times, n = extract_features_batch(model, config, args.source, args.target, config.voxel_size, device,
-                                          gather=args.gather)
+                                          gather=args.gather, workers=args.workers)
     if times:
         print(f"[rank {rank}] All Time:{np.sum(times)},AVG:{np.sum(times) / len(times)} "
               f"({len(times)} of {n} fragments)")

@@ -98,7 +98,8 @@ class ResUNet2(ME.MinkowskiNetwork):
         return super().load_state_dict(*a, **k)
 
     def train(self, mode=True):
-        self._invalidate()
+        if bool(mode) != self.training:               # extract_features calls model.eval() per fragment:
+            self._invalidate()                        # only a real mode change drops the plan / image graph
         return super().train(mode)
 
     # ---- image branch: independent of the sparse encoder until the bottleneck ------------------

@@ -40,6 +40,12 @@ def test_generate_desc_cli_matches_oracle(tmp_path, clouds, seeded_sd):
     torch.save({"state_dict": seeded_sd, "config": dict(Config(voxel_size=0.05)), "epoch": 1}, ckpt)
     gd.main(["--source", str(src), "--target", str(dst), "-m", str(ckpt)])
     assert sorted(os.listdir(dst)) == ["sceneA", "sceneB"]
+    dst_seq = tmp_path / "dst_sequential"                                 # loader/writer threads change nothing
+    gd.main(["--source", str(src), "--target", str(dst_seq), "-m", str(ckpt), "--workers", "0"])
+    for scene, k in frags:
+        a = np.load(dst / scene / "seq-01" / f"cloud_bin_{k}.npz")
+        b = np.load(dst_seq / scene / "seq-01" / f"cloud_bin_{k}.npz")
+        assert all((a[key] == b[key]).all() for key in ("points", "xyz", "feature"))
     for (scene, k), (pts, img) in frags.items():
         out = np.load(dst / scene / "seq-01" / f"cloud_bin_{k}.npz")
         assert sorted(out.files) == ["feature", "points", "xyz"]
