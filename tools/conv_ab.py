@@ -26,9 +26,10 @@ cases = [  # name, rulebook, cin, cout, rows_in
     ("k3@8 256->256", cm.conv_rulebook(8, 3, 1), 256, 256, n[3]),
     ("up@4 256->128", cm.transpose_rulebook(8, 3, 2), 256, 128, n[3]),
 ]
-variants = [("v0 auto", dict(variant=0)), ("v0 s1", dict(variant=0, split_k=1)),
+variants = [("v0 auto", dict(variant=0)),
             ("v6 auto", dict(variant=6)), ("v6 s1", dict(variant=6, split_k=1)), ("v6 s2", dict(variant=6, split_k=2)),
-            ("v6 s4", dict(variant=6, split_k=4)), ("v6 s8", dict(variant=6, split_k=8))]
+            ("v6 s3", dict(variant=6, split_k=3)), ("v6 s4", dict(variant=6, split_k=4)), ("v6 s6", dict(variant=6, split_k=6)),
+            ("v6 s8", dict(variant=6, split_k=8)), ("v6 s13", dict(variant=6, split_k=13))]
 g = torch.Generator().manual_seed(0)
 for name, rb, cin, cout, rows in cases:
     f = torch.randn(rows, cin, generator=g).to(dev)
@@ -38,10 +39,13 @@ for name, rb, cin, cout, rows in cases:
     outs = {}
     for rnd in range(6):
         for vn, kw in variants:
-            ops.TRACE = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ws_warm = ops.spconv(f, wp[kw['variant']], cout, rb, **kw)       # allocator warm
+            e0.record()
             outs[vn] = ops.spconv(f, wp[kw['variant']], cout, rb, **kw)
+            e1.record()
             torch.cuda.synchronize()
-            ms = ops.TRACE[0]["ev"].elapsed_ms(); ops.TRACE = None
+            ms = e0.elapsed_time(e1)                                         # whole op: main kernel + split-K reduce
             if rnd: res.setdefault(vn, []).append(ms * 1e3)
     ref = outs["v0 auto"]
     line = f"{name:16s} n_slots={rb.n_slots:6d} " + "  ".join(f"{vn}: {np.median(v):7.1f}us" for vn, v in res.items())
