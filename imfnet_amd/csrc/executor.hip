@@ -221,6 +221,9 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   const size_t ws_bytes = ((char *)fusion_ws - (char *)ws);
   (void)total_floats;
 
+  for (int i = 0; i < NBUF; ++i)   // variant 6 reads its inputs through a 2 GiB buffer window
+    IMF_REQUIRE(cnt[i] * sizeof(float) < (1ull << 31), "imf_resunet_forward: feature buffer %d exceeds 2 GiB", i);
+
   // ---- schedule (model/resunet.py:168-226) ---------------------------------------------------------
   Step sched[24];
   int n_steps = 0, n_enc = 0;

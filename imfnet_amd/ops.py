@@ -390,6 +390,8 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
         if fused_reduce and variant == 0:
             tk = torch.zeros(rb.n_slots // TILE_ROWS * max(1, cout // 32), dtype=torch.int32, device=in_a.device)
             a.tickets = tk.data_ptr()
+    if variant == 6 and max(in_a.numel(), 0 if in_b is None else in_b.numel()) * 4 >= 2 ** 31:
+        raise ImfError("variant 6 addresses its inputs through a 2 GiB buffer window: use variant 0 for larger matrices")
     if w_packed.numel() != rb.kvol * (a.c_a + a.c_b) * cout:
         raise ImfError(f"packed weight has {w_packed.numel()} floats, expected "
                        f"{rb.kvol}x{a.c_a + a.c_b}x{cout}")

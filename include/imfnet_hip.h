@@ -176,7 +176,8 @@ typedef struct imf_conv_args {
                              3 = 128-row workgroup kernel with per-offset row compaction;
                              4 / 5 = barrier-free register kernel, 32 / 16 rows per wavefront;
                              6 = variant 0's pipeline on the f16 matrix pipe with split operands
-                                 (w_packed from imf_pack_weights_split16; kvol <= 27; |input| < 65504) */
+                                 (w_packed from imf_pack_weights_split16; kvol <= 27; |input| < 65504;
+                                 in_a / in_b smaller than 2 GiB each: raw-buffer addressing) */
   void *workspace;        /* split-K partial sums (NULL allowed iff split_k resolves to 1); with split 1 and
                              variant 6 an optional scratch that lets launches of >= 512 tiles balance
                              their last round of workgroups (imf_spconv_workspace_bytes says how much) */
