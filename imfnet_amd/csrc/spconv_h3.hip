@@ -254,7 +254,7 @@ k_spconv_h3(const ConvParams p) {
   if (S == 1) {
     conv_epilogue<CO_BLK>(p, acc, tile, y, wave, r16, q4);
     IMF_STAMP(5);
-  } else {   // raw partial sums, slot-major (k_spconv_reduce finishes)
+  } else {   // raw partial sums, slot-major (k_spconv_reduce finishes, or the last arriver below)
     const int CW = 16 * CO_BLK;
 #pragma unroll
     for (int cb = 0; cb < CO_BLK; ++cb) {
@@ -264,6 +264,27 @@ k_spconv_h3(const ConvParams p) {
         const long long slot = tile_slot0 + wave * 16 + q4 * 4 + r;
         p.partial[((long long)z * part_slots + (slot - part_slot0)) * p.cout + col] = acc[cb][r];
       }
+    }
+    if (p.tickets && part_slot0 == 0) {
+      // In-launch split-K combine (same protocol as variant 0): every wave drains its stores, one lane
+      // releases at agent scope and takes a ticket; the last arriver acquires and reduces the tile.
+      __shared__ int s_last;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int *cnt = p.tickets + (long long)tile * gridDim.y + y;
+        const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == S - 1);
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        s_last = last;
+      }
+      __syncthreads();
+      if (s_last) fused_reduce_tile<16 * CO_BLK>(p, S, tile_slot0, y, tid);
     }
   }
 }

@@ -93,6 +93,44 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (
   }
 }
 
+// Sum of the S partial slabs of one 64-row tile (ascending partition order) + epilogue, by the 256
+// threads of the LAST workgroup to arrive at the tile (same arithmetic as k_spconv_reduce).
+template <int CW>
+__device__ __forceinline__ void fused_reduce_tile(const ConvParams &p, int S, long long slot0, int y, int tid) {
+  constexpr int LPR = CW / 4, RPI = 256 / LPR;
+  const int c4 = tid % LPR, rsub = tid / LPR;
+  const int col = y * CW + 4 * c4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + col);
+  if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + col);
+#pragma unroll 1
+  for (int it = 0; it < IMF_TILE_ROWS / RPI; ++it) {
+    const long long slot = slot0 + it * RPI + rsub;
+    const int orow = row_of_slot(p, slot);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (orow >= 0) {
+      for (int zz = 0; zz < S; ++zz) {
+        const float4 v = *reinterpret_cast<const float4 *>(p.partial + ((long long)zz * p.n_slots + slot) * p.cout + col);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      s.x = s.x * sc.x + sh.x; s.y = s.y * sc.y + sh.y; s.z = s.z * sc.z + sh.z; s.w = s.w * sc.w + sh.w;
+      if (p.residual) {
+        const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (long long)orow * p.cout + col);
+        s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
+      }
+      if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    }
+    if (p.l2norm) {
+      float ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      const float nrm = sqrtf(ss);
+      s.x /= nrm; s.y /= nrm; s.z /= nrm; s.w /= nrm;
+    }
+    if (orow >= 0) *reinterpret_cast<float4 *>(p.out + (long long)orow * p.cout + col) = s;
+  }
+}
+
 constexpr int kKCache = 28;   // active offsets cached per workgroup (kvol <= 27 uses the pipelined kernels)
 
 // spconv_h3.hip: variant 6 (split-f16 MFMA); grid = (tiles, cout / (16 CB), split)

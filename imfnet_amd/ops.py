@@ -387,7 +387,7 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=in_a.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     if split > 1:
-        if fused_reduce and variant == 0:
+        if fused_reduce and variant in (0, 6):
             tk = torch.zeros(rb.n_slots // TILE_ROWS * max(1, cout // 32), dtype=torch.int32, device=in_a.device)
             a.tickets = tk.data_ptr()
     if variant == 6 and max(in_a.numel(), 0 if in_b is None else in_b.numel()) * 4 >= 2 ** 31:

@@ -173,7 +173,7 @@ def _rb_and_ref(cm, g, which):
 
 
 @pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple", "wave", "wave_split3", "c", "c_split3",
-                                  "reg2", "reg1", "reg2_split3", "h3", "h3_split1", "h3_split5"])
+                                  "reg2", "reg1", "reg2_split3", "h3", "h3_split1", "h3_split5", "h3_split5_fused"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
     """Plain convolution (no epilogue) vs the oracle; error measured against an fp64 evaluation and
@@ -189,8 +189,9 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
           "c": {"variant": 3, "split_k": 1}, "c_split3": {"variant": 3, "split_k": 3},
           "reg2": {"variant": 4, "split_k": 1}, "reg1": {"variant": 5, "split_k": 1},
           "reg2_split3": {"variant": 4, "split_k": 3}, "h3": {"variant": 6},
-          "h3_split1": {"variant": 6, "split_k": 1}, "h3_split5": {"variant": 6, "split_k": 5}}[mode]
-    if mode in ("split5", "split5_fused", "wave_split3", "c_split3", "reg2_split3", "h3_split5") and kvol == 1:
+          "h3_split1": {"variant": 6, "split_k": 1}, "h3_split5": {"variant": 6, "split_k": 5},
+          "h3_split5_fused": {"variant": 6, "split_k": 5, "fused_reduce": True}}[mode]
+    if mode in ("split5", "split5_fused", "wave_split3", "c_split3", "reg2_split3", "h3_split5", "h3_split5_fused") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")
     out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV), split16=mode.startswith("h3")), cout, rb,
                      in_b=None if fb is None else fb.to(DEV), **kw).cpu()
