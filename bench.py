@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- descriptors/sec of IMFNet's descriptor-generation hot path on MI355X.
 
-A "step" = one full pass of the path over one fragment whose raw points and image are already
+A "step" = one full pass of the path over one fragment PAIR whose raw points and images are already
 resident in HBM: voxelise (fp64 quantise + hash + first-occurrence unique) -> 4-level pyramid ->
 8 rulebooks -> image encoder -> 23 sparse convolutions + fusion attention -> L2-normalised
 [M,32] descriptors in HBM.  Nothing is cached between steps (every fragment is new geometry in
-the real workload).  Workload at N=1: BASELINE.json configs[1] scaled to the 3DMatch-shaped size
-its metric is quoted on (SURVEY §8d "S50k": fixture fragment cloud_bin_0 x1.7 @ 2.5 cm voxels,
-51,232 voxels).  Weights are seeded random (no checkpoint is reachable), data says so.
+the real workload).  Workload at N=1: BASELINE.json configs[1] ("single 3DMatch fragment pair, voxel
+2.5 cm") at the 3DMatch-shaped size its metric is quoted on (SURVEY §8d "S50k"): the in-tree pair
+cloud_bin_0 / cloud_bin_1 x1.7 @ 2.5 cm = 51,232 + 52,164 voxels, run as ONE batched sparse tensor
+(the model's batched call, model/resunet.py:241-250; per-fragment results equal the single-fragment
+forwards, tests/test_gpu_parity.py::test_native_batched_pair_matches_single_fragments).  --batch 1 runs
+one fragment per step.  Weights are seeded random (no checkpoint is reachable), data says so.
 
   python bench.py [--gpus N --steps K --warmup W]        one JSON line on rank 0
 """
@@ -27,6 +30,15 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def load_pair(scale):
+    """Both in-tree fragments (7-scenes-redkitchen 0 and 1) scaled to the 3DMatch-shaped size, with their images."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "fixture_clouds.npz"))
+    im = np.load(os.path.join(ROOT, "tests", "golden", "fixture_images.npz"))
+    pts = [z[f"cloud_bin_{k}"].astype(np.float64) * scale for k in (0, 1)]
+    imgs = np.stack([np.transpose(im[f"image_{k}"], (2, 0, 1)) for k in (0, 1)]).copy()
+    return pts, imgs
 
 
 def load_workload(scale, voxel):
@@ -112,6 +124,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scale", type=float, default=1.7)
     ap.add_argument("--voxel", type=float, default=0.025)
+    ap.add_argument("--batch", type=int, default=2, choices=(1, 2),
+                    help="fragments per forward: 2 = the in-tree fragment PAIR (cloud_bin_0 + cloud_bin_1, one image "
+                         "each) as ONE batched sparse tensor, the batched call of model/resunet.py:241-250")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-every", type=int, default=5,
                     help="record the per-launch HIP events of the roofline measurement on every n-th timed step "
@@ -149,6 +164,12 @@ def main():
     model = model.eval().to(dev)
     xyz_d = torch.as_tensor(xyz).to(dev)               # inputs resident in HBM before timing
     img_d = torch.as_tensor(img).to(dev)
+    item_starts = None
+    if args.batch == 2:                                # the pair, points back to back, resident in HBM
+        pts, imgs = load_pair(args.scale)
+        xyz_d = torch.as_tensor(np.concatenate(pts, 0)).to(dev)
+        img_d = torch.as_tensor(imgs).to(dev)
+        item_starts = [0, len(pts[0])]
 
     lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.pipelines))]
     counter = [0]
@@ -158,7 +179,7 @@ def main():
         # Queued from inside fragment i's forward (right after its bottleneck fusion): fragment i+1's
         # voxel pyramid and image branch then run under fragment i's decoder instead of waiting for
         # CUs behind its big fine-level convolutions.  Every step still does exactly one of each.
-        queued.append(start_geometry(xyz_d, voxel, dev, inputs_ready=True))
+        queued.append(start_geometry(xyz_d, voxel, dev, inputs_ready=True, item_starts=item_starts))
         model.start_image_branch(img_d, inputs_ready=True)
 
     def step():
@@ -249,12 +270,17 @@ def main():
             "unit": "descriptors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (reference fixture fragment cloud_bin_0 scaled x%.2f, seeded random weights)" % args.scale,
-            "config": {"workload": f"3DMatch-shaped fragment: {xyz.shape[0]} points -> {M} voxels @ "
-                                   f"{voxel * 100:.1f} cm, image 120x160, ResUNetBN2C 32-D, conv1 k5; "
-                                   f"one fragment per step per GPU, geometry rebuilt every step",
-                       "voxels_per_fragment": M, "points_per_fragment": int(xyz.shape[0]),
-                       "fragments_per_step": world, "fragments_in_flight_per_gpu": len(lanes),
+            "data": ("synthetic (reference fixture fragment%s scaled x%.2f, seeded random weights)"
+                     % (" PAIR cloud_bin_0 + cloud_bin_1" if args.batch == 2 else " cloud_bin_0", args.scale)),
+            "config": {"workload": (f"3DMatch-shaped fragment pair: {int(xyz_d.shape[0])} points -> {M} voxels @ "
+                                    f"{voxel * 100:.1f} cm, one 120x160 image each, ResUNetBN2C 32-D, conv1 k5; the pair is "
+                                    f"ONE batched forward per step per GPU, geometry rebuilt every step"
+                                    if args.batch == 2 else
+                                    f"3DMatch-shaped fragment: {xyz.shape[0]} points -> {M} voxels @ "
+                                    f"{voxel * 100:.1f} cm, image 120x160, ResUNetBN2C 32-D, conv1 k5; "
+                                    f"one fragment per step per GPU, geometry rebuilt every step"),
+                       "voxels_per_step_per_gpu": M, "points_per_step_per_gpu": int(xyz_d.shape[0]),
+                       "fragments_per_step": world * args.batch, "fragments_in_flight_per_gpu": len(lanes) * args.batch,
                        "conv_arithmetic": ("fp32 operands split into f16 hi+lo, 3x v_mfma_f32_16x16x32_f16 with fp32 "
                                            "accumulation (fp32-class: max |dF| 3e-7 vs an fp64-accumulated network)"
                                            if ops.CONV_VARIANT == 6 else "fp32 MFMA")},

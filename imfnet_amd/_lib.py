@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("IMF_LIB") or os.path.join(_HERE, "libimfnet_hip.so") 
 TILE_ROWS = 64
 MASK_WORDS = 4
 MAX_KVOL = 125
+MAX_BATCH = 8
 
 
 class ImfError(RuntimeError):
@@ -75,7 +76,9 @@ class NetTrace(C.Structure):
 class ResunetIO(C.Structure):
     """struct imf_resunet_io."""
     _fields_ = [("level", LevelDesc * 4), ("n", C.c_int64 * 4), ("bbox", C.c_void_p), ("x", C.c_void_p),
-                ("x_all_ones", C.c_int32), ("kt_packed", C.c_void_p), ("v_packed", C.c_void_p),
+                ("x_all_ones", C.c_int32), ("n_items", C.c_int32), ("item_row0", C.c_int64 * MAX_BATCH),
+                ("item_rows", C.c_int64 * MAX_BATCH), ("kt_packed", C.c_void_p * MAX_BATCH),
+                ("v_packed", C.c_void_p * MAX_BATCH),
                 ("n_tokens", C.c_int32), ("tokens_padded", C.c_int32), ("image_ready", C.c_void_p),
                 ("fusion_done", C.c_void_p), ("int_arena", C.c_void_p), ("int_arena_bytes", C.c_size_t),
                 ("float_arena", C.c_void_p), ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p),
@@ -108,6 +111,8 @@ SIGNATURES = {
     "imf_downsample": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _L, _P, _P]),
     "imf_pyramid_arena_bytes": (_Z, [_L, _I]),
     "imf_pyramid_build": (_I, [_P, _I, _L, _D, _I, _I, _P, _Z, _P, C.POINTER(LevelDesc), _P]),
+    "imf_pyramid_build_batched": (_I, [_P, _I, _L, _D, C.POINTER(C.c_int64), _I, _I, _P, _Z, _P,
+                                       C.POINTER(LevelDesc), _P]),
     "imf_rulebook_slots": (_L, [_L]),
     "imf_rulebook_conv": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _P, _P, _P]),
     "imf_rulebook_transpose_slots": (_L, [_L]),
@@ -121,6 +126,9 @@ SIGNATURES = {
     "imf_spconv_fwd": (_I, [C.POINTER(ConvArgs), _P]),
     "imf_spconv_small_cin": (_I, [_P, _I, _P, _I, _I, _P, _L, _L, _P, _P, _I, _P, _P]),
     "imf_fusion_workspace_bytes": (_Z, [_L]),
+    "imf_fusion_attention_batched": (_I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P,
+                                          _Z, _P]),
     "imf_fusion_attention": (_I, [_P, _L, _P, _P, _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P, _Z, _P]),
     "imf_bitgrid_words": (_Z, [_P, _I]),
     "imf_conv_first_bitgrid": (_I, [_P, _L, _P, _I, _P, _Z, _P, _I, _P, _P, _I, _P, _P]),

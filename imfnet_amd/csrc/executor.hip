@@ -138,6 +138,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     IMF_REQUIRE(io->n[i] > 0 && io->level[i].coords && io->level[i].keys && io->level[i].vals,
                 "imf_resunet_forward: level %d missing", i);
   IMF_REQUIRE(net->small_first || io->x, "imf_resunet_forward: input features required");
+  IMF_REQUIRE(io->n_items >= 1 && io->n_items <= IMF_MAX_BATCH, "imf_resunet_forward: n_items=%d", io->n_items);
   const Sizes s = sizes_of(net, io->n);
   IMF_REQUIRE(io->int_arena_bytes >= imf_resunet_int_arena_bytes(net, io->n, io->bbox),
               "imf_resunet_forward: int arena %zu < %zu bytes", io->int_arena_bytes,
@@ -307,8 +308,9 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
 
   // ---- bottleneck fusion (model/resunet.py:237-273) ----------------------------------------------------
   if (io->image_ready) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
-  rc = imf_fusion_attention(buf[ebuf(3, 2)], s.n[3], io->kt_packed, io->v_packed, io->n_tokens, io->tokens_padded,
-                            &net->fusion, net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4, main);
+  rc = imf_fusion_attention_batched(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
+                                    io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion, net->fusion_scale,
+                                    buf[FUSED], fusion_ws, fusion_ws_floats * 4, main);
   if (rc) return rc;
   if (io->fusion_done) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->fusion_done, main));
 

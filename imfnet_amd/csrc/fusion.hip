@@ -9,6 +9,7 @@
 // fragment-major layout as the convolution weights (imf_pack_weights with kvol = 1), so every B
 // fragment is one coalesced float4 per lane.  Deterministic (fixed summation order), fp32 throughout.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -23,8 +24,10 @@ constexpr int kFRows = 16;
 
 struct FusionParams {
   const float *x;
-  long long n;
-  const float *ktp, *vp;     // packed K^T [kFQ x tokp] and V [tokp x kFQ]
+  long long n;               // total rows (all items)
+  int n_items;               // batch items: rows [row0[b], row0[b] + rows[b]) attend to image b (gridDim.z)
+  long long row0[IMF_MAX_BATCH], rows[IMF_MAX_BATCH];
+  const float *ktp_b[IMF_MAX_BATCH], *vp_b[IMF_MAX_BATCH];   // packed K^T [kFQ x tokp] and V [tokp x kFQ] per item
   int ntok, tokp;            // valid tokens, padded to a multiple of 64
   float scale;
   const float *ln1g, *ln1b, *wq, *wo, *bo, *ln2g, *ln2b, *w1, *b1, *w2, *b2;
@@ -118,13 +121,17 @@ k_fusion_attention(const FusionParams p) {
   float *Q = S + kFRows * kLdS;            // [16][132]  q, later attention output
   float *G = Q + kFRows * kLdQ;            // [16][1028] GEGLU hidden
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
-  const long long row0 = (long long)blockIdx.x * kFRows;
+  const int item = blockIdx.z;
+  if ((long long)blockIdx.x * kFRows >= p.rows[item]) return;       // grid.x covers the largest item
+  const long long row0 = p.row0[item] + (long long)blockIdx.x * kFRows;
+  const long long row_end = p.row0[item] + p.rows[item];
+  const float *ktp = p.ktp_b[item], *vp = p.vp_b[item];
 
   // ---- load x, LayerNorm 1 (wave w: rows 2w, 2w+1) ------------------------------------------
   for (int rr = 0; rr < 2; ++rr) {
     const int r = 2 * wave + rr;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < p.n) v = *reinterpret_cast<const float4 *>(p.x + (row0 + r) * kFD + 4 * lane);
+    if (row0 + r < row_end) v = *reinterpret_cast<const float4 *>(p.x + (row0 + r) * kFD + 4 * lane);
     *reinterpret_cast<float4 *>(X + r * kLdX + 4 * lane) = v;
   }
   __syncthreads();
@@ -146,7 +153,7 @@ k_fusion_attention(const FusionParams p) {
   for (int c = wave; c < ncb_s; c += 8) {
     f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
     const int cb[1] = {c};
-    gemm16<1, 8>(acc, Q, kLdQ, kFQ, p.ktp, cb, lane);
+    gemm16<1, 8>(acc, Q, kLdQ, kFQ, ktp, cb, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[(4 * q4 + r) * kLdS + c * 16 + r16] = acc[0][r] * p.scale;
   }
@@ -184,7 +191,7 @@ k_fusion_attention(const FusionParams p) {
   {
     f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
     const int cb[1] = {wave};
-    gemm16<1, 4>(acc, S, kLdS, p.tokp, p.vp, cb, lane);   // q was last read before the previous barrier
+    gemm16<1, 4>(acc, S, kLdS, p.tokp, vp, cb, lane);   // q was last read before the previous barrier
 #pragma unroll
     for (int r = 0; r < 4; ++r) Q[(4 * q4 + r) * kLdQ + wave * 16 + r16] = acc[0][r];
   }
@@ -252,7 +259,7 @@ k_fusion_attention(const FusionParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long row = row0 + 4 * q4 + r;
-        if (row < p.n) {
+        if (row < row_end) {
           float v = acc[i][r];
           if (hs == 0) v += bias + X[(4 * q4 + r) * kLdX + col];   // bias and residual enter once
           dst[row * kFD + col] = v;
@@ -283,7 +290,9 @@ static int launch_fusion(const FusionParams &p, hipStream_t st) {
     IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_fusion_attention<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  k_fusion_attention<HS><<<dim3((unsigned)div_up(p.n, kFRows), HS), 512, lds, st>>>(p);
+  long long max_rows = 0;
+  for (int b = 0; b < p.n_items; ++b) max_rows = p.rows[b] > max_rows ? p.rows[b] : max_rows;
+  k_fusion_attention<HS><<<dim3((unsigned)div_up(max_rows, kFRows), HS, p.n_items), 512, lds, st>>>(p);
   IMF_CHECK_LAUNCH("k_fusion_attention");
   if (HS > 1) {
     const long long n4 = p.n * kFD / 4;
@@ -297,7 +306,7 @@ static int launch_fusion(const FusionParams &p, hipStream_t st) {
 static int fusion_slices(int64_t n) {
   const int64_t blocks = div_up(n, kFRows);
   if (const char *e = getenv("IMF_FUSION_SLICES")) return atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
-  return blocks <= 64 ? 4 : (blocks <= 128 ? 2 : 1);   // measured: 272 workgroups on 256 CUs lose to 136
+  return blocks <= 64 ? 4 : (blocks <= 160 ? 2 : 1);   // measured: 272 workgroups on 256 CUs lose to 136
 }
 
 }  // namespace imf
@@ -311,24 +320,47 @@ size_t imf_fusion_workspace_bytes(int64_t n) {
   return hs > 1 ? (size_t)hs * (size_t)n * kFD * sizeof(float) : 0;
 }
 
-int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed, int n_tokens,
-                         int tokens_padded, const imf_fusion_weights *w, float scale, float *out, void *workspace,
-                         size_t workspace_bytes, void *stream) {
-  IMF_REQUIRE(x && kt_packed && v_packed && w && out, "imf_fusion_attention: null pointer");
+int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
+                                 const float *const *kt_packed, const float *const *v_packed, int n_tokens,
+                                 int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+  IMF_REQUIRE(x && item_row0 && item_rows && kt_packed && v_packed && w && out, "imf_fusion_attention: null pointer");
+  IMF_REQUIRE(n_items >= 1 && n_items <= IMF_MAX_BATCH, "imf_fusion_attention: n_items=%d", n_items);
   IMF_REQUIRE(w->ln1_g && w->ln1_b && w->wq_p && w->wo_p && w->bo && w->ln2_g && w->ln2_b && w->w1_p && w->b1 &&
                   w->w2_p && w->b2, "imf_fusion_attention: null weight pointer");
-  IMF_REQUIRE(n > 0, "imf_fusion_attention: n");
   IMF_REQUIRE(tokens_padded % 64 == 0 && tokens_padded <= kMaxTokP && n_tokens > 0 && n_tokens <= tokens_padded,
               "imf_fusion_attention: tokens=%d padded=%d (padded %% 64 == 0, <= %d)", n_tokens, tokens_padded, kMaxTokP);
+  FusionParams p;
+  memset(&p, 0, sizeof(p));
+  long long n = 0;
+  for (int b = 0; b < n_items; ++b) {
+    IMF_REQUIRE(item_rows[b] > 0 && item_row0[b] >= 0 && kt_packed[b] && v_packed[b], "imf_fusion_attention: item %d", b);
+    p.row0[b] = item_row0[b];
+    p.rows[b] = item_rows[b];
+    p.ktp_b[b] = kt_packed[b];
+    p.vp_b[b] = v_packed[b];
+    n = n > item_row0[b] + item_rows[b] ? n : item_row0[b] + item_rows[b];
+  }
   const int hs = fusion_slices(n);
   IMF_REQUIRE(hs == 1 || (workspace && workspace_bytes >= imf_fusion_workspace_bytes(n)),
               "imf_fusion_attention: needs %zu workspace bytes", imf_fusion_workspace_bytes(n));
-  FusionParams p{x, (long long)n, kt_packed, v_packed, n_tokens, tokens_padded, scale, w->ln1_g, w->ln1_b,
-                 w->wq_p, w->wo_p, w->bo, w->ln2_g, w->ln2_b, w->w1_p, w->b1, w->w2_p, w->b2, out, (float *)workspace};
+  p.x = x; p.n = n; p.n_items = n_items; p.ntok = n_tokens; p.tokp = tokens_padded; p.scale = scale;
+  p.ln1g = w->ln1_g; p.ln1b = w->ln1_b; p.wq = w->wq_p; p.wo = w->wo_p; p.bo = w->bo; p.ln2g = w->ln2_g;
+  p.ln2b = w->ln2_b; p.w1 = w->w1_p; p.b1 = w->b1; p.w2 = w->w2_p; p.b2 = w->b2; p.out = out;
+  p.partial = (float *)workspace;
   hipStream_t st = (hipStream_t)stream;
   if (hs == 4) return launch_fusion<4>(p, st);
   if (hs == 2) return launch_fusion<2>(p, st);
   return launch_fusion<1>(p, st);
+}
+
+int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed, int n_tokens,
+                         int tokens_padded, const imf_fusion_weights *w, float scale, float *out, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+  IMF_REQUIRE(n > 0, "imf_fusion_attention: n");
+  const int64_t row0 = 0;
+  return imf_fusion_attention_batched(x, 1, &row0, &n, &kt_packed, &v_packed, n_tokens, tokens_padded, w, scale, out,
+                                      workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

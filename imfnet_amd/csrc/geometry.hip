@@ -1,6 +1,8 @@
 // Geometry kernels: voxel hash build, first-occurrence unique, pyramid levels, rulebooks.
 // Integer / byte work, HBM- and L2-latency bound: coalesced streams over points and slots,
 // random probes into an L2-resident open-addressing table.  No MFMA here by design.
+#include <string.h>
+
 #include "common.h"
 
 namespace imf {
@@ -14,12 +16,29 @@ __device__ __forceinline__ int floor_div(int a, int s) {
 }
 
 // ---- K1: quantise + insert (atomicCAS on the key, atomicMin on the row index) -----------------
+// Point ranges of the items of a batched build: item b = points [start[b], start[b+1]).
+struct BatchStarts {
+  long long start[IMF_MAX_BATCH];
+  int nb;
+};
+
+// first row of every batch item at one level (rows are grouped by batch index, ascending)
+__global__ void __launch_bounds__(256)
+k_item_starts(const int32_t *__restrict__ coords, const int32_t *__restrict__ n_dev, int32_t *__restrict__ starts) {
+  const int n = *n_dev;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = coords[4 * i];
+  if ((i == 0 || coords[4 * (i - 1)] != b) && b >= 0 && b < IMF_MAX_BATCH) starts[b] = i;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch,
+k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, const BatchStarts bs,
                 uint64_t *keys, int32_t *vals, uint32_t capmask, int32_t *slot_of, int32_t *err) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  for (int b = 1; b < bs.nb; ++b) batch += (i >= bs.start[b]) ? 1 : 0;   // items are contiguous point ranges
   // util/misc.py:82 -- np.floor(xyz / voxel_size) in float64 (IEEE division, exact floor)
   double fx = floor((double)xyz[3 * i + 0] / voxel);
   double fy = floor((double)xyz[3 * i + 1] / voxel);
@@ -355,12 +374,15 @@ int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, 
   int rc = init_table(keys, vals, capacity, st);
   if (rc) return rc;
   const int nblk = (int)div_up(n, 256);
+  BatchStarts one;
+  memset(&one, 0, sizeof(one));
+  one.nb = 1;
   if (xyz_is_f64)
-    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index,
+    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index, one,
                                                   keys, vals, (uint32_t)(capacity - 1), slot_of,
                                                   err_out);
   else
-    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index,
+    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index, one,
                                                  keys, vals, (uint32_t)(capacity - 1), slot_of,
                                                  err_out);
   IMF_CHECK_LAUNCH("k_insert_points");
@@ -397,9 +419,9 @@ size_t imf_pyramid_arena_bytes(int64_t n, int n_levels) {
          + align_up(imf_unique_workspace_bytes(n), 256);
 }
 
-int imf_pyramid_build(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
-                      int n_levels, void *arena, size_t arena_bytes, int32_t *meta,
-                      imf_level *levels_out, void *stream) {
+static int pyramid_build_impl(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
+                              const BatchStarts &bs, int n_levels, void *arena, size_t arena_bytes, int32_t *meta,
+                              imf_level *levels_out, void *stream) {
   IMF_REQUIRE(xyz && arena && meta && levels_out, "imf_pyramid_build: null pointer");
   IMF_REQUIRE(n > 0 && n < (1ll << 31) - 2048, "imf_pyramid_build: n=%lld out of range", (long long)n);
   IMF_REQUIRE(n_levels >= 1 && n_levels <= 8, "imf_pyramid_build: n_levels=%d", n_levels);
@@ -431,11 +453,11 @@ int imf_pyramid_build(const void *xyz, int xyz_is_f64, int64_t n, double voxel_s
   IMF_CHECK_LAUNCH("k_init_tables");
   const int nblk = (int)div_up(n, 256);
   if (xyz_is_f64)
-    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index,
+    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index, bs,
                                                   levels_out[0].keys, levels_out[0].vals,
                                                   (uint32_t)(cap - 1), slot_of, meta + 1);
   else
-    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index,
+    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index, bs,
                                                  levels_out[0].keys, levels_out[0].vals,
                                                  (uint32_t)(cap - 1), slot_of, meta + 1);
   IMF_CHECK_LAUNCH("k_insert_points");
@@ -451,7 +473,42 @@ int imf_pyramid_build(const void *xyz, int xyz_is_f64, int64_t n, double voxel_s
                          meta + 2 * (l - 1), levels_out[l].coords, nullptr, meta + 2 * l, st);
     if (rc) return rc;
   }
+  if (bs.nb > 1) {   // where every item's rows begin at every level: meta[2L+8 + IMF_MAX_BATCH*l + b]
+    int32_t *starts = meta + 2 * n_levels + 8;
+    IMF_CHECK_HIP(hipMemsetAsync(starts, 0xFF, sizeof(int32_t) * IMF_MAX_BATCH * n_levels, st));
+    for (int l = 0; l < n_levels; ++l) {
+      k_item_starts<<<nblk, 256, 0, st>>>(levels_out[l].coords, meta + 2 * l, starts + IMF_MAX_BATCH * l);
+      IMF_CHECK_LAUNCH("k_item_starts");
+    }
+  }
   return IMF_OK;
+}
+
+int imf_pyramid_build(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
+                      int n_levels, void *arena, size_t arena_bytes, int32_t *meta,
+                      imf_level *levels_out, void *stream) {
+  BatchStarts bs;
+  memset(&bs, 0, sizeof(bs));
+  bs.nb = 1;
+  return pyramid_build_impl(xyz, xyz_is_f64, n, voxel_size, batch_index, bs, n_levels, arena, arena_bytes, meta,
+                            levels_out, stream);
+}
+
+int imf_pyramid_build_batched(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size,
+                              const int64_t *item_starts, int n_items, int n_levels, void *arena,
+                              size_t arena_bytes, int32_t *meta, imf_level *levels_out, void *stream) {
+  IMF_REQUIRE(item_starts && n_items >= 1 && n_items <= IMF_MAX_BATCH, "imf_pyramid_build_batched: n_items=%d (1..%d)",
+              n_items, IMF_MAX_BATCH);
+  BatchStarts bs;
+  memset(&bs, 0, sizeof(bs));
+  bs.nb = n_items;
+  for (int b = 0; b < n_items; ++b) {
+    IMF_REQUIRE(item_starts[b] >= 0 && item_starts[b] < n && (b == 0 ? item_starts[0] == 0 : item_starts[b] > item_starts[b - 1]),
+                "imf_pyramid_build_batched: item_starts must start at 0 and ascend strictly below n");
+    bs.start[b] = item_starts[b];
+  }
+  return pyramid_build_impl(xyz, xyz_is_f64, n, voxel_size, 0, bs, n_levels, arena, arena_bytes, meta, levels_out,
+                            stream);
 }
 
 int64_t imf_rulebook_slots(int64_t n_out) { return div_up(n_out, IMF_TILE_ROWS) * IMF_TILE_ROWS; }

@@ -28,10 +28,27 @@ def _as_device_points(xyz, device):
     return t.to(device, non_blocking=True).contiguous()
 
 
-def start_geometry(xyz, voxel_size, device, inputs_ready=False):
+def start_geometry(xyz, voxel_size, device, inputs_ready=False, item_starts=None):
     """Queue the geometry build of a fragment (upload included when xyz is a host array) and return
     at once.  Handing the result to `sparse_tensor_from_points(geometry=...)` later lets the harness
-    build fragment i+1's voxel pyramid while fragment i's decoder is still running."""
+    build fragment i+1's voxel pyramid while fragment i's decoder is still running.
+    A BATCH of fragments (the reference's batched SparseTensor, model/resunet.py:241-250): pass a list of
+    point arrays, or one array holding the items back to back plus `item_starts` (first point of each)."""
+    if isinstance(xyz, (list, tuple)):
+        dev = torch.device(device)
+        on_host = not all(torch.is_tensor(a) and a.is_cuda for a in xyz)
+        stream = ops.geometry_stream(dev) if on_host else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(stream):
+            parts = [_as_device_points(a, device) for a in xyz]
+            if len({t.dtype for t in parts}) > 1:
+                parts = [t.double() for t in parts]
+            pts = torch.cat(parts, 0)
+        item_starts = [0]
+        for t in parts[:-1]:
+            item_starts.append(item_starts[-1] + t.shape[0])
+        if not on_host and not inputs_ready:
+            pass                                      # the concatenation ran on the current stream: ordered
+        return ops.PyramidFuture(pts, voxel_size, 4, 0, inputs_ready=on_host, item_starts=item_starts)
     on_host = not (torch.is_tensor(xyz) and xyz.is_cuda)
     if on_host:                                       # upload on the geometry stream itself: in order
         with torch.cuda.stream(ops.geometry_stream(torch.device(device))):
@@ -39,7 +56,7 @@ def start_geometry(xyz, voxel_size, device, inputs_ready=False):
         inputs_ready = True
     else:
         pts = _as_device_points(xyz, device)
-    return ops.PyramidFuture(pts, voxel_size, 4, 0, inputs_ready=inputs_ready)
+    return ops.PyramidFuture(pts, voxel_size, 4, 0, inputs_ready=inputs_ready, item_starts=item_starts)
 
 
 def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=None, inputs_ready=False,
@@ -119,3 +136,25 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
         host = xyz.detach().numpy() if torch.is_tensor(xyz) else np.asarray(xyz)
         return_coords = host[inds_host].astype(np.float64, copy=False)
     return return_coords, F
+
+
+def extract_features_batch(model, xyz_list, voxel_size, device, images):
+    """Several fragments in ONE forward (rows grouped by fragment, one image each -- the batched call the
+    reference's model accepts, model/resunet.py:241-250).  xyz_list: point arrays; images: [B,3,H,W].
+    Returns [(xyz_down float64 [M_b,3], F_b device view [M_b,32])] in input order.  Small fragments share
+    the per-forward fixed costs (about 0.5 ms of launch-latency-bound coarse layers) this way."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise ImfError('imfnet_amd runs on the GPU only; there is no CPU fallback')
+    if model.training:
+        model.eval()
+    fut = start_geometry(list(xyz_list), voxel_size, device)
+    start = getattr(model, "start_image_branch", None)
+    img = start(images, device=device) if start is not None else torch.as_tensor(images, dtype=torch.float32, device=device)
+    if img is None:
+        img = torch.as_tensor(images, dtype=torch.float32, device=device)
+    stensor, inds = sparse_tensor_from_points(None, voxel_size, device, geometry=fut)
+    F = model(stensor, img).F
+    sel = fut.xyz[inds.long()].cpu().numpy().astype(np.float64)
+    items = stensor.coordinate_manager.level(1).items
+    return [(sel[r0:r0 + rn], F[r0:r0 + rn]) for r0, rn in items]

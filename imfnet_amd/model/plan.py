@@ -340,8 +340,9 @@ class NativePlan:
         except Exception:                             # noqa: BLE001 -- interpreter shutdown
             pass
 
-    def run(self, x, packed, image_ready, fusion_done):
-        """x: stride-1 SparseTensor with the pyramid built; packed = (K^T, V, n_tokens, tokens_padded);
+    def run(self, x, packed, items, image_ready, fusion_done):
+        """x: stride-1 SparseTensor with the pyramid built; packed = ([K^T per item], [V per item], n_tokens,
+        tokens_padded); items = [(first stride-8 row, rows)] per batch item;
         image_ready / fusion_done: torch.cuda.Event (already recorded / to be recorded).  Returns F."""
         L, io, d = self.L, self.io, self.desc
         cm = x.coordinate_manager
@@ -363,8 +364,11 @@ class NativePlan:
         else:
             io.bbox = None
         io.x, io.x_all_ones = x.F.data_ptr(), int(bool(getattr(x, "_all_ones", False)))
-        io.kt_packed, io.v_packed, io.n_tokens, io.tokens_padded = (packed[0].data_ptr(), packed[1].data_ptr(),
-                                                                     int(packed[2]), int(packed[3]))
+        io.n_items = len(items)
+        for b, (r0, rn) in enumerate(items):
+            io.item_row0[b], io.item_rows[b] = int(r0), int(rn)
+            io.kt_packed[b], io.v_packed[b] = packed[0][b].data_ptr(), packed[1][b].data_ptr()
+        io.n_tokens, io.tokens_padded = int(packed[2]), int(packed[3])
         ibytes = L.imf_resunet_int_arena_bytes(C.byref(d), self._n, io.bbox)
         fbytes = L.imf_resunet_float_arena_bytes(C.byref(d), self._n)
         with torch.cuda.stream(side):                 # side-stream pool: rulebooks are written there first

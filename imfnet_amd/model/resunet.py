@@ -30,6 +30,11 @@ from .layers import get_block, get_norm
 MEF = ME.MinkowskiFunctional
 
 
+def _lib_max_batch():
+    from .._lib import MAX_BATCH
+    return MAX_BATCH
+
+
 class ResUNet2(ME.MinkowskiNetwork):
     NORM_TYPE = None
     BLOCK_NORM_TYPE = 'BN'
@@ -106,7 +111,10 @@ class ResUNet2(ME.MinkowskiNetwork):
     def _image_branch(self, image):
         """Image encoder + the context half of the cross attention (LayerNorm + K/V projection of
         the image tokens): everything that depends on the image only."""
-        feat = self.img_encoder(image)
+        # MIOpen picks atomically-accumulating algorithms for batch > 1 unless told not to: run-to-run 1e-5
+        # differences in the image features; the descriptor path is bit-reproducible everywhere else
+        with torch.backends.cudnn.flags(enabled=True, deterministic=True):
+            feat = self.img_encoder(image)
         kv = kt = vp = None
         blk = self.attention_fusion.cross_attend_blocks[0]
         if blk.fn.heads == 1 and len(self.attention_fusion.layers) == 0:
@@ -114,12 +122,13 @@ class ResUNet2(ME.MinkowskiNetwork):
             kv = blk.fn.to_kv(blk.norm_context(tokens))                       # [B, T, 2*d]
             T, d = kv.shape[1], kv.shape[2] // 2
             tp = (T + 63) // 64 * 64
-            if feat.shape[0] == 1 and tp <= 320:
-                # zero-padded K^T [d, tp] and V [tp, d] for the fused fusion kernel (packed right after)
-                kt = torch.zeros((d, tp), dtype=kv.dtype, device=kv.device)
-                kt[:, :T] = kv[0, :, :d].t()
-                vp = torch.zeros((tp, d), dtype=kv.dtype, device=kv.device)
-                vp[:T] = kv[0, :, d:]
+            if feat.shape[0] <= _lib_max_batch() and tp <= 320:
+                # zero-padded K^T [B, d, tp] and V [B, tp, d] for the fused fusion kernel (packed right after)
+                B = feat.shape[0]
+                kt = torch.zeros((B, d, tp), dtype=kv.dtype, device=kv.device)
+                kt[:, :, :T] = kv[:, :, :d].transpose(1, 2)
+                vp = torch.zeros((B, tp, d), dtype=kv.dtype, device=kv.device)
+                vp[:, :T] = kv[:, :, d:]
         return feat, kv, kt, vp
 
     def start_image_branch(self, image, device=None, inputs_ready=False):
@@ -148,12 +157,14 @@ class ResUNet2(ME.MinkowskiNetwork):
             if kt is not None and self._fusion_weights().supported:
                 key = (dev, tuple(image.shape))
                 bufs = self._kv_packed.get(key)
+                B = kt.shape[0]
                 if bufs is None:
-                    bufs = self._kv_packed[key] = (torch.empty(kt.numel(), dtype=torch.float32, device=dev),
-                                                   torch.empty(vp.numel(), dtype=torch.float32, device=dev))
-                ops.pack_weights(kt, out=bufs[0])          # fragment-major K^T / V, on the side stream
-                ops.pack_weights(vp, out=bufs[1])
-                packed = (bufs[0], bufs[1], kv.shape[1], kt.shape[1])
+                    bufs = self._kv_packed[key] = ([torch.empty(kt[0].numel(), dtype=torch.float32, device=dev) for _ in range(B)],
+                                                   [torch.empty(vp[0].numel(), dtype=torch.float32, device=dev) for _ in range(B)])
+                for b in range(B):                         # fragment-major K^T / V per image, on the side stream
+                    ops.pack_weights(kt[b], out=bufs[0][b])
+                    ops.pack_weights(vp[b], out=bufs[1][b])
+                packed = (bufs[0], bufs[1], kv.shape[1], kt.shape[2])
             ev = torch.cuda.Event()
             ev.record(side)
         image.record_stream(side)
@@ -214,14 +225,23 @@ class ResUNet2(ME.MinkowskiNetwork):
         if image_feat.device != x.F.device:
             raise ME.ImfError("image and sparse tensor live on different devices")
 
+        # rows of every batch item at the bottleneck: known for pyramids built by imf_pyramid_build(_batched)
+        lv8 = x.coordinate_manager.level(8)
+        items = getattr(lv8, "items", None)
+        if items is None and image_feat.shape[0] == 1:
+            items = [(0, lv8.n)]
+        if packed is not None and (items is None or len(items) != len(packed[0])):
+            packed = None                                  # batched tensor built from raw coordinates: torch path
+
         def fuse(f8):                                                                 # :189
             cur = torch.cuda.current_stream(f8.device)
             cur.wait_event(ev)                            # join the image branch
             image_feat.record_stream(cur)
             if packed is not None:                         # one HIP kernel: attention + GEGLU feed-forward
-                for t in packed[:2]:
+                for t in packed[0] + packed[1]:
                     t.record_stream(cur)
-                out = ops.fusion_attention(f8, packed[0], packed[1], packed[2], packed[3], self._fusion_weights())
+                out = ops.fusion_attention_batched(f8, items, packed[0], packed[1], packed[2], packed[3],
+                                                   self._fusion_weights())
             elif kv is not None and image_feat.shape[0] == 1:
                 kv.record_stream(cur)
                 out = self._fusion_fast(f8, kv[0])
@@ -243,10 +263,10 @@ class ResUNet2(ME.MinkowskiNetwork):
                 self._native_plan = NativePlan(self, self._plan)
             cur = torch.cuda.current_stream(x.F.device)
             image_feat.record_stream(cur)
-            for t in packed[:2]:
+            for t in packed[0] + packed[1]:
                 t.record_stream(cur)
             self._fuse_done = torch.cuda.Event()
-            return x._like(self._native_plan.run(x, packed, ev, self._fuse_done))
+            return x._like(self._native_plan.run(x, packed, items, ev, self._fuse_done))
         return x._like(self._plan.run(x, fuse, hook))
 
     def forward_layers(self, x, image):

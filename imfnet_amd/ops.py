@@ -91,13 +91,14 @@ class _Addr:
 class ArenaLevel(Level):
     """A Level whose buffers live inside one arena built by imf_pyramid_build (raw addresses; the
     coords / first_idx tensors are materialised as views only when somebody asks for them)."""
-    __slots__ = ("arena", "_desc", "_coords_view", "_first_view", "bbox")
+    __slots__ = ("arena", "_desc", "_coords_view", "_first_view", "bbox", "items")
 
     def __init__(self, arena, desc, n_dev):
         Level.__init__(self, _Addr(desc.coords), n_dev, _Addr(desc.keys), _Addr(desc.vals), desc.capacity,
                        desc.tensor_stride, _Addr(desc.first_idx) if desc.first_idx else None)
         self.arena, self._desc, self._coords_view, self._first_view = arena, desc, None, None
         self.bbox = None              # level 0: [min b,x,y,z, max b,x,y,z] (host ints)
+        self.items = None             # [(first row, rows)] per batch item
 
     def _view(self, addr, count):
         off = addr - self.arena.data_ptr()
@@ -136,7 +137,7 @@ def geometry_stream(device):
 class PyramidFuture:
     """Geometry of one fragment queued on the geometry stream; `result()` blocks on ITS event only."""
 
-    def __init__(self, xyz, voxel_size, n_levels=4, batch_index=0, inputs_ready=False):
+    def __init__(self, xyz, voxel_size, n_levels=4, batch_index=0, inputs_ready=False, item_starts=None):
         if xyz.dtype not in (torch.float64, torch.float32):
             raise ImfError(f"xyz must be float64/float32, got {xyz.dtype}")
         _req(xyz, xyz.dtype, "xyz", 2)
@@ -145,20 +146,31 @@ class PyramidFuture:
             raise ImfError(f"xyz must be [N>0, 3], got {tuple(xyz.shape)}")
         L = _lib.lib()
         self.n_levels, self.dev = n_levels, dev
+        self.n_items = 1 if item_starts is None else len(item_starts)   # batch of fragments: points back to back
+        if self.n_items > _lib.MAX_BATCH:
+            raise ImfError(f"at most {_lib.MAX_BATCH} fragments per batch, got {self.n_items}")
+        n_meta = 2 * n_levels + 8 + (_lib.MAX_BATCH * n_levels if self.n_items > 1 else 0)
         main = torch.cuda.current_stream(dev)
         gs = geometry_stream(dev)
         if not inputs_ready:
             gs.wait_stream(main)
-        pool = _PINNED.setdefault((dev, n_levels), [])
-        self.host = pool.pop() if pool else torch.empty(2 * n_levels + 8, dtype=torch.int32).pin_memory()
+        pool = _PINNED.setdefault((dev, n_meta), [])
+        self.host = pool.pop() if pool else torch.empty(n_meta, dtype=torch.int32).pin_memory()
         self.descs = (LevelDesc * n_levels)()
         with torch.cuda.stream(gs):
             nbytes = L.imf_pyramid_arena_bytes(n, n_levels)
             self.arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self.meta = torch.empty(2 * n_levels + 8, dtype=torch.int32, device=dev)   # counts/flags + bbox
-            check(L.imf_pyramid_build(xyz.data_ptr(), int(xyz.dtype == torch.float64), n, float(voxel_size),
-                                      int(batch_index), n_levels, self.arena.data_ptr(), nbytes,
-                                      self.meta.data_ptr(), self.descs, gs.cuda_stream), "imf_pyramid_build")
+            self.meta = torch.empty(n_meta, dtype=torch.int32, device=dev)   # counts/flags + bbox (+ item starts)
+            if self.n_items > 1:
+                starts = (C.c_int64 * self.n_items)(*[int(v) for v in item_starts])
+                check(L.imf_pyramid_build_batched(xyz.data_ptr(), int(xyz.dtype == torch.float64), n,
+                                                  float(voxel_size), starts, self.n_items, n_levels,
+                                                  self.arena.data_ptr(), nbytes, self.meta.data_ptr(), self.descs,
+                                                  gs.cuda_stream), "imf_pyramid_build_batched")
+            else:
+                check(L.imf_pyramid_build(xyz.data_ptr(), int(xyz.dtype == torch.float64), n, float(voxel_size),
+                                          int(batch_index), n_levels, self.arena.data_ptr(), nbytes,
+                                          self.meta.data_ptr(), self.descs, gs.cuda_stream), "imf_pyramid_build")
             self.host.copy_(self.meta, non_blocking=True)
             self.ev = torch.cuda.Event()
             self.ev.record(gs)
@@ -178,7 +190,7 @@ class PyramidFuture:
         self.arena.record_stream(main)
         self.meta.record_stream(main)
         counts = self.host.tolist()
-        _PINNED[(self.dev, n_levels)].append(self.host)
+        _PINNED[(self.dev, len(counts))].append(self.host)
         self.host = None
         levels = []
         for i in range(n_levels):
@@ -188,6 +200,14 @@ class PyramidFuture:
             lv.n = int(counts[2 * i])
             levels.append(lv)
         levels[0].bbox = counts[2 * n_levels:2 * n_levels + 8]
+        for i, lv in enumerate(levels):              # (first row, rows) of every batch item at this level
+            if self.n_items > 1:
+                st = counts[2 * n_levels + 8 + _lib.MAX_BATCH * i:][: self.n_items]
+                if any(v < 0 for v in st):
+                    raise ImfError("batched pyramid: an item has no voxel")
+                lv.items = [(st[b], (st[b + 1] if b + 1 < self.n_items else lv.n) - st[b]) for b in range(self.n_items)]
+            else:
+                lv.items = [(0, lv.n)]
         self._levels = levels
         return levels
 
@@ -480,6 +500,26 @@ class FusionKernelWeights:
                       ln2_b=f(blk1.norm.bias), w1_p=pack_weights(f(ff[0].weight).t()), b1=f(ff[0].bias),
                       w2_p=pack_weights(f(ff[2].weight).t()), b2=f(ff[2].bias))
         self.c = FusionWeights(**{k: v.data_ptr() for k, v in self.t.items()})
+
+
+def fusion_attention_batched(x, items, kt_packed, v_packed, n_tokens, tokens_padded, fw, out=None):
+    """Rows [row0, row0+rows) of x for every (row0, rows) in `items` attend to image b's packed K^T / V
+    (lists, one per item): imf_fusion_attention_batched."""
+    _req(x, torch.float32, "x", 2)
+    if out is None:
+        out = torch.empty_like(x)
+    B = len(items)
+    L = _lib.lib()
+    r0 = (C.c_int64 * B)(*[int(a) for a, _ in items])
+    rn = (C.c_int64 * B)(*[int(b) for _, b in items])
+    kp = (C.c_void_p * B)(*[t.data_ptr() for t in kt_packed])
+    vp = (C.c_void_p * B)(*[t.data_ptr() for t in v_packed])
+    nbytes = L.imf_fusion_workspace_bytes(x.shape[0])
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+    check(L.imf_fusion_attention_batched(x.data_ptr(), B, r0, rn, kp, vp, int(n_tokens), int(tokens_padded),
+                                         C.byref(fw.c), C.c_float(fw.scale), out.data_ptr(), ws.data_ptr(), nbytes,
+                                         _stream()), "imf_fusion_attention_batched")
+    return out
 
 
 def fusion_attention(x, kt_packed, v_packed, n_tokens, tokens_padded, fw, out=None):

@@ -35,6 +35,7 @@ extern "C" {
 
 #define IMF_TILE_ROWS    64   /* output rows per rulebook tile (= 4 wavefronts x 16-row MFMA blocks) */
 #define IMF_MAX_KVOL     125  /* largest kernel volume (5x5x5, config_3dmatch.py:68) */
+#define IMF_MAX_BATCH    8    /* items of a batched pyramid / forward */
 #define IMF_MASK_WORDS   4    /* 128-bit active-offset mask per tile */
 
 int imf_version(void);
@@ -101,6 +102,15 @@ size_t imf_pyramid_arena_bytes(int64_t n_points, int n_levels);
 int imf_pyramid_build(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
                       int n_levels, void *arena, size_t arena_bytes, int32_t *meta,
                       imf_level *levels_out /* [host] */, void *stream);
+/* The same for a batch of fragments (the reference's ME.utils.batched_coordinates + one SparseTensor,
+ * model/resunet.py:241-250): xyz holds the items' points back to back, item b = points
+ * [item_starts[b], item_starts[b+1]) ([host], item_starts[0] == 0), batch index b.  Rows come out grouped
+ * by item in first-occurrence order, exactly as concatenating the single-fragment results.  meta:
+ * int32[2*n_levels + 8 + IMF_MAX_BATCH*n_levels]; the last block holds the first row of item b at level
+ * l at [IMF_MAX_BATCH*l + b]. */
+int imf_pyramid_build_batched(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size,
+                              const int64_t *item_starts /* [host] */, int n_items, int n_levels, void *arena,
+                              size_t arena_bytes, int32_t *meta, imf_level *levels_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Rulebook (MinkowskiEngine "kernel map"), tiled for the MFMA kernel:
@@ -253,6 +263,13 @@ size_t imf_fusion_workspace_bytes(int64_t n);
 int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed,
                          int n_tokens, int tokens_padded, const imf_fusion_weights *w /* [host] */,
                          float scale, float *out, void *workspace, size_t workspace_bytes, void *stream);
+/* Batched form (one image per batch item, model/resunet.py:241-250): rows [item_row0[b], +item_rows[b]) of x
+ * attend to the tokens of image b (kt_packed[b], v_packed[b]); arrays are [host], n_items <= IMF_MAX_BATCH.
+ * Workspace as imf_fusion_workspace_bytes(total rows). */
+int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
+                                 const float *const *kt_packed, const float *const *v_packed, int n_tokens,
+                                 int tokens_padded, const imf_fusion_weights *w /* [host] */, float scale, float *out,
+                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Native executor for the ResUNet layer schedule -----------------------------------------------
  * One call per fragment replaces the ~100 per-layer calls of model/resunet.py:163-235 (rulebook builds
@@ -294,7 +311,10 @@ typedef struct imf_resunet_io {        /* per fragment */
   const int32_t *bbox;                 /* [host] level-0 bounding box (8 ints) or NULL */
   const float *x;                      /* [n0, in_channels] input features (may be NULL when x_all_ones) */
   int32_t x_all_ones;                  /* util/misc.py:76-79 occupancy feature */
-  const float *kt_packed, *v_packed;   /* image tokens' K^T / V, packed (imf_fusion_attention) */
+  int32_t n_items;                     /* fragments in the batch (1..IMF_MAX_BATCH), rows grouped by item */
+  int64_t item_row0[IMF_MAX_BATCH];    /* first stride-8 row of item b ... */
+  int64_t item_rows[IMF_MAX_BATCH];    /* ... and how many (imf_pyramid_build_batched's meta) */
+  const float *kt_packed[IMF_MAX_BATCH], *v_packed[IMF_MAX_BATCH];   /* image b's tokens: K^T / V, packed */
   int32_t n_tokens, tokens_padded;
   void *image_ready;                   /* hipEvent_t the main stream waits on before the fusion, or NULL */
   void *fusion_done;                   /* hipEvent_t recorded on the main stream right after the fusion

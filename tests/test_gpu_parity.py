@@ -495,3 +495,37 @@ def test_determinism_end_to_end(model, clouds, images):
         b = extract_features(model, clouds[0], voxel_size=0.05, device=torch.device(DEV), skip_check=True,
                              image=images[0])[1]
     assert torch.equal(a, b)
+
+
+def test_native_batched_pair_matches_single_fragments(model, clouds, images, monkeypatch):
+    """A PAIR of fragments in one forward through the native batched path (imf_pyramid_build_batched, one
+    image each, imf_fusion_attention_batched): voxel rows are the concatenation of the single-fragment
+    results, descriptors agree with the single-fragment forwards to rounding (split-K partitions differ
+    with the tile count, so not bit for bit)."""
+    from imfnet_amd.extract import extract_features, extract_features_batch
+    pts = [clouds[0].astype(np.float64), clouds[1].astype(np.float64)]
+    imgs = np.concatenate([images[0], images[1]], 0)
+    for voxel in (0.05, 0.025):
+        with torch.no_grad():
+            single = [extract_features(model, xyz=pts[k], voxel_size=voxel, device=DEV, skip_check=True,
+                                       image=torch.as_tensor(images[k])) for k in (0, 1)]
+            single = [(a, b.clone()) for a, b in single]
+            batched = extract_features_batch(model, pts, voxel, DEV, imgs)
+            monkeypatch.setenv("IMFNET_PYTHON_EXECUTOR", "1")
+            batched_py = extract_features_batch(model, pts, voxel, DEV, imgs)
+            monkeypatch.delenv("IMFNET_PYTHON_EXECUTOR")
+        assert len(batched) == 2
+        for k in (0, 1):
+            assert (batched[k][0] == single[k][0]).all()                       # same voxels, same order
+            assert batched[k][1].shape == single[k][1].shape
+            assert (batched[k][1] - single[k][1]).abs().max() < 2e-6
+            assert (batched_py[k][1] - batched[k][1]).abs().max() == 0.0       # both executors, same launches
+    # three items, different sizes, float32 points
+    three = [clouds[0][::3], clouds[1][::5], clouds[0][1::7]]
+    imgs3 = np.concatenate([images[0], images[1], images[0]], 0)
+    with torch.no_grad():
+        out3 = extract_features_batch(model, three, 0.05, DEV, imgs3)
+        for k in range(3):
+            xd, F = extract_features(model, xyz=three[k].astype(np.float64), voxel_size=0.05, device=DEV,
+                                     skip_check=True, image=torch.as_tensor(imgs3[k:k + 1]))
+            assert (out3[k][0] == xd).all() and (out3[k][1] - F).abs().max() < 2e-6
