@@ -306,7 +306,9 @@ static int launch_fusion(const FusionParams &p, hipStream_t st) {
 static int fusion_slices(int64_t n) {
   const int64_t blocks = div_up(n, kFRows);
   if (const char *e = getenv("IMF_FUSION_SLICES")) return atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
-  return blocks <= 64 ? 4 : (blocks <= 160 ? 2 : 1);   // measured: 272 workgroups on 256 CUs lose to 136
+  // measured: 68 blocks x 2 = 136 workgroups beat x4 = 272 (> 256 CUs); a pair's 136 blocks: x4 (two co-resident
+  // 79 KB workgroups per CU) = x1 > x2
+  return blocks <= 64 ? 4 : (blocks <= 128 ? 2 : (blocks <= 256 ? 4 : 1));   // measured: 272 workgroups on 256 CUs lose to 136
 }
 
 }  // namespace imf

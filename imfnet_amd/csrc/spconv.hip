@@ -1131,7 +1131,8 @@ int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol) {
   if (kvol <= 1 || kvol >= kKCache) return 1;
   const int64_t blocks = (n_slots / IMF_TILE_ROWS) * (cout / (16 * co_blk_of(cout)));
   if (blocks >= 512) return 1;
-  int64_t s = div_up(768, blocks);
+  static const int target = getenv("IMF_SPLIT_TARGET") ? atoi(getenv("IMF_SPLIT_TARGET")) : 768;   // tuning aid
+  int64_t s = div_up(target, blocks);
   if (s > 8) s = 8;
   if (s > kvol / 2) s = kvol / 2;
   return s < 1 ? 1 : (int)s;

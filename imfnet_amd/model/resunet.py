@@ -113,8 +113,11 @@ class ResUNet2(ME.MinkowskiNetwork):
         the image tokens): everything that depends on the image only."""
         # MIOpen picks atomically-accumulating algorithms for batch > 1 unless told not to: run-to-run 1e-5
         # differences in the image features; the descriptor path is bit-reproducible everywhere else
-        with torch.backends.cudnn.flags(enabled=True, deterministic=True):
+        prev, torch.backends.cudnn.deterministic = torch.backends.cudnn.deterministic, True
+        try:
             feat = self.img_encoder(image)
+        finally:
+            torch.backends.cudnn.deterministic = prev
         kv = kt = vp = None
         blk = self.attention_fusion.cross_attend_blocks[0]
         if blk.fn.heads == 1 and len(self.attention_fusion.layers) == 0:
