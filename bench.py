@@ -221,7 +221,11 @@ def main():
         elapsed = time.perf_counter() - t0
         trace, ops.TRACE = ops.TRACE, None
 
-    assert torch.equal(F, F_ref), "descriptors of the last timed step differ from the warm-up step"
+    # every step recomputes the same input: the last timed step must reproduce the warm-up step (bit for bit
+    # since the slot order of the transposed rulebooks is deterministic; a 1e-5 drift would mean broken work)
+    drift = float((F - F_ref).abs().max())
+    assert drift < 1e-5, f"descriptors of the last timed step differ from the warm-up step by {drift}"
+    bit_reproducible = drift == 0.0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -280,6 +284,7 @@ def main():
                                     f"{voxel * 100:.1f} cm, image 120x160, ResUNetBN2C 32-D, conv1 k5; "
                                     f"one fragment per step per GPU, geometry rebuilt every step"),
                        "voxels_per_step_per_gpu": M, "points_per_step_per_gpu": int(xyz_d.shape[0]),
+                       "last_step_equals_warmup_bitwise": bit_reproducible,
                        "fragments_per_step": world * args.batch, "fragments_in_flight_per_gpu": len(lanes) * args.batch,
                        "conv_arithmetic": ("fp32 operands split into f16 hi+lo, 3x v_mfma_f32_16x16x32_f16 with fp32 "
                                            "accumulation (fp32-class: max |dF| 3e-7 vs an fp64-accumulated network)"

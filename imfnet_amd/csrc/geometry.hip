@@ -261,49 +261,82 @@ __device__ __forceinline__ int parity_class(int4 c, int ts) {
   return (((c.y / ts) & 1)) | (((c.z / ts) & 1) << 1) | (((c.w / ts) & 1) << 2);
 }
 
+// Parity-class grouping of the transposed rulebook, DETERMINISTIC: a row's slot is
+//   class base + (rows of its class in earlier blocks) + (its rank among its class inside the block),
+// all three order-defined (no arrival-order atomics), so the slot table -- and with it the split-K
+// partition a row falls into -- is the same on every run.  blockcnt: [n_blocks][8] scratch (the head of
+// the not-yet-written neighbour table).
 __global__ void __launch_bounds__(256)
-k_class_count(const int32_t *__restrict__ coords, int64_t n, int ts, int32_t *counters) {
+k_class_count(const int32_t *__restrict__ coords, int64_t n, int ts, int32_t *__restrict__ blockcnt) {
   __shared__ int cnt[8];
   if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(&cnt[parity_class(reinterpret_cast<const int4 *>(coords)[i], ts)], 1);
+  if (i < n) atomicAdd(&cnt[parity_class(reinterpret_cast<const int4 *>(coords)[i], ts)], 1);   // a count: order-free
   __syncthreads();
-  if (threadIdx.x < 8 && cnt[threadIdx.x]) atomicAdd(counters + threadIdx.x, cnt[threadIdx.x]);
+  if (threadIdx.x < 8) blockcnt[blockIdx.x * 8 + threadIdx.x] = cnt[threadIdx.x];
 }
 
-__global__ void k_class_bases(int32_t *counters) {
-  // counters[0..7] = counts -> cursors (0); counters[8..15] = tile-aligned class bases
-  int base = 0;
-  for (int p = 0; p < 8; ++p) {
-    int c = counters[p];
-    counters[8 + p] = base;
-    counters[p] = 0;
-    base += (c + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
+// one workgroup: per class, exclusive scan of the block counts (in place) and the tile-aligned class bases
+__global__ void __launch_bounds__(256)
+k_class_bases(int32_t *__restrict__ blockcnt, int nb, int32_t *__restrict__ counters) {
+  __shared__ int part[8][32], total[8];
+  const int p = threadIdx.x >> 5, t = threadIdx.x & 31;       // 8 classes x 32 threads
+  const int per = (nb + 31) / 32;
+  const int lo = min(nb, t * per), hi = min(nb, lo + per);
+  int s = 0;
+  for (int b = lo; b < hi; ++b) s += blockcnt[b * 8 + p];
+  part[p][t] = s;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int q = 0; q < 32; ++q) {
+      const int v = part[p][q];
+      part[p][q] = run;
+      run += v;
+    }
+    total[p] = run;
+  }
+  __syncthreads();
+  int run = part[p][t];
+  for (int b = lo; b < hi; ++b) {
+    const int v = blockcnt[b * 8 + p];
+    blockcnt[b * 8 + p] = run;
+    run += v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int base = 0;
+    for (int q = 0; q < 8; ++q) {
+      counters[q] = total[q];
+      counters[8 + q] = base;
+      base += (total[q] + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
+    }
   }
 }
 
 __global__ void __launch_bounds__(256)
-k_class_assign(const int32_t *__restrict__ coords, int64_t n, int ts, int32_t *counters,
-               int32_t *tile_rows) {
-  // block-aggregated: LDS atomics give the rank inside the block, ONE global atomic per class and
-  // block reserves the range (51k single-address atomics cost 300 us; this costs ~5).
-  __shared__ int cnt[8], base[8];
-  if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
-  __syncthreads();
+k_class_assign(const int32_t *__restrict__ coords, int64_t n, int ts, const int32_t *__restrict__ counters,
+               const int32_t *__restrict__ blockbase, int32_t *__restrict__ tile_rows) {
+  __shared__ int wcnt[4][8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int p = 0, local = 0;
-  if (i < n) {
-    p = parity_class(reinterpret_cast<const int4 *>(coords)[i], ts);
-    local = atomicAdd(&cnt[p], 1);
+  const int p = (i < n) ? parity_class(reinterpret_cast<const int4 *>(coords)[i], ts) : -1;
+  int local = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {               // rank among the wave's rows of the same class, in lane order
+    const unsigned long long bal = __ballot(p == q);
+    if (p == q) local = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[w][q] = __popcll(bal);
   }
   __syncthreads();
-  if (threadIdx.x < 8) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(counters + threadIdx.x, cnt[threadIdx.x]) : 0;
-  __syncthreads();
-  if (i < n) tile_rows[counters[8 + p] + base[p] + local] = (int32_t)i;
+  if (p >= 0) {
+    int off = counters[8 + p] + blockbase[blockIdx.x * 8 + p] + local;
+    for (int v = 0; v < w; ++v) off += wcnt[v][p];
+    tile_rows[off] = (int32_t)i;
+  }
 }
 
-// one launch instead of three memsets: counters = 0, tile_rows = -1, tile_mask = 0
 __global__ void __launch_bounds__(256)
 k_init_transpose(int32_t *counters, int32_t *tile_rows, int64_t n_slots, uint32_t *tile_mask,
                  int64_t n_mask) {
@@ -551,9 +584,10 @@ int imf_rulebook_transpose(const uint64_t *coarse_keys, const int32_t *coarse_va
   k_init_transpose<<<(unsigned)div_up(n_slots, 256), 256, 0, st>>>(
       counters, tile_rows, n_slots, tile_mask, n_slots / IMF_TILE_ROWS * IMF_MASK_WORDS);
   const unsigned nb = (unsigned)div_up(n_fine, 256);
-  k_class_count<<<nb, 256, 0, st>>>(fine_coords, n_fine, ts_fine, counters);
-  k_class_bases<<<1, 1, 0, st>>>(counters);
-  k_class_assign<<<nb, 256, 0, st>>>(fine_coords, n_fine, ts_fine, counters, tile_rows);
+  int32_t *blockcnt = nbr;   // scratch: the neighbour table is written by k_rulebook below (nb*8 <= 27*n_slots)
+  k_class_count<<<nb, 256, 0, st>>>(fine_coords, n_fine, ts_fine, blockcnt);
+  k_class_bases<<<1, 256, 0, st>>>(blockcnt, (int)nb, counters);
+  k_class_assign<<<nb, 256, 0, st>>>(fine_coords, n_fine, ts_fine, counters, blockcnt, tile_rows);
   k_rulebook<-1, true><<<(unsigned)div_up(n_slots * kvol, 256), 256, 0, st>>>(
       coarse_keys, coarse_vals, (uint32_t)(coarse_capacity - 1), fine_coords, n_fine, ts_fine, ksize,
       kvol, tile_rows, nbr, tile_mask, n_slots);
