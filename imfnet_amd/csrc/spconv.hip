@@ -1130,7 +1130,8 @@ int imf_spconv_occupancy(int variant, int co_blk, int j) {
 int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol) {
   if (kvol <= 1 || kvol >= kKCache) return 1;
   const int64_t blocks = (n_slots / IMF_TILE_ROWS) * (cout / (16 * co_blk_of(cout)));
-  if (blocks >= 512) return 1;
+  static const int min_blocks = getenv("IMF_SPLIT_MIN_BLOCKS") ? atoi(getenv("IMF_SPLIT_MIN_BLOCKS")) : 400;   // measured: 438 unsplit workgroups (a pair's stride-2 level) beat split 2 + reduce by 1.5 % per step
+  if (blocks >= min_blocks) return 1;
   static const int target = getenv("IMF_SPLIT_TARGET") ? atoi(getenv("IMF_SPLIT_TARGET")) : 768;   // tuning aid
   int64_t s = div_up(target, blocks);
   if (s > 8) s = 8;
