@@ -16,6 +16,10 @@
 // 32cc + 8(l>>4).. of row nbr[k][l&15], split to hi/lo in registers).
 #include "spconv_shared.h"
 
+#ifndef IMF_H3_ABL
+#define IMF_H3_ABL 0   // timing experiments only (tools/h3_ablations.sh): 1 no MFMA, 2 no split, 4 no A loads, 8 no W loads, 16 no LDS write, 32 no LDS read, 64 no barrier
+#endif
+
 namespace imf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -148,8 +152,8 @@ k_spconv_h3(const ConvParams p) {
   const int n_macro = (n_sub + KG - 1) / KG;
 
   // prefetch registers: named scalars for the weight quads (an array would land in scratch)
-  float4 w0, w1, w2, w3;
-  float4 a_next[KG][2];
+  float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, w3 = w0;
+  float4 a_next[KG][2] = {};
 
   // The (offset, input row) of a sub-stage come from LDS; they are looked up one macro stage before
   // the loads that use them are issued, so the prefetch never waits on an LDS round trip, and the
@@ -191,13 +195,17 @@ k_spconv_h3(const ConvParams p) {
       const unsigned stride = (unsigned)(first ? p.c_a : p.c_b) * 4u;                              \
       const unsigned voff = irow >= 0 ? (unsigned)irow * stride + 32u * q4 : 0x80000000u;          \
       const int soff = (first ? ch0 : ch0 - p.c_a) * 4;                                            \
+      if (!(IMF_H3_ABL & 4)) {                                                                     \
       a_next[g][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));      \
       a_next[g][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16u, soff, 0)); \
+      } else { a_next[g][0].x += (float)voff + (float)soff; }                                      \
     }                                                                                              \
+    if (IMF_H3_ABL & 8) { w0.x += (float)wso[0]; w1.x += (float)wso[KG - 1]; } else {             \
     w0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff0 + (0 % QPS) * 4096u, wso[0 / QPS], 0)); \
     w1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff0 + (1 % QPS) * 4096u, wso[1 / QPS], 0)); \
     w2 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff0 + (2 % QPS) * 4096u, wso[2 / QPS], 0)); \
     w3 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff0 + (3 % QPS) * 4096u, wso[3 / QPS], 0)); \
+    }                                                                                              \
   }
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(p.w_packed), (short)0, 0x7FFFFFFF, 0x00020000);
@@ -212,15 +220,24 @@ k_spconv_h3(const ConvParams p) {
   for (int n = 0; n < n_macro; ++n) {
     IMF_STAMP(8 + 4 * n);
     float4 *wbuf = wlds[n & 1];
-    wbuf[0 * 256 + tid] = w0;
-    wbuf[1 * 256 + tid] = w1;
-    wbuf[2 * 256 + tid] = w2;
-    wbuf[3 * 256 + tid] = w3;
+    if (!(IMF_H3_ABL & 16)) {
+      wbuf[0 * 256 + tid] = w0;
+      wbuf[1 * 256 + tid] = w1;
+      wbuf[2 * 256 + tid] = w2;
+      wbuf[3 * 256 + tid] = w3;
+    }
     f16x8 ah[KG], al[KG];
 #pragma unroll
-    for (int g = 0; g < KG; ++g) split8(a_next[g][0], a_next[g][1], ah[g], al[g]);
+    for (int g = 0; g < KG; ++g) {
+      if (IMF_H3_ABL & 2) {
+        ah[g] = __builtin_bit_cast(f16x8, a_next[g][0]);
+        al[g] = __builtin_bit_cast(f16x8, a_next[g][1]);
+      } else {
+        split8(a_next[g][0], a_next[g][1], ah[g], al[g]);
+      }
+    }
     IMF_STAMP(9 + 4 * n);
-    __syncthreads();   // stage n visible; every wave is past its reads of this buffer (stage n-2)
+    if (!(IMF_H3_ABL & 64)) __syncthreads();   // stage n visible; every wave is past its reads of this buffer (stage n-2)
     IMF_STAMP(10 + 4 * n);
     if (n + 1 < n_macro) {
       IMF_PREFETCH(n + 1)
@@ -232,8 +249,19 @@ k_spconv_h3(const ConvParams p) {
       f16x8 bh[CO_BLK], bl[CO_BLK];
 #pragma unroll
       for (int cb = 0; cb < CO_BLK; ++cb) {
-        bh[cb] = *reinterpret_cast<const f16x8 *>(&wbuf[g * SUB_F4 + (2 * cb) * 64 + lane]);
-        bl[cb] = *reinterpret_cast<const f16x8 *>(&wbuf[g * SUB_F4 + (2 * cb + 1) * 64 + lane]);
+        if (IMF_H3_ABL & 32) {
+          bh[cb] = __builtin_bit_cast(f16x8, w0);
+          bl[cb] = __builtin_bit_cast(f16x8, w1);
+        } else {
+          bh[cb] = *reinterpret_cast<const f16x8 *>(&wbuf[g * SUB_F4 + (2 * cb) * 64 + lane]);
+          bl[cb] = *reinterpret_cast<const f16x8 *>(&wbuf[g * SUB_F4 + (2 * cb + 1) * 64 + lane]);
+        }
+      }
+      if (IMF_H3_ABL & 1) {   // keep the operands alive
+#pragma unroll
+        for (int cb = 0; cb < CO_BLK; ++cb)
+          acc[cb][0] += (float)bh[cb][0] + (float)bl[cb][1] + (float)ah[g][0] + (float)al[g][1];
+        continue;
       }
       // small terms first; consecutive MFMAs use different accumulators
 #pragma unroll
