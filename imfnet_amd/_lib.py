@@ -66,6 +66,13 @@ class ResunetDesc(C.Structure):
                 ("first_shift", C.c_void_p), ("fusion", FusionWeights), ("fusion_scale", C.c_float)]
 
 
+class ImageDesc(C.Structure):
+    """struct imf_image_desc."""
+    _fields_ = [("stem_w", C.c_void_p), ("stem_scale", C.c_void_p), ("stem_shift", C.c_void_p),
+                ("conv", NetConv * 15), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("kv_w", C.c_void_p),
+                ("variant", C.c_int32)]
+
+
 class NetTrace(C.Structure):
     """struct imf_net_trace."""
     _fields_ = [("ev_begin", C.c_void_p), ("ev_end", C.c_void_p), ("nbr", C.c_void_p), ("kvol", C.c_int32),
@@ -118,6 +125,7 @@ SIGNATURES = {
     "imf_rulebook_transpose_slots": (_L, [_L]),
     "imf_rulebook_transpose": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P]),
     "imf_packed_weight_floats": (_L, [_I, _I, _I]),
+    "imf_packed_weight_floats_split16": (_L, [_I, _I, _I]),
     "imf_pack_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "imf_pack_weights_split16": (_I, [_P, _I, _I, _I, _P, _P]),
     "imf_spconv_auto_split": (_I, [_L, _I, _I]),
@@ -130,6 +138,10 @@ SIGNATURES = {
                                           C.POINTER(C.c_void_p), _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P,
                                           _Z, _P]),
     "imf_fusion_attention": (_I, [_P, _L, _P, _P, _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P, _Z, _P]),
+    "imf_image_workspace_bytes": (_Z, [_I, _I, _I]),
+    "imf_image_tokens": (_I, [_I, _I]),
+    "imf_image_tables_build": (_I, [_I, _I, _I, _P, _Z, _P]),
+    "imf_image_branch": (_I, [C.POINTER(ImageDesc), _P, _I, _I, _I, _P, _Z, _P, _P, _P, _I, _P]),
     "imf_bitgrid_words": (_Z, [_P, _I]),
     "imf_conv_first_bitgrid": (_I, [_P, _L, _P, _I, _P, _Z, _P, _I, _P, _P, _I, _P, _P]),
     "imf_conv_first_fused": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P]),

@@ -840,10 +840,11 @@ k_spconv_reduce(const ConvParams p, int S, long long slot0) {
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     float x[4] = {s.x, s.y, s.z, s.w};
+    const float un = p.w_unscale ? *p.w_unscale : 1.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int col = 4 * c4 + e;
-      float v = x[e] * (p.scale ? p.scale[col] : 1.f) + (p.shift ? p.shift[col] : 0.f);
+      float v = (x[e] * un) * (p.scale ? p.scale[col] : 1.f) + (p.shift ? p.shift[col] : 0.f);
       if (p.residual) v += p.residual[(long long)orow * p.cout + col];
       if (p.relu) v = fmaxf(v, 0.f);
       x[e] = v;
@@ -1092,6 +1093,7 @@ using namespace imf;
 extern "C" {
 
 int64_t imf_packed_weight_floats(int kvol, int cin, int cout) { return (int64_t)kvol * cin * cout; }
+int64_t imf_packed_weight_floats_split16(int kvol, int cin, int cout) { return (int64_t)kvol * cin * cout + 64; }
 
 int imf_pack_weights(const float *w, int kvol, int cin, int cout, float *packed, void *stream) {
   IMF_REQUIRE(w && packed, "imf_pack_weights: null pointer");
@@ -1178,6 +1180,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
                ((a->variant == 0 && !simple) || a->variant == 6) ? a->tickets : nullptr, 0};
   if (const char *e = getenv("IMF_ABLATE")) p.ablate = atoi(e);
   p.tail_begin = p.tail_split = 0;
+  p.w_unscale = a->variant == 6 ? a->w_packed + (long long)a->kvol * cin * a->cout + 1 : nullptr;
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));

@@ -25,6 +25,9 @@ struct ConvParams {
   // active offsets so that the last, partial round of workgroups per CU is made of small pieces; their
   // partial sums live in `partial` as [tail_split][n_slots - 64 tail_begin][cout].  0 = off.
   int tail_begin, tail_split;
+  // variant 6: the split-f16 weight image is stored scaled by a power of two (so that the lo halves stay
+  // normal f16 numbers); *w_unscale = 2^-s is multiplied back into the fp32 accumulators (exact).  NULL = 1.
+  const float *w_unscale;
 };
 
 // Packed weight image: [y][k][cc][j][cb][lane][t] with
@@ -48,7 +51,7 @@ __device__ __forceinline__ float4 gather_a(const ConvParams &p, int irow, int ci
 // acc[cb][r] = out[row 4*q4 + r of the wavefront's 16][col 16*cb + r16]
 template <int CO_BLK>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (&acc)[CO_BLK], int tile,
-                                              int y, int wave, int r16, int q4) {
+                                              int y, int wave, int r16, int q4, float unscale = 1.f) {
   const int CW = 16 * CO_BLK;
   int orow[4];
 #pragma unroll
@@ -63,7 +66,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (
     const float sh = p.shift ? p.shift[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float x = acc[cb][r] * sc + sh;
+      float x = (acc[cb][r] * unscale) * sc + sh;
       if (p.residual && orow[r] >= 0) x += p.residual[(long long)orow[r] * p.cout + col];
       if (p.relu) x = fmaxf(x, 0.f);
       v[cb][r] = x;
@@ -103,6 +106,7 @@ __device__ __forceinline__ void fused_reduce_tile(const ConvParams &p, int S, lo
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + col);
   if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + col);
+  const float un = p.w_unscale ? *p.w_unscale : 1.f;
 #pragma unroll 1
   for (int it = 0; it < IMF_TILE_ROWS / RPI; ++it) {
     const long long slot = slot0 + it * RPI + rsub;
@@ -113,7 +117,7 @@ __device__ __forceinline__ void fused_reduce_tile(const ConvParams &p, int S, lo
         const float4 v = *reinterpret_cast<const float4 *>(p.partial + ((long long)zz * p.n_slots + slot) * p.cout + col);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
-      s.x = s.x * sc.x + sh.x; s.y = s.y * sc.y + sh.y; s.z = s.z * sc.z + sh.z; s.w = s.w * sc.w + sh.w;
+      s.x = (s.x * un) * sc.x + sh.x; s.y = (s.y * un) * sc.y + sh.y; s.z = (s.z * un) * sc.z + sh.z; s.w = (s.w * un) * sc.w + sh.w;
       if (p.residual) {
         const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (long long)orow * p.cout + col);
         s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;

@@ -30,6 +30,13 @@ from .layers import get_block, get_norm
 MEF = ME.MinkowskiFunctional
 
 
+def _down8(h):
+    """Height / width of the stride-8 map (conv7x7/2 pad 3, maxpool3/2 pad 1, conv3x3/2 pad 1)."""
+    for k, p in ((7, 3), (3, 1), (3, 1)):
+        h = (h + 2 * p - k) // 2 + 1
+    return h
+
+
 def _lib_max_batch():
     from .._lib import MAX_BATCH
     return MAX_BATCH
@@ -84,6 +91,8 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._side = {}                   # device -> side stream
         self._img_graph = {}              # (device, shape) -> captured image branch
         self._fw = None                   # packed weights of the fused fusion kernel
+        self._img_plan = None             # native image branch (model/image_plan.py, csrc/image.hip)
+        self.image_branch_mode = None     # how the last image branch ran: native-hip | torch-graph | torch-eager
 
     # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
     def _invalidate(self):
@@ -93,6 +102,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._pending_image = None
         self._img_graph = {}
         self._fw = None
+        self._img_plan = None
 
     def _apply(self, fn, *a, **k):
         self._invalidate()
@@ -155,9 +165,18 @@ class ResUNet2(ME.MinkowskiNetwork):
         with torch.cuda.stream(side), torch.no_grad():
             if not on_device:
                 image = torch.as_tensor(image, dtype=torch.float32).to(dev, non_blocking=True)
-            feat, kv, kt, vp = self._run_image_graph(image, side)
-            packed = None
-            if kt is not None and self._fusion_weights().supported:
+            plan = None if os.environ.get("IMFNET_TORCH_IMAGE") else self._native_image()
+            packed = kt = None
+            if (plan is not None and plan.supported and image.dtype == torch.float32 and image.dim() == 4 and
+                    image.shape[0] <= _lib_max_batch() and image.shape[2] >= 8 and image.shape[3] >= 8):
+                # ~22 launches of the sparse-conv kernel over static pixel tables (csrc/image.hip)
+                rows, packed = plan.run(image.contiguous(), want_kv=self._fusion_weights().supported)
+                B, h8, w8 = image.shape[0], _down8(image.shape[2]), _down8(image.shape[3])
+                feat, kv = rows.view(B, h8, w8, rows.shape[1]).permute(0, 3, 1, 2), None
+                self.image_branch_mode = "native-hip"
+            else:
+                feat, kv, kt, vp = self._run_image_graph(image, side)
+            if packed is None and kt is not None and self._fusion_weights().supported:
                 key = (dev, tuple(image.shape))
                 bufs = self._kv_packed.get(key)
                 B = kt.shape[0]
@@ -174,13 +193,23 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._pending_image = (image, feat, kv, ev, packed)
         return image
 
+    def _native_image(self):
+        if self._img_plan is None:
+            from .image_plan import ImagePlan
+            blk = self.attention_fusion.cross_attend_blocks[0]
+            one_head = blk.fn.heads == 1 and len(self.attention_fusion.layers) == 0
+            self._img_plan = ImagePlan(self.img_encoder, blk if one_head else None, ops.conv_variant_for(9))
+        return self._img_plan
+
     def _run_image_graph(self, image, side):
         key = (image.device, tuple(image.shape))
         g = self._img_graph.get(key)
         if g is None:
             g = self._img_graph[key] = self._capture_image_graph(image, side)
         if g is False:                                   # capture unavailable: eager on the side stream
+            self.image_branch_mode = "torch-eager"
             return self._image_branch(image)
+        self.image_branch_mode = "torch-graph"
         graph, static_in, outs = g
         static_in.copy_(image)
         graph.replay()

@@ -367,8 +367,12 @@ def pack_weights(kernel, out=None, split16=False):
         k = k.unsqueeze(0)
     k = _req(k.contiguous().float(), torch.float32, "kernel", 3)
     kvol, cin, cout = k.shape
-    packed = out if out is not None else torch.empty(kvol * cin * cout, dtype=torch.float32, device=k.device)
-    fn = _lib.lib().imf_pack_weights_split16 if split16 else _lib.lib().imf_pack_weights
+    L = _lib.lib()
+    need = (L.imf_packed_weight_floats_split16 if split16 else L.imf_packed_weight_floats)(kvol, cin, cout)
+    packed = out if out is not None else torch.empty(need, dtype=torch.float32, device=k.device)
+    if packed.numel() < need:
+        raise ImfError(f"packed weight buffer has {packed.numel()} floats, needs {need}")
+    fn = L.imf_pack_weights_split16 if split16 else L.imf_pack_weights
     check(fn(k.data_ptr(), kvol, cin, cout, packed.data_ptr(), _stream()), "imf_pack_weights")
     return packed
 
@@ -412,9 +416,10 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
             a.tickets = tk.data_ptr()
     if variant == 6 and max(in_a.numel(), 0 if in_b is None else in_b.numel()) * 4 >= 2 ** 31:
         raise ImfError("variant 6 addresses its inputs through a 2 GiB buffer window: use variant 0 for larger matrices")
-    if w_packed.numel() != rb.kvol * (a.c_a + a.c_b) * cout:
-        raise ImfError(f"packed weight has {w_packed.numel()} floats, expected "
-                       f"{rb.kvol}x{a.c_a + a.c_b}x{cout}")
+    need = (L.imf_packed_weight_floats_split16 if variant == 6 else L.imf_packed_weight_floats)(rb.kvol, a.c_a + a.c_b, cout)
+    if w_packed.numel() != need:
+        raise ImfError(f"packed weight has {w_packed.numel()} floats, expected {need} "
+                       f"({rb.kvol}x{a.c_a + a.c_b}x{cout}, variant {variant})")
     ev = None
     if TRACE is not None:
         ev = _Ev()

@@ -160,8 +160,11 @@ int64_t imf_packed_weight_floats(int kvol, int cin, int cout);
  * load.  cin % 32 == 0, cout % 32 == 0. */
 int imf_pack_weights(const float *w, int kvol, int cin, int cout, float *packed, void *stream);
 /* The same weights as hi/lo f16 B fragments for imf_conv_args.variant == 6 (split-f16 MFMA: every
- * fp32 operand x = f16(x) + f16(x - f16(x)); products hi*hi + hi*lo + lo*hi accumulate in fp32).  The
- * image has the size of the fp32 one (imf_packed_weight_floats). */
+ * fp32 operand x = f16(x) + f16(x - f16(x)); products hi*hi + hi*lo + lo*hi accumulate in fp32).  The kernel
+ * is stored scaled by the power of two that puts max|w| in [2^13, 2^14) (keeps the lo halves normal f16
+ * numbers; exact) and the convolution multiplies 2^-s back into its fp32 accumulators.  The image is
+ * imf_packed_weight_floats_split16 floats: the fp32 image's size + a 64-float trailer holding 2^-s. */
+int64_t imf_packed_weight_floats_split16(int kvol, int cin, int cout);
 int imf_pack_weights_split16(const float *w, int kvol, int cin, int cout, float *packed, void *stream);
 
 typedef struct imf_conv_args {
@@ -271,18 +274,54 @@ int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *ite
                                  int tokens_padded, const imf_fusion_weights *w /* [host] */, float scale, float *out,
                                  void *workspace, size_t workspace_bytes, void *stream);
 
-/* ---- Native executor for the ResUNet layer schedule -----------------------------------------------
- * One call per fragment replaces the ~100 per-layer calls of model/resunet.py:163-235 (rulebook builds
- * on a side stream, first convolution, encoder, bottleneck fusion, decoder, head), in the launch order
- * and with the arithmetic of the per-layer entry points above.  Configuration: batch 1, one attention
- * head, fusion depth 0 (IMFNet's).  All pointers inside the structs are device pointers except where
- * noted; the structs themselves live on the host. */
 typedef struct imf_net_conv {          /* static half of one fused convolution */
   const float *w_packed;               /* imf_pack_weights / imf_pack_weights_split16 image (see variant) */
   int32_t kvol, cin, cout;
   const float *scale, *shift;          /* folded BatchNorm or bias; NULL = identity */
   int32_t relu, l2norm, variant;
 } imf_net_conv;
+
+/* ---- Image branch of the fusion block ------------------------------------------------------------
+ * Replaces: ImageEncoder / ResNet.forward (model/Img_Encoder.py:15-18, model/resnet.py:195-216: conv7x7/2 -
+ *           bn - relu - maxpool3/2 - layer1 (3 BasicBlocks, 64) - layer2 (4 BasicBlocks, 128, first stride 2 with
+ *           the 1x1 projection), model/resnet.py:35-72) and the image-only half of the cross attention
+ *           (norm_context + to_kv, model/attention_fusion.py:36-46,84; token layout of model/resunet.py:257-261).
+ * Every convolution runs on imf_spconv_fwd's kernel over static pixel tables (a dense 3x3 conv is a
+ * sparse conv with a full rulebook; rows = NHWC pixels), BatchNorm folded into scale / shift.
+ * Weight images (device, built once per model): conv weights torch [co][ci][ky][kx] re-laid as
+ * [k = ky*3+kx][ci][co] and packed with imf_pack_weights(_split16) according to `variant`; the stem as a
+ * [1][160][64] kernel whose row (ky*7+kx)*3 + ch holds w[co][ch][ky][kx] (rows 147..159 zero);
+ * kv_w = to_kv.weight^T [128][256].
+ * conv order: layer1.{0,1,2}.{conv1,conv2} (0-5), layer2.0.conv1 (6), layer2.0.downsample (7), layer2.0.conv2 (8),
+ * layer2.{1,2,3}.{conv1,conv2} (9-14); relu = 1 on every entry except the projection (7). */
+typedef struct imf_image_desc {
+  const float *stem_w, *stem_scale, *stem_shift;
+  imf_net_conv conv[15];
+  const float *ln_g, *ln_b;            /* norm_context (LayerNorm 128, eps 1e-5); NULL if K/V are not wanted */
+  const float *kv_w;                   /* packed to_kv^T [1][128][256] */
+  int32_t variant;                     /* imf_conv_args.variant of the stem and K/V projections */
+} imf_image_desc;
+
+/* Bytes of the per-(B,H,W) workspace: static pixel tables (filled once by imf_image_tables_build) followed
+ * by the feature buffers of one pass.  256-byte aligned. */
+size_t imf_image_workspace_bytes(int B, int H, int W);
+int imf_image_tokens(int H, int W);    /* tokens per image = (H/8)*(W/8) for H, W divisible by 8 */
+int imf_image_tables_build(int B, int H, int W, void *workspace, size_t workspace_bytes, void *stream);
+/* image: [B,3,H,W] fp32.  feat_out (optional): [B*tokens, 128] = the stride-8 map in NHWC order, i.e.
+ * image_features.view(B,128,-1).permute(0,2,1) of model/resunet.py:257-261.  kt_packed / v_packed (optional,
+ * both or neither): per image b at offset b*128*tokens_padded floats, K^T [128, tokens_padded] and
+ * V [tokens_padded, 128] in imf_pack_weights(kvol = 1) order, zero-padded -- what imf_fusion_attention reads.
+ * About 22 launches, no host synchronisation. */
+int imf_image_branch(const imf_image_desc *net /* [host] */, const float *image, int B, int H, int W,
+                     void *workspace, size_t workspace_bytes, float *feat_out, float *kt_packed,
+                     float *v_packed, int tokens_padded, void *stream);
+
+/* ---- Native executor for the ResUNet layer schedule -----------------------------------------------
+ * One call per fragment replaces the ~100 per-layer calls of model/resunet.py:163-235 (rulebook builds
+ * on a side stream, first convolution, encoder, bottleneck fusion, decoder, head), in the launch order
+ * and with the arithmetic of the per-layer entry points above.  Configuration: batch 1, one attention
+ * head, fusion depth 0 (IMFNet's).  All pointers inside the structs are device pointers except where
+ * noted; the structs themselves live on the host. */
 
 typedef struct imf_resunet_desc {
   int32_t channels[5], tr_channels[5]; /* CHANNELS / TR_CHANNELS of model/resunet.py:22-23 (index 0 unused) */

@@ -36,6 +36,9 @@ def test_library_exports_every_declared_symbol():
     assert L.imf_rulebook_slots(65) == 128
     assert L.imf_rulebook_transpose_slots(65) == (2 + 8) * 64
     assert L.imf_packed_weight_floats(27, 64, 64) == 27 * 64 * 64
+    assert L.imf_packed_weight_floats_split16(27, 64, 64) == 27 * 64 * 64 + 64
+    assert L.imf_image_tokens(120, 160) == 300 and L.imf_image_tokens(64, 96) == 96
+    assert L.imf_image_workspace_bytes(1, 120, 160) > 0 and L.imf_image_workspace_bytes(0, 120, 160) == 0
     assert L.imf_spconv_auto_split(51264, 64, 27) == 1          # 801 tiles: no split
     assert L.imf_spconv_auto_split(1088, 256, 27) == 8          # 17 tiles x 4 slabs: split 8
     assert L.imf_spconv_auto_split(1088, 64, 1) == 1

@@ -238,12 +238,20 @@ def test_spconv_split16_variant(ops, geom_s5):
     rb, nbr_ref = cm.conv_rulebook(1, 3, 1), g.k3[0]
     n = len(g.levels[0])
     w = _rand((27, 64, 32), 40, 0.05)
-    img = ops.pack_weights(w.to(DEV), split16=True).cpu().view(torch.float16)
-    # [y][k][cc][q = 2 cb + h][lane][t]: ci = 32 cc + 8 (lane >> 4) + t, co = 16 cb + (lane & 15)
-    v = img.view(1, 27, 2, 2, 2, 4, 16, 8).float()              # y k cc cb h g c t
-    rec = (v[:, :, :, :, 0] + v[:, :, :, :, 1])[0]              # k cc cb g c t
-    rec = rec.permute(0, 1, 3, 5, 2, 4).reshape(27, 64, 32)     # k (cc g t) (cb c)
-    assert ((rec - w).abs() <= w.abs() * 2.0 ** -21 + 2.0 ** -24).all()
+    for wscale in (1.0, 1e-3, 1e-6, 3e4):                       # trained kernels are ~1e-2 .. 1e-3: lo would be subnormal unscaled
+        ws = w * wscale
+        full = ops.pack_weights(ws.to(DEV), split16=True).cpu()
+        assert full.numel() == 27 * 64 * 32 + 64                # image + trailer (max |w| bits, 2^-shift)
+        unscale = float(full[27 * 64 * 32 + 1])
+        assert unscale > 0 and np.log2(unscale) == round(np.log2(unscale))          # a power of two
+        assert 2.0 ** 13 <= float(ws.abs().max()) / unscale < 2.0 ** 14
+        img = full[:27 * 64 * 32].view(torch.float16)
+        # [y][k][cc][q = 2 cb + h][lane][t]: ci = 32 cc + 8 (lane >> 4) + t, co = 16 cb + (lane & 15)
+        v = img.view(1, 27, 2, 2, 2, 4, 16, 8).double()             # y k cc cb h g c t
+        rec = (v[:, :, :, :, 0] + v[:, :, :, :, 1])[0]              # k cc cb g c t
+        rec = rec.permute(0, 1, 3, 5, 2, 4).reshape(27, 64, 32) * unscale   # k (cc g t) (cb c)
+        # hi + lo carries >= 21 bits of every weight down to 2^-17 of the largest one (lo stays a normal f16)
+        assert ((rec - ws.double()).abs() <= ws.abs().double() * 2.0 ** -21 + float(ws.abs().max()) * 2.0 ** -39).all()
     f = _rand((n, 64), 41)
     sc, sh, res = _rand((32,), 42).abs() + 0.5, _rand((32,), 43), _rand((n, 32), 44)
     wp = ops.pack_weights(w.to(DEV), split16=True)
