@@ -35,6 +35,8 @@ class ConvArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("tickets", C.c_void_p),
         ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p),
+        ("n_out_dev", C.c_void_p), ("dyn_split_kvol", C.c_int32), ("slots_extra", C.c_int32),
+        ("dyn_err", C.c_void_p),
     ]
 
 
@@ -89,8 +91,31 @@ class ResunetIO(C.Structure):
                 ("n_tokens", C.c_int32), ("tokens_padded", C.c_int32), ("image_ready", C.c_void_p),
                 ("fusion_done", C.c_void_p), ("int_arena", C.c_void_p), ("int_arena_bytes", C.c_size_t),
                 ("float_arena", C.c_void_p), ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p),
-                ("events", C.c_void_p * 8), ("side_stream", C.c_void_p), ("main_stream", C.c_void_p),
-                ("trace", C.POINTER(NetTrace))]
+                ("events", C.c_void_p * 16), ("side_stream", C.c_void_p), ("main_stream", C.c_void_p),
+                ("trace", C.POINTER(NetTrace)), ("dyn", C.c_int32), ("meta", C.c_void_p),
+                ("bitgrid_words", C.c_size_t), ("pyramid", C.c_void_p)]
+
+
+DYN_WORDS = 16
+META_WORDS = 64
+
+
+class FragmentCaps(C.Structure):
+    """struct imf_fragment_caps."""
+    _fields_ = [("n_points", C.c_int64), ("rows", C.c_int64 * 4), ("n_items", C.c_int32), ("img_h", C.c_int32),
+                ("img_w", C.c_int32), ("bitgrid_words", C.c_size_t)]
+
+
+class FragmentIO(C.Structure):
+    """struct imf_fragment_io."""
+    _fields_ = [("xyz", C.c_void_p), ("xyz_is_f64", C.c_int32), ("voxel_size", C.c_double), ("dyn", C.c_void_p),
+                ("image", C.c_void_p), ("meta", C.c_void_p), ("pyramid_arena", C.c_void_p),
+                ("pyramid_arena_bytes", C.c_size_t), ("image_ws", C.c_void_p), ("image_ws_bytes", C.c_size_t),
+                ("kt_packed", C.c_void_p), ("v_packed", C.c_void_p), ("tokens_padded", C.c_int32),
+                ("int_arena", C.c_void_p), ("int_arena_bytes", C.c_size_t), ("float_arena", C.c_void_p),
+                ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p), ("events", C.c_void_p * 16),
+                ("main_stream", C.c_void_p), ("side_stream", C.c_void_p), ("image_stream", C.c_void_p),
+                ("trace", C.POINTER(NetTrace)), ("levels", LevelDesc * 4)]
 
 
 _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
@@ -110,6 +135,24 @@ SIGNATURES = {
     "imf_resunet_int_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64), _P]),
     "imf_resunet_float_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64)]),
     "imf_resunet_forward": (_I, [C.POINTER(ResunetDesc), C.POINTER(ResunetIO)]),
+    "imf_resunet_int_arena_bytes_cap": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64), _Z]),
+    "imf_resunet_float_arena_bytes_cap": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64)]),
+    "imf_fragment_pyramid_bytes": (_Z, [C.POINTER(FragmentCaps)]),
+    "imf_fragment_forward": (_I, [C.POINTER(ResunetDesc), C.POINTER(ImageDesc), C.POINTER(FragmentCaps),
+                                  C.POINTER(FragmentIO)]),
+    "imf_graph_begin_capture": (_I, [_P]),
+    "imf_graph_end_capture": (_I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "imf_graph_abort_capture": (_I, [_P]),
+    "imf_graph_launch": (_I, [_P, _P]),
+    "imf_graph_destroy": (None, [_P]),
+    "imf_pyramid_arena_bytes_caps": (_Z, [_L, _I, C.POINTER(C.c_int64)]),
+    "imf_pyramid_build_dyn": (_I, [_P, _I, _P, _L, C.POINTER(C.c_int64), _D, _I, _P, _Z, _P, C.POINTER(LevelDesc), _P]),
+    "imf_rulebook_conv_dyn": (_I, [_P, _P, _L, _P, _L, _P, _I, _I, _P, _P, _P, _P]),
+    "imf_rulebook_transpose_dyn": (_I, [_P, _P, _L, _P, _L, _P, _I, _I, _P, _P, _P, _L, _P, _P]),
+    "imf_conv_first_bitgrid_dyn": (_I, [_P, _L, _P, _P, _P, _I, _P, _Z, _P, _I, _P, _P, _I, _P, _P]),
+    "imf_fusion_workspace_bytes_cap": (_Z, [_L]),
+    "imf_fusion_attention_dyn": (_I, [_P, _L, _P, _P, _I, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _I,
+                                      C.POINTER(FusionWeights), C.c_float, _P, _P, _Z, _P]),
     "imf_ransac_workspace_bytes": (_Z, [_I]),
     "imf_ransac_registration": (_I, [_P, _L, _P, _L, _P, _I, _D, _D, _I, C.c_uint64, _P, _P, _P, _P, _Z, _P]),
     "imf_hash_capacity": (_L, [_L]),
@@ -129,6 +172,7 @@ SIGNATURES = {
     "imf_pack_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "imf_pack_weights_split16": (_I, [_P, _I, _I, _I, _P, _P]),
     "imf_spconv_auto_split": (_I, [_L, _I, _I]),
+    "imf_spconv_max_split": (_I, [_I, _I]),
     "imf_spconv_occupancy": (_I, [_I, _I, _I]),
     "imf_spconv_workspace_bytes": (_Z, [_L, _I, _I]),
     "imf_spconv_fwd": (_I, [C.POINTER(ConvArgs), _P]),

@@ -1,16 +1,24 @@
-// Native executor for the ResUNet layer schedule (host code only: no kernels here).
+// Native executor for the ResUNet layer schedule and for a whole fragment (host code only: no kernels here).
 //
 // The reference runs one fragment as ~100 Python-level MinkowskiEngine calls
-// (model/resunet.py:163-235).  The Python arena executor (imfnet_amd/model/plan.py) already reduced
-// that to one ctypes call per launch, but at 0.88 ms per fragment its 0.5 ms of interpreter time per
-// forward is as long as the GPU work.  imf_resunet_forward walks the same schedule natively: rulebook
+// (model/resunet.py:163-235).  imf_resunet_forward walks the same schedule natively: rulebook
 // builds on a side stream joined by events, the first convolution, the encoder, the fused bottleneck
-// attention (after the image branch's event), the decoder and the head -- one call per fragment,
-// ~100 launches at C++ cost.  Arithmetic, launch order and buffers are those of plan.py
-// (tests/test_gpu_parity.py::test_native_executor_equals_python_plan).
+// attention (after the image branch's event), the decoder and the head -- one call per fragment.
+//
+// Two modes:
+//   exact     the row count of every level is known on the host (one D2H readback after the pyramid build);
+//             arenas, grids and split-K partitions are sized for exactly those rows.
+//   capacity  (io->dyn) nothing is read back: arenas, rulebooks and grids are sized for CAPACITIES, the kernels
+//             take the actual counts from the pyramid's device meta block, and the per-launch choices that depend
+//             on the row count (split-K partitions, fusion hidden-split) are made on the device with the same rule
+//             as the host -- so a capacity-mode forward is bit-identical to the exact one.  Because every address,
+//             grid and argument is then a function of the capacities only, the whole fragment
+//             (imf_fragment_forward: pyramid + rulebooks + image branch + 23 convolutions + fusion) can be
+//             captured ONCE per capacity bucket as a hipGraph and replayed with no host work but one launch.
 #include <string.h>
 
 #include "common.h"
+#include "geometry_internal.h"
 
 namespace imf {
 namespace {
@@ -20,6 +28,8 @@ struct Rb {   // rulebook inside the int arena
   uint32_t *tile_mask = nullptr;
   int64_t n_slots = 0, n_out = 0;
   int kvol = 1, max_active = 1;
+  int level = 0;          // pyramid level of the OUTPUT rows (row count: meta[2 * level] in capacity mode)
+  int slots_extra = 0;    // parity-class padding of transposed maps (slots beyond roundup64(rows))
   int ready_event = -1;   // index into io->events that the main stream must wait on before first use
   size_t words() const { return (size_t)n_slots + (size_t)kvol * n_slots + (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS; }
   int32_t *place(int32_t *p) {
@@ -57,6 +67,14 @@ Sizes sizes_of(const imf_resunet_desc *net, const int64_t *n) {
   return s;
 }
 
+// Capacity mode: the device picks the split from the actual rows; the launch covers what the rule returns for a
+// quarter of the capacity (fewer rows than that are flagged and the caller redoes the fragment exactly).
+int split_cover(int64_t n_slots, int cout, int kvol) {
+  int64_t q = n_slots / 4 / IMF_TILE_ROWS * IMF_TILE_ROWS;
+  if (q < IMF_TILE_ROWS) q = IMF_TILE_ROWS;
+  return imf_spconv_auto_split(q, cout, kvol);
+}
+
 size_t rb_words(int64_t n_slots, int kvol) {
   return (size_t)n_slots + (size_t)kvol * n_slots + (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS;
 }
@@ -84,11 +102,38 @@ void buffer_floats(const Sizes &s, size_t (&cnt)[NBUF]) {
   cnt[FUSED] = (size_t)s.n[3] * s.ch[4];
 }
 
+size_t float_arena_bytes(const Sizes &s, bool dyn) {
+  size_t cnt[NBUF];
+  buffer_floats(s, cnt);
+  size_t total = 0;
+  for (int i = 0; i < NBUF; ++i) total += (cnt[i] + 63) / 64 * 64;
+  // largest split-K workspace of any launch (same rule as imf_spconv_fwd's automatic split)
+  size_t ws = 0;
+  auto consider = [&](int64_t n_slots, int cout, int max_active) {
+    const int sp = dyn ? split_cover(n_slots, cout, max_active) : imf_spconv_auto_split(n_slots, cout, max_active);
+    const size_t need = imf_spconv_workspace_bytes(n_slots, cout, sp) / 4;
+    ws = ws > need ? ws : need;
+  };
+  for (int i = 0; i < 4; ++i) {
+    consider(s.slots[i], s.ch[i + 1], 27);
+    if (i < 3) consider(s.slots[i], s.dec[i], 27);
+    if (i > 0) consider(s.slots[i], s.ch[i + 1], 27);   // strided conv into level i
+  }
+  for (int i = 0; i < 3; ++i) consider(s.up_slots[i], s.dec[i], 8);
+  if (!s.small_first) consider(s.slots[0], s.ch[1], s.first_kvol);
+  total += ws;
+  total += (dyn ? imf_fusion_workspace_bytes_cap(s.n[3]) : imf_fusion_workspace_bytes(s.n[3])) / 4;
+  return total * 4 + 2048;   // alignment slack of the three carved regions
+}
+
 struct Step {   // one fused convolution of the schedule
   int conv;     // index into imf_resunet_desc::conv
   Rb *rb;
   int in_a, c_a, out, in_b, c_b, residual;   // buffer ids (-1 none; -2 = io->x; -3 = io->out)
 };
+
+constexpr int kMetaBBox = 8;                        // meta[2 * n_levels + 0..7] with n_levels = 4
+constexpr int kMetaStarts = 16;                     // meta[16 + IMF_MAX_BATCH * level + item]
 
 }  // namespace
 }  // namespace imf
@@ -107,47 +152,56 @@ size_t imf_resunet_int_arena_bytes(const imf_resunet_desc *net, const int64_t *n
 
 size_t imf_resunet_float_arena_bytes(const imf_resunet_desc *net, const int64_t *n) {
   if (!net || !n) return 0;
-  const Sizes s = sizes_of(net, n);
-  size_t cnt[NBUF];
-  buffer_floats(s, cnt);
-  size_t total = 0;
-  for (int i = 0; i < NBUF; ++i) total += (cnt[i] + 63) / 64 * 64;
-  // largest split-K workspace of any launch (same rule as imf_spconv_fwd's automatic split)
-  size_t ws = 0;
-  auto consider = [&](int64_t n_slots, int cout, int max_active) {
-    const int sp = imf_spconv_auto_split(n_slots, cout, max_active);
-    const size_t need = imf_spconv_workspace_bytes(n_slots, cout, sp) / 4;
-    ws = ws > need ? ws : need;
-  };
-  for (int i = 0; i < 4; ++i) {
-    consider(s.slots[i], s.ch[i + 1], 27);
-    if (i < 3) consider(s.slots[i], s.dec[i], 27);
-    if (i > 0) consider(s.slots[i], s.ch[i + 1], 27);   // strided conv into level i
-  }
-  for (int i = 0; i < 3; ++i) consider(s.up_slots[i], s.dec[i], 8);
-  if (!s.small_first) consider(s.slots[0], s.ch[1], s.first_kvol);
-  total += ws;
-  total += imf_fusion_workspace_bytes(s.n[3]) / 4;
-  return total * 4 + 2048;   // alignment slack of the three carved regions
+  return float_arena_bytes(sizes_of(net, n), false);
+}
+
+size_t imf_resunet_int_arena_bytes_cap(const imf_resunet_desc *net, const int64_t *row_caps, size_t bitgrid_words) {
+  if (!net || !row_caps) return 0;
+  return (int_words(sizes_of(net, row_caps)) + bitgrid_words) * 4 + 256;
+}
+
+size_t imf_resunet_float_arena_bytes_cap(const imf_resunet_desc *net, const int64_t *row_caps) {
+  if (!net || !row_caps) return 0;
+  return float_arena_bytes(sizes_of(net, row_caps), true);
 }
 
 int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   IMF_REQUIRE(net && io, "imf_resunet_forward: null pointer");
   IMF_REQUIRE(io->int_arena && io->float_arena && io->out, "imf_resunet_forward: null arena / out");
+  const bool dyn = io->dyn != 0;
+  const PyramidBuild *pyr = (const PyramidBuild *)io->pyramid;   // coarse levels still to build (fragment forward)
   for (int i = 0; i < 4; ++i)
     IMF_REQUIRE(io->n[i] > 0 && io->level[i].coords && io->level[i].keys && io->level[i].vals,
                 "imf_resunet_forward: level %d missing", i);
   IMF_REQUIRE(net->small_first || io->x, "imf_resunet_forward: input features required");
   IMF_REQUIRE(io->n_items >= 1 && io->n_items <= IMF_MAX_BATCH, "imf_resunet_forward: n_items=%d", io->n_items);
   const Sizes s = sizes_of(net, io->n);
-  IMF_REQUIRE(io->int_arena_bytes >= imf_resunet_int_arena_bytes(net, io->n, io->bbox),
-              "imf_resunet_forward: int arena %zu < %zu bytes", io->int_arena_bytes,
-              imf_resunet_int_arena_bytes(net, io->n, io->bbox));
-  IMF_REQUIRE(io->float_arena_bytes >= imf_resunet_float_arena_bytes(net, io->n),
-              "imf_resunet_forward: float arena %zu < %zu bytes", io->float_arena_bytes,
-              imf_resunet_float_arena_bytes(net, io->n));
+  const int32_t *meta = io->meta;
+  if (dyn) {
+    IMF_REQUIRE(meta && io->bitgrid_words > 0, "imf_resunet_forward: capacity mode needs meta and a bit-grid capacity");
+    IMF_REQUIRE(s.small_first && io->x_all_ones && net->in_channels == 1 && (net->first_ksize == 3 || net->first_ksize == 5),
+                "imf_resunet_forward: capacity mode covers the occupancy-feature first convolution only");
+    for (int i = 0; i < 23; ++i)
+      IMF_REQUIRE(!net->conv[i].w_packed || net->conv[i].variant == 6, "imf_resunet_forward: capacity mode needs variant 6");
+    IMF_REQUIRE(io->int_arena_bytes >= imf_resunet_int_arena_bytes_cap(net, io->n, io->bitgrid_words),
+                "imf_resunet_forward: int arena %zu < %zu bytes", io->int_arena_bytes,
+                imf_resunet_int_arena_bytes_cap(net, io->n, io->bitgrid_words));
+    IMF_REQUIRE(io->float_arena_bytes >= imf_resunet_float_arena_bytes_cap(net, io->n),
+                "imf_resunet_forward: float arena %zu < %zu bytes", io->float_arena_bytes,
+                imf_resunet_float_arena_bytes_cap(net, io->n));
+  } else {
+    IMF_REQUIRE(!pyr, "imf_resunet_forward: a pending pyramid needs capacity mode");
+    IMF_REQUIRE(io->int_arena_bytes >= imf_resunet_int_arena_bytes(net, io->n, io->bbox),
+                "imf_resunet_forward: int arena %zu < %zu bytes", io->int_arena_bytes,
+                imf_resunet_int_arena_bytes(net, io->n, io->bbox));
+    IMF_REQUIRE(io->float_arena_bytes >= imf_resunet_float_arena_bytes(net, io->n),
+                "imf_resunet_forward: float arena %zu < %zu bytes", io->float_arena_bytes,
+                imf_resunet_float_arena_bytes(net, io->n));
+  }
   hipStream_t main = (hipStream_t)io->main_stream, side = (hipStream_t)io->side_stream;
-  for (int i = 0; i < 7; ++i) IMF_REQUIRE(io->events[i], "imf_resunet_forward: events[%d] missing", i);
+  const int n_events = pyr ? 9 : 7;
+  for (int i = 0; i < n_events; ++i) IMF_REQUIRE(io->events[i], "imf_resunet_forward: events[%d] missing", i);
+  int32_t *err = dyn ? const_cast<int32_t *>(meta) + 1 : nullptr;   // level-0 error word collects every flag
 
   // ---- rulebooks in the int arena --------------------------------------------------------------
   Rb rb_first, rb_k3[4], rb_dn[3], rb_up[3], rb_id;
@@ -158,24 +212,32 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   }
   for (int i = 0; i < 4; ++i) {
     rb_k3[i].n_slots = s.slots[i]; rb_k3[i].n_out = s.n[i]; rb_k3[i].kvol = rb_k3[i].max_active = 27;
+    rb_k3[i].level = i;
     p = rb_k3[i].place(p);
   }
   for (int i = 0; i < 3; ++i) {
     rb_dn[i].n_slots = s.slots[i + 1]; rb_dn[i].n_out = s.n[i + 1]; rb_dn[i].kvol = rb_dn[i].max_active = 27;
+    rb_dn[i].level = i + 1;
     p = rb_dn[i].place(p);
   }
   for (int i = 0; i < 3; ++i) {
     rb_up[i].n_slots = s.up_slots[i]; rb_up[i].n_out = s.n[i]; rb_up[i].kvol = 27; rb_up[i].max_active = 8;
+    rb_up[i].level = i;
+    rb_up[i].slots_extra = 8 * IMF_TILE_ROWS;
     p = rb_up[i].place(p);
   }
   int32_t *counters = p;
   p += 16 * 3;
   uint32_t *bitgrid = (uint32_t *)p;
   rb_id.n_slots = s.slots[0]; rb_id.n_out = s.n[0]; rb_id.kvol = rb_id.max_active = 1;   // no tables: identity
+  rb_id.level = 0;
 
-  auto build_conv = [&](Rb &rb, const imf_level &in, const imf_level &out, int64_t n_out, int ksize,
-                        hipStream_t st) -> int {
-    return imf_rulebook_conv(in.keys, in.vals, in.capacity, out.coords, n_out, in.tensor_stride, ksize,
+  auto build_conv = [&](Rb &rb, int lin, int lout, int ksize, hipStream_t st) -> int {
+    const imf_level &in = io->level[lin], &out = io->level[lout];
+    if (dyn)
+      return imf_rulebook_conv_dyn(in.keys, in.vals, in.capacity, out.coords, s.n[lout], meta + 2 * lout,
+                                   in.tensor_stride, ksize, rb.tile_rows, rb.nbr, rb.tile_mask, st);
+    return imf_rulebook_conv(in.keys, in.vals, in.capacity, out.coords, s.n[lout], in.tensor_stride, ksize,
                              rb.tile_rows, rb.nbr, rb.tile_mask, st);
   };
   int ev = 0;
@@ -185,22 +247,38 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     return IMF_OK;
   };
   int rc;
+  int items_event = -1;
+  if (pyr) {   // level 0 was built on the main stream: the side stream (coarse levels, rulebooks) starts after it
+    IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[7], main));
+    IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->events[7], 0));
+  }
   if (!s.small_first) {
-    if ((rc = build_conv(rb_first, io->level[0], io->level[0], s.n[0], net->first_ksize, main))) return rc;
-    if ((rc = build_conv(rb_k3[0], io->level[0], io->level[0], s.n[0], 3, main))) return rc;
+    if ((rc = build_conv(rb_first, 0, 0, net->first_ksize, main))) return rc;
+    if ((rc = build_conv(rb_k3[0], 0, 0, 3, main))) return rc;
   } else {   // conv1 needs no rulebook: k3@1 is built under it
-    if ((rc = build_conv(rb_k3[0], io->level[0], io->level[0], s.n[0], 3, side))) return rc;
+    if ((rc = build_conv(rb_k3[0], 0, 0, 3, side))) return rc;
     if ((rc = mark(rb_k3[0]))) return rc;
   }
   for (int i = 0; i < 3; ++i) {
-    if ((rc = build_conv(rb_dn[i], io->level[i], io->level[i + 1], s.n[i + 1], 3, side))) return rc;
-    if ((rc = build_conv(rb_k3[i + 1], io->level[i + 1], io->level[i + 1], s.n[i + 1], 3, side))) return rc;
+    if (pyr && (rc = pyramid_coarse_level(*pyr, i + 1, side))) return rc;
+    if ((rc = build_conv(rb_dn[i], i, i + 1, 3, side))) return rc;
+    if ((rc = build_conv(rb_k3[i + 1], i + 1, i + 1, 3, side))) return rc;
     if ((rc = mark(rb_dn[i]))) return rc;
   }
+  if (pyr) {   // first row of every item at every level (the fusion reads the stride-8 ones)
+    if ((rc = pyramid_item_starts(*pyr, side, 0, 4))) return rc;
+    IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[8], side));
+    items_event = 8;
+  }
   for (int i = 2; i >= 0; --i) {
-    rc = imf_rulebook_transpose(io->level[i + 1].keys, io->level[i + 1].vals, io->level[i + 1].capacity,
-                                io->level[i].coords, s.n[i], 1 << i, 3, rb_up[i].tile_rows, rb_up[i].nbr,
-                                rb_up[i].tile_mask, rb_up[i].n_slots, counters + 16 * i, side);
+    const imf_level &co = io->level[i + 1], &fi = io->level[i];
+    if (dyn)
+      rc = imf_rulebook_transpose_dyn(co.keys, co.vals, co.capacity, fi.coords, s.n[i], meta + 2 * i, 1 << i, 3,
+                                      rb_up[i].tile_rows, rb_up[i].nbr, rb_up[i].tile_mask, rb_up[i].n_slots,
+                                      counters + 16 * i, side);
+    else
+      rc = imf_rulebook_transpose(co.keys, co.vals, co.capacity, fi.coords, s.n[i], 1 << i, 3, rb_up[i].tile_rows,
+                                  rb_up[i].nbr, rb_up[i].tile_mask, rb_up[i].n_slots, counters + 16 * i, side);
     if (rc) return rc;
     if ((rc = mark(rb_up[i]))) return rc;
   }
@@ -215,12 +293,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     fp += (cnt[i] + 63) / 64 * 64;
   }
   float *ws = fp;
-  const size_t total_floats = (io->float_arena_bytes - ((char *)fp - (char *)io->float_arena)) / 4;
-  const size_t fusion_ws_floats = imf_fusion_workspace_bytes(s.n[3]) / 4;
+  const size_t fusion_ws_floats = (dyn ? imf_fusion_workspace_bytes_cap(s.n[3]) : imf_fusion_workspace_bytes(s.n[3])) / 4;
   float *fusion_ws = (float *)io->float_arena + (io->float_arena_bytes / 4) - fusion_ws_floats - 64;
   fusion_ws = (float *)((uintptr_t)fusion_ws & ~(uintptr_t)255);
   const size_t ws_bytes = ((char *)fusion_ws - (char *)ws);
-  (void)total_floats;
 
   for (int i = 0; i < NBUF; ++i)   // variant 6 reads its inputs through a 2 GiB buffer window
     IMF_REQUIRE(cnt[i] * sizeof(float) < (1ull << 31), "imf_resunet_forward: feature buffer %d exceeds 2 GiB", i);
@@ -257,17 +333,23 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
 
   // ---- first convolution (Cin <= 4): occupancy bit grid for the all-ones feature, else hash probing --
   if (s.small_first) {
-    size_t words = 0;
-    if (io->x_all_ones && io->bbox && net->in_channels == 1) words = imf_bitgrid_words(io->bbox, net->first_ksize);
-    if (words) {
-      rc = imf_conv_first_bitgrid(io->level[0].coords, s.n[0], io->bbox, net->first_ksize, bitgrid, words,
+    if (dyn) {
+      rc = imf_conv_first_bitgrid_dyn(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
+                                      io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale,
+                                      net->first_shift, 0, buf[ebuf(0, 0)], main);
+    } else {
+      size_t words = 0;
+      if (io->x_all_ones && io->bbox && net->in_channels == 1) words = imf_bitgrid_words(io->bbox, net->first_ksize);
+      if (words) {
+        rc = imf_conv_first_bitgrid(io->level[0].coords, s.n[0], io->bbox, net->first_ksize, bitgrid, words,
+                                    net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
+                                    buf[ebuf(0, 0)], main);
+      } else {
+        rc = imf_conv_first_fused(io->level[0].keys, io->level[0].vals, io->level[0].capacity, io->level[0].coords,
+                                  s.n[0], 1, net->first_ksize, io->x_all_ones ? nullptr : io->x, net->in_channels,
                                   net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
                                   buf[ebuf(0, 0)], main);
-    } else {
-      rc = imf_conv_first_fused(io->level[0].keys, io->level[0].vals, io->level[0].capacity, io->level[0].coords,
-                                s.n[0], 1, net->first_ksize, io->x_all_ones ? nullptr : io->x, net->in_channels,
-                                net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
-                                buf[ebuf(0, 0)], main);
+      }
     }
     if (rc) return rc;
   }
@@ -290,8 +372,20 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     a.n_slots = rb.n_slots; a.n_out = rb.n_out;
     a.scale = c.scale; a.shift = c.shift; a.residual = addr(st.residual);
     a.relu = c.relu; a.l2norm = c.l2norm; a.out = addr(st.out);
-    const int split = imf_spconv_auto_split(rb.n_slots, c.cout, rb.max_active);
-    a.split_k = c.kvol == 1 ? 1 : split;
+    if (dyn) {
+      a.n_out_dev = meta + 2 * rb.level;
+      a.slots_extra = rb.slots_extra;
+      a.dyn_err = err;
+      if (c.kvol == 1) {
+        a.split_k = 1;
+      } else {
+        a.dyn_split_kvol = rb.max_active;
+        a.split_k = split_cover(rb.n_slots, c.cout, rb.max_active);
+      }
+    } else {
+      const int split = imf_spconv_auto_split(rb.n_slots, c.cout, rb.max_active);
+      a.split_k = c.kvol == 1 ? 1 : split;
+    }
     a.variant = c.variant;
     a.workspace = ws; a.workspace_bytes = ws_bytes;   // split-K partials or the balanced tail's
     if (io->trace) {
@@ -308,15 +402,124 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
 
   // ---- bottleneck fusion (model/resunet.py:237-273) ----------------------------------------------------
   if (io->image_ready) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
-  rc = imf_fusion_attention_batched(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
-                                    io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion, net->fusion_scale,
-                                    buf[FUSED], fusion_ws, fusion_ws_floats * 4, main);
+  if (items_event >= 0) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->events[items_event], 0));
+  if (dyn)
+    rc = imf_fusion_attention_dyn(buf[ebuf(3, 2)], s.n[3], meta + 6, meta + kMetaStarts + IMF_MAX_BATCH * 3, io->n_items,
+                                  err, io->kt_packed, io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
+                                  net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4, main);
+  else
+    rc = imf_fusion_attention_batched(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
+                                      io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion, net->fusion_scale,
+                                      buf[FUSED], fusion_ws, fusion_ws_floats * 4, main);
   if (rc) return rc;
   if (io->fusion_done) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->fusion_done, main));
 
   for (int i = n_enc; i < n_steps; ++i)
     if ((rc = launch(sched[i]))) return rc;
   return IMF_OK;
+}
+
+/* ---- one fragment (or batch of fragments), points to descriptors, with no host synchronisation -------- */
+size_t imf_fragment_pyramid_bytes(const imf_fragment_caps *caps) {
+  if (!caps) return 0;
+  return imf_pyramid_arena_bytes_caps(caps->n_points, 4, caps->rows);
+}
+
+int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img, const imf_fragment_caps *caps,
+                         imf_fragment_io *fio) {
+  IMF_REQUIRE(net && img && caps && fio, "imf_fragment_forward: null pointer");
+  IMF_REQUIRE(fio->xyz && fio->dyn && fio->image && fio->meta && fio->pyramid_arena && fio->image_ws && fio->kt_packed &&
+                  fio->v_packed && fio->out, "imf_fragment_forward: null buffer");
+  IMF_REQUIRE(caps->n_items >= 1 && caps->n_items <= IMF_MAX_BATCH, "imf_fragment_forward: n_items=%d", caps->n_items);
+  hipStream_t main = (hipStream_t)fio->main_stream, side = (hipStream_t)fio->side_stream,
+              imgs = (hipStream_t)fio->image_stream;
+  IMF_REQUIRE(side && imgs && side != main && imgs != main && side != imgs, "imf_fragment_forward: three distinct streams");
+  for (int i = 0; i < 11; ++i) IMF_REQUIRE(fio->events[i], "imf_fragment_forward: events[%d] missing", i);
+  const int ntok = imf_image_tokens(caps->img_h, caps->img_w);
+  IMF_REQUIRE(fio->tokens_padded % 64 == 0 && fio->tokens_padded >= ntok && fio->tokens_padded <= 320,
+              "imf_fragment_forward: tokens_padded=%d for %d tokens", fio->tokens_padded, ntok);
+
+  // image branch on its own stream, forked from and later joined to the main one (events 9 / 10)
+  IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[9], main));
+  IMF_CHECK_HIP(hipStreamWaitEvent(imgs, (hipEvent_t)fio->events[9], 0));
+  int rc = imf_image_branch(img, fio->image, caps->n_items, caps->img_h, caps->img_w, fio->image_ws, fio->image_ws_bytes,
+                            nullptr, fio->kt_packed, fio->v_packed, fio->tokens_padded, imgs);
+  if (rc) return rc;
+  IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[10], imgs));
+
+  // level 0 of the pyramid on the main stream (conv1 needs it first); the coarse levels go to the side stream
+  PyramidBuild pb;
+  rc = pyramid_prepare(pb, fio->xyz, fio->xyz_is_f64, caps->n_points, fio->voxel_size, 0, nullptr, 1, 4, fio->pyramid_arena,
+                       fio->pyramid_arena_bytes, fio->meta, fio->levels, fio->dyn, caps->rows);
+  if (rc) return rc;
+  if ((rc = pyramid_level0(pb, main))) return rc;
+
+  imf_resunet_io io;
+  memset(&io, 0, sizeof(io));
+  const size_t per = (size_t)128 * fio->tokens_padded;
+  for (int i = 0; i < 4; ++i) {
+    io.level[i] = fio->levels[i];
+    io.n[i] = caps->rows[i];
+  }
+  io.x_all_ones = 1;
+  io.n_items = caps->n_items;
+  for (int b = 0; b < caps->n_items; ++b) {
+    io.kt_packed[b] = fio->kt_packed + b * per;
+    io.v_packed[b] = fio->v_packed + b * per;
+  }
+  io.n_tokens = ntok; io.tokens_padded = fio->tokens_padded;
+  io.image_ready = fio->events[10];
+  io.int_arena = fio->int_arena; io.int_arena_bytes = fio->int_arena_bytes;
+  io.float_arena = fio->float_arena; io.float_arena_bytes = fio->float_arena_bytes;
+  io.out = fio->out;
+  for (int i = 0; i < 9; ++i) io.events[i] = fio->events[i];
+  io.side_stream = side; io.main_stream = main;
+  io.trace = fio->trace;
+  io.dyn = 1; io.meta = fio->meta; io.bitgrid_words = caps->bitgrid_words; io.pyramid = &pb;
+  return imf_resunet_forward(net, &io);
+}
+
+/* ---- hipGraph helpers: capture a launch sequence once, replay it per fragment ---------------------------- */
+int imf_graph_begin_capture(void *stream) {
+  IMF_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return IMF_OK;
+}
+
+int imf_graph_end_capture(void *stream, void **graph_exec_out, int *n_nodes_out) {
+  IMF_REQUIRE(graph_exec_out, "imf_graph_end_capture: null pointer");
+  hipGraph_t graph = nullptr;
+  IMF_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
+  IMF_REQUIRE(graph, "imf_graph_end_capture: the capture was invalidated");
+  size_t n_nodes = 0;
+  (void)hipGraphGetNodes(graph, nullptr, &n_nodes);
+  if (n_nodes_out) *n_nodes_out = (int)n_nodes;
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+    return IMF_ELAUNCH;
+  }
+  *graph_exec_out = (void *)exec;
+  return IMF_OK;
+}
+
+int imf_graph_abort_capture(void *stream) {   // after a failed enqueue: leave capture mode, drop the partial graph
+  hipGraph_t graph = nullptr;
+  (void)hipStreamEndCapture((hipStream_t)stream, &graph);
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipGetLastError();
+  return IMF_OK;
+}
+
+int imf_graph_launch(void *graph_exec, void *stream) {
+  IMF_REQUIRE(graph_exec, "imf_graph_launch: null graph");
+  IMF_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return IMF_OK;
+}
+
+void imf_graph_destroy(void *graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
 }
 
 }  // extern "C"

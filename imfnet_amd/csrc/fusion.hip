@@ -33,7 +33,44 @@ struct FusionParams {
   const float *ln1g, *ln1b, *wq, *wo, *bo, *ln2g, *ln2b, *w1, *b1, *w2, *b2;
   float *out;
   float *partial;   // [HS][n][256] when the GEGLU hidden dimension is split over gridDim.y (HS > 1)
+  // Capacity mode: n is a capacity; the row count and every item's first row are read from the device (meta
+  // block of imf_pyramid_build: count of the stride-8 level, its item-start words).  The launcher issues every
+  // hidden-split variant and each one runs only if the rule picks it for the ACTUAL rows (same sums as exact-size).
+  const int32_t *n_dev, *starts_dev;
+  int32_t *err;
+  int hs_override;
 };
+
+// slices of the hidden dimension: fill ~256 CUs, one workgroup each
+__host__ __device__ inline int fusion_slices_rule(long long n, int hs_override) {
+  if (hs_override) return hs_override;
+  const long long blocks = (n + 15) / 16;
+  // measured: 68 blocks x 2 = 136 workgroups beat x4 = 272 (> 256 CUs); a pair's 136 blocks: x4 (two co-resident
+  // 79 KB workgroups per CU) = x1 > x2
+  return blocks <= 64 ? 4 : (blocks <= 128 ? 2 : (blocks <= 256 ? 4 : 1));   // measured: 272 workgroups on 256 CUs lose to 136
+}
+
+// rows [row0, row_end) of batch item `item`; false = nothing to do for this workgroup
+template <int HS>
+__device__ __forceinline__ bool fusion_item_rows(const FusionParams &p, int item, long long &row0, long long &row_end) {
+  if (!p.n_dev) {
+    row0 = p.row0[item];
+    row_end = p.row0[item] + p.rows[item];
+    return true;
+  }
+  long long n = *p.n_dev;
+  n = n < p.n ? n : p.n;
+  if (fusion_slices_rule(n, p.hs_override) != HS) return false;
+  const int s0 = p.starts_dev[item];
+  const int s1 = item + 1 < p.n_items ? p.starts_dev[item + 1] : (int)n;
+  if (s0 < 0 || s1 < s0) {          // an item without rows: flagged, as the exact-size path raises
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(p.err, 8);
+    return false;
+  }
+  row0 = s0;
+  row_end = s1;
+  return true;
+}
 
 // float4 holding the B fragments of MFMA steps 4u'..4u'+3 (u = 16-channel step) for column block c
 __device__ __forceinline__ const float4 *bfrag(const float *packed, int ncc, int u, int c, int lane) {
@@ -122,9 +159,10 @@ k_fusion_attention(const FusionParams p) {
   float *G = Q + kFRows * kLdQ;            // [16][1028] GEGLU hidden
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
   const int item = blockIdx.z;
-  if ((long long)blockIdx.x * kFRows >= p.rows[item]) return;       // grid.x covers the largest item
-  const long long row0 = p.row0[item] + (long long)blockIdx.x * kFRows;
-  const long long row_end = p.row0[item] + p.rows[item];
+  long long row0, row_end;
+  if (!fusion_item_rows<HS>(p, item, row0, row_end)) return;
+  row0 += (long long)blockIdx.x * kFRows;
+  if (row0 >= row_end) return;                                      // grid.x covers the largest item
   const float *ktp = p.ktp_b[item], *vp = p.vp_b[item];
 
   // ---- load x, LayerNorm 1 (wave w: rows 2w, 2w+1) ------------------------------------------
@@ -271,12 +309,19 @@ k_fusion_attention(const FusionParams p) {
 
 // out = sum over the HS partial slices, ascending (deterministic)
 __global__ void __launch_bounds__(256) k_fusion_reduce(const float *__restrict__ partial, long long n4, int hs,
-                                                       float *__restrict__ out) {
+                                                       float *__restrict__ out, const int32_t *__restrict__ n_dev,
+                                                       int hs_override) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride4 = n4;
+  if (n_dev) {   // capacity mode: n4 is the capacity (and the slice stride); only the variant the rule picks runs
+    const long long n = *n_dev;
+    if (fusion_slices_rule(n, hs_override) != hs) return;
+    n4 = n * (kFD / 4) < n4 ? n * (kFD / 4) : n4;
+  }
   if (i >= n4) return;
   float4 s = reinterpret_cast<const float4 *>(partial)[i];
   for (int h = 1; h < hs; ++h) {
-    const float4 v = reinterpret_cast<const float4 *>(partial)[(long long)h * n4 + i];
+    const float4 v = reinterpret_cast<const float4 *>(partial)[(long long)h * stride4 + i];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   reinterpret_cast<float4 *>(out)[i] = s;
@@ -290,26 +335,23 @@ static int launch_fusion(const FusionParams &p, hipStream_t st) {
     IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_fusion_attention<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  long long max_rows = 0;
+  long long max_rows = p.n_dev ? p.n : 0;
   for (int b = 0; b < p.n_items; ++b) max_rows = p.rows[b] > max_rows ? p.rows[b] : max_rows;
   k_fusion_attention<HS><<<dim3((unsigned)div_up(max_rows, kFRows), HS, p.n_items), 512, lds, st>>>(p);
   IMF_CHECK_LAUNCH("k_fusion_attention");
   if (HS > 1) {
     const long long n4 = p.n * kFD / 4;
-    k_fusion_reduce<<<(unsigned)div_up(n4, 256), 256, 0, st>>>(p.partial, n4, HS, p.out);
+    k_fusion_reduce<<<(unsigned)div_up(n4, 256), 256, 0, st>>>(p.partial, n4, HS, p.out, p.n_dev, p.hs_override);
     IMF_CHECK_LAUNCH("k_fusion_reduce");
   }
   return IMF_OK;
 }
 
-// slices of the hidden dimension: fill ~256 CUs, one workgroup each
-static int fusion_slices(int64_t n) {
-  const int64_t blocks = div_up(n, kFRows);
-  if (const char *e = getenv("IMF_FUSION_SLICES")) return atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
-  // measured: 68 blocks x 2 = 136 workgroups beat x4 = 272 (> 256 CUs); a pair's 136 blocks: x4 (two co-resident
-  // 79 KB workgroups per CU) = x1 > x2
-  return blocks <= 64 ? 4 : (blocks <= 128 ? 2 : (blocks <= 256 ? 4 : 1));   // measured: 272 workgroups on 256 CUs lose to 136
+static int fusion_hs_override() {
+  static const int v = getenv("IMF_FUSION_SLICES") ? (atoi(getenv("IMF_FUSION_SLICES")) == 4 ? 4 : (atoi(getenv("IMF_FUSION_SLICES")) == 2 ? 2 : 1)) : 0;
+  return v;
 }
+static int fusion_slices(int64_t n) { return fusion_slices_rule(n, fusion_hs_override()); }
 
 }  // namespace imf
 
@@ -320,6 +362,39 @@ extern "C" {
 size_t imf_fusion_workspace_bytes(int64_t n) {
   const int hs = fusion_slices(n);
   return hs > 1 ? (size_t)hs * (size_t)n * kFD * sizeof(float) : 0;
+}
+
+size_t imf_fusion_workspace_bytes_cap(int64_t n_cap) { return (size_t)4 * (size_t)n_cap * kFD * sizeof(float); }
+
+int imf_fusion_attention_dyn(const float *x, int64_t n_cap, const int32_t *n_dev, const int32_t *item_starts_dev,
+                             int n_items, int32_t *err, const float *const *kt_packed, const float *const *v_packed,
+                             int n_tokens, int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+  IMF_REQUIRE(x && n_dev && item_starts_dev && err && kt_packed && v_packed && w && out && workspace,
+              "imf_fusion_attention_dyn: null pointer");
+  IMF_REQUIRE(n_items >= 1 && n_items <= IMF_MAX_BATCH && n_cap > 0, "imf_fusion_attention_dyn: n_items=%d", n_items);
+  IMF_REQUIRE(tokens_padded % 64 == 0 && tokens_padded <= kMaxTokP && n_tokens > 0 && n_tokens <= tokens_padded,
+              "imf_fusion_attention_dyn: tokens=%d padded=%d", n_tokens, tokens_padded);
+  IMF_REQUIRE(workspace_bytes >= imf_fusion_workspace_bytes_cap(n_cap), "imf_fusion_attention_dyn: needs %zu workspace bytes",
+              imf_fusion_workspace_bytes_cap(n_cap));
+  FusionParams p;
+  memset(&p, 0, sizeof(p));
+  for (int b = 0; b < n_items; ++b) {
+    IMF_REQUIRE(kt_packed[b] && v_packed[b], "imf_fusion_attention_dyn: item %d", b);
+    p.ktp_b[b] = kt_packed[b];
+    p.vp_b[b] = v_packed[b];
+  }
+  p.x = x; p.n = n_cap; p.n_items = n_items; p.ntok = n_tokens; p.tokp = tokens_padded; p.scale = scale;
+  p.ln1g = w->ln1_g; p.ln1b = w->ln1_b; p.wq = w->wq_p; p.wo = w->wo_p; p.bo = w->bo; p.ln2g = w->ln2_g;
+  p.ln2b = w->ln2_b; p.w1 = w->w1_p; p.b1 = w->b1; p.w2 = w->w2_p; p.b2 = w->b2; p.out = out;
+  p.partial = (float *)workspace;
+  p.n_dev = n_dev; p.starts_dev = item_starts_dev; p.err = err; p.hs_override = fusion_hs_override();
+  hipStream_t st = (hipStream_t)stream;
+  // every variant is issued; on the device exactly one of them finds its slice count selected
+  int rc;
+  if ((rc = launch_fusion<1>(p, st))) return rc;
+  if ((rc = launch_fusion<2>(p, st))) return rc;
+  return launch_fusion<4>(p, st);
 }
 
 int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,

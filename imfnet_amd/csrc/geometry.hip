@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "geometry_internal.h"
 
 namespace imf {
 
@@ -32,13 +33,22 @@ k_item_starts(const int32_t *__restrict__ coords, const int32_t *__restrict__ n_
   if ((i == 0 || coords[4 * (i - 1)] != b) && b >= 0 && b < IMF_MAX_BATCH) starts[b] = i;
 }
 
+// dyn (optional, device): [0] = number of points, [1] = number of items, [2 + b] = first point of item b --
+// the per-fragment scalars of a captured launch sequence (IMF_DYN_WORDS ints).
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, const BatchStarts bs,
+                const int32_t *__restrict__ dyn,
                 uint64_t *keys, int32_t *vals, uint32_t capmask, int32_t *slot_of, int32_t *err) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  for (int b = 1; b < bs.nb; ++b) batch += (i >= bs.start[b]) ? 1 : 0;   // items are contiguous point ranges
+  if (dyn) {
+    if (i >= min((int64_t)dyn[0], n)) return;
+    const int nb = min(max(dyn[1], 1), IMF_MAX_BATCH);
+    for (int b = 1; b < nb; ++b) batch += (i >= dyn[2 + b]) ? 1 : 0;
+  } else {
+    if (i >= n) return;
+    for (int b = 1; b < bs.nb; ++b) batch += (i >= bs.start[b]) ? 1 : 0;   // items are contiguous point ranges
+  }
   // util/misc.py:82 -- np.floor(xyz / voxel_size) in float64 (IEEE division, exact floor)
   double fx = floor((double)xyz[3 * i + 0] / voxel);
   double fy = floor((double)xyz[3 * i + 1] / voxel);
@@ -82,7 +92,7 @@ __global__ void __launch_bounds__(kScanThreads)
 k_flag_first(int32_t *slot_of, const int32_t *__restrict__ vals, int64_t n_static,
              const int32_t *__restrict__ n_dev, int32_t *block_sums) {
   __shared__ int lds4[4];
-  const int64_t n = n_dev ? (int64_t)*n_dev : n_static;
+  const int64_t n = n_dev ? min((int64_t)*n_dev, n_static) : n_static;
   int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   int cnt = 0;
 #pragma unroll
@@ -100,8 +110,9 @@ k_flag_first(int32_t *slot_of, const int32_t *__restrict__ vals, int64_t n_stati
 }
 
 // ---- K3: exclusive scan of the block counts (one block), total -> m_out ------------------------
+// row_cap > 0: the level holds at most row_cap rows; a larger count is clamped and flagged (bit 1 of err)
 __global__ void __launch_bounds__(256)
-k_scan_block_sums(int32_t *block_sums, int nb, int32_t *m_out) {
+k_scan_block_sums(int32_t *block_sums, int nb, int32_t *m_out, int64_t row_cap = 0, int32_t *err = nullptr) {
   __shared__ int part[256];
   const int t = threadIdx.x;
   const int per = (nb + 255) / 256;
@@ -123,7 +134,14 @@ k_scan_block_sums(int32_t *block_sums, int nb, int32_t *m_out) {
     block_sums[i] = run;
     run += v;
   }
-  if (t == 255) *m_out = part[255];
+  if (t == 255) {
+    int m = part[255];
+    if (row_cap > 0 && m > row_cap) {
+      m = (int)row_cap;
+      if (err) atomicOr(err, 2);
+    }
+    *m_out = m;
+  }
 }
 
 // ---- K4: order-preserving compaction: row r = rank of the first-occurrence point ---------------
@@ -131,9 +149,9 @@ __global__ void __launch_bounds__(kScanThreads)
 k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ keys, int32_t *vals,
               int64_t n_static, const int32_t *__restrict__ n_dev,
               const int32_t *__restrict__ block_offs, int32_t *coords_out, int32_t *first_idx,
-              int32_t *bbox) {
+              int32_t *bbox, int64_t row_cap = 0) {
   __shared__ int wsum[4];
-  const int64_t n = n_dev ? (int64_t)*n_dev : n_static;
+  const int64_t n = n_dev ? min((int64_t)*n_dev, n_static) : n_static;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   int64_t base = (int64_t)blockIdx.x * kScanTile + t * kScanItems;
   int s[kScanItems];
@@ -159,7 +177,10 @@ k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ 
   int4 hi = make_int4(-0x7FFFFFFF - 1, -0x7FFFFFFF - 1, -0x7FFFFFFF - 1, -0x7FFFFFFF - 1);
 #pragma unroll
   for (int e = 0; e < kScanItems; ++e) {
-    if (s[e] >= 0) {
+    if (s[e] >= 0 && row_cap > 0 && r >= row_cap) {
+      vals[s[e]] = -1;            // over capacity (flagged by the scan): the voxel has no row
+      ++r;
+    } else if (s[e] >= 0) {
       uint64_t key = keys[s[e]];
       int4 c;
       c.x = (int)(key >> (3 * kCoordBits));
@@ -205,12 +226,13 @@ k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ 
 
 static int run_unique_tail(int32_t *slot_of, int32_t *block_sums, uint64_t *keys, int32_t *vals,
                            int64_t n_max, const int32_t *n_dev, int32_t *coords_out,
-                           int32_t *first_idx, int32_t *m_out, hipStream_t st, int32_t *bbox = nullptr) {
+                           int32_t *first_idx, int32_t *m_out, hipStream_t st, int32_t *bbox = nullptr,
+                           int64_t row_cap = 0) {
   const int nb = (int)div_up(n_max, kScanTile);
   k_flag_first<<<nb, kScanThreads, 0, st>>>(slot_of, vals, n_max, n_dev, block_sums);
-  k_scan_block_sums<<<1, 256, 0, st>>>(block_sums, nb, m_out);
+  k_scan_block_sums<<<1, 256, 0, st>>>(block_sums, nb, m_out, row_cap, row_cap > 0 ? m_out + 1 : nullptr);
   k_emit_unique<<<nb, kScanThreads, 0, st>>>(slot_of, keys, vals, n_max, n_dev, block_sums,
-                                             coords_out, first_idx, bbox);
+                                             coords_out, first_idx, bbox, row_cap);
   IMF_CHECK_LAUNCH("unique pipeline");
   return IMF_OK;
 }
@@ -229,10 +251,11 @@ __device__ __forceinline__ void kernel_offset(int k, int ksize, int &dx, int &dy
 template <int SIGN, bool INDIRECT>
 __global__ void __launch_bounds__(256)
 k_rulebook(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, uint32_t capmask,
-           const int32_t *__restrict__ out_coords, int64_t n_out, int ts, int ksize, int kvol,
-           int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots) {
+           const int32_t *__restrict__ out_coords, int64_t n_out, const int32_t *__restrict__ n_out_dev, int ts,
+           int ksize, int kvol, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_slots * kvol) return;     // n_slots % 64 == 0 -> whole wavefronts exit together
+  if (n_out_dev) n_out = min((int64_t)*n_out_dev, n_out);   // capacity-sized table, actual rows on the device
   const int k = (int)(idx / n_slots);
   const int64_t slot = idx - (int64_t)k * n_slots;
   int row;
@@ -242,6 +265,8 @@ k_rulebook(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, 
     row = slot < n_out ? (int)slot : -1;
     if (k == 0) tile_rows[slot] = row;
   }
+  // a tile without rows (capacity padding) keeps mask 0: the convolution never looks at its neighbour slice
+  if (n_out_dev && __ballot(row >= 0) == 0ull) return;
   int found = -1;
   if (row >= 0) {
     int4 c = reinterpret_cast<const int4 *>(out_coords)[row];
@@ -267,8 +292,10 @@ __device__ __forceinline__ int parity_class(int4 c, int ts) {
 // partition a row falls into -- is the same on every run.  blockcnt: [n_blocks][8] scratch (the head of
 // the not-yet-written neighbour table).
 __global__ void __launch_bounds__(256)
-k_class_count(const int32_t *__restrict__ coords, int64_t n, int ts, int32_t *__restrict__ blockcnt) {
+k_class_count(const int32_t *__restrict__ coords, int64_t n, const int32_t *__restrict__ n_dev, int ts,
+              int32_t *__restrict__ blockcnt) {
   __shared__ int cnt[8];
+  if (n_dev) n = min((int64_t)*n_dev, n);
   if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,9 +343,11 @@ k_class_bases(int32_t *__restrict__ blockcnt, int nb, int32_t *__restrict__ coun
 }
 
 __global__ void __launch_bounds__(256)
-k_class_assign(const int32_t *__restrict__ coords, int64_t n, int ts, const int32_t *__restrict__ counters,
-               const int32_t *__restrict__ blockbase, int32_t *__restrict__ tile_rows) {
+k_class_assign(const int32_t *__restrict__ coords, int64_t n, const int32_t *__restrict__ n_dev, int ts,
+               const int32_t *__restrict__ counters, const int32_t *__restrict__ blockbase,
+               int32_t *__restrict__ tile_rows) {
   __shared__ int wcnt[4][8];
+  if (n_dev) n = min((int64_t)*n_dev, n);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int p = (i < n) ? parity_class(reinterpret_cast<const int4 *>(coords)[i], ts) : -1;
@@ -344,20 +373,6 @@ k_init_transpose(int32_t *counters, int32_t *tile_rows, int64_t n_slots, uint32_
   if (i < 16) counters[i] = 0;
   if (i < n_slots) tile_rows[i] = -1;
   if (i < n_mask) tile_mask[i] = 0u;
-}
-
-// every level's table (same capacity, level stride in bytes) and the [n_levels,2] count block
-__global__ void __launch_bounds__(256)
-k_init_tables(uint64_t *keys0, int32_t *vals0, int64_t capacity, int n_levels, size_t level_stride,
-              int32_t *meta) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * n_levels) meta[i] = 0;
-  if (i < 8) meta[2 * n_levels + i] = i < 4 ? 0x7FFFFFFF : -0x7FFFFFFF - 1;   // level-0 bounding box
-  if (i >= capacity) return;
-  for (int l = 0; l < n_levels; ++l) {
-    reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(keys0) + l * level_stride)[i] = kEmptyKey;
-    reinterpret_cast<int32_t *>(reinterpret_cast<char *>(vals0) + l * level_stride)[i] = 0x7FFFFFFF;
-  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -411,11 +426,11 @@ int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, 
   memset(&one, 0, sizeof(one));
   one.nb = 1;
   if (xyz_is_f64)
-    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index, one,
+    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index, one, nullptr,
                                                   keys, vals, (uint32_t)(capacity - 1), slot_of,
                                                   err_out);
   else
-    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index, one,
+    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index, one, nullptr,
                                                  keys, vals, (uint32_t)(capacity - 1), slot_of,
                                                  err_out);
   IMF_CHECK_LAUNCH("k_insert_points");
@@ -445,85 +460,169 @@ int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-size_t imf_pyramid_arena_bytes(int64_t n, int n_levels) {
-  const size_t cap = (size_t)imf_hash_capacity(n);
-  size_t per_level = align_up((size_t)n * 16, 256) + align_up(cap * 8, 256) + align_up(cap * 4, 256);
-  return (size_t)n_levels * per_level + align_up((size_t)n * 4, 256)          /* first_idx */
-         + align_up(imf_unique_workspace_bytes(n), 256);
+// Arena layout shared by the sizing query and the build.  row_caps == NULL: every level is sized for n rows and
+// an n-point table (the exact-size path: a level cannot have more rows than points).  row_caps given (capacity
+// mode): level l holds at most row_caps[l] rows and its table is sized for the rows that can be INSERTED into
+// it -- n points at level 0, row_caps[l-1] rows above -- so an over-full level can never fill a table.
+struct PyramidLayout {
+  size_t coords_off[8], keys_off[8], vals_off[8];
+  int64_t cap[8], rows[8];
+  size_t first_off, slot_off, total;
+};
+
+static PyramidLayout pyramid_layout(int64_t n, int n_levels, const int64_t *row_caps) {
+  PyramidLayout L;
+  size_t p = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    L.rows[l] = row_caps ? row_caps[l] : n;
+    L.cap[l] = imf_hash_capacity(row_caps && l > 0 ? row_caps[l - 1] : n);
+    L.coords_off[l] = p;  p += align_up((size_t)L.rows[l] * 16, 256);
+  }
+  // the tables are contiguous (keys of all levels, then vals) so that one launch initialises them
+  for (int l = 0; l < n_levels; ++l) { L.keys_off[l] = p; p += align_up((size_t)L.cap[l] * 8, 256); }
+  for (int l = 0; l < n_levels; ++l) { L.vals_off[l] = p; p += align_up((size_t)L.cap[l] * 4, 256); }
+  L.first_off = p;  p += align_up((size_t)L.rows[0] * 4, 256);
+  L.slot_off = p;   p += align_up(imf_unique_workspace_bytes(n), 256);
+  L.total = p;
+  return L;
 }
 
-static int pyramid_build_impl(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
-                              const BatchStarts &bs, int n_levels, void *arena, size_t arena_bytes, int32_t *meta,
-                              imf_level *levels_out, void *stream) {
+size_t imf_pyramid_arena_bytes(int64_t n, int n_levels) {
+  if (n <= 0 || n_levels < 1 || n_levels > 8) return 0;
+  return pyramid_layout(n, n_levels, nullptr).total;
+}
+
+size_t imf_pyramid_arena_bytes_caps(int64_t n_points_cap, int n_levels, const int64_t *row_caps) {
+  if (n_points_cap <= 0 || n_levels < 1 || n_levels > 8 || !row_caps) return 0;
+  return pyramid_layout(n_points_cap, n_levels, row_caps).total;
+}
+
+// keys / vals of all levels are two contiguous regions: one grid-stride launch fills both
+__global__ void __launch_bounds__(256)
+k_init_tables2(uint64_t *keys, int64_t n_keys, int32_t *vals, int64_t n_vals, int n_levels, int32_t *meta,
+               int n_meta) {
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  if (i0 < n_meta) meta[i0] = (i0 >= 2 * n_levels && i0 < 2 * n_levels + 8)
+                                  ? (i0 < 2 * n_levels + 4 ? 0x7FFFFFFF : -0x7FFFFFFF - 1)    // level-0 bounding box
+                                  : (i0 >= 2 * n_levels + 8 ? -1 : 0);                       // item starts / counts
+  for (int64_t i = i0; i < n_keys; i += step) keys[i] = kEmptyKey;
+  for (int64_t i = i0; i < n_vals; i += step) vals[i] = 0x7FFFFFFF;
+}
+
+}  // extern "C"
+
+namespace imf {
+
+int pyramid_prepare(PyramidBuild &b, const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
+                    const int64_t *item_starts, int n_items, int n_levels, void *arena, size_t arena_bytes,
+                    int32_t *meta, imf_level *levels_out, const int32_t *dyn, const int64_t *row_caps) {
   IMF_REQUIRE(xyz && arena && meta && levels_out, "imf_pyramid_build: null pointer");
   IMF_REQUIRE(n > 0 && n < (1ll << 31) - 2048, "imf_pyramid_build: n=%lld out of range", (long long)n);
   IMF_REQUIRE(n_levels >= 1 && n_levels <= 8, "imf_pyramid_build: n_levels=%d", n_levels);
   IMF_REQUIRE(voxel_size > 0.0, "imf_pyramid_build: voxel_size must be > 0");
   IMF_REQUIRE(batch_index >= 0 && batch_index < 512, "imf_pyramid_build: batch_index out of [0,512)");
-  IMF_REQUIRE(arena_bytes >= imf_pyramid_arena_bytes(n, n_levels), "imf_pyramid_build: arena too small");
+  if (row_caps)
+    for (int l = 0; l < n_levels; ++l)
+      IMF_REQUIRE(row_caps[l] > 0 && row_caps[l] <= n && (l == 0 || row_caps[l] <= row_caps[l - 1]),
+                  "imf_pyramid_build: row capacity of level %d", l);
+  memset(&b, 0, sizeof(b));
+  BatchStarts &bs = *reinterpret_cast<BatchStarts *>(b.batch_starts);
+  static_assert(sizeof(BatchStarts) <= sizeof(b.batch_starts), "PyramidBuild::batch_starts too small");
+  bs.nb = n_items;
+  for (int i = 0; i < n_items && item_starts; ++i) bs.start[i] = item_starts[i];
+  const PyramidLayout lay = pyramid_layout(n, n_levels, row_caps);
+  IMF_REQUIRE(arena_bytes >= lay.total, "imf_pyramid_build: arena too small");
   IMF_REQUIRE(((uintptr_t)arena & 255) == 0, "imf_pyramid_build: arena must be 256-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t cap = imf_hash_capacity(n);
-  char *p = (char *)arena;
+  char *base = (char *)arena;
   for (int l = 0; l < n_levels; ++l) {
     imf_level &L = levels_out[l];
-    L.coords = (int32_t *)p;  p += align_up((size_t)n * 16, 256);
-    L.keys = (uint64_t *)p;   p += align_up((size_t)cap * 8, 256);
-    L.vals = (int32_t *)p;    p += align_up((size_t)cap * 4, 256);
-    L.capacity = cap;
+    L.coords = (int32_t *)(base + lay.coords_off[l]);
+    L.keys = (uint64_t *)(base + lay.keys_off[l]);
+    L.vals = (int32_t *)(base + lay.vals_off[l]);
+    L.capacity = lay.cap[l];
     L.first_idx = nullptr;
-    L.cap_rows = n;
+    L.cap_rows = lay.rows[l];
     L.tensor_stride = 1 << l;
+    b.row_cap[l] = row_caps ? row_caps[l] : 0;
   }
-  levels_out[0].first_idx = (int32_t *)p;  p += align_up((size_t)n * 4, 256);
-  int32_t *slot_of = (int32_t *)p;
-  int32_t *block_sums = slot_of + n;
+  levels_out[0].first_idx = (int32_t *)(base + lay.first_off);
+  b.xyz = xyz; b.xyz_is_f64 = xyz_is_f64; b.n = n; b.voxel = voxel_size; b.batch_index = batch_index;
+  b.n_levels = n_levels; b.meta = meta; b.levels = levels_out; b.dyn = dyn;
+  b.slot_of = (int32_t *)(base + lay.slot_off);
+  b.block_sums = b.slot_of + n;
+  b.batched = n_items > 1 || dyn != nullptr;
+  b.n_meta = 2 * n_levels + 8 + (b.batched ? IMF_MAX_BATCH * n_levels : 0);
+  b.n_keys = (int64_t)((lay.vals_off[0] - lay.keys_off[0]) / 8);
+  b.n_vals = (int64_t)((lay.first_off - lay.vals_off[0]) / 4);
+  return IMF_OK;
+}
 
-  // all keys / vals regions are contiguous per level; initialise every table + meta in one launch
-  k_init_tables<<<(unsigned)div_up(cap, 256), 256, 0, st>>>(
-      levels_out[0].keys, levels_out[0].vals, cap, n_levels,
-      (size_t)((char *)levels_out[n_levels > 1 ? 1 : 0].keys - (char *)levels_out[0].keys), meta);
-  IMF_CHECK_LAUNCH("k_init_tables");
-  const int nblk = (int)div_up(n, 256);
-  if (xyz_is_f64)
-    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index, bs,
-                                                  levels_out[0].keys, levels_out[0].vals,
-                                                  (uint32_t)(cap - 1), slot_of, meta + 1);
+int pyramid_level0(const PyramidBuild &b, hipStream_t st) {
+  const BatchStarts &bs = *reinterpret_cast<const BatchStarts *>(b.batch_starts);
+  imf_level *lv = b.levels;
+  int64_t nb = div_up(b.n_keys, 256 * 4);
+  nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+  k_init_tables2<<<(unsigned)nb, 256, 0, st>>>(lv[0].keys, b.n_keys, lv[0].vals, b.n_vals, b.n_levels, b.meta, b.n_meta);
+  IMF_CHECK_LAUNCH("k_init_tables2");
+  const int nblk = (int)div_up(b.n, 256);
+  if (b.xyz_is_f64)
+    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
+                                                  lv[0].keys, lv[0].vals, (uint32_t)(lv[0].capacity - 1), b.slot_of,
+                                                  b.meta + 1);
   else
-    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index, bs,
-                                                 levels_out[0].keys, levels_out[0].vals,
-                                                 (uint32_t)(cap - 1), slot_of, meta + 1);
+    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
+                                                 lv[0].keys, lv[0].vals, (uint32_t)(lv[0].capacity - 1), b.slot_of,
+                                                 b.meta + 1);
   IMF_CHECK_LAUNCH("k_insert_points");
-  int rc = run_unique_tail(slot_of, block_sums, levels_out[0].keys, levels_out[0].vals, n, nullptr,
-                           levels_out[0].coords, levels_out[0].first_idx, meta, st, meta + 2 * n_levels);
-  if (rc) return rc;
-  for (int l = 1; l < n_levels; ++l) {
-    k_insert_coords<<<nblk, 256, 0, st>>>(levels_out[l - 1].coords, meta + 2 * (l - 1), 1 << l,
-                                          levels_out[l].keys, levels_out[l].vals, (uint32_t)(cap - 1),
-                                          slot_of);
-    IMF_CHECK_LAUNCH("k_insert_coords");
-    rc = run_unique_tail(slot_of, block_sums, levels_out[l].keys, levels_out[l].vals, n,
-                         meta + 2 * (l - 1), levels_out[l].coords, nullptr, meta + 2 * l, st);
-    if (rc) return rc;
-  }
-  if (bs.nb > 1) {   // where every item's rows begin at every level: meta[2L+8 + IMF_MAX_BATCH*l + b]
-    int32_t *starts = meta + 2 * n_levels + 8;
-    IMF_CHECK_HIP(hipMemsetAsync(starts, 0xFF, sizeof(int32_t) * IMF_MAX_BATCH * n_levels, st));
-    for (int l = 0; l < n_levels; ++l) {
-      k_item_starts<<<nblk, 256, 0, st>>>(levels_out[l].coords, meta + 2 * l, starts + IMF_MAX_BATCH * l);
-      IMF_CHECK_LAUNCH("k_item_starts");
-    }
+  return run_unique_tail(b.slot_of, b.block_sums, lv[0].keys, lv[0].vals, b.n, b.dyn, lv[0].coords, lv[0].first_idx,
+                         b.meta, st, b.meta + 2 * b.n_levels, b.row_cap[0]);
+}
+
+int pyramid_coarse_level(const PyramidBuild &b, int l, hipStream_t st) {
+  imf_level *lv = b.levels;
+  const int64_t n_in = lv[l - 1].cap_rows;
+  k_insert_coords<<<(unsigned)div_up(n_in, 256), 256, 0, st>>>(lv[l - 1].coords, b.meta + 2 * (l - 1), 1 << l, lv[l].keys,
+                                                              lv[l].vals, (uint32_t)(lv[l].capacity - 1), b.slot_of);
+  IMF_CHECK_LAUNCH("k_insert_coords");
+  return run_unique_tail(b.slot_of, b.block_sums, lv[l].keys, lv[l].vals, n_in, b.meta + 2 * (l - 1), lv[l].coords, nullptr,
+                         b.meta + 2 * l, st, nullptr, b.row_cap[l]);
+}
+
+// where every item's rows begin at every level: meta[2L+8 + IMF_MAX_BATCH*l + b] (-1 = no row)
+int pyramid_item_starts(const PyramidBuild &b, hipStream_t st, int l_begin, int l_end) {
+  if (!b.batched) return IMF_OK;
+  int32_t *starts = b.meta + 2 * b.n_levels + 8;
+  for (int l = l_begin; l < l_end; ++l) {
+    k_item_starts<<<(unsigned)div_up(b.levels[l].cap_rows, 256), 256, 0, st>>>(b.levels[l].coords, b.meta + 2 * l,
+                                                                                starts + IMF_MAX_BATCH * l);
+    IMF_CHECK_LAUNCH("k_item_starts");
   }
   return IMF_OK;
 }
 
+}  // namespace imf
+
+static int pyramid_build_impl(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
+                              const int64_t *item_starts, int n_items, int n_levels, void *arena, size_t arena_bytes,
+                              int32_t *meta, imf_level *levels_out, void *stream, const int32_t *dyn = nullptr,
+                              const int64_t *row_caps = nullptr) {
+  PyramidBuild b;
+  int rc = pyramid_prepare(b, xyz, xyz_is_f64, n, voxel_size, batch_index, item_starts, n_items, n_levels, arena,
+                           arena_bytes, meta, levels_out, dyn, row_caps);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = pyramid_level0(b, st))) return rc;
+  for (int l = 1; l < n_levels; ++l)
+    if ((rc = pyramid_coarse_level(b, l, st))) return rc;
+  return pyramid_item_starts(b, st, 0, n_levels);
+}
+
+extern "C" {
+
 int imf_pyramid_build(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
                       int n_levels, void *arena, size_t arena_bytes, int32_t *meta,
                       imf_level *levels_out, void *stream) {
-  BatchStarts bs;
-  memset(&bs, 0, sizeof(bs));
-  bs.nb = 1;
-  return pyramid_build_impl(xyz, xyz_is_f64, n, voxel_size, batch_index, bs, n_levels, arena, arena_bytes, meta,
+  return pyramid_build_impl(xyz, xyz_is_f64, n, voxel_size, batch_index, nullptr, 1, n_levels, arena, arena_bytes, meta,
                             levels_out, stream);
 }
 
@@ -532,23 +631,26 @@ int imf_pyramid_build_batched(const void *xyz, int xyz_is_f64, int64_t n, double
                               size_t arena_bytes, int32_t *meta, imf_level *levels_out, void *stream) {
   IMF_REQUIRE(item_starts && n_items >= 1 && n_items <= IMF_MAX_BATCH, "imf_pyramid_build_batched: n_items=%d (1..%d)",
               n_items, IMF_MAX_BATCH);
-  BatchStarts bs;
-  memset(&bs, 0, sizeof(bs));
-  bs.nb = n_items;
-  for (int b = 0; b < n_items; ++b) {
+  for (int b = 0; b < n_items; ++b)
     IMF_REQUIRE(item_starts[b] >= 0 && item_starts[b] < n && (b == 0 ? item_starts[0] == 0 : item_starts[b] > item_starts[b - 1]),
                 "imf_pyramid_build_batched: item_starts must start at 0 and ascend strictly below n");
-    bs.start[b] = item_starts[b];
-  }
-  return pyramid_build_impl(xyz, xyz_is_f64, n, voxel_size, 0, bs, n_levels, arena, arena_bytes, meta, levels_out,
-                            stream);
+  return pyramid_build_impl(xyz, xyz_is_f64, n, voxel_size, 0, item_starts, n_items, n_levels, arena, arena_bytes, meta,
+                            levels_out, stream);
+}
+
+int imf_pyramid_build_dyn(const void *xyz, int xyz_is_f64, const int32_t *dyn, int64_t n_points_cap,
+                          const int64_t *row_caps, double voxel_size, int n_levels, void *arena, size_t arena_bytes,
+                          int32_t *meta, imf_level *levels_out, void *stream) {
+  IMF_REQUIRE(dyn && row_caps, "imf_pyramid_build_dyn: null pointer");
+  return pyramid_build_impl(xyz, xyz_is_f64, n_points_cap, voxel_size, 0, nullptr, 1, n_levels, arena, arena_bytes, meta,
+                            levels_out, stream, dyn, row_caps);
 }
 
 int64_t imf_rulebook_slots(int64_t n_out) { return div_up(n_out, IMF_TILE_ROWS) * IMF_TILE_ROWS; }
 
-int imf_rulebook_conv(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
-                      const int32_t *out_coords, int64_t n_out, int ts_in, int ksize,
-                      int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream) {
+static int rulebook_conv_impl(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+                              const int32_t *out_coords, int64_t n_out, const int32_t *n_out_dev, int ts_in, int ksize,
+                              int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream) {
   IMF_REQUIRE(in_keys && in_vals && out_coords && tile_rows && nbr && tile_mask,
               "imf_rulebook_conv: null pointer");
   IMF_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "imf_rulebook_conv: ksize must be 1, 3 or 5");
@@ -559,20 +661,35 @@ int imf_rulebook_conv(const uint64_t *in_keys, const int32_t *in_vals, int64_t i
   const int64_t n_slots = imf_rulebook_slots(n_out);
   IMF_CHECK_HIP(hipMemsetAsync(tile_mask, 0, (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS * 4, st));
   k_rulebook<+1, false><<<(unsigned)div_up(n_slots * kvol, 256), 256, 0, st>>>(
-      in_keys, in_vals, (uint32_t)(in_capacity - 1), out_coords, n_out, ts_in, ksize, kvol,
+      in_keys, in_vals, (uint32_t)(in_capacity - 1), out_coords, n_out, n_out_dev, ts_in, ksize, kvol,
       tile_rows, nbr, tile_mask, n_slots);
   IMF_CHECK_LAUNCH("k_rulebook");
   return IMF_OK;
+}
+
+int imf_rulebook_conv(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+                      const int32_t *out_coords, int64_t n_out, int ts_in, int ksize,
+                      int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream) {
+  return rulebook_conv_impl(in_keys, in_vals, in_capacity, out_coords, n_out, nullptr, ts_in, ksize, tile_rows, nbr,
+                            tile_mask, stream);
+}
+
+int imf_rulebook_conv_dyn(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+                          const int32_t *out_coords, int64_t n_out_cap, const int32_t *n_out_dev, int ts_in,
+                          int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream) {
+  IMF_REQUIRE(n_out_dev, "imf_rulebook_conv_dyn: null pointer");
+  return rulebook_conv_impl(in_keys, in_vals, in_capacity, out_coords, n_out_cap, n_out_dev, ts_in, ksize, tile_rows,
+                            nbr, tile_mask, stream);
 }
 
 int64_t imf_rulebook_transpose_slots(int64_t n_fine) {
   return (div_up(n_fine, IMF_TILE_ROWS) + 8) * IMF_TILE_ROWS;
 }
 
-int imf_rulebook_transpose(const uint64_t *coarse_keys, const int32_t *coarse_vals,
-                           int64_t coarse_capacity, const int32_t *fine_coords, int64_t n_fine,
-                           int ts_fine, int ksize, int32_t *tile_rows, int32_t *nbr,
-                           uint32_t *tile_mask, int64_t n_slots, int32_t *counters, void *stream) {
+static int rulebook_transpose_impl(const uint64_t *coarse_keys, const int32_t *coarse_vals, int64_t coarse_capacity,
+                                   const int32_t *fine_coords, int64_t n_fine, const int32_t *n_fine_dev, int ts_fine,
+                                   int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots,
+                                   int32_t *counters, void *stream) {
   IMF_REQUIRE(coarse_keys && coarse_vals && fine_coords && tile_rows && nbr && tile_mask && counters,
               "imf_rulebook_transpose: null pointer");
   IMF_REQUIRE(ksize == 3, "imf_rulebook_transpose: only kernel_size 3 / stride 2 is supported");
@@ -585,14 +702,31 @@ int imf_rulebook_transpose(const uint64_t *coarse_keys, const int32_t *coarse_va
       counters, tile_rows, n_slots, tile_mask, n_slots / IMF_TILE_ROWS * IMF_MASK_WORDS);
   const unsigned nb = (unsigned)div_up(n_fine, 256);
   int32_t *blockcnt = nbr;   // scratch: the neighbour table is written by k_rulebook below (nb*8 <= 27*n_slots)
-  k_class_count<<<nb, 256, 0, st>>>(fine_coords, n_fine, ts_fine, blockcnt);
+  k_class_count<<<nb, 256, 0, st>>>(fine_coords, n_fine, n_fine_dev, ts_fine, blockcnt);
   k_class_bases<<<1, 256, 0, st>>>(blockcnt, (int)nb, counters);
-  k_class_assign<<<nb, 256, 0, st>>>(fine_coords, n_fine, ts_fine, counters, blockcnt, tile_rows);
+  k_class_assign<<<nb, 256, 0, st>>>(fine_coords, n_fine, n_fine_dev, ts_fine, counters, blockcnt, tile_rows);
   k_rulebook<-1, true><<<(unsigned)div_up(n_slots * kvol, 256), 256, 0, st>>>(
-      coarse_keys, coarse_vals, (uint32_t)(coarse_capacity - 1), fine_coords, n_fine, ts_fine, ksize,
+      coarse_keys, coarse_vals, (uint32_t)(coarse_capacity - 1), fine_coords, n_fine, n_fine_dev, ts_fine, ksize,
       kvol, tile_rows, nbr, tile_mask, n_slots);
   IMF_CHECK_LAUNCH("transpose rulebook");
   return IMF_OK;
+}
+
+int imf_rulebook_transpose(const uint64_t *coarse_keys, const int32_t *coarse_vals,
+                           int64_t coarse_capacity, const int32_t *fine_coords, int64_t n_fine,
+                           int ts_fine, int ksize, int32_t *tile_rows, int32_t *nbr,
+                           uint32_t *tile_mask, int64_t n_slots, int32_t *counters, void *stream) {
+  return rulebook_transpose_impl(coarse_keys, coarse_vals, coarse_capacity, fine_coords, n_fine, nullptr, ts_fine, ksize,
+                                 tile_rows, nbr, tile_mask, n_slots, counters, stream);
+}
+
+int imf_rulebook_transpose_dyn(const uint64_t *coarse_keys, const int32_t *coarse_vals, int64_t coarse_capacity,
+                               const int32_t *fine_coords, int64_t n_fine_cap, const int32_t *n_fine_dev, int ts_fine,
+                               int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots,
+                               int32_t *counters, void *stream) {
+  IMF_REQUIRE(n_fine_dev, "imf_rulebook_transpose_dyn: null pointer");
+  return rulebook_transpose_impl(coarse_keys, coarse_vals, coarse_capacity, fine_coords, n_fine_cap, n_fine_dev, ts_fine,
+                                 ksize, tile_rows, nbr, tile_mask, n_slots, counters, stream);
 }
 
 }  // extern "C"

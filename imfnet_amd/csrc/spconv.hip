@@ -18,6 +18,7 @@
 //   that write raw partial sums; k_spconv_reduce adds them in a fixed order and applies the
 //   epilogue.  The accumulation order per output element is fixed => bit-reproducible, no atomics.
 #include <stdlib.h>
+#include <string.h>
 
 #include "spconv_shared.h"
 
@@ -826,6 +827,12 @@ k_spconv_reg(const ConvParams p) {
 __global__ void __launch_bounds__(256)
 k_spconv_reduce(const ConvParams p, int S, long long slot0) {
   // slots [slot0, n_slots): the whole table for split-K, the balanced tail's tiles otherwise
+  if (p.n_out_dev && p.dyn_split_kvol) {   // capacity mode: the main kernel chose the split from the actual rows
+    const int cover = S;
+    S = auto_split_rule(conv_slots(p, conv_rows(p)), p.cout, p.dyn_split_kvol, p.split_min_blocks, p.split_target);
+    S = S > cover ? cover : S;
+    if (S == 1) return;                    // unsplit: the main kernel already wrote the output
+  }
   const int c4n = p.cout / 4;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long rel = idx / c4n, slot = slot0 + rel, nrel = p.n_slots - slot0;
@@ -1010,12 +1017,51 @@ struct GridDesc {
   int row_words;           // 32-bit words per x-row (>= nx/32 + 2: an unaligned window never leaves the row)
 };
 
+__host__ __device__ inline bool grid_desc_from_bbox(const int32_t *bbox, int ksize, GridDesc &g, size_t &words) {
+  const int r = ksize >> 1;
+  g.b0 = bbox[0]; g.x0 = bbox[1] - r; g.y0 = bbox[2] - r; g.z0 = bbox[3] - r;
+  g.nb = bbox[4] - bbox[0] + 1;
+  g.nx = bbox[5] - bbox[1] + 1 + 2 * r; g.ny = bbox[6] - bbox[2] + 1 + 2 * r; g.nz = bbox[7] - bbox[3] + 1 + 2 * r;
+  if (g.nb <= 0 || g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
+  g.row_words = g.nx / 32 + 2;
+  const double w = (double)g.nb * g.nz * g.ny * g.row_words;
+  if (w > (double)(1ull << 28)) return false;            // > 1 GiB of grid: use the hash path
+  words = (size_t)w;
+  return true;
+}
+
+// capacity mode: the grid descriptor is derived on the device from the level's bounding box (meta block of
+// imf_pyramid_build); a box that does not fit the provided grid raises bit 2 of *err and the launch does nothing
+struct DynGrid {
+  const int32_t *n_dev, *bbox_dev;
+  int32_t *err;
+  unsigned long long words_cap;
+};
+
+__device__ __forceinline__ bool dyn_grid(const DynGrid &d, int ksize, GridDesc &g, long long &n) {
+  if (!d.bbox_dev) return true;
+  const long long nd = *d.n_dev;
+  n = nd < n ? nd : n;
+  int32_t bb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bb[i] = d.bbox_dev[i];
+  size_t words = 0;
+  if (n <= 0) return false;
+  if (!grid_desc_from_bbox(bb, ksize, g, words) || words > d.words_cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(d.err, 4);
+    return false;
+  }
+  return true;
+}
+
 __device__ __forceinline__ long long grid_row(const GridDesc &g, int b, int y, int z) {
   return ((((long long)(b - g.b0) * g.nz + (z - g.z0)) * g.ny + (y - g.y0)) * g.row_words);
 }
 
 __global__ void __launch_bounds__(256)
-k_bitgrid_fill(const int32_t *__restrict__ coords, long long n, uint32_t *grid, const GridDesc g) {
+k_bitgrid_fill(const int32_t *__restrict__ coords, long long n, uint32_t *grid, GridDesc g, int ksize,
+               const DynGrid dg) {
+  if (!dyn_grid(dg, ksize, g, n)) return;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = reinterpret_cast<const int4 *>(coords)[i];
@@ -1029,10 +1075,12 @@ constexpr int kBitsLda = 130;    // 2*row + kslot distinct mod 32 => conflict-fr
 template <int COUT>
 __global__ void __launch_bounds__(256)
 k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_t *__restrict__ grid,
-                  const GridDesc g, int ksize, int kvol, const float *__restrict__ w,
+                  GridDesc g, int ksize, int kvol, const float *__restrict__ w,
                   const float *__restrict__ scale, const float *__restrict__ shift, int relu,
-                  float *__restrict__ out) {
+                  float *__restrict__ out, const DynGrid dg) {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  if (!dyn_grid(dg, ksize, g, n)) return;
+  if ((long long)blockIdx.x * kBitsRows >= n) return;
   float *A_l = lds_f;                                    // [64][kBitsLda]
   float *W_l = lds_f + kBitsRows * kBitsLda;             // [128][COUT], rows >= kvol are zero
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1129,16 +1177,22 @@ int imf_spconv_occupancy(int variant, int co_blk, int j) {
   return n;
 }
 
+static int split_min_blocks() {
+  static const int v = getenv("IMF_SPLIT_MIN_BLOCKS") ? atoi(getenv("IMF_SPLIT_MIN_BLOCKS")) : 400;   // measured: 438 unsplit workgroups (a pair's stride-2 level) beat split 2 + reduce by 1.5 % per step
+  return v;
+}
+static int split_target() {
+  static const int v = getenv("IMF_SPLIT_TARGET") ? atoi(getenv("IMF_SPLIT_TARGET")) : 768;   // tuning aid
+  return v;
+}
+
 int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol) {
-  if (kvol <= 1 || kvol >= kKCache) return 1;
-  const int64_t blocks = (n_slots / IMF_TILE_ROWS) * (cout / (16 * co_blk_of(cout)));
-  static const int min_blocks = getenv("IMF_SPLIT_MIN_BLOCKS") ? atoi(getenv("IMF_SPLIT_MIN_BLOCKS")) : 400;   // measured: 438 unsplit workgroups (a pair's stride-2 level) beat split 2 + reduce by 1.5 % per step
-  if (blocks >= min_blocks) return 1;
-  static const int target = getenv("IMF_SPLIT_TARGET") ? atoi(getenv("IMF_SPLIT_TARGET")) : 768;   // tuning aid
-  int64_t s = div_up(target, blocks);
-  if (s > 8) s = 8;
-  if (s > kvol / 2) s = kvol / 2;
-  return s < 1 ? 1 : (int)s;
+  return auto_split_rule(n_slots, cout, kvol, split_min_blocks(), split_target());
+}
+
+/* Largest split the rule can return for any row count up to the capacity (fewer rows -> more partitions). */
+int imf_spconv_max_split(int cout, int kvol) {
+  return auto_split_rule(IMF_TILE_ROWS, cout, kvol, split_min_blocks(), split_target());
 }
 
 size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split) {
@@ -1181,6 +1235,14 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   if (const char *e = getenv("IMF_ABLATE")) p.ablate = atoi(e);
   p.tail_begin = p.tail_split = 0;
   p.w_unscale = a->variant == 6 ? a->w_packed + (long long)a->kvol * cin * a->cout + 1 : nullptr;
+  p.n_out_dev = a->n_out_dev;
+  p.dyn_split_kvol = a->n_out_dev ? a->dyn_split_kvol : 0;
+  p.slots_extra = a->slots_extra;
+  p.split_min_blocks = split_min_blocks();
+  p.split_target = split_target();
+  IMF_REQUIRE(!a->n_out_dev || a->variant == 6, "imf_spconv_fwd: n_out_dev (capacity mode) needs variant 6");
+  p.err = a->dyn_err;
+  IMF_REQUIRE(!p.dyn_split_kvol || (!p.tickets && a->split_k >= 1), "imf_spconv_fwd: dyn_split_kvol needs an explicit split_k cover and no tickets");
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
@@ -1297,19 +1359,6 @@ int imf_conv_first_fused(const uint64_t *keys, const int32_t *vals, int64_t capa
   return IMF_OK;
 }
 
-static bool grid_desc_from_bbox(const int32_t *bbox, int ksize, GridDesc &g, size_t &words) {
-  const int r = ksize >> 1;
-  g.b0 = bbox[0]; g.x0 = bbox[1] - r; g.y0 = bbox[2] - r; g.z0 = bbox[3] - r;
-  g.nb = bbox[4] - bbox[0] + 1;
-  g.nx = bbox[5] - bbox[1] + 1 + 2 * r; g.ny = bbox[6] - bbox[2] + 1 + 2 * r; g.nz = bbox[7] - bbox[3] + 1 + 2 * r;
-  if (g.nb <= 0 || g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
-  g.row_words = g.nx / 32 + 2;
-  const double w = (double)g.nb * g.nz * g.ny * g.row_words;
-  if (w > (double)(1ull << 28)) return false;            // > 1 GiB of grid: use the hash path
-  words = (size_t)w;
-  return true;
-}
-
 size_t imf_bitgrid_words(const int32_t *bbox, int ksize) {
   GridDesc g;
   size_t words = 0;
@@ -1317,32 +1366,52 @@ size_t imf_bitgrid_words(const int32_t *bbox, int ksize) {
   return grid_desc_from_bbox(bbox, ksize, g, words) ? words : 0;
 }
 
-int imf_conv_first_bitgrid(const int32_t *coords, int64_t n, const int32_t *bbox, int ksize,
-                           uint32_t *grid, size_t grid_words, const float *w, int cout,
-                           const float *scale, const float *shift, int relu, float *out, void *stream) {
-  IMF_REQUIRE(coords && bbox && grid && w && out, "imf_conv_first_bitgrid: null pointer");
+static int conv_first_bitgrid_impl(const int32_t *coords, int64_t n, const int32_t *bbox, const DynGrid &dg, int ksize,
+                                   uint32_t *grid, size_t grid_words, const float *w, int cout,
+                                   const float *scale, const float *shift, int relu, float *out, void *stream) {
+  IMF_REQUIRE(coords && grid && w && out, "imf_conv_first_bitgrid: null pointer");
   IMF_REQUIRE(ksize == 3 || ksize == 5, "imf_conv_first_bitgrid: ksize must be 3 or 5");
   IMF_REQUIRE(cout == 32 || cout == 64, "imf_conv_first_bitgrid: cout=%d not in {32,64}", cout);
   IMF_REQUIRE(n > 0, "imf_conv_first_bitgrid: n");
   GridDesc g;
-  size_t words = 0;
-  IMF_REQUIRE(grid_desc_from_bbox(bbox, ksize, g, words) && words <= grid_words,
-              "imf_conv_first_bitgrid: bounding box too large for the provided grid");
+  memset(&g, 0, sizeof(g));
+  size_t words = grid_words;
+  if (!dg.bbox_dev)
+    IMF_REQUIRE(bbox && grid_desc_from_bbox(bbox, ksize, g, words) && words <= grid_words,
+                "imf_conv_first_bitgrid: bounding box too large for the provided grid");
   hipStream_t st = (hipStream_t)stream;
   IMF_CHECK_HIP(hipMemsetAsync(grid, 0, words * sizeof(uint32_t), st));
-  k_bitgrid_fill<<<(unsigned)div_up(n, 256), 256, 0, st>>>(coords, n, grid, g);
+  k_bitgrid_fill<<<(unsigned)div_up(n, 256), 256, 0, st>>>(coords, n, grid, g, ksize, dg);
   const int kvol = ksize * ksize * ksize;
   const size_t lds = ((size_t)kBitsRows * kBitsLda + 128 * (size_t)cout) * sizeof(float);
   const unsigned nb = (unsigned)div_up(n, kBitsRows);
   if (cout == 32) {
-    k_conv_first_bits<32><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out);
+    k_conv_first_bits<32><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
   } else {
     IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_first_bits<64>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_conv_first_bits<64><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out);
+    k_conv_first_bits<64><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
   }
   IMF_CHECK_LAUNCH("k_conv_first_bits");
   return IMF_OK;
+}
+
+int imf_conv_first_bitgrid(const int32_t *coords, int64_t n, const int32_t *bbox, int ksize,
+                           uint32_t *grid, size_t grid_words, const float *w, int cout,
+                           const float *scale, const float *shift, int relu, float *out, void *stream) {
+  IMF_REQUIRE(bbox, "imf_conv_first_bitgrid: null pointer");
+  DynGrid dg;
+  memset(&dg, 0, sizeof(dg));
+  return conv_first_bitgrid_impl(coords, n, bbox, dg, ksize, grid, grid_words, w, cout, scale, shift, relu, out, stream);
+}
+
+int imf_conv_first_bitgrid_dyn(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
+                               int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
+                               const float *scale, const float *shift, int relu, float *out, void *stream) {
+  IMF_REQUIRE(n_dev && bbox_dev && err && grid_words > 0, "imf_conv_first_bitgrid_dyn: null pointer");
+  DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words};
+  return conv_first_bitgrid_impl(coords, n_cap, nullptr, dg, ksize, grid, grid_words, w, cout, scale, shift, relu, out,
+                                 stream);
 }
 
 }  // extern "C"

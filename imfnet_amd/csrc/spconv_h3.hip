@@ -126,6 +126,18 @@ k_spconv_h3(const ConvParams p) {
     part_slot0 = (long long)p.tail_begin * IMF_TILE_ROWS;
     part_slots = p.n_slots - part_slot0;
   }
+  if (p.n_out_dev) {   // capacity mode: padding tiles leave; the split is the rule applied to the actual rows
+    const long long slots_act = conv_slots(p, conv_rows(p));
+    if ((long long)tile * IMF_TILE_ROWS >= slots_act) return;
+    if (p.dyn_split_kvol) {
+      S = auto_split_rule(slots_act, p.cout, p.dyn_split_kvol, p.split_min_blocks, p.split_target);
+      if (S > (int)gridDim.z) {   // far fewer rows than the capacity was chosen for: flagged, result to be discarded
+        if (p.err && blockIdx.x == 0 && blockIdx.y == 0 && z == 0 && threadIdx.x == 0) atomicOr(p.err, 16);
+        S = gridDim.z;
+      }
+      if (z >= S) return;
+    }
+  }
   const int y = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
   const int cin = p.c_a + p.c_b;

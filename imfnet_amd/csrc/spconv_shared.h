@@ -28,7 +28,38 @@ struct ConvParams {
   // variant 6: the split-f16 weight image is stored scaled by a power of two (so that the lo halves stay
   // normal f16 numbers); *w_unscale = 2^-s is multiplied back into the fp32 accumulators (exact).  NULL = 1.
   const float *w_unscale;
+  // Capacity mode (whole-forward graphs): n_slots / n_out are capacities, the actual row count lives on the
+  // device.  Tiles beyond the actual slots exit at once; with dyn_split_kvol != 0 the number of kernel-offset
+  // partitions is the automatic rule evaluated on the ACTUAL rows (gridDim.z covers the largest it can return),
+  // so the sums are formed exactly as by an exact-size launch.
+  const int32_t *n_out_dev;
+  int dyn_split_kvol;       // third argument of the split rule (active offsets per tile); 0 = gridDim.z is the split
+  int slots_extra;          // slots the rulebook lays out beyond roundup64(rows): 0, or 512 for transposed maps
+  int split_min_blocks, split_target;
+  int32_t *err;             // capacity mode: bit 4 (16) = the rule wanted more partitions than the launch covers
 };
+
+// The automatic split-K rule (imf_spconv_auto_split), shared by host and device.
+__host__ __device__ inline int auto_split_rule(long long n_slots, int cout, int kvol, int min_blocks, int target) {
+  if (kvol <= 1 || kvol >= 28) return 1;
+  const long long blocks = (n_slots / IMF_TILE_ROWS) * (cout / (16 * ((cout % 64 == 0) ? 4 : 2)));
+  if (blocks >= min_blocks || blocks <= 0) return 1;
+  long long s = (target + blocks - 1) / blocks;
+  if (s > 8) s = 8;
+  if (s > kvol / 2) s = kvol / 2;
+  return s < 1 ? 1 : (int)s;
+}
+
+// actual rows / slots of a launch (capacity mode reads them from the device)
+__device__ __forceinline__ long long conv_rows(const ConvParams &p) {
+  if (!p.n_out_dev) return p.n_out;
+  const long long n = *p.n_out_dev;
+  return n < p.n_out ? n : p.n_out;
+}
+__device__ __forceinline__ long long conv_slots(const ConvParams &p, long long rows) {
+  const long long s = (rows + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS + p.slots_extra;
+  return s < p.n_slots ? s : p.n_slots;
+}
 
 // Packed weight image: [y][k][cc][j][cb][lane][t] with
 //   ci = cc*CI_CHUNK + 16 j + 4 (lane>>4) + t,  co = y*CW + 16 cb + (lane&15)
@@ -38,7 +69,7 @@ __host__ __device__ inline int co_blk_of(int cout) { return (cout % 64 == 0) ? 4
 
 __device__ __forceinline__ int row_of_slot(const ConvParams &p, long long slot) {
   if (p.tile_rows) return p.tile_rows[slot];
-  return slot < p.n_out ? (int)slot : -1;
+  return slot < conv_rows(p) ? (int)slot : -1;
 }
 
 __device__ __forceinline__ float4 gather_a(const ConvParams &p, int irow, int ci) {

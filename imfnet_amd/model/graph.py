@@ -1,0 +1,308 @@
+"""Whole-fragment execution without the host in the loop: `imf_fragment_forward` (csrc/executor.hip) in
+capacity mode, captured once per capacity bucket as a hipGraph and replayed per fragment.
+
+The exact path (extract.py -> ResUNet2.forward -> NativePlan) reads the four level counts back after the
+pyramid build and spends ~0.5 ms of host time enqueueing ~150 launches per fragment.  Here every buffer,
+rulebook and grid is sized for a CAPACITY; the kernels read the actual counts from the pyramid's device meta
+block and take the row-count-dependent decisions (split-K partitions, fusion hidden split) on the device with the
+host's rule, so the descriptors are bit-identical to the exact path.  Per fragment the host writes 16 ints (point
+count, item starts), the inputs land in the bucket's static buffers, and ONE hipGraphLaunch runs
+util/misc.py:82-104 + model/resunet.py:163-235 end to end.  The counts come back with the descriptors.
+
+Capacities are chosen from the point count and the voxel-per-point ratios of fragments seen so far (with a margin,
+on a geometric grid so that fragments of similar size share a bucket).  A fragment that does not fit (flag word in
+meta[1]) is redone on the exact path, which also updates the ratios.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import DYN_WORDS, META_WORDS, FragmentCaps, FragmentIO, ImfError, MAX_BATCH, NetTrace, check
+
+FLAG_NAMES = {1: "coordinate out of range", 2: "a level exceeded its row capacity", 4: "bounding box exceeds the bit grid",
+              8: "an item has no voxel", 16: "far fewer rows than the capacity (split cover)"}
+
+
+def _grid_up(v, ratio, lo):
+    """Smallest lo * ratio^k >= v on a geometric grid (k integer), rounded up to a multiple of lo's granule."""
+    c = float(lo)
+    while c < v:
+        c *= ratio
+    return int(-(-int(c + 0.5) // 64) * 64)
+
+
+class FragmentResult:
+    """Device-side result of one launch; `sync()` reads the counts back (one small pinned D2H + event wait)."""
+
+    def __init__(self, bucket, n_points, n_items, meta_host, done):
+        self.bucket, self.n_points, self.n_items = bucket, n_points, n_items
+        self._host, self._done, self._meta = meta_host, done, None
+
+    def sync(self):
+        if self._meta is None:
+            self._done.synchronize()
+            self._meta = self._host.numpy().copy()
+            self.bucket.pool.append((self._host, self._done))
+            self._host = self._done = None
+        return self._meta
+
+    def __del__(self):
+        try:
+            if self._host is not None:
+                self._done.synchronize()
+                self.bucket.pool.append((self._host, self._done))
+        except Exception:                             # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    @property
+    def flags(self):
+        return int(self.sync()[1]) | int(self.sync()[3]) | int(self.sync()[5]) | int(self.sync()[7])
+
+    @property
+    def counts(self):
+        m = self.sync()
+        return [int(m[2 * l]) for l in range(4)]
+
+    def items(self, level=0):
+        m, n = self.sync(), self.counts[level]
+        st = [int(v) for v in m[16 + MAX_BATCH * level:16 + MAX_BATCH * level + self.n_items]]
+        return [(st[b], (st[b + 1] if b + 1 < self.n_items else n) - st[b]) for b in range(self.n_items)]
+
+    @property
+    def bbox(self):
+        return [int(v) for v in self.sync()[8:16]]
+
+    @property
+    def F(self):
+        """[M,32] descriptors: a VIEW into the bucket's static output (valid until the bucket is launched again)."""
+        return self.bucket.out[: self.counts[0]]
+
+    @property
+    def first_idx(self):
+        return self.bucket.first_idx_view()[: self.counts[0]]
+
+
+class _Bucket:
+    def __init__(self, runner, caps_tuple, dev):
+        L = self.L = runner.L
+        n_points, rows, n_items, H, W, grid_words, voxel, is_f64 = caps_tuple
+        self.key, self.dev = caps_tuple, dev
+        c = self.caps = FragmentCaps()
+        c.n_points, c.n_items, c.img_h, c.img_w, c.bitgrid_words = n_points, n_items, H, W, grid_words
+        for i in range(4):
+            c.rows[i] = rows[i]
+        net, img = runner.net_desc, runner.img_plan
+        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)      # noqa: E731
+        self.xyz = torch.zeros((n_points, 3), dtype=torch.float64 if is_f64 else torch.float32, device=dev)
+        self.image = torch.zeros((n_items, 3, H, W), dtype=torch.float32, device=dev)
+        self.dyn = torch.zeros(DYN_WORDS, dtype=torch.int32, device=dev)
+        self.dyn_values = None                        # what the device copy currently holds
+        self.meta = torch.zeros(META_WORDS, dtype=torch.int32, device=dev)
+        self.pool = []                                # (pinned meta copy, event) pairs of finished results
+        self.pyr = u8(L.imf_fragment_pyramid_bytes(C.byref(c)))
+        ib = img.buffers(dev, n_items, H, W, private=True)
+        self.img_bufs = ib
+        rows_c = (C.c_int64 * 4)(*rows)
+        self.iarena = u8(L.imf_resunet_int_arena_bytes_cap(C.byref(net), rows_c, grid_words))
+        self.farena = u8(L.imf_resunet_float_arena_bytes_cap(C.byref(net), rows_c))
+        self.out = torch.empty((rows[0], net.out_channels), dtype=torch.float32, device=dev)
+        self.events = [L.imf_event_create() for _ in range(11)]
+        self.side, self.imgs = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        io = self.io = FragmentIO()
+        io.xyz, io.xyz_is_f64, io.voxel_size = self.xyz.data_ptr(), int(is_f64), float(voxel)
+        io.dyn, io.image, io.meta = self.dyn.data_ptr(), self.image.data_ptr(), self.meta.data_ptr()
+        io.pyramid_arena, io.pyramid_arena_bytes = self.pyr.data_ptr(), self.pyr.numel()
+        io.image_ws, io.image_ws_bytes = ib["ws"].data_ptr(), ib["nbytes"]
+        io.kt_packed, io.v_packed, io.tokens_padded = ib["kt"].data_ptr(), ib["vp"].data_ptr(), ib["tp"]
+        io.int_arena, io.int_arena_bytes = self.iarena.data_ptr(), self.iarena.numel()
+        io.float_arena, io.float_arena_bytes = self.farena.data_ptr(), self.farena.numel()
+        io.out = self.out.data_ptr()
+        for i, e in enumerate(self.events):
+            io.events[i] = e
+        io.side_stream, io.image_stream = self.side.cuda_stream, self.imgs.cuda_stream
+        io.trace = None
+        self.graph = C.c_void_p()
+        self.n_nodes = 0
+        self.launches = 0
+        self._first_view = None
+
+    def first_idx_view(self):
+        if self._first_view is None:
+            off = self.io.levels[0].first_idx - self.pyr.data_ptr()
+            self._first_view = self.pyr[off:off + 4 * self.caps.rows[0]].view(torch.int32)
+        return self._first_view
+
+    def enqueue(self, runner, stream, trace=None):
+        """All launches of one fragment on `stream` (+ the bucket's side / image streams), eagerly."""
+        self.io.main_stream = stream.cuda_stream
+        self.io.trace = trace
+        check(self.L.imf_fragment_forward(C.byref(runner.net_desc), C.byref(runner.img_plan.desc), C.byref(self.caps),
+                                          C.byref(self.io)), "imf_fragment_forward")
+
+    def capture(self, runner, stream):
+        L = self.L
+        self.enqueue(runner, stream)                 # warm-up: lazy module loads, function attributes
+        stream.synchronize()
+        check(L.imf_graph_begin_capture(stream.cuda_stream), "imf_graph_begin_capture")
+        try:
+            self.enqueue(runner, stream)
+        except Exception:
+            L.imf_graph_abort_capture(stream.cuda_stream)
+            raise
+        n = C.c_int(0)
+        check(L.imf_graph_end_capture(stream.cuda_stream, C.byref(self.graph), C.byref(n)), "imf_graph_end_capture")
+        self.n_nodes = n.value
+
+    def __del__(self):
+        try:
+            if self.graph:
+                self.L.imf_graph_destroy(self.graph)
+            for e in self.events:
+                self.L.imf_event_destroy(e)
+        except Exception:                             # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+class FragmentRunner:
+    """Capacity-mode / hipGraph front end of one model (eval mode, IMFNet's configuration)."""
+
+    MARGIN = 1.2          # head room over the largest voxel-per-point ratio seen
+    MAX_BUCKETS = 12
+
+    def __init__(self, model):
+        from .plan import FusedPlan, NativePlan
+        self.L = _lib.lib()
+        self.model = model
+        if not model._can_fuse():
+            raise ImfError("FragmentRunner needs the model in eval mode with BatchNorm blocks")
+        if model._plan is None:
+            model._plan = FusedPlan(model)
+        if model._native_plan is None:
+            model._native_plan = NativePlan(model, model._plan)
+        self.net_desc = model._native_plan.desc
+        self.img_plan = model._native_image()
+        fw = model._fusion_weights()
+        self.supported = bool(self.img_plan.supported and self.img_plan.with_kv and fw.supported and
+                              model._plan.small_first and model.conv1.in_channels == 1 and
+                              all(c.variant == 6 for c in self.net_desc.conv if c.w_packed))
+        self.ratios = None            # max rows_l / n_points seen (4 levels)
+        self.grid_words = 0           # largest conv1 bit grid seen
+        self.buckets = {}
+        self._own = {}
+        self.use_graph = True
+        self.stats = dict(graph=0, eager=0, redone=0, captured=0)
+
+    # -- capacity policy ----------------------------------------------------------------------------
+    def observe(self, n_points, counts, bbox):
+        r = [c / float(n_points) for c in counts]
+        self.ratios = r if self.ratios is None else [max(a, b) for a, b in zip(self.ratios, r)]
+        box = (C.c_int32 * 8)(*bbox)
+        self.grid_words = max(self.grid_words, int(self.L.imf_bitgrid_words(box, self.model.conv1.kernel_size)))
+
+    def caps_for(self, n_points, n_items, H, W, voxel, is_f64):
+        if self.ratios is None or self.grid_words == 0:
+            return None
+        npc = _grid_up(n_points, 1.25, 65536)
+        rows, prev = [], npc
+        for l in range(4):
+            want = self.ratios[l] * n_points * self.MARGIN
+            c = min(_grid_up(want, 1.125, (4096, 1024, 256, 128)[l]), prev)
+            rows.append(c)
+            prev = c
+        gw = _grid_up(self.grid_words * 1.5, 2.0, 1 << 18)
+        return (npc, tuple(rows), n_items, H, W, gw, float(voxel), bool(is_f64))
+
+    def bucket(self, key, dev, stream=None):
+        b = self.buckets.get(key)
+        if b is None:
+            if len(self.buckets) >= self.MAX_BUCKETS:           # drop the least used
+                victim = min(self.buckets, key=lambda k: self.buckets[k].launches)
+                torch.cuda.synchronize(dev)
+                del self.buckets[victim]
+            with torch.cuda.stream(stream or torch.cuda.current_stream(dev)):   # static tables are built on it
+                b = self.buckets[key] = _Bucket(self, key, dev)
+        return b
+
+    def _stream_for(self, dev, stream):
+        """Graph capture needs a real stream: work submitted on the legacy default stream goes through an own one."""
+        stream = stream or torch.cuda.current_stream(dev)
+        if stream.cuda_stream != 0:
+            return stream, None
+        own = self._own.get(dev)
+        if own is None:
+            own = self._own[dev] = torch.cuda.Stream(device=dev)
+        own.wait_stream(stream)
+        return own, stream
+
+    # -- execution ------------------------------------------------------------------------------------
+    def stage(self, b, xyz, item_starts, image, stream):
+        """Copy the inputs into the bucket's static buffers (skipped for tensors that already ARE those buffers)
+        and write the per-fragment scalars."""
+        n = xyz.shape[0]
+        with torch.cuda.stream(stream):
+            if xyz.data_ptr() != b.xyz.data_ptr():
+                b.xyz[:n].copy_(torch.as_tensor(xyz), non_blocking=True)
+            if image.data_ptr() != b.image.data_ptr():
+                b.image.copy_(torch.as_tensor(image, dtype=torch.float32), non_blocking=True)
+            vals = [n, len(item_starts)] + [int(s) for s in item_starts]
+            if vals != b.dyn_values:                  # pageable source: staged by the runtime, safe to run ahead
+                b.dyn.copy_(torch.tensor(vals + [0] * (DYN_WORDS - len(vals)), dtype=torch.int32))
+                b.dyn_values = vals
+        return n
+
+    def launch(self, b, n_points, n_items, stream, trace_list=None):
+        """One fragment on `stream`: graph replay (captured on first use) or eager capacity-mode launches (always
+        when `trace_list` is given: per-convolution HIP events are appended to it as ops.TRACE records)."""
+        from .. import ops
+        from .plan import NativePlan, _RB
+        with torch.cuda.stream(stream):
+            if trace_list is not None or not self.use_graph:
+                trace = evs = None
+                if trace_list is not None:
+                    trace = (NetTrace * 23)()
+                    evs = [ops._Ev() for _ in range(23)]
+                    for i, e in enumerate(evs):
+                        trace[i].ev_begin, trace[i].ev_end, trace[i].launched = e.begin, e.end, 0
+                b.enqueue(self, stream, trace)
+                if trace_list is not None:
+                    arena = b.iarena.view(torch.int32)
+                    for i, e in enumerate(evs):
+                        t = trace[i]
+                        if not t.launched:
+                            continue
+                        rb = _RB(t.n_slots, t.n_out, t.kvol, t.kvol)
+                        rb.nbr = t.nbr or 0
+                        trace_list.append(dict(kernel=ops.conv_kernel_name(self.net_desc.conv[i].variant, t.cin, t.cout),
+                                               kvol=t.kvol, cin=t.cin, cout=t.cout, rb=rb, split=t.split, ev=e,
+                                               name=NativePlan.ORDER[i], arena=arena))
+                self.stats["eager"] += 1
+            else:
+                if not b.graph:
+                    b.capture(self, stream)
+                    self.stats["captured"] += 1
+                check(self.L.imf_graph_launch(b.graph, stream.cuda_stream), "imf_graph_launch")
+                self.stats["graph"] += 1
+            host, done = b.pool.pop() if b.pool else (torch.zeros(META_WORDS, dtype=torch.int32).pin_memory(),
+                                                     torch.cuda.Event())
+            host.copy_(b.meta, non_blocking=True)
+            done.record(stream)
+        b.launches += 1
+        return FragmentResult(b, n_points, n_items, host, done)
+
+    def run(self, xyz, item_starts, image, voxel, stream=None):
+        """xyz [N,3] (device tensor, f64/f32), image [B,3,H,W] device tensor.  Returns a FragmentResult, or None
+        when no capacities are known yet (the caller runs the exact path and calls observe())."""
+        dev = xyz.device
+        key = self.caps_for(xyz.shape[0], len(item_starts), image.shape[2], image.shape[3], voxel,
+                            xyz.dtype == torch.float64)
+        if key is None:
+            return None
+        stream, outer = self._stream_for(dev, stream)
+        b = self.bucket(key, dev, stream)
+        n = self.stage(b, xyz, item_starts, image, stream)
+        res = self.launch(b, n, len(item_starts), stream)
+        if outer is not None:
+            outer.wait_stream(stream)
+        return res

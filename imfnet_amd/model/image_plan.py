@@ -85,10 +85,11 @@ class ImagePlan:
             d.kv_w = keep(ops.pack_weights(att.to_kv.weight.detach().float().t().contiguous().unsqueeze(0), split16=split16))
         self._shapes = {}
 
-    def buffers(self, dev, B, H, W):
-        """Per (device, shape): workspace with the static tables built, and the output buffers."""
+    def buffers(self, dev, B, H, W, private=False):
+        """Per (device, shape): workspace with the static tables built, and the output buffers.  `private`: a fresh
+        set the caller owns (a graph bucket's), not the shared one of the eager path."""
         key = (dev, B, H, W)
-        b = self._shapes.get(key)
+        b = None if private else self._shapes.get(key)
         if b is None:
             L = self.L
             nbytes = L.imf_image_workspace_bytes(B, H, W)
@@ -101,9 +102,11 @@ class ImagePlan:
             kt = torch.empty(B * 128 * tp, dtype=torch.float32, device=dev)
             vp = torch.empty(B * 128 * tp, dtype=torch.float32, device=dev)
             per = 128 * tp
-            b = self._shapes[key] = dict(ws=ws, nbytes=nbytes, T=T, tp=tp, feat=feat, kt=kt, vp=vp,
-                                         kt_items=[kt[i * per:(i + 1) * per] for i in range(B)],
-                                         vp_items=[vp[i * per:(i + 1) * per] for i in range(B)])
+            b = dict(ws=ws, nbytes=nbytes, T=T, tp=tp, feat=feat, kt=kt, vp=vp,
+                     kt_items=[kt[i * per:(i + 1) * per] for i in range(B)],
+                     vp_items=[vp[i * per:(i + 1) * per] for i in range(B)])
+            if not private:
+                self._shapes[key] = b
         return b
 
     def run(self, image, want_kv=True):

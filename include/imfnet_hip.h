@@ -112,6 +112,17 @@ int imf_pyramid_build_batched(const void *xyz, int xyz_is_f64, int64_t n, double
                               const int64_t *item_starts /* [host] */, int n_items, int n_levels, void *arena,
                               size_t arena_bytes, int32_t *meta, imf_level *levels_out, void *stream);
 
+/* Capacity mode of the pyramid (for launch sequences captured once and replayed): the point count, the number
+ * of items and the items' first points are read from the device (dyn int32[16]: [0] points <= n_points_cap, [1]
+ * items, [2 + b] first point of item b); level l holds at most row_caps[l] rows ([host], non-increasing, <=
+ * n_points_cap) and its table is sized for the rows that can be inserted into it, so an over-full level cannot
+ * fill a table: its count is clamped, the surplus voxels map to "no row" and bit 1 of meta[2l + 1] is raised.
+ * meta always has the batched layout (int32[2*n_levels + 8 + IMF_MAX_BATCH*n_levels]). */
+size_t imf_pyramid_arena_bytes_caps(int64_t n_points_cap, int n_levels, const int64_t *row_caps /* [host] */);
+int imf_pyramid_build_dyn(const void *xyz, int xyz_is_f64, const int32_t *dyn, int64_t n_points_cap,
+                          const int64_t *row_caps /* [host] */, double voxel_size, int n_levels, void *arena,
+                          size_t arena_bytes, int32_t *meta, imf_level *levels_out /* [host] */, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Rulebook (MinkowskiEngine "kernel map"), tiled for the MFMA kernel:
  *   tile_rows int32[n_slots]             output row of every slot, -1 = padding
@@ -133,6 +144,12 @@ int imf_rulebook_conv(const uint64_t *in_keys, const int32_t *in_vals, int64_t i
                       const int32_t *out_coords, int64_t n_out, int ts_in, int ksize,
                       int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream);
 
+/* Capacity mode: tables sized for n_out_cap rows, the actual count read from *n_out_dev; tiles without rows keep
+ * mask 0 and their neighbour slices are left unwritten (imf_spconv_fwd never looks at them). */
+int imf_rulebook_conv_dyn(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+                          const int32_t *out_coords, int64_t n_out_cap, const int32_t *n_out_dev, int ts_in,
+                          int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream);
+
 /* Upper bound of slots for the transposed rulebook (rows grouped into 8 parity classes, every
  * class padded to whole tiles). */
 int64_t imf_rulebook_transpose_slots(int64_t n_fine);
@@ -147,6 +164,11 @@ int imf_rulebook_transpose(const uint64_t *coarse_keys, const int32_t *coarse_va
                            const int32_t *fine_coords, int64_t n_fine, int ts_fine, int ksize,
                            int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask,
                            int64_t n_slots, int32_t *counters, void *stream);
+
+int imf_rulebook_transpose_dyn(const uint64_t *coarse_keys, const int32_t *coarse_vals, int64_t coarse_capacity,
+                               const int32_t *fine_coords, int64_t n_fine_cap, const int32_t *n_fine_dev, int ts_fine,
+                               int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots,
+                               int32_t *counters, void *stream);   /* n_slots = imf_rulebook_transpose_slots(n_fine_cap) */
 
 /* ------------------------------------------------------------------------------------------------
  * Sparse convolution.
@@ -200,6 +222,17 @@ typedef struct imf_conv_args {
                              the same launch (agent-scope release/acquire) -- no second kernel            */
   void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded on `stream` immediately around the
                               main MFMA kernel (not the split-K reduce): live roofline timing     */
+  /* Capacity mode (variant 6), for launch sequences captured once and replayed on fragments of different
+   * size: n_out / n_slots (and the rulebook) are sized for a CAPACITY and the actual row count is read from
+   * device memory; tiles beyond it exit at once.  dyn_split_kvol != 0: the number of kernel-offset partitions
+   * is imf_spconv_auto_split(actual slots, cout, dyn_split_kvol) evaluated on the device -- split_k then only
+   * sizes the grid and the workspace: it must cover the largest value expected (imf_spconv_max_split covers any
+   * row count; a smaller cover raises bit 4 of *dyn_err when exceeded) -- so the result is bit-identical to an
+   * exact-size launch.  slots_extra: slots the rulebook lays out beyond roundup64(rows) (512 for
+   * imf_rulebook_transpose's parity classes, else 0). */
+  const int32_t *n_out_dev;
+  int32_t dyn_split_kvol, slots_extra;
+  int32_t *dyn_err;       /* device flag word: bit 4 is raised when the rule asks for more partitions than split_k covers */
 } imf_conv_args;
 
 /* Kernel-offset partitions imf_spconv_fwd will use for this shape when args.split_k == 0: small
@@ -207,6 +240,7 @@ typedef struct imf_conv_args {
  * partial sums are combined -- in a fixed order, hence still bit-reproducible -- by a second
  * kernel that also applies the epilogue. */
 int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol);
+int imf_spconv_max_split(int cout, int kvol);   /* largest value the rule returns for any row count */
 /* Tuning aid: resident workgroups per CU reported by the runtime for kernel `variant`. */
 int imf_spconv_occupancy(int variant, int co_blk, int j);
 size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split);
@@ -248,6 +282,12 @@ int imf_conv_first_bitgrid(const int32_t *coords, int64_t n, const int32_t *bbox
                            uint32_t *grid, size_t grid_words, const float *w /* [kvol][1][cout] */,
                            int cout, const float *scale, const float *shift, int relu, float *out,
                            void *stream);
+
+/* Capacity mode: row count and bounding box (8 ints) read from the device; a box that needs more than grid_words
+ * raises bit 2 (value 4) of *err and the launch does nothing. */
+int imf_conv_first_bitgrid_dyn(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
+                               int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
+                               const float *scale, const float *shift, int relu, float *out, void *stream);
 
 /* Bottleneck fusion block (one image, one attention head, depth 0) as ONE kernel.
  * Replaces: ResUNet2.transformer + AttentionFusion.forward (model/resunet.py:237-273,
@@ -316,6 +356,16 @@ int imf_image_branch(const imf_image_desc *net /* [host] */, const float *image,
                      void *workspace, size_t workspace_bytes, float *feat_out, float *kt_packed,
                      float *v_packed, int tokens_padded, void *stream);
 
+/* Capacity mode: x has room for n_cap rows, the count is *n_dev and item b covers rows [item_starts_dev[b],
+ * item_starts_dev[b+1]) (the last one up to the count); an item without rows raises bit 3 (value 8) of *err.  All
+ * three hidden-split variants are launched and the one the rule picks for the actual rows does the work.
+ * workspace: imf_fusion_workspace_bytes_cap(n_cap). */
+size_t imf_fusion_workspace_bytes_cap(int64_t n_cap);
+int imf_fusion_attention_dyn(const float *x, int64_t n_cap, const int32_t *n_dev, const int32_t *item_starts_dev,
+                             int n_items, int32_t *err, const float *const *kt_packed, const float *const *v_packed,
+                             int n_tokens, int tokens_padded, const imf_fusion_weights *w /* [host] */, float scale,
+                             float *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- Native executor for the ResUNet layer schedule -----------------------------------------------
  * One call per fragment replaces the ~100 per-layer calls of model/resunet.py:163-235 (rulebook builds
  * on a side stream, first convolution, encoder, bottleneck fusion, decoder, head), in the launch order
@@ -361,15 +411,80 @@ typedef struct imf_resunet_io {        /* per fragment */
   void *int_arena;  size_t int_arena_bytes;     /* >= imf_resunet_int_arena_bytes   */
   void *float_arena; size_t float_arena_bytes;  /* >= imf_resunet_float_arena_bytes */
   float *out;                          /* [n0, out_channels] descriptors */
-  void *events[8];                     /* caller-owned hipEvent_t (imf_event_create): side-stream joins */
+  void *events[16];                    /* caller-owned hipEvent_t (imf_event_create): side-stream joins (7 used; 9 with
+                                          `pyramid`) */
   void *side_stream, *main_stream;
   imf_net_trace *trace;                /* [host] 23 records or NULL */
+  /* Capacity mode (dyn != 0): n[] are CAPACITIES (arenas: the *_cap size queries), the row counts, the level-0
+   * bounding box and the items' first rows are read on the device from `meta`, the block imf_pyramid_build_dyn
+   * writes (item_row0 / item_rows / bbox above are ignored); flags raised by the kernels are OR-ed into meta[1]:
+   * 1 coordinate out of range, 2 a level exceeded its capacity, 4 bounding box larger than the bit grid, 8 an item
+   * without rows, 16 fewer rows than a quarter of the capacity (split cover exceeded).  A flagged result must be
+   * discarded and the fragment redone with larger capacities or in exact mode.  Needs variant 6, the all-ones
+   * occupancy input and in_channels 1.  Bit-identical to the exact mode. */
+  int32_t dyn;
+  const int32_t *meta;
+  size_t bitgrid_words;                /* capacity (uint32 words) of the conv1 occupancy grid inside the int arena */
+  const void *pyramid;                 /* internal (imf_fragment_forward): coarse pyramid levels still to be built */
 } imf_resunet_io;
 
 size_t imf_resunet_int_arena_bytes(const imf_resunet_desc *net, const int64_t *n /* [4] */,
                                    const int32_t *bbox /* [host] or NULL */);
 size_t imf_resunet_float_arena_bytes(const imf_resunet_desc *net, const int64_t *n /* [4] */);
 int imf_resunet_forward(const imf_resunet_desc *net /* [host] */, const imf_resunet_io *io /* [host] */);
+size_t imf_resunet_int_arena_bytes_cap(const imf_resunet_desc *net, const int64_t *row_caps /* [4] */, size_t bitgrid_words);
+size_t imf_resunet_float_arena_bytes_cap(const imf_resunet_desc *net, const int64_t *row_caps /* [4] */);
+
+/* ---- Whole fragment in one call, capturable as a hipGraph -----------------------------------------------
+ * Replaces: util/misc.py:67-104 extract_features (voxelise -> SparseTensor -> model(stensor, image)) for a fragment
+ * or a batch of fragments: pyramid (level 0 on the main stream, coarser levels interleaved with the rulebook
+ * builds on the side stream), image branch on its own stream, conv1, encoder, fusion, decoder, head -- about 150
+ * launches and no host synchronisation.  Every size below is a CAPACITY; the per-fragment scalars live in `dyn`
+ * (device int32[IMF_DYN_WORDS]: [0] points, [1] items, [2 + b] first point of item b), which the caller writes
+ * before the launch (or before each replay).  After completion meta (device int32[IMF_META_WORDS]) holds, for
+ * level l, the row count at [2l], flags at [1] (imf_resunet_io), the level-0 bounding box at [8..15] and the first
+ * row of item b of level l at [16 + IMF_MAX_BATCH*l + b]; out[0 .. meta[0]) are the descriptors, levels[0].first_idx
+ * the voxels' first points.  Because addresses and grids depend on the capacities only, the call can be recorded
+ * between imf_graph_begin_capture / imf_graph_end_capture on main_stream and replayed for every fragment that
+ * fits the capacities (side_stream / image_stream join the capture through the events). */
+#define IMF_DYN_WORDS  16
+#define IMF_META_WORDS 64
+typedef struct imf_fragment_caps {     /* [host] one capacity bucket */
+  int64_t n_points;                    /* points (all items together) */
+  int64_t rows[4];                     /* voxels at tensor strides 1, 2, 4, 8 */
+  int32_t n_items, img_h, img_w;
+  size_t bitgrid_words;                /* conv1 occupancy grid: >= imf_bitgrid_words of the largest bounding box */
+} imf_fragment_caps;
+
+typedef struct imf_fragment_io {       /* [host]; all buffers device memory owned by the caller */
+  const void *xyz; int32_t xyz_is_f64; /* [caps.n_points, 3] */
+  double voxel_size;
+  const int32_t *dyn;                  /* IMF_DYN_WORDS */
+  const float *image;                  /* [n_items, 3, img_h, img_w] */
+  int32_t *meta;                       /* IMF_META_WORDS, written */
+  void *pyramid_arena; size_t pyramid_arena_bytes;   /* >= imf_fragment_pyramid_bytes(caps), 256-byte aligned */
+  void *image_ws; size_t image_ws_bytes;             /* imf_image_workspace_bytes, tables built */
+  float *kt_packed, *v_packed; int32_t tokens_padded; /* n_items * 128 * tokens_padded floats each (scratch) */
+  void *int_arena; size_t int_arena_bytes;           /* >= imf_resunet_int_arena_bytes_cap   */
+  void *float_arena; size_t float_arena_bytes;       /* >= imf_resunet_float_arena_bytes_cap */
+  float *out;                          /* [caps.rows[0], out_channels] */
+  void *events[16];                    /* 11 caller-owned hipEvent_t */
+  void *main_stream, *side_stream, *image_stream;
+  imf_net_trace *trace;                /* [host] 23 records or NULL */
+  imf_level levels[4];                 /* out [host]: where the levels live inside pyramid_arena */
+} imf_fragment_io;
+
+size_t imf_fragment_pyramid_bytes(const imf_fragment_caps *caps);
+int imf_fragment_forward(const imf_resunet_desc *net /* [host] */, const imf_image_desc *img /* [host] */,
+                         const imf_fragment_caps *caps, imf_fragment_io *io);
+
+/* hipGraph plumbing for the above (thread-local capture mode: other host threads may keep using HIP).
+ * imf_graph_end_capture instantiates; the handle is replayed with imf_graph_launch on any stream. */
+int imf_graph_begin_capture(void *stream);
+int imf_graph_end_capture(void *stream, void **graph_exec_out /* [host] */, int *n_nodes_out /* [host] or NULL */);
+int imf_graph_abort_capture(void *stream);
+int imf_graph_launch(void *graph_exec, void *stream);
+void imf_graph_destroy(void *graph_exec);
 
 /* ---- Descriptor matching for feature-match recall ---------------------------------
  * imf_nn_search replaces util/uio.py:245-258 `knn_search(points_src, points_dst, k=1)` (one Open3D
