@@ -8,16 +8,25 @@ resident in HBM: voxelise (fp64 quantise + hash + first-occurrence unique) -> 4-
 the real workload).  Workload at N=1: BASELINE.json configs[1] ("single 3DMatch fragment pair, voxel
 2.5 cm") at the 3DMatch-shaped size its metric is quoted on (SURVEY §8d "S50k"): the in-tree pair
 cloud_bin_0 / cloud_bin_1 x1.7 @ 2.5 cm = 51,232 + 52,164 voxels, run as ONE batched sparse tensor
-(the model's batched call, model/resunet.py:241-250; per-fragment results equal the single-fragment
-forwards, tests/test_gpu_parity.py::test_native_batched_pair_matches_single_fragments).  --batch 1 runs
-one fragment per step.  Weights are seeded random (no checkpoint is reachable), data says so.
+(the model's batched call, model/resunet.py:241-250).  --batch 1 runs one fragment per step.
+Weights are seeded random (no checkpoint is reachable), data says so.
+
+Default execution (--mode capacity): one imf_fragment_forward call per step in capacity mode -- device-side row
+counts, no host readback, ~150 launches issued natively on three streams; bit-identical to the exact path
+(asserted below).  --mode graph replays the same call as ONE captured hipGraph: also bit-identical, but ROCm 7.2
+executes a graph's independent branches one after the other (profiles/r02_graph_replay_kernel_stats.txt), which
+puts the image branch, the coarse pyramid levels and the rulebook builds on the critical path -- measured slower,
+reported in config.graph_replay.  --mode exact is round 1's path (count readback + native executor).  Every
+--trace-every'th timed step records HIP events around each convolution for the live roofline block.
 
   python bench.py [--gpus N --steps K --warmup W]        one JSON line on rank 0
+With --gpus N > 1 and no torchrun environment the script launches its own N ranks.
 """
 import argparse
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
 
@@ -30,6 +39,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+PMC_FILE = "r02_pmc_traffic.json"
 
 
 def load_pair(scale):
@@ -52,7 +62,10 @@ def load_workload(scale, voxel):
 def algorithmic_bytes(rec):
     """pairs*(Cin+Cout)*4 + pairs*8 (rulebook index) + kvol*Cin*Cout*4 (weights)."""
     rb = rec["rb"]
-    if "arena" in rec:
+    if "res" in rec:                                     # capacity mode: only the slots of the actual rows were written
+        rows = rec["res"].counts[rec["level"]]
+        pairs = rb.count_pairs(rec["arena"], min(rb.n_slots, (rows + 63) // 64 * 64 + rec["slots_extra"]), rows)
+    elif "arena" in rec:
         pairs = rb.count_pairs(rec["arena"])
     else:
         pairs = int((rb.nbr >= 0).sum().item()) if rb.nbr is not None else rb.n_out
@@ -61,10 +74,13 @@ def algorithmic_bytes(rec):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
+    (profiles/r02_pmc_traffic.json, produced by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
     separate runs; read side doubled per the gfx950 FETCH_SIZE correction).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    for name in (PMC_FILE, "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
         return None, "no PMC profile committed"
     ks = json.load(open(path))["kernels"]
     key = "imf::" + kernel.replace(",", ", ")
@@ -77,13 +93,13 @@ def pmc_traffic(kernel):
                                      f"feature rows are re-gathered from L2 / Infinity Cache, not HBM")
 
 
-def cpu_baseline(xyz, img, voxel, sd, seconds_budget=15.0):
+def cpu_baseline(xyz, img, voxel, sd, seconds_budget=12.0):
     """The oracle (C hash-map geometry + torch-CPU gather-GEMM-scatter convolutions =
     MinkowskiEngine's CPU algorithm restated; dense parts are the torch-CPU ops the reference itself
     would run) timed on this box's host cores over a bounded sample of the same workload.  torch's
     intra-op pool does not scale to all cores of a large host on these small GEMMs (256 threads are
     6x SLOWER than 16 on the EPYC 9575F GPU box), so the thread count is picked by a short probe and
-    reported as `cores`."""
+    reported as `cores`; the single-thread rate is reported beside it ("1 thread and all cores")."""
     import imf_oracle as O
     import imf_oracle_cbind as OC
 
@@ -104,17 +120,113 @@ def cpu_baseline(xyz, img, voxel, sd, seconds_budget=15.0):
         if dt < best_t:
             best_nt, best_t = nt, dt
     torch.set_num_threads(best_nt)
+    os.environ["OMP_NUM_THREADS"] = str(best_nt)
     times, m, spent = [], 0, 0.0
     while spent < seconds_budget and len(times) < 12:
         dt, m = once()
         times.append(dt)
         spent += dt
     med = statistics.median(times)
+    torch.set_num_threads(1)                           # one thread: one run (a few seconds)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    one_t, _ = once()
+    torch.set_num_threads(best_nt)
+    os.environ["OMP_NUM_THREADS"] = str(best_nt)
     return {"value": round(m / med, 1), "unit": "descriptors/s", "cores": best_nt, "kind": "port",
+            "value_1_thread": round(m / one_t, 1),
             "sample": f"the same fragment (M={m}) end to end on the host, median of {len(times)} runs "
-                      f"({med * 1e3:.0f} ms each), {best_nt} threads (best of 8/16/32 on a {ncpu}-cpu host): "
+                      f"({med * 1e3:.0f} ms each), {best_nt} threads (best of 8/16/32 on a {ncpu}-cpu host; one run "
+                      f"on 1 thread: {one_t * 1e3:.0f} ms): "
                       f"C hash-map voxelise/pyramid/rulebooks (OpenMP) + torch-CPU per-offset "
                       f"gather-GEMM-scatter convolutions, image encoder and attention"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def build_model(O, dev, variant=None):
+    from imfnet_amd import ops
+    from imfnet_amd.model import load_model
+    prev = ops.CONV_VARIANT
+    if variant is not None:
+        ops.CONV_VARIANT = variant
+    try:
+        sd = O.seeded_state_dict(seed=0, with_unused_image_layers=True)
+        model = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True,
+                                          conv1_kernel_size=5, D=3, config=None)
+        model.load_state_dict(sd, strict=True)
+        model = model.eval().to(dev)
+        if variant is not None:                        # plans pack their weights lazily: force it under this variant
+            from imfnet_amd.model.plan import FusedPlan
+            model._plan = FusedPlan(model)
+            model._native_image()
+    finally:
+        ops.CONV_VARIANT = prev
+    return model, sd
+
+
+class Workload:
+    """Inputs resident in HBM + the two ways of running one step on them."""
+
+    def __init__(self, model, dev, pts_list, imgs, voxel):
+        from imfnet_amd.extract import sparse_tensor_from_points, start_geometry
+        self.model, self.dev, self.voxel = model, dev, voxel
+        self.xyz = torch.as_tensor(np.concatenate(pts_list, 0)).to(dev)
+        self.img = torch.as_tensor(imgs).to(dev)
+        self.starts, n = [], 0
+        for p in pts_list:
+            self.starts.append(n)
+            n += len(p)
+        self.item_starts = self.starts if len(pts_list) > 1 else None
+        self._sp, self._geo = sparse_tensor_from_points, start_geometry
+        self.runner = self.bucket = None
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def exact_step(self):
+        """Round 1's path: geometry stream + one count readback + native executor."""
+        with torch.cuda.stream(self.stream):
+            fut = self._geo(self.xyz, self.voxel, self.dev, inputs_ready=True, item_starts=self.item_starts)
+            st, _ = self._sp(None, self.voxel, self.dev, geometry=fut)
+            self.last_st = st
+            return self.model(st, self.img).F
+
+    def prepare_graph(self):
+        """Capacity bucket from one exact step's counts; inputs staged in the bucket's static buffers."""
+        F = self.exact_step()
+        torch.cuda.synchronize()
+        cm = self.last_st.coordinate_manager
+        lv = [cm.level(ts) for ts in (1, 2, 4, 8)]
+        r = self.runner = self.model.fragment_runner()
+        assert r is not None, "this model configuration is not covered by the fragment graph"
+        r.observe(int(self.xyz.shape[0]), [l.n for l in lv], lv[0].bbox)
+        key = r.caps_for(int(self.xyz.shape[0]), len(self.starts), int(self.img.shape[2]), int(self.img.shape[3]),
+                         self.voxel, self.xyz.dtype == torch.float64)
+        b = self.bucket = r.bucket(key, self.dev, self.stream)
+        self.n_points = r.stage(b, self.xyz, self.starts, self.img, self.stream)
+        return F
+
+    def graph_step(self, trace_list=None):
+        res = self.runner.launch(self.bucket, self.n_points, len(self.starts), self.stream, trace_list=trace_list)
+        self.last_res = res
+        return res
+
+
+def timed(fn, steps, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
 
 
 def main():
@@ -127,21 +239,21 @@ def main():
     ap.add_argument("--batch", type=int, default=2, choices=(1, 2),
                     help="fragments per forward: 2 = the in-tree fragment PAIR (cloud_bin_0 + cloud_bin_1, one image "
                          "each) as ONE batched sparse tensor, the batched call of model/resunet.py:241-250")
+    ap.add_argument("--mode", default="capacity", choices=("capacity", "graph", "exact"),
+                    help="capacity: imf_fragment_forward per step (device-side counts, no host readback); graph: the same "
+                         "as one hipGraph replay; exact: count readback + native executor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-fragment / end-to-end / fp32-MFMA legs")
     ap.add_argument("--trace-every", type=int, default=5,
                     help="record the per-launch HIP events of the roofline measurement on every n-th timed step "
-                         "(two event records per launch cost ~0.14 ms/step when taken on every step)")
-    ap.add_argument("--prefetch", action="store_true",
-                    help="queue the next fragment's geometry / image branch under the current decoder "
-                         "(measured neutral on MI355X: the main stream is GPU-bound)")
-    ap.add_argument("--pipelines", type=int, default=int(os.environ.get("IMF_PIPELINES", "1")),
-                    help="independent fragments in flight per GPU (round-robin over this many streams)")
+                         "(eager launches with two event records per convolution instead of the graph replay)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     from imfnet_amd import dist as idist
     from imfnet_amd import ops
-    from imfnet_amd.extract import sparse_tensor_from_points, start_geometry
-    from imfnet_amd.model import load_model
     import imf_oracle as O                              # seeded weights + cpu_baseline only
 
     # test hooks (single-GPU box): IMF_DIST_BACKEND=gloo IMF_FORCE_DEVICE=0 run N ranks on one device
@@ -156,76 +268,69 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    xyz, img, voxel = load_workload(args.scale, args.voxel)
-    sd = O.seeded_state_dict(seed=0, with_unused_image_layers=True)
-    model = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True,
-                                      conv1_kernel_size=5, D=3, config=None)
-    model.load_state_dict(sd, strict=True)
-    model = model.eval().to(dev)
-    xyz_d = torch.as_tensor(xyz).to(dev)               # inputs resident in HBM before timing
-    img_d = torch.as_tensor(img).to(dev)
-    item_starts = None
-    if args.batch == 2:                                # the pair, points back to back, resident in HBM
+    xyz1, img1, voxel = load_workload(args.scale, args.voxel)
+    model, sd = build_model(O, dev)
+    if args.batch == 2:
         pts, imgs = load_pair(args.scale)
-        xyz_d = torch.as_tensor(np.concatenate(pts, 0)).to(dev)
-        img_d = torch.as_tensor(imgs).to(dev)
-        item_starts = [0, len(pts[0])]
-
-    lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.pipelines))]
-    counter = [0]
-    queued = []                                        # geometry of upcoming fragments (queued early)
-
-    def prefetch_next():
-        # Queued from inside fragment i's forward (right after its bottleneck fusion): fragment i+1's
-        # voxel pyramid and image branch then run under fragment i's decoder instead of waiting for
-        # CUs behind its big fine-level convolutions.  Every step still does exactly one of each.
-        queued.append(start_geometry(xyz_d, voxel, dev, inputs_ready=True, item_starts=item_starts))
-        model.start_image_branch(img_d, inputs_ready=True)
-
-    def step():
-        # fragment i runs on stream i % pipelines
-        s = lanes[counter[0] % len(lanes)]
-        counter[0] += 1
-        with torch.cuda.stream(s):
-            if not queued:
-                prefetch_next()
-            st, _ = sparse_tensor_from_points(None, voxel, dev, geometry=queued.pop(0))
-            if args.prefetch:
-                model.after_fusion_hook = prefetch_next
-            return model(st, img_d).F
+    else:
+        pts, imgs = [xyz1], img1
+    wl = Workload(model, dev, pts, imgs, voxel)
 
     def barrier():
         if world > 1:
             dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
 
+    sync = torch.cuda.synchronize
+    graph_info = None
     with torch.no_grad():
+        dyn = args.mode in ("capacity", "graph")
+        F_exact = wl.prepare_graph().clone() if dyn else None
+        if dyn:
+            wl.runner.use_graph = args.mode == "graph"
+        step = (lambda tl=None: wl.graph_step(tl)) if dyn else (lambda tl=None: wl.exact_step())
         for _ in range(args.warmup):
-            F = step()
-        torch.cuda.synchronize()
-        M = F.shape[0]
-        F_ref = F.clone()
+            out = step()
+        sync()
+        if dyn:
+            assert out.flags == 0, f"capacity flags {out.flags}"
+            M = out.counts[0]
+            F_ref = out.F.clone()
+            same = bool(torch.equal(F_ref, F_exact))
+            assert float((F_ref - F_exact).abs().max()) < 1e-5, "graph path differs from the exact path"
+            graph_info = {"hipgraph_replay": bool(wl.bucket.graph), "graph_nodes": wl.bucket.n_nodes,
+                          "equals_exact_path_bitwise": same, "host_readbacks_per_step": 0,
+                          "capacities": {"points": wl.bucket.caps.n_points, "rows": list(wl.bucket.caps.rows)}}
+        else:
+            M = out.shape[0]
+            F_ref = out.clone()
 
-        ops.TRACE = []
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         trace_all = []
+        barrier()
+        sync()
+        t0 = time.perf_counter()
         for i in range(args.steps):
-            ops.TRACE = trace_all if (i % args.trace_every == 0) else None
-            F = step()
-        ops.TRACE = trace_all
+            traced = (i % args.trace_every == 0)
+            if dyn:
+                out = step(trace_all if traced else None)
+            else:
+                ops.TRACE = trace_all if traced else None
+                out = step()
+        ops.TRACE = None
         # fragments are independent units: no data-path collective inside the timed region (each
         # rank would write its own <frag>.npz; the optional --gather of generate_desc is not the path)
-        torch.cuda.synchronize()
+        sync()
         barrier()
         elapsed = time.perf_counter() - t0
-        trace, ops.TRACE = ops.TRACE, None
+        trace = trace_all
+        F_last = out.F if dyn else out
 
-    # every step recomputes the same input: the last timed step must reproduce the warm-up step (bit for bit
-    # since the slot order of the transposed rulebooks is deterministic; a 1e-5 drift would mean broken work)
-    drift = float((F - F_ref).abs().max())
-    assert drift < 1e-5, f"descriptors of the last timed step differ from the warm-up step by {drift}"
-    bit_reproducible = drift == 0.0
+        # every step recomputes the same input: the last timed step must reproduce the warm-up step bit for bit
+        drift = float((F_last - F_ref).abs().max())
+        assert drift < 1e-5, f"descriptors of the last timed step differ from the warm-up step by {drift}"
+        bit_reproducible = drift == 0.0
+        if graph_info is not None:
+            graph_info["traced_steps_in_timed_region"] = len(range(0, args.steps, args.trace_every))
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -238,19 +343,22 @@ def main():
 
     if rank == 0:
         # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
-        groups = {}
-        bytes_cache = {}
-        for rec in trace:
-            ms = rec["ev"].elapsed_ms()
-            assert ms >= 0.0
-            key = id(rec["rb"]), rec["cin"], rec["cout"]
-            if key not in bytes_cache:
-                bytes_cache[key] = algorithmic_bytes(rec)
-            g = groups.setdefault(rec["kernel"], {"ms": 0.0, "bytes": 0, "n": 0, "flops": 0})
-            g["ms"] += ms
-            g["bytes"] += bytes_cache[key][0]
-            g["flops"] += 2 * bytes_cache[key][1] * rec["cin"] * rec["cout"]
-            g["n"] += 1
+        def group(records):
+            groups, cache = {}, {}
+            for rec in records:
+                ms = rec["ev"].elapsed_ms()
+                assert ms >= 0.0
+                key = id(rec["rb"]) if "arena" not in rec else (rec["rb"].nbr, rec["rb"].n_slots), rec["cin"], rec["cout"]
+                if key not in cache:
+                    cache[key] = algorithmic_bytes(rec)
+                g = groups.setdefault(rec["kernel"], {"ms": 0.0, "bytes": 0, "n": 0, "flops": 0})
+                g["ms"] += ms
+                g["bytes"] += cache[key][0]
+                g["flops"] += 2 * cache[key][1] * rec["cin"] * rec["cout"]
+                g["n"] += 1
+            return groups
+
+        groups = group(trace)
         dom = max(groups, key=lambda k: groups[k]["ms"])
         g = groups[dom]
         achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
@@ -264,10 +372,30 @@ def main():
                     "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),
                     "algorithmic_bytes_per_launch": g["bytes"] // g["n"],
                     "achieved_tflops_useful": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2),
-                    "all_sparse_conv_ms_per_step": round(conv_ms, 3)}
+                    "all_sparse_conv_ms_per_step": round(conv_ms, 3),
+                    "timing": "HIP events around each launch, in situ (other streams' kernels of the same step overlap)"}
+        extras = {}
+        with torch.no_grad():
+            if dyn and world == 1:
+                # the same launches with nothing else on the GPU: every stream collapsed onto one (serialised)
+                iso = []
+                for _ in range(3):
+                    wl.bucket.io.serialize = 1
+                    try:
+                        wl.graph_step(iso)
+                    finally:
+                        wl.bucket.io.serialize = 0
+                    sync()
+                gi = group(iso).get(dom)
+                if gi:
+                    roofline["isolated_avg_launch_us"] = round(gi["ms"] * 1e3 / gi["n"], 2)
+                    roofline["isolated_frac"] = round(gi["bytes"] / (gi["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if world == 1 and not args.no_extras:
+                extras = extra_legs(O, model, dev, args, sync)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(xyz, img, voxel, sd)
+            cpu = cpu_baseline(xyz1, img1, voxel, sd)
+        n_pts = int(wl.xyz.shape[0])
         out = {
             "metric": "descriptors/sec (32-D) on 3DMatch fragments",
             "value": round(total_m * args.steps / elapsed, 1),
@@ -276,24 +404,97 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": ("synthetic (reference fixture fragment%s scaled x%.2f, seeded random weights)"
                      % (" PAIR cloud_bin_0 + cloud_bin_1" if args.batch == 2 else " cloud_bin_0", args.scale)),
-            "config": {"workload": (f"3DMatch-shaped fragment pair: {int(xyz_d.shape[0])} points -> {M} voxels @ "
+            "config": {"workload": (f"3DMatch-shaped fragment pair: {n_pts} points -> {M} voxels @ "
                                     f"{voxel * 100:.1f} cm, one 120x160 image each, ResUNetBN2C 32-D, conv1 k5; the pair is "
                                     f"ONE batched forward per step per GPU, geometry rebuilt every step"
                                     if args.batch == 2 else
-                                    f"3DMatch-shaped fragment: {xyz.shape[0]} points -> {M} voxels @ "
+                                    f"3DMatch-shaped fragment: {n_pts} points -> {M} voxels @ "
                                     f"{voxel * 100:.1f} cm, image 120x160, ResUNetBN2C 32-D, conv1 k5; "
                                     f"one fragment per step per GPU, geometry rebuilt every step"),
-                       "voxels_per_step_per_gpu": M, "points_per_step_per_gpu": int(xyz_d.shape[0]),
+                       "voxels_per_step_per_gpu": M, "points_per_step_per_gpu": n_pts,
                        "last_step_equals_warmup_bitwise": bit_reproducible,
-                       "fragments_per_step": world * args.batch, "fragments_in_flight_per_gpu": len(lanes) * args.batch,
-                       "conv_arithmetic": ("fp32 operands split into f16 hi+lo, 3x v_mfma_f32_16x16x32_f16 with fp32 "
-                                           "accumulation (fp32-class: max |dF| 3e-7 vs an fp64-accumulated network)"
-                                           if ops.CONV_VARIANT == 6 else "fp32 MFMA")},
+                       "fragments_per_step": world * args.batch,
+                       "execution": {"capacity": "one imf_fragment_forward call per step in capacity mode: device-side row counts, "
+                                                 "no host readback, launches issued natively on three streams",
+                                     "graph": "one hipGraph replay per step of imf_fragment_forward in capacity mode",
+                                     "exact": "exact mode: row-count readback + native executor (imf_resunet_forward)"}[args.mode],
+                       "capacity_mode": graph_info,
+                       "image_branch": model.image_branch_mode if args.mode == "exact" else "native-hip (csrc/image.hip)",
+                       "conv_arithmetic": ("fp32 operands split into f16 hi+lo (weights pre-scaled by a power of two), "
+                                           "3x v_mfma_f32_16x16x32_f16 with fp32 accumulation (fp32-class: max |dF| 3e-7 vs "
+                                           "an fp64-accumulated network)" if ops.CONV_VARIANT == 6 else "fp32 MFMA"),
+                       **extras},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def extra_legs(O, model, dev, args, sync):
+    """Numbers the headline does not show (each a few hundred ms of GPU time):
+      single_fragment        one S50k fragment per step (the reference harness is one fragment per call)
+      e2e_extract_features   SURVEY §8(d)'s span: host arrays in -> voxelise + forward -> sync -> F copied back to the host
+      fp32_mfma_variant0     the same pair with true-fp32 matrix instructions (v_mfma_f32_16x16x4_f32) everywhere"""
+    from imfnet_amd.extract import extract_features
+    xyz1, img1, voxel = load_workload(args.scale, args.voxel)
+    out = {}
+    wl1 = Workload(model, dev, [xyz1], img1, voxel)
+    wl1.prepare_graph()
+    wl1.runner.use_graph = False
+    for _ in range(3):
+        r = wl1.graph_step()
+    dt = timed(wl1.graph_step, 20, sync)
+    m1 = wl1.last_res.counts[0]
+    out["single_fragment"] = {"descriptors_per_s": round(m1 / dt, 1), "ms_per_fragment": round(dt * 1e3, 4), "voxels": m1,
+                              "execution": "capacity mode, one fragment per forward"}
+    dt = timed(wl1.exact_step, 20, sync)
+    out["single_fragment"]["exact_mode_ms_per_fragment"] = round(dt * 1e3, 4)
+
+    xyz_host = xyz1.astype(np.float64)
+    def e2e():
+        xd, F = extract_features(model, xyz_host, voxel_size=voxel, device=dev, skip_check=True, image=img1)
+        return xd, F.cpu().numpy()
+    for _ in range(3):
+        xd, Fh = e2e()
+    t0 = time.perf_counter()
+    n_it = 10
+    for _ in range(n_it):
+        xd, Fh = e2e()
+    dt = (time.perf_counter() - t0) / n_it
+    out["e2e_extract_features"] = {"descriptors_per_s": round(Fh.shape[0] / dt, 1), "ms_per_fragment": round(dt * 1e3, 3),
+                                   "span": "extract_features(host float64 points [%d,3] + host image) -> xyz_down on the host, "
+                                           "F synchronised and copied to the host (PCIe both ways, pageable memory), "
+                                           "one fragment at a time, synchronous" % len(xyz_host),
+                                   "runner": dict(model.fragment_runner().stats) if model.fragment_runner() else None}
+
+    pts2, imgs2 = load_pair(args.scale)
+    wl2 = Workload(model, dev, pts2, imgs2, voxel)
+    wl2.prepare_graph()
+    r = wl2.runner
+    prev = r.use_graph
+    r.use_graph = True
+    for _ in range(3):
+        res = wl2.graph_step()
+    dt = timed(wl2.graph_step, 20, sync)
+    out["graph_replay"] = {"descriptors_per_s": round(wl2.last_res.counts[0] / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+                           "graph_nodes": wl2.bucket.n_nodes,
+                           "note": "the pair as ONE hipGraph replay per step (same launches, bit-identical descriptors): ROCm 7.2 "
+                                   "runs the graph's independent branches back to back, so the image branch, coarse pyramid "
+                                   "levels and rulebook builds no longer overlap the convolutions"}
+    r.use_graph = prev
+    del wl2
+
+    m0, _ = build_model(O, dev, variant=0)
+    pts, imgs = load_pair(args.scale)
+    wl0 = Workload(m0, dev, pts, imgs, voxel)
+    for _ in range(3):
+        F0 = wl0.exact_step()
+    dt = timed(wl0.exact_step, 10, sync)
+    out["fp32_mfma_variant0"] = {"descriptors_per_s": round(F0.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+                                 "note": "the pair, exact mode, every convolution on v_mfma_f32_16x16x4_f32 (IMF_CONV_VARIANT=0)"}
+    del m0, wl0
+    return out
 
 
 if __name__ == "__main__":

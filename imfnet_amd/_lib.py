@@ -79,7 +79,7 @@ class NetTrace(C.Structure):
     """struct imf_net_trace."""
     _fields_ = [("ev_begin", C.c_void_p), ("ev_end", C.c_void_p), ("nbr", C.c_void_p), ("kvol", C.c_int32),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("split", C.c_int32), ("n_slots", C.c_int64),
-                ("n_out", C.c_int64), ("launched", C.c_int32)]
+                ("n_out", C.c_int64), ("launched", C.c_int32), ("level", C.c_int32), ("slots_extra", C.c_int32)]
 
 
 class ResunetIO(C.Structure):
@@ -115,7 +115,7 @@ class FragmentIO(C.Structure):
                 ("int_arena", C.c_void_p), ("int_arena_bytes", C.c_size_t), ("float_arena", C.c_void_p),
                 ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p), ("events", C.c_void_p * 16),
                 ("main_stream", C.c_void_p), ("side_stream", C.c_void_p), ("image_stream", C.c_void_p),
-                ("trace", C.POINTER(NetTrace)), ("levels", LevelDesc * 4)]
+                ("trace", C.POINTER(NetTrace)), ("levels", LevelDesc * 4), ("serialize", C.c_int32)]
 
 
 _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t

@@ -393,6 +393,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
       a.ev_begin = t.ev_begin; a.ev_end = t.ev_end;
       t.nbr = rb.nbr; t.kvol = c.kvol; t.cin = c.cin; t.cout = c.cout; t.split = a.split_k;
       t.n_slots = rb.n_slots; t.n_out = rb.n_out; t.launched = 1;
+      t.level = rb.level; t.slots_extra = rb.slots_extra;
     }
     return imf_spconv_fwd(&a, main);
   };
@@ -433,7 +434,8 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   IMF_REQUIRE(caps->n_items >= 1 && caps->n_items <= IMF_MAX_BATCH, "imf_fragment_forward: n_items=%d", caps->n_items);
   hipStream_t main = (hipStream_t)fio->main_stream, side = (hipStream_t)fio->side_stream,
               imgs = (hipStream_t)fio->image_stream;
-  IMF_REQUIRE(side && imgs && side != main && imgs != main && side != imgs, "imf_fragment_forward: three distinct streams");
+  if (fio->serialize) side = imgs = main;
+  else IMF_REQUIRE(side && imgs && side != main && imgs != main && side != imgs, "imf_fragment_forward: three distinct streams");
   for (int i = 0; i < 11; ++i) IMF_REQUIRE(fio->events[i], "imf_fragment_forward: events[%d] missing", i);
   const int ntok = imf_image_tokens(caps->img_h, caps->img_w);
   IMF_REQUIRE(fio->tokens_padded % 64 == 0 && fio->tokens_padded >= ntok && fio->tokens_padded <= 320,

@@ -86,6 +86,40 @@ def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=N
     return st, inds
 
 
+def _extract_with_runner(runner, xyz, voxel_size, device, image):
+    """extract_features through the capacity-mode graph; None = not applicable / flagged (caller runs the exact path)."""
+    n = int(xyz.shape[0])
+    is_f64 = (xyz.dtype == torch.float64) if torch.is_tensor(xyz) else (np.asarray(xyz).dtype != np.float32)
+    img = image if torch.is_tensor(image) else torch.as_tensor(np.asarray(image), dtype=torch.float32)
+    if img.dim() != 4 or img.shape[0] != 1:
+        return None
+    key = runner.caps_for(n, 1, int(img.shape[2]), int(img.shape[3]), voxel_size, is_f64)
+    if key is None:
+        return None
+    stream, outer = runner._stream_for(device, None)
+    b = runner.bucket(key, device, stream)
+    src = xyz if torch.is_tensor(xyz) else torch.from_numpy(np.ascontiguousarray(np.asarray(xyz)))
+    runner.stage(b, src, [0], img, stream)
+    res = runner.launch(b, n, 1, stream)
+    if res.flags:                                     # does not fit this bucket: exact path (which re-observes)
+        runner.stats["redone"] += 1
+        if outer is not None:
+            outer.wait_stream(stream)
+        return None
+    with torch.cuda.stream(stream):
+        F = res.F.clone()                             # the caller owns its descriptors (the bucket is reused)
+        inds = res.first_idx.long()
+        if torch.is_tensor(xyz) and xyz.is_cuda:
+            sel = xyz.detach()[inds].cpu().numpy().astype(np.float64)
+        else:
+            inds_host = inds.cpu().numpy()
+            host = xyz.detach().numpy() if torch.is_tensor(xyz) else np.asarray(xyz)
+            sel = host[inds_host].astype(np.float64, copy=False)
+    if outer is not None:
+        outer.wait_stream(stream)
+    return sel, F
+
+
 def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=None,
                      skip_check=False, is_eval=True, image=None):
     """xyz: [N,3] points (numpy float64/float32, or a tensor already on the device).
@@ -117,6 +151,14 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
         feats.append(np.asarray(normal) / 2)
     feats = np.hstack(feats) if feats else None
 
+    # Whole-fragment graph (model/graph.py): no count readback, one launch.  Used once the runner has seen a
+    # fragment (it needs voxel-per-point ratios to size its capacity buckets); anything it flags is redone here.
+    runner = model.fragment_runner() if (feats is None and image is not None and hasattr(model, "fragment_runner")) else None
+    if runner is not None:
+        got = _extract_with_runner(runner, xyz, voxel_size, device, image)
+        if got is not None:
+            return got
+
     start = getattr(model, "start_image_branch", None)
     box = {}
     if start is not None:
@@ -128,6 +170,11 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
     if image_dev is None:
         image_dev = torch.as_tensor(image, dtype=torch.float32, device=device)
     F = model(stensor, image_dev).F
+    if runner is not None:                            # teach the runner this fragment's voxel-per-point ratios
+        cm = stensor.coordinate_manager
+        lv = [cm.level(ts) for ts in (1, 2, 4, 8)]
+        if getattr(lv[0], "bbox", None) is not None:
+            runner.observe(int(xyz.shape[0]), [l.n for l in lv], lv[0].bbox)
 
     if torch.is_tensor(xyz) and xyz.is_cuda:          # gather on the device, copy only the M selected rows
         return_coords = xyz.detach()[inds.long()].cpu().numpy().astype(np.float64)

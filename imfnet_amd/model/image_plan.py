@@ -9,6 +9,7 @@ tables + feature workspace and the output buffers.  Reference: model/resnet.py:1
 model/attention_fusion.py:36-46,84.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -102,6 +103,10 @@ class ImagePlan:
             kt = torch.empty(B * 128 * tp, dtype=torch.float32, device=dev)
             vp = torch.empty(B * 128 * tp, dtype=torch.float32, device=dev)
             per = 128 * tp
+            if os.environ.get("IMF_POISON"):           # debugging aid: a read-before-write shows up as NaN
+                for t in (feat, kt, vp):
+                    t.fill_(float("nan"))
+                ws.view(torch.float32)[L.imf_image_workspace_bytes(B, H, W) // 8:].fill_(float("nan"))
             b = dict(ws=ws, nbytes=nbytes, T=T, tp=tp, feat=feat, kt=kt, vp=vp,
                      kt_items=[kt[i * per:(i + 1) * per] for i in range(B)],
                      vp_items=[vp[i * per:(i + 1) * per] for i in range(B)])

@@ -17,6 +17,10 @@ from .. import _lib, ops
 from .._lib import ConvArgs, ImfError, MASK_WORDS, TILE_ROWS, check
 
 
+import os
+_POISON = bool(os.environ.get("IMF_POISON"))
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -25,12 +29,16 @@ class _RB:
     """Rulebook living inside the plan's int32 arena (raw device addresses)."""
     __slots__ = ("tile_rows", "nbr", "tile_mask", "n_slots", "n_out", "kvol", "max_active")
 
-    def count_pairs(self, arena):
-        """Valid (input,output) pairs -- bench.py's algorithmic-bytes accounting, outside timing."""
+    def count_pairs(self, arena, valid_slots=None, rows=None):
+        """Valid (input,output) pairs -- bench.py's algorithmic-bytes accounting, outside timing.  Capacity mode:
+        only the first `valid_slots` slots of every offset were written (`rows` actual output rows)."""
         if self.kvol == 1:
-            return self.n_out
+            return self.n_out if rows is None else rows
         start = (self.nbr - arena.data_ptr()) // 4
-        return int((arena[start:start + self.kvol * self.n_slots] >= 0).sum().item())
+        tab = arena[start:start + self.kvol * self.n_slots].view(self.kvol, self.n_slots)
+        if valid_slots is not None:
+            tab = tab[:, :valid_slots]
+        return int((tab >= 0).sum().item())
 
     def __init__(self, n_slots, n_out, kvol, max_active):
         self.tile_rows = self.nbr = self.tile_mask = 0
@@ -376,6 +384,12 @@ class NativePlan:
         iarena.record_stream(main)
         farena = torch.empty(fbytes, dtype=torch.uint8, device=dev)
         F = torch.empty((lv[0].n, d.out_channels), dtype=torch.float32, device=dev)
+        if _POISON:                                   # debugging aid: a read-before-write shows up as NaN
+            farena.view(torch.float32).fill_(float("nan"))
+            F.fill_(float("nan"))
+            with torch.cuda.stream(side):
+                iarena.view(torch.int32).fill_(0x7FC00000)
+            main.wait_stream(side)
         io.int_arena, io.int_arena_bytes = iarena.data_ptr(), ibytes
         io.float_arena, io.float_arena_bytes = farena.data_ptr(), fbytes
         io.out = F.data_ptr()

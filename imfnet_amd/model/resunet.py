@@ -92,6 +92,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._img_graph = {}              # (device, shape) -> captured image branch
         self._fw = None                   # packed weights of the fused fusion kernel
         self._img_plan = None             # native image branch (model/image_plan.py, csrc/image.hip)
+        self._runner = None               # whole-fragment capacity-mode / hipGraph runner (model/graph.py)
         self.image_branch_mode = None     # how the last image branch ran: native-hip | torch-graph | torch-eager
 
     # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
@@ -103,6 +104,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._img_graph = {}
         self._fw = None
         self._img_plan = None
+        self._runner = None
 
     def _apply(self, fn, *a, **k):
         self._invalidate()
@@ -193,12 +195,29 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._pending_image = (image, feat, kv, ev, packed)
         return image
 
+    def fragment_runner(self):
+        """The capacity-mode / hipGraph executor of whole fragments (model/graph.py), or None when this model
+        configuration is not covered (training mode, non-BatchNorm blocks, per-point input features, ...)."""
+        if os.environ.get("IMFNET_NO_FRAGMENT_GRAPH") or not self._can_fuse():
+            return None
+        if self._runner is None:
+            try:
+                if next(self.parameters()).device.type != "cuda":
+                    return None
+                from .graph import FragmentRunner
+                r = FragmentRunner(self)
+                self._runner = r if r.supported else False
+            except ME.ImfError:
+                self._runner = False
+        return self._runner or None
+
     def _native_image(self):
         if self._img_plan is None:
             from .image_plan import ImagePlan
             blk = self.attention_fusion.cross_attend_blocks[0]
             one_head = blk.fn.heads == 1 and len(self.attention_fusion.layers) == 0
             self._img_plan = ImagePlan(self.img_encoder, blk if one_head else None, ops.conv_variant_for(9))
+            torch.cuda.synchronize()                 # once per model: packed weights visible to every stream
         return self._img_plan
 
     def _run_image_graph(self, image, side):
@@ -286,6 +305,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         if self._plan is None:
             from .plan import FusedPlan
             self._plan = FusedPlan(self)
+            torch.cuda.synchronize()                 # once per model: packed weights visible to every stream
         hook, self.after_fusion_hook = self.after_fusion_hook, None      # one-shot
         native = (packed is not None and hook is None and x.F.is_cuda and
                   not os.environ.get("IMFNET_PYTHON_EXECUTOR"))
@@ -293,6 +313,7 @@ class ResUNet2(ME.MinkowskiNetwork):
             if self._native_plan is None:
                 from .plan import NativePlan
                 self._native_plan = NativePlan(self, self._plan)
+                torch.cuda.synchronize()
             cur = torch.cuda.current_stream(x.F.device)
             image_feat.record_stream(cur)
             for t in packed[0] + packed[1]:

@@ -392,6 +392,7 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
   int32_t kvol, cin, cout, split;
   int64_t n_slots, n_out;
   int32_t launched;
+  int32_t level, slots_extra;          /* out: pyramid level of the output rows; rulebook slots beyond roundup64(rows) */
 } imf_net_trace;
 
 typedef struct imf_resunet_io {        /* per fragment */
@@ -472,6 +473,7 @@ typedef struct imf_fragment_io {       /* [host]; all buffers device memory owne
   void *main_stream, *side_stream, *image_stream;
   imf_net_trace *trace;                /* [host] 23 records or NULL */
   imf_level levels[4];                 /* out [host]: where the levels live inside pyramid_arena */
+  int32_t serialize;                   /* measurement aid: issue everything on main_stream (no overlap between branches) */
 } imf_fragment_io;
 
 size_t imf_fragment_pyramid_bytes(const imf_fragment_caps *caps);

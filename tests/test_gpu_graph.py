@@ -36,6 +36,7 @@ def _runner(model):
     from imfnet_amd.model.graph import FragmentRunner
     r = FragmentRunner(model)
     assert r.supported
+    r.use_graph = True
     return r
 
 

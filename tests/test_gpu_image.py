@@ -107,6 +107,7 @@ def test_forward_uses_native_image_branch(model, clouds, images, golden, monkeyp
     assert model.image_branch_mode == "native-hip"
     assert np.abs(F.cpu().numpy() - golden["crop_F"]).max() < 1e-4
     monkeypatch.setenv("IMFNET_TORCH_IMAGE", "1")
+    monkeypatch.setenv("IMFNET_NO_FRAGMENT_GRAPH", "1")    # the capacity-mode runner always uses the native branch
     with torch.no_grad():
         _, F2 = extract_features(model, crop, voxel_size=0.025, device=torch.device(DEV), skip_check=True, image=images[0])
     assert model.image_branch_mode in ("torch-graph", "torch-eager")
