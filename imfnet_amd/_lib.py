@@ -12,6 +12,7 @@ TILE_ROWS = 64
 MASK_WORDS = 4
 MAX_KVOL = 125
 MAX_BATCH = 8
+FLAG_RANGE = 32
 
 
 class ImfError(RuntimeError):
@@ -93,7 +94,7 @@ class ResunetIO(C.Structure):
                 ("float_arena", C.c_void_p), ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p),
                 ("events", C.c_void_p * 16), ("side_stream", C.c_void_p), ("main_stream", C.c_void_p),
                 ("trace", C.POINTER(NetTrace)), ("dyn", C.c_int32), ("meta", C.c_void_p),
-                ("bitgrid_words", C.c_size_t), ("pyramid", C.c_void_p)]
+                ("bitgrid_words", C.c_size_t), ("pyramid", C.c_void_p), ("flags", C.c_void_p)]
 
 
 DYN_WORDS = 16
@@ -185,7 +186,11 @@ SIGNATURES = {
     "imf_image_workspace_bytes": (_Z, [_I, _I, _I]),
     "imf_image_tokens": (_I, [_I, _I]),
     "imf_image_tables_build": (_I, [_I, _I, _I, _P, _Z, _P]),
-    "imf_image_branch": (_I, [C.POINTER(ImageDesc), _P, _I, _I, _I, _P, _Z, _P, _P, _P, _I, _P]),
+    "imf_image_branch": (_I, [C.POINTER(ImageDesc), _P, _I, _I, _I, _P, _Z, _P, _P, _P, _I, _P, _P]),
+    "imf_conv_first_bitgrid_flags": (_I, [_P, _L, _P, _I, _P, _Z, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "imf_fusion_attention_batched_flags": (_I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                                C.POINTER(C.c_void_p), _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P,
+                                                _Z, _P, _P]),
     "imf_bitgrid_words": (_Z, [_P, _I]),
     "imf_conv_first_bitgrid": (_I, [_P, _L, _P, _I, _P, _Z, _P, _I, _P, _P, _I, _P, _P]),
     "imf_conv_first_fused": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P]),

@@ -201,7 +201,8 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   hipStream_t main = (hipStream_t)io->main_stream, side = (hipStream_t)io->side_stream;
   const int n_events = pyr ? 9 : 7;
   for (int i = 0; i < n_events; ++i) IMF_REQUIRE(io->events[i], "imf_resunet_forward: events[%d] missing", i);
-  int32_t *err = dyn ? const_cast<int32_t *>(meta) + 1 : nullptr;   // level-0 error word collects every flag
+  // flag word: capacity mode collects every flag in the level-0 error word; exact mode takes the caller's (optional)
+  int32_t *err = dyn ? const_cast<int32_t *>(meta) + 1 : io->flags;
 
   // ---- rulebooks in the int arena --------------------------------------------------------------
   Rb rb_first, rb_k3[4], rb_dn[3], rb_up[3], rb_id;
@@ -341,9 +342,9 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
       size_t words = 0;
       if (io->x_all_ones && io->bbox && net->in_channels == 1) words = imf_bitgrid_words(io->bbox, net->first_ksize);
       if (words) {
-        rc = imf_conv_first_bitgrid(io->level[0].coords, s.n[0], io->bbox, net->first_ksize, bitgrid, words,
-                                    net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
-                                    buf[ebuf(0, 0)], main);
+        rc = imf_conv_first_bitgrid_flags(io->level[0].coords, s.n[0], io->bbox, net->first_ksize, bitgrid, words,
+                                          net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
+                                          buf[ebuf(0, 0)], err, main);
       } else {
         rc = imf_conv_first_fused(io->level[0].keys, io->level[0].vals, io->level[0].capacity, io->level[0].coords,
                                   s.n[0], 1, net->first_ksize, io->x_all_ones ? nullptr : io->x, net->in_channels,
@@ -372,6 +373,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     a.n_slots = rb.n_slots; a.n_out = rb.n_out;
     a.scale = c.scale; a.shift = c.shift; a.residual = addr(st.residual);
     a.relu = c.relu; a.l2norm = c.l2norm; a.out = addr(st.out);
+    a.dyn_err = c.variant == 6 && !c.l2norm ? err : nullptr;   // outputs that feed another split-f16 convolution
     if (dyn) {
       a.n_out_dev = meta + 2 * rb.level;
       a.slots_extra = rb.slots_extra;
@@ -409,9 +411,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
                                   err, io->kt_packed, io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
                                   net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4, main);
   else
-    rc = imf_fusion_attention_batched(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
-                                      io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion, net->fusion_scale,
-                                      buf[FUSED], fusion_ws, fusion_ws_floats * 4, main);
+    rc = imf_fusion_attention_batched_flags(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
+                                            io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
+                                            net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4,
+                                            net->conv[12].variant == 6 ? err : nullptr, main);
   if (rc) return rc;
   if (io->fusion_done) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->fusion_done, main));
 
@@ -445,7 +448,7 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[9], main));
   IMF_CHECK_HIP(hipStreamWaitEvent(imgs, (hipEvent_t)fio->events[9], 0));
   int rc = imf_image_branch(img, fio->image, caps->n_items, caps->img_h, caps->img_w, fio->image_ws, fio->image_ws_bytes,
-                            nullptr, fio->kt_packed, fio->v_packed, fio->tokens_padded, imgs);
+                            nullptr, fio->kt_packed, fio->v_packed, fio->tokens_padded, fio->meta + 1, imgs);
   if (rc) return rc;
   IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[10], imgs));
 

@@ -300,6 +300,7 @@ k_fusion_attention(const FusionParams p) {
         if (row < row_end) {
           float v = acc[i][r];
           if (hs == 0) v += bias + X[(4 * q4 + r) * kLdX + col];   // bias and residual enter once
+          if (HS == 1 && p.err && !(fabsf(v) < 65504.f)) atomicOr(p.err, 32);   // f16 range of the next convolution
           dst[row * kFD + col] = v;
         }
       }
@@ -310,7 +311,7 @@ k_fusion_attention(const FusionParams p) {
 // out = sum over the HS partial slices, ascending (deterministic)
 __global__ void __launch_bounds__(256) k_fusion_reduce(const float *__restrict__ partial, long long n4, int hs,
                                                        float *__restrict__ out, const int32_t *__restrict__ n_dev,
-                                                       int hs_override) {
+                                                       int hs_override, int32_t *err) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride4 = n4;
   if (n_dev) {   // capacity mode: n4 is the capacity (and the slice stride); only the variant the rule picks runs
@@ -324,6 +325,8 @@ __global__ void __launch_bounds__(256) k_fusion_reduce(const float *__restrict__
     const float4 v = reinterpret_cast<const float4 *>(partial)[(long long)h * stride4 + i];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
+  if (err && (!(fabsf(s.x) < 65504.f) || !(fabsf(s.y) < 65504.f) || !(fabsf(s.z) < 65504.f) || !(fabsf(s.w) < 65504.f)))
+    atomicOr(err, 32);
   reinterpret_cast<float4 *>(out)[i] = s;
 }
 
@@ -341,7 +344,7 @@ static int launch_fusion(const FusionParams &p, hipStream_t st) {
   IMF_CHECK_LAUNCH("k_fusion_attention");
   if (HS > 1) {
     const long long n4 = p.n * kFD / 4;
-    k_fusion_reduce<<<(unsigned)div_up(n4, 256), 256, 0, st>>>(p.partial, n4, HS, p.out, p.n_dev, p.hs_override);
+    k_fusion_reduce<<<(unsigned)div_up(n4, 256), 256, 0, st>>>(p.partial, n4, HS, p.out, p.n_dev, p.hs_override, p.err);
     IMF_CHECK_LAUNCH("k_fusion_reduce");
   }
   return IMF_OK;
@@ -401,6 +404,14 @@ int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *ite
                                  const float *const *kt_packed, const float *const *v_packed, int n_tokens,
                                  int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
                                  void *workspace, size_t workspace_bytes, void *stream) {
+  return imf_fusion_attention_batched_flags(x, n_items, item_row0, item_rows, kt_packed, v_packed, n_tokens, tokens_padded,
+                                            w, scale, out, workspace, workspace_bytes, nullptr, stream);
+}
+
+int imf_fusion_attention_batched_flags(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
+                                       const float *const *kt_packed, const float *const *v_packed, int n_tokens,
+                                       int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
+                                       void *workspace, size_t workspace_bytes, int32_t *flags, void *stream) {
   IMF_REQUIRE(x && item_row0 && item_rows && kt_packed && v_packed && w && out, "imf_fusion_attention: null pointer");
   IMF_REQUIRE(n_items >= 1 && n_items <= IMF_MAX_BATCH, "imf_fusion_attention: n_items=%d", n_items);
   IMF_REQUIRE(w->ln1_g && w->ln1_b && w->wq_p && w->wo_p && w->bo && w->ln2_g && w->ln2_b && w->w1_p && w->b1 &&
@@ -425,6 +436,7 @@ int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *ite
   p.ln1g = w->ln1_g; p.ln1b = w->ln1_b; p.wq = w->wq_p; p.wo = w->wo_p; p.bo = w->bo; p.ln2g = w->ln2_g;
   p.ln2b = w->ln2_b; p.w1 = w->w1_p; p.b1 = w->b1; p.w2 = w->w2_p; p.b2 = w->b2; p.out = out;
   p.partial = (float *)workspace;
+  p.err = flags;
   hipStream_t st = (hipStream_t)stream;
   if (hs == 4) return launch_fusion<4>(p, st);
   if (hs == 2) return launch_fusion<2>(p, st);

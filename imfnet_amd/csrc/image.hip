@@ -139,7 +139,8 @@ k_img_rulebook(int B, int Hin, int Win, int Hout, int Wout, int ksize, int strid
 // ---- stem: im2col of the 7x7 stride-2 pad-3 convolution (model/resnet.py:141,199) ---------------------
 // column c = (ky*7 + kx)*3 + ch (the order the host lays the stem weight out in); columns 147..159 = 0
 __global__ void __launch_bounds__(256)
-k_img_im2col7(const float *__restrict__ img, int B, int H, int W, int Ho, int Wo, float *__restrict__ out) {
+k_img_im2col7(const float *__restrict__ img, int B, int H, int W, int Ho, int Wo, float *__restrict__ out,
+              int32_t *flags) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)B * Ho * Wo * kStemK;
   if (idx >= total) return;
@@ -153,6 +154,7 @@ k_img_im2col7(const float *__restrict__ img, int B, int H, int W, int Ho, int Wo
     const int iy = 2 * oy + ky - 3, ix = 2 * ox + kx - 3;
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((int64_t)b * 3 + ch) * H + iy) * W + ix];
   }
+  if (flags && !(fabsf(v) < 65504.f)) atomicOr(flags, 32);   // pixel values must fit the f16 operands of the stem
   out[idx] = v;
 }
 
@@ -187,7 +189,7 @@ k_img_maxpool(const float *__restrict__ in, int B, int Hin, int Win, int Hout, i
 // ---- LayerNorm over 128-wide token rows (norm_context, attention_fusion.py:36-46): one wave per row -----
 __global__ void __launch_bounds__(256)
 k_img_layernorm128(const float *__restrict__ x, int64_t n, const float *__restrict__ g, const float *__restrict__ b,
-                   float *__restrict__ y) {
+                   float *__restrict__ y, int32_t *flags) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
@@ -200,7 +202,9 @@ k_img_layernorm128(const float *__restrict__ x, int64_t n, const float *__restri
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = rsqrtf(q * (1.f / kC2) + 1e-5f);
   const float2 gg = *reinterpret_cast<const float2 *>(g + 2 * lane), bb = *reinterpret_cast<const float2 *>(b + 2 * lane);
-  *reinterpret_cast<float2 *>(y + row * kC2 + 2 * lane) = make_float2(dx * rstd * gg.x + bb.x, dy * rstd * gg.y + bb.y);
+  const float2 o = make_float2(dx * rstd * gg.x + bb.x, dy * rstd * gg.y + bb.y);
+  if (flags && (!(fabsf(o.x) < 65504.f) || !(fabsf(o.y) < 65504.f))) atomicOr(flags, 32);
+  *reinterpret_cast<float2 *>(y + row * kC2 + 2 * lane) = o;
 }
 
 // ---- K^T / V of every image in the fragment-major fp32 layout the fusion kernel streams ------------------
@@ -275,7 +279,7 @@ int imf_image_tables_build(int B, int H, int W, void *workspace, size_t workspac
 
 int imf_image_branch(const imf_image_desc *net, const float *image, int B, int H, int W, void *workspace,
                      size_t workspace_bytes, float *feat_out, float *kt_packed, float *v_packed,
-                     int tokens_padded, void *stream) {
+                     int tokens_padded, int32_t *flags, void *stream) {
   IMF_REQUIRE(net && image && workspace, "imf_image_branch: null pointer");
   IMF_REQUIRE(B >= 1 && B <= IMF_MAX_BATCH && H >= 8 && W >= 8, "imf_image_branch: B=%d H=%d W=%d", B, H, W);
   IMF_REQUIRE(((uintptr_t)workspace & 255) == 0, "imf_image_branch: workspace must be 256-byte aligned");
@@ -308,6 +312,7 @@ int imf_image_branch(const imf_image_desc *net, const float *image, int B, int H
     }
     a.scale = c.scale; a.shift = c.shift; a.residual = residual; a.relu = c.relu; a.out = out;
     a.variant = c.variant; a.split_k = 0;
+    a.dyn_err = c.variant == 6 ? flags : nullptr;
     a.workspace = p.splitk; a.workspace_bytes = p.splitk_bytes;
     return imf_spconv_fwd(&a, st);
   };
@@ -315,7 +320,7 @@ int imf_image_branch(const imf_image_desc *net, const float *image, int B, int H
   // stem: conv7x7/2 + bn + relu (im2col + pointwise), 3x3/2 max pool
   {
     const int64_t total = s.n2 * kStemK;
-    k_img_im2col7<<<(unsigned)div_up(total, 256), 256, 0, st>>>(image, B, H, W, s.H2, s.W2, p.im2col);
+    k_img_im2col7<<<(unsigned)div_up(total, 256), 256, 0, st>>>(image, B, H, W, s.H2, s.W2, p.im2col, net->variant == 6 ? flags : nullptr);
     IMF_CHECK_LAUNCH("k_img_im2col7");
     imf_net_conv c;
     memset(&c, 0, sizeof(c));
@@ -353,7 +358,7 @@ int imf_image_branch(const imf_image_desc *net, const float *image, int B, int H
   if (!want_kv) return IMF_OK;
 
   // context half of the cross attention: LayerNorm(tokens) -> to_kv (no bias) -> packed K^T / V per image
-  k_img_layernorm128<<<(unsigned)div_up(s.n8, 4), 256, 0, st>>>(feat, s.n8, net->ln_g, net->ln_b, p.ln);
+  k_img_layernorm128<<<(unsigned)div_up(s.n8, 4), 256, 0, st>>>(feat, s.n8, net->ln_g, net->ln_b, p.ln, net->variant == 6 ? flags : nullptr);
   IMF_CHECK_LAUNCH("k_img_layernorm128");
   {
     imf_net_conv c;

@@ -857,6 +857,8 @@ k_spconv_reduce(const ConvParams p, int S, long long slot0) {
       x[e] = v;
     }
     s = make_float4(x[0], x[1], x[2], x[3]);
+    if (p.err && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) || out_of_f16_range(s.w)))
+      atomicOr(p.err, 32);
   }
   if (p.l2norm) {   // cout in {32, 64}: a row = 8 or 16 consecutive lanes (all lanes take part)
     float ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
@@ -1128,6 +1130,7 @@ k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_
       if (row < n) {
         float v = acc[cb][e] * sc + sh;
         if (relu) v = fmaxf(v, 0.f);
+        if (dg.err && out_of_f16_range(v)) atomicOr(dg.err, 32);
         out[row * COUT + col] = v;
       }
     }
@@ -1394,6 +1397,16 @@ static int conv_first_bitgrid_impl(const int32_t *coords, int64_t n, const int32
   }
   IMF_CHECK_LAUNCH("k_conv_first_bits");
   return IMF_OK;
+}
+
+int imf_conv_first_bitgrid_flags(const int32_t *coords, int64_t n, const int32_t *bbox, int ksize,
+                                 uint32_t *grid, size_t grid_words, const float *w, int cout, const float *scale,
+                                 const float *shift, int relu, float *out, int32_t *flags, void *stream) {
+  IMF_REQUIRE(bbox, "imf_conv_first_bitgrid: null pointer");
+  DynGrid dg;
+  memset(&dg, 0, sizeof(dg));
+  dg.err = flags;
+  return conv_first_bitgrid_impl(coords, n, bbox, dg, ksize, grid, grid_words, w, cout, scale, shift, relu, out, stream);
 }
 
 int imf_conv_first_bitgrid(const int32_t *coords, int64_t n, const int32_t *bbox, int ksize,

@@ -36,8 +36,14 @@ struct ConvParams {
   int dyn_split_kvol;       // third argument of the split rule (active offsets per tile); 0 = gridDim.z is the split
   int slots_extra;          // slots the rulebook lays out beyond roundup64(rows): 0, or 512 for transposed maps
   int split_min_blocks, split_target;
-  int32_t *err;             // capacity mode: bit 4 (16) = the rule wanted more partitions than the launch covers
+  int32_t *err;             // flag word (optional): 16 = the rule wanted more partitions than the launch covers
+                            // (capacity mode); 32 = an output value left the f16 range (|y| >= 65504 or NaN): the
+                            // next split-f16 convolution would turn it into inf -- see IMF_FLAG_RANGE
 };
+
+constexpr float kF16Max = 65504.f;
+// true when y cannot be carried by the split-f16 operands of the next convolution (also for NaN)
+__device__ __forceinline__ bool out_of_f16_range(float y) { return !(fabsf(y) < kF16Max); }
 
 // The automatic split-K rule (imf_spconv_auto_split), shared by host and device.
 __host__ __device__ inline int auto_split_rule(long long n_slots, int cout, int kvol, int min_blocks, int target) {
@@ -103,6 +109,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (
       v[cb][r] = x;
     }
   }
+  if (p.err) {      // range guard for the consumer's f16 operands: one atomic per offending wavefront, none normally
+    bool bad = false;
+#pragma unroll
+    for (int cb = 0; cb < CO_BLK; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bad |= orow[r] >= 0 && out_of_f16_range(v[cb][r]);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(p.err, 32);
+  }
   if (p.l2norm) {   // whole row lives in this workgroup slab (cout == CW): reduce over 16 lanes
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -154,6 +168,8 @@ __device__ __forceinline__ void fused_reduce_tile(const ConvParams &p, int S, lo
         s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
       }
       if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+      if (p.err && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) || out_of_f16_range(s.w)))
+        atomicOr(p.err, 32);
     }
     if (p.l2norm) {
       float ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;

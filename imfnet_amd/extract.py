@@ -12,7 +12,7 @@ import torch
 
 from . import ops
 from . import sparse as ME
-from ._lib import ImfError
+from ._lib import FLAG_RANGE, ImfError
 
 
 def _as_device_points(xyz, device):
@@ -158,7 +158,18 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
         got = _extract_with_runner(runner, xyz, voxel_size, device, image)
         if got is not None:
             return got
+    out = _extract_exact(model, runner, xyz, feats, voxel_size, device, image)
+    if hasattr(model, "take_flags") and model.take_flags(device) & FLAG_RANGE:
+        # an activation left the f16 range of the split-f16 convolutions (it would have become inf): the
+        # fragment is redone on the true-fp32 matrix instructions -- slower, never silently wrong
+        import warnings
+        warnings.warn("imfnet_amd: activation outside the f16 range; fragment recomputed with fp32 MFMA (variant 0)")
+        out = model.forward_fp32(lambda: _extract_exact(model, None, xyz, feats, voxel_size, device, image))
+    return out
 
+
+def _extract_exact(model, runner, xyz, feats, voxel_size, device, image):
+    """The exact path: geometry with one row-count readback, then the model's forward."""
     start = getattr(model, "start_image_branch", None)
     box = {}
     if start is not None:

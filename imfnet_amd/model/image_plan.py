@@ -114,7 +114,7 @@ class ImagePlan:
                 self._shapes[key] = b
         return b
 
-    def run(self, image, want_kv=True):
+    def run(self, image, want_kv=True, flags=None):
         """image: CUDA float32 [B,3,H,W] (contiguous).  Launches on the CURRENT stream.  Returns
         (feat [B*T,128] NHWC rows, packed) with packed = ([K^T per item], [V per item], T, tokens_padded) or None."""
         B, _, H, W = image.shape
@@ -123,6 +123,7 @@ class ImagePlan:
         check(self.L.imf_image_branch(C.byref(self.desc), image.data_ptr(), B, H, W, b["ws"].data_ptr(), b["nbytes"],
                                       b["feat"].data_ptr(), b["kt"].data_ptr() if kv else None,
                                       b["vp"].data_ptr() if kv else None, b["tp"],
+                                      None if flags is None else flags.data_ptr(),
                                       torch.cuda.current_stream(image.device).cuda_stream), "imf_image_branch")
         packed = (b["kt_items"], b["vp_items"], b["T"], b["tp"]) if kv else None
         return b["feat"], packed

@@ -125,6 +125,7 @@ class FusedPlan:
         a.split_k = split
         a.workspace, a.workspace_bytes = (ws[0] or None, ws[1])
         a.tickets = (self._tickets or None) if (split > 1 and self.fused_reduce) else None
+        a.dyn_err = self._flags if (a.variant == 6 and not a.l2norm) else None
         ev = None
         if ops.TRACE is not None:
             ev = ops._Ev()
@@ -206,6 +207,7 @@ class FusedPlan:
             e.record(side)
             ready[id(rb_up[i])] = e
         self._ready, self._main = ready, main
+        self._flags = m.flag_word(dev).data_ptr()
 
         # ---- schedule: (conv name, rulebook, in_a, c_a, out, in_b, c_b, residual) ---------------
         sched = []
@@ -405,6 +407,7 @@ class NativePlan:
             io.trace = self._trace
         else:
             io.trace = None
+        io.flags = self.model.flag_word(dev).data_ptr()
         check(L.imf_resunet_forward(C.byref(d), C.byref(io)), "imf_resunet_forward")
         if tracing:
             for i, e in enumerate(evs):

@@ -93,6 +93,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._fw = None                   # packed weights of the fused fusion kernel
         self._img_plan = None             # native image branch (model/image_plan.py, csrc/image.hip)
         self._runner = None               # whole-fragment capacity-mode / hipGraph runner (model/graph.py)
+        self._flag_words = {}             # device -> int32[1]: IMF_FLAG_* bits OR-ed by the kernels (sticky)
         self.image_branch_mode = None     # how the last image branch ran: native-hip | torch-graph | torch-eager
 
     # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
@@ -172,7 +173,8 @@ class ResUNet2(ME.MinkowskiNetwork):
             if (plan is not None and plan.supported and image.dtype == torch.float32 and image.dim() == 4 and
                     image.shape[0] <= _lib_max_batch() and image.shape[2] >= 8 and image.shape[3] >= 8):
                 # ~22 launches of the sparse-conv kernel over static pixel tables (csrc/image.hip)
-                rows, packed = plan.run(image.contiguous(), want_kv=self._fusion_weights().supported)
+                rows, packed = plan.run(image.contiguous(), want_kv=self._fusion_weights().supported,
+                                        flags=self.flag_word(dev))
                 B, h8, w8 = image.shape[0], _down8(image.shape[2]), _down8(image.shape[3])
                 feat, kv = rows.view(B, h8, w8, rows.shape[1]).permute(0, 3, 1, 2), None
                 self.image_branch_mode = "native-hip"
@@ -194,6 +196,41 @@ class ResUNet2(ME.MinkowskiNetwork):
         image.record_stream(side)
         self._pending_image = (image, feat, kv, ev, packed)
         return image
+
+    # ---- f16 range guard of the split-f16 convolutions -------------------------------------------------
+    def flag_word(self, device):
+        """Device int32[1] the kernels OR IMF_FLAG_RANGE (32) into when an activation that feeds a split-f16
+        convolution is NaN or >= 65504 in magnitude (it would become inf as an f16 operand)."""
+        w = self._flag_words.get(device)
+        if w is None:
+            w = self._flag_words[device] = torch.zeros(1, dtype=torch.int32, device=device)
+        return w
+
+    def take_flags(self, device):
+        """Read and clear the flag word (one 4-byte readback: synchronises with the current stream)."""
+        w = self._flag_words.get(device)
+        if w is None:
+            return 0
+        v = int(w.item())
+        if v:
+            w.zero_()
+        return v
+
+    def forward_fp32(self, fn):
+        """Run `fn()` with every convolution on the true-fp32 matrix instructions (variant 0): the fallback for
+        activations outside the f16 range.  Plans and packed weights are rebuilt on entry and exit."""
+        prev = ops.CONV_VARIANT
+        ops.CONV_VARIANT = 0
+        self._invalidate()
+        try:
+            out = fn()
+            torch.cuda.synchronize()
+            return out
+        finally:
+            ops.CONV_VARIANT = prev
+            self._invalidate()
+            for w in self._flag_words.values():
+                w.zero_()
 
     def fragment_runner(self):
         """The capacity-mode / hipGraph executor of whole fragments (model/graph.py), or None when this model

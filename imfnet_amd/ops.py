@@ -384,8 +384,9 @@ def conv_kernel_name(variant, cin, cout):
 
 
 def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual=None,
-           relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False):
-    """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd."""
+           relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False, flags=None):
+    """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd.  `flags`: optional int32[1] device word that
+    receives IMF_FLAG_RANGE (32) when an output is NaN or >= 65504 in magnitude."""
     _req(in_a, torch.float32, "in_a", 2)
     if in_b is not None:
         _req(in_b, torch.float32, "in_b", 2)
@@ -405,6 +406,7 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     if rb.kvol == 1:
         split = 1
     a.split_k, a.variant = split, int(variant)
+    a.dyn_err = None if flags is None else flags.data_ptr()
     ws = None
     nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)   # split-K partials / balanced-tail partials
     if nbytes:

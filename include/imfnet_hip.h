@@ -232,8 +232,20 @@ typedef struct imf_conv_args {
    * imf_rulebook_transpose's parity classes, else 0). */
   const int32_t *n_out_dev;
   int32_t dyn_split_kvol, slots_extra;
-  int32_t *dyn_err;       /* device flag word: bit 4 is raised when the rule asks for more partitions than split_k covers */
+  int32_t *dyn_err;       /* optional device flag word (any mode): IMF_FLAG_SPLIT_COVER when the rule asks for more
+                             partitions than split_k covers; IMF_FLAG_RANGE when an OUTPUT value is NaN or |y| >= 65504,
+                             i.e. cannot be an operand of a following variant-6 convolution */
 } imf_conv_args;
+
+/* Flag bits the kernels OR into a caller-provided device word (imf_conv_args.dyn_err, imf_resunet_io.flags, meta[1]
+ * of the capacity mode).  A flagged result must not be used: redo the fragment (larger capacities / exact mode for
+ * 2..16; the fp32-MFMA variant 0 for IMF_FLAG_RANGE). */
+#define IMF_FLAG_COORD_RANGE  1   /* a point fell outside [-2^17, 2^17) voxels or was NaN */
+#define IMF_FLAG_CAPACITY     2   /* a pyramid level exceeded its row capacity */
+#define IMF_FLAG_BITGRID      4   /* level-0 bounding box larger than the conv1 bit grid */
+#define IMF_FLAG_EMPTY_ITEM   8   /* a batch item without voxels */
+#define IMF_FLAG_SPLIT_COVER 16   /* fewer rows than a quarter of the capacity */
+#define IMF_FLAG_RANGE       32   /* an activation left the f16 range of the split-f16 convolution operands */
 
 /* Kernel-offset partitions imf_spconv_fwd will use for this shape when args.split_k == 0: small
  * levels (few tiles) are latency-bound, so their offsets are spread over several workgroups whose
@@ -285,6 +297,10 @@ int imf_conv_first_bitgrid(const int32_t *coords, int64_t n, const int32_t *bbox
 
 /* Capacity mode: row count and bounding box (8 ints) read from the device; a box that needs more than grid_words
  * raises bit 2 (value 4) of *err and the launch does nothing. */
+/* The same with a flag word for IMF_FLAG_RANGE on the outputs (flags may be NULL). */
+int imf_conv_first_bitgrid_flags(const int32_t *coords, int64_t n, const int32_t *bbox /* [host] */, int ksize,
+                                 uint32_t *grid, size_t grid_words, const float *w, int cout, const float *scale,
+                                 const float *shift, int relu, float *out, int32_t *flags, void *stream);
 int imf_conv_first_bitgrid_dyn(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
                                int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
                                const float *scale, const float *shift, int relu, float *out, void *stream);
@@ -354,8 +370,14 @@ int imf_image_tables_build(int B, int H, int W, void *workspace, size_t workspac
  * About 22 launches, no host synchronisation. */
 int imf_image_branch(const imf_image_desc *net /* [host] */, const float *image, int B, int H, int W,
                      void *workspace, size_t workspace_bytes, float *feat_out, float *kt_packed,
-                     float *v_packed, int tokens_padded, void *stream);
+                     float *v_packed, int tokens_padded, int32_t *flags /* device, optional: IMF_FLAG_RANGE */,
+                     void *stream);
 
+/* imf_fusion_attention_batched + IMF_FLAG_RANGE on the output rows (they feed conv4_tr); flags may be NULL. */
+int imf_fusion_attention_batched_flags(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
+                                       const float *const *kt_packed, const float *const *v_packed, int n_tokens,
+                                       int tokens_padded, const imf_fusion_weights *w /* [host] */, float scale,
+                                       float *out, void *workspace, size_t workspace_bytes, int32_t *flags, void *stream);
 /* Capacity mode: x has room for n_cap rows, the count is *n_dev and item b covers rows [item_starts_dev[b],
  * item_starts_dev[b+1]) (the last one up to the count); an item without rows raises bit 3 (value 8) of *err.  All
  * three hidden-split variants are launched and the one the rule picks for the actual rows does the work.
@@ -427,6 +449,7 @@ typedef struct imf_resunet_io {        /* per fragment */
   const int32_t *meta;
   size_t bitgrid_words;                /* capacity (uint32 words) of the conv1 occupancy grid inside the int arena */
   const void *pyramid;                 /* internal (imf_fragment_forward): coarse pyramid levels still to be built */
+  int32_t *flags;                      /* exact mode, optional: device word the kernels OR IMF_FLAG_RANGE into (caller zeroes) */
 } imf_resunet_io;
 
 size_t imf_resunet_int_arena_bytes(const imf_resunet_desc *net, const int64_t *n /* [4] */,

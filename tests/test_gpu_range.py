@@ -1,0 +1,122 @@
+"""The f16 range of the split-f16 convolution (variant 6) is guarded, never silent (ADVICE):
+every kernel whose output feeds a variant-6 convolution raises IMF_FLAG_RANGE for NaN / |y| >= 65504, and the
+harness recomputes a flagged fragment on the true-fp32 matrix instructions.  Plus a trained-checkpoint-like weight
+distribution (small kernels, small running variances => large folded BatchNorm scales) through the default path."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import imf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(sd):
+    from imfnet_amd.model import load_model
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3, config=None)
+    m.load_state_dict(sd, strict=True)
+    return m.eval().to(DEV)
+
+
+def test_conv_flags_outputs_beyond_f16(clouds):
+    from imfnet_amd import ops
+    from imfnet_amd import sparse as ME
+    xyz = torch.as_tensor(clouds[0][::3].astype(np.float64)).to(DEV)
+    lv = ops.voxelize(xyz, 0.05)
+    ops.sync_levels([lv])
+    cm = ME.CoordinateManager(lv)
+    rb = cm.conv_rulebook(1, 3, 1)
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(27, 32, 32, generator=g) * 0.05
+    f = torch.randn(lv.n, 32, generator=g)
+    wp = ops.pack_weights(w.to(DEV), split16=True)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.spconv(f.to(DEV), wp, 32, rb, variant=6, flags=flags)
+    assert int(flags.item()) == 0                                        # ordinary magnitudes: silent
+    wbig = ops.pack_weights((w * 10).to(DEV), split16=True)
+    fin = (f.clamp(-3, 3) * 1.5e4).to(DEV)                              # inputs inside the range, outputs beyond it
+    for kw in ({}, {"split_k": 3}):                                      # epilogue and split-K reduce paths
+        flags.zero_()
+        y = ops.spconv(fin, wbig, 32, rb, variant=6, flags=flags, **kw)
+        assert torch.isfinite(y).all() and float(y.abs().max()) > 65504 and int(flags.item()) == 32   # flagged for the consumer
+    flags.zero_()
+    bad = ops.spconv((f * 1e5).to(DEV), wp, 32, rb, variant=6, flags=flags)   # inputs beyond f16: NaN/inf out, flagged
+    assert not torch.isfinite(bad).all() and int(flags.item()) == 32
+    flags.zero_()
+    ok = ops.spconv((f * 1e5).to(DEV), ops.pack_weights(w.to(DEV)), 32, rb, variant=0, flags=flags)
+    assert torch.isfinite(ok).all()                                      # the fp32-MFMA kernel has no such limit
+
+
+def _huge_bottleneck_sd(seeded_sd):
+    """Fusion output ~1e5 (bias of the last feed-forward layer), conv4_tr kernel 1e-5: its inputs leave the f16
+    range while every product stays O(1) -- the un-normalised residual stream the verdict asked to exercise."""
+    sd = {k: v.clone() for k, v in seeded_sd.items()}
+    sd["attention_fusion.cross_attend_blocks.1.fn.net.2.bias"] += 1.0e5
+    sd["conv4_tr.kernel"] *= 1.0e-5
+    return sd
+
+
+def test_out_of_range_fragment_is_recomputed_in_fp32(clouds, images, seeded_sd, monkeypatch):
+    from imfnet_amd.extract import extract_features
+    sd = _huge_bottleneck_sd(seeded_sd)
+    xyz = clouds[0][::4].astype(np.float64)
+    xd_ref, F_ref = O.extract_features(sd, xyz, 0.05, images[0])
+    m = _model(sd)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        xd, F = extract_features(m, xyz, voxel_size=0.05, device=torch.device(DEV), skip_check=True, image=images[0])
+    assert any("f16 range" in str(w.message) for w in rec)
+    assert (xd == xd_ref).all() and torch.isfinite(F).all()
+    assert float((F.cpu() - F_ref).abs().max()) < 1e-4
+    # the model is back on the default kernels afterwards, and a second fragment takes the same route (also via the runner)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        xd, F2 = extract_features(m, xyz, voxel_size=0.05, device=torch.device(DEV), skip_check=True, image=images[0])
+    assert any("f16 range" in str(w.message) for w in rec) and torch.equal(F, F2)
+    # red without the guard: ignoring the flag gives a silently WRONG result (the NaNs of conv4_tr are squashed to
+    # zero by the next ReLU epilogue -- fmaxf(NaN, 0) = 0 -- so the descriptors even look plausible)
+    monkeypatch.setattr(type(m), "take_flags", lambda self, dev: 0)
+    monkeypatch.setenv("IMFNET_NO_FRAGMENT_GRAPH", "1")
+    with torch.no_grad():
+        _, F3 = extract_features(m, xyz, voxel_size=0.05, device=torch.device(DEV), skip_check=True, image=images[0])
+    assert float((F3.cpu() - F_ref).abs().max()) > 1e-3          # 10x the 1e-4 tolerance the guarded path meets
+
+
+def test_capacity_mode_raises_the_range_flag(clouds, images, seeded_sd):
+    from imfnet_amd.model.graph import FragmentRunner
+    m = _model(_huge_bottleneck_sd(seeded_sd))
+    r = FragmentRunner(m)
+    xyz = torch.as_tensor(clouds[0][::4].astype(np.float64)).to(DEV)
+    r.ratios, r.grid_words = [0.2, 0.06, 0.02, 0.006], 1 << 16
+    res = r.run(xyz, [0], torch.as_tensor(images[0]).to(DEV), 0.05, stream=torch.cuda.Stream())
+    assert res.flags & 32
+
+
+def test_checkpoint_like_weight_distribution(clouds, images, seeded_sd):
+    """Small kernels (x0.05) under small running variances (x0.0025: folded scales x20) and wide BatchNorm affine
+    terms -- what a trained checkpoint looks like, unlike the O(1) seeded one.  Default path vs the oracle: 1e-4,
+    no range flag."""
+    from imfnet_amd.extract import extract_features
+    g = torch.Generator().manual_seed(11)
+    sd = {k: v.clone() for k, v in seeded_sd.items()}
+    for k in list(sd):
+        sparse = not k.startswith("img_encoder") and not k.startswith("attention_fusion")
+        if k.endswith(".kernel") and sparse and k != "final.kernel":
+            sd[k] *= 0.05
+        elif k.endswith("running_var") and sparse:
+            sd[k] *= 0.0025
+        elif k.endswith("running_mean") and sparse:
+            sd[k] *= 0.05
+        elif k.endswith("bn.weight") and sparse:
+            sd[k] = sd[k] * torch.empty_like(sd[k]).uniform_(0.2, 3.0, generator=g)
+    xyz = clouds[1][::2].astype(np.float64)
+    xd_ref, F_ref = O.extract_features(sd, xyz, 0.05, images[1])
+    m = _model(sd)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        xd, F = extract_features(m, xyz, voxel_size=0.05, device=torch.device(DEV), skip_check=True, image=images[1])
+    assert not any("f16 range" in str(w.message) for w in rec)
+    assert (xd == xd_ref).all() and float((F.cpu() - F_ref).abs().max()) < 1e-4
