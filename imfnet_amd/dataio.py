@@ -76,9 +76,39 @@ def process_image(image, aim_H=480, aim_W=640, mode="resize", clip_mode="center"
         return img
     if mode != "resize":
         raise NotImplementedError("only mode='resize' is on the descriptor-generation path (SURVEY §8a H2)")
+    if img.dtype == np.uint8:
+        # cv2.resize on 8-bit input (the .jpg branch of generate_desc.py:88-95) interpolates in fixed point and returns
+        # uint8: 11-bit coefficients, result rounded to the nearest integer (OpenCV resize.cpp, INTER_RESIZE_COEF_BITS = 11;
+        # [RECALLED], within 1 LSB of every OpenCV code path).  The reference then casts to float32 0..255.
+        return _resize_linear_u8(img, aim_H, aim_W)
     t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).permute(2, 0, 1)[None]
     out = F.interpolate(t, size=(aim_H, aim_W), mode="bilinear", align_corners=False)
     return out[0].permute(1, 2, 0).contiguous().numpy()
+
+
+def _linear_taps(n_in, n_out, bits=11):
+    """Source index pairs and fixed-point weights of cv2's INTER_LINEAR along one axis (half-pixel centres, edge clamp)."""
+    scale = n_in / n_out
+    f = (np.arange(n_out) + 0.5) * scale - 0.5
+    i0 = np.floor(f).astype(np.int64)
+    frac = f - i0
+    frac = np.where(i0 < 0, 0.0, frac)
+    i0 = np.clip(i0, 0, n_in - 1)
+    i1 = np.minimum(i0 + 1, n_in - 1)
+    frac = np.where(i0 >= n_in - 1, 0.0, frac)
+    w1 = np.rint(frac * (1 << bits)).astype(np.int64)
+    return i0, i1, (1 << bits) - w1, w1
+
+
+def _resize_linear_u8(img, aim_H, aim_W):
+    H, W, _ = img.shape
+    y0, y1, b0, b1 = _linear_taps(H, aim_H)
+    x0, x1, a0, a1 = _linear_taps(W, aim_W)
+    src = img.astype(np.int64)
+    rows0 = src[y0][:, x0] * a0[None, :, None] + src[y0][:, x1] * a1[None, :, None]     # horizontal pass, scale 2^11
+    rows1 = src[y1][:, x0] * a0[None, :, None] + src[y1][:, x1] * a1[None, :, None]
+    out = (rows0 * b0[:, None, None] + rows1 * b1[:, None, None] + (1 << 21)) >> 22        # vertical pass, round
+    return np.clip(out, 0, 255).astype(np.uint8)
 
 
 def image_to_nchw(image):

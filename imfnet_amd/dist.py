@@ -68,20 +68,30 @@ def gather_blocks(block, dst=0, group=None):
     return out
 
 
-def gather_fragment_descriptors(results, n_fragments, shards, dst=0):
+def _collective_device():
+    """Where tensors of a collective must live: the rank's GPU under the nccl (RCCL) backend, the host under gloo."""
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_fragment_descriptors(results, n_fragments, shards, dst=0, device=None, dtype=torch.float32):
     """results: {fragment index: F [M_i, D]} computed by this rank (its shard).  Gathers every
     rank's blocks to `dst` and returns {fragment index: F} for ALL fragments there (None elsewhere).
-    One count exchange + one block exchange per rank, independent of the number of fragments."""
+    One count exchange + one block exchange per rank, independent of the number of fragments.
+    A rank whose shard is empty (more ranks than fragments) still takes part, on `device` (default: the backend's)."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = shards[rank]
-    dev = next(iter(results.values())).device if results else torch.device("cpu")
+    dev = device if device is not None else (next(iter(results.values())).device if results else _collective_device())
+    if results:
+        dtype = next(iter(results.values())).dtype
     D = next(iter(results.values())).shape[1] if results else 0
     if dist.is_initialized() and dist.get_world_size() > 1:
         d = torch.tensor([D], dtype=torch.int64, device=dev)
         dist.all_reduce(d, op=dist.ReduceOp.MAX)
         D = int(d.item())
     rows = torch.tensor([[results[i].shape[0]] for i in mine], dtype=torch.int64, device=dev).reshape(-1, 1)
-    feats = torch.cat([results[i] for i in mine], 0) if mine else torch.empty((0, D), device=dev)
+    feats = torch.cat([results[i] for i in mine], 0).to(dev) if mine else torch.empty((0, D), dtype=dtype, device=dev)
     all_rows = gather_blocks(rows, dst)
     all_feats = gather_blocks(feats, dst)
     if all_rows is None:

@@ -94,9 +94,35 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._img_plan = None             # native image branch (model/image_plan.py, csrc/image.hip)
         self._runner = None               # whole-fragment capacity-mode / hipGraph runner (model/graph.py)
         self._flag_words = {}             # device -> int32[1]: IMF_FLAG_* bits OR-ed by the kernels (sticky)
+        self._fp_tensors, self._fp_value = None, None   # parameter / buffer version fingerprint (see _stale)
         self.image_branch_mode = None     # how the last image branch ran: native-hip | torch-graph | torch-eager
 
     # ---- folded BatchNorm cache (eval) ----------------------------------------------------------
+    def _stale(self):
+        """In-place edits of parameters / buffers (optimizer step in eval mode, submodule.load_state_dict,
+        param.data.copy_, BatchNorm statistics set by hand) bump the tensors' version counters: the folded
+        BatchNorm terms, packed weights and plans (which hold raw pointers) are rebuilt when the sum moves."""
+        ts = self._fp_tensors
+        if ts is None:
+            ts = self._fp_tensors = list(self.parameters()) + list(self.buffers())
+        v = 0
+        for t in ts:
+            v += t._version
+        if v != self._fp_value:
+            stale = self._fp_value is not None
+            self._fp_value = v
+            return stale
+        return False
+
+    def invalidate(self):
+        """Drop every derived copy of the parameters (folded BatchNorm, packed weights, plans, captured graphs).
+        Needed only after edits torch cannot see -- `param.data.<op>_()`; everything else is detected (see _stale)."""
+        self._invalidate()
+
+    def _refresh(self):
+        if self._stale():
+            self._invalidate()
+
     def _invalidate(self):
         self._plan = None
         self._native_plan = None
@@ -109,6 +135,7 @@ class ResUNet2(ME.MinkowskiNetwork):
 
     def _apply(self, fn, *a, **k):
         self._invalidate()
+        self._fp_tensors = self._fp_value = None      # .to() / .cuda() replace the tensors
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -155,6 +182,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         for the main stream.  Returns the device tensor to hand to forward()."""
         if not self._can_fuse():
             return None
+        self._refresh()
         on_device = torch.is_tensor(image) and image.is_cuda
         dev = image.device if on_device else torch.device(device if device is not None else "cuda")
         side = self._side.get(dev)
@@ -237,6 +265,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         configuration is not covered (training mode, non-BatchNorm blocks, per-point input features, ...)."""
         if os.environ.get("IMFNET_NO_FRAGMENT_GRAPH") or not self._can_fuse():
             return None
+        self._refresh()
         if self._runner is None:
             try:
                 if next(self.parameters()).device.type != "cuda":
@@ -303,6 +332,8 @@ class ResUNet2(ME.MinkowskiNetwork):
     def forward(self, x, image):
         if not self._can_fuse():
             return self.forward_layers(x, image)
+        if self._pending_image is None:
+            self._refresh()
         bn = self._bn()
         pend, self._pending_image = self._pending_image, None
         kv = None

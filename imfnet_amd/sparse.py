@@ -263,6 +263,10 @@ class _ConvBase(nn.Module):
 
     def run(self, x, in_b=None, scale=None, shift=None, residual=None, relu=False, l2norm=False):
         """Fused convolution on raw feature matrices; returns (features, output tensor stride)."""
+        if torch.is_grad_enabled() and self.kernel.requires_grad:
+            # the kernels have no backward: fail loudly instead of silently cutting the graph at every convolution
+            raise ImfError("imfnet_amd is inference-only (no sparse-convolution backward): run under torch.no_grad() "
+                           "or model.requires_grad_(False)")
         rb, ts_out = self.rulebook(x)
         feat = x.F
         cin = feat.shape[1] + (0 if in_b is None else in_b.shape[1])

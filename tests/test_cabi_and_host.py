@@ -198,3 +198,31 @@ def test_c_restatement_equals_numpy_oracle(clouds):
     for a, b in zip(g.levels + [g.k_first] + g.k3 + g.down + g.up,
                     g2.levels + [g2.k_first] + g2.k3 + g2.down + g2.up):
         assert (a == b).all()
+
+
+def test_resize_uint8_rounds_like_cv2():
+    """process_image on 8-bit input (the .jpg branch, generate_desc.py:88-95): fixed-point bilinear, uint8 out --
+    within 0.5 of the float interpolation, exact on a 2x down-sample of even blocks, identity when already sized."""
+    from imfnet_amd.dataio import process_image
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    out = process_image(img, aim_H=12, aim_W=16)
+    assert out.dtype == np.uint8 and out.shape == (12, 16, 3)
+    ref = process_image(img.astype(np.float32), aim_H=12, aim_W=16)
+    assert np.abs(out.astype(np.float32) - ref).max() <= 0.5 + 1e-3
+    half = process_image(img, aim_H=24, aim_W=32).astype(np.int64)
+    blk = img.astype(np.int64).reshape(24, 2, 32, 2, 3).sum((1, 3))
+    assert (half == (blk + 2) // 4).all()                                # centre average of 2x2 blocks, rounded
+    assert process_image(img, aim_H=48, aim_W=64) is img
+    up = process_image(img, aim_H=96, aim_W=128)
+    assert up.dtype == np.uint8 and (up[0, 0] == img[0, 0]).all() and (up[-1, -1] == img[-1, -1]).all()
+
+
+def test_conv_refuses_autograd():
+    """No backward is implemented: a convolution whose kernel requires grad must fail loudly under autograd."""
+    import torch
+    from imfnet_amd import sparse as ME
+    from imfnet_amd._lib import ImfError
+    conv = ME.MinkowskiConvolution(32, 32, kernel_size=3, stride=1, dilation=1, bias=False, dimension=3)
+    with pytest.raises(ImfError, match="inference-only"):
+        conv.run(None)

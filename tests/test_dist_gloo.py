@@ -65,6 +65,29 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_more_ranks(rank, world, port, out_dir):
+    """More ranks than fragments: the ranks with an empty shard still take part in both exchanges."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from imfnet_amd import dist as idist
+    idist.init_from_env("gloo")
+    shards = idist.shard_fragments([5, 9], world)
+    assert sum(1 for s in shards if not s) == world - 2
+    mine = {i: torch.full((i + 3, 32), float(i)) for i in shards[rank]}
+    got = idist.gather_fragment_descriptors(mine, 2, shards, dst=0)
+    if rank == 0:
+        assert sorted(got) == [0, 1] and got[0].shape == (3, 32) and float(got[1].mean()) == 1.0
+        np.save(os.path.join(out_dir, "ok2.npy"), np.array([1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_with_more_ranks_than_fragments(tmp_path):
+    mp.spawn(_worker_more_ranks, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert os.path.exists(tmp_path / "ok2.npy")
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_gather_over_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)

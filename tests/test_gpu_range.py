@@ -120,3 +120,32 @@ def test_checkpoint_like_weight_distribution(clouds, images, seeded_sd):
         xd, F = extract_features(m, xyz, voxel_size=0.05, device=torch.device(DEV), skip_check=True, image=images[1])
     assert not any("f16 range" in str(w.message) for w in rec)
     assert (xd == xd_ref).all() and float((F.cpu() - F_ref).abs().max()) < 1e-4
+
+
+def test_in_place_parameter_edits_invalidate_the_plans(clouds, images, seeded_sd):
+    """packed weights / folded BatchNorm / native plans hold raw copies; an in-place edit in eval mode
+    (param.data.copy_, running statistics set by hand, submodule.load_state_dict) must be picked up."""
+    from imfnet_amd.extract import extract_features
+    m = _model(seeded_sd)
+    xyz = clouds[0][::6].astype(np.float64)
+    run = lambda: extract_features(m, xyz, voxel_size=0.05, device=torch.device(DEV), skip_check=True, image=images[0])[1].clone()
+    with torch.no_grad():
+        F0 = run()
+        assert torch.equal(run(), F0)
+        m.block2.conv1.kernel.mul_(1.5)                            # a sparse-conv kernel (in place, under no_grad)
+        F1 = run()
+        m.norm3.bn.running_var.mul_(2.0)                           # a BatchNorm buffer
+        F2 = run()
+        m.img_encoder.backbone.layer1[0].conv1.weight.data.mul_(0.5)   # `.data` edits bypass torch's version counters:
+        m.invalidate()                                                  # ... they need the explicit call
+        F3 = run()
+    sd = {k: v.clone() for k, v in seeded_sd.items()}
+    sd["block2.conv1.kernel"] = sd["block2.conv1.kernel"] * 1.5
+    _, R1 = O.extract_features(sd, xyz, 0.05, images[0])
+    sd["norm3.bn.running_var"] = sd["norm3.bn.running_var"] * 2.0
+    _, R2 = O.extract_features(sd, xyz, 0.05, images[0])
+    sd["img_encoder.backbone.layer1.0.conv1.weight"] = sd["img_encoder.backbone.layer1.0.conv1.weight"] * 0.5
+    _, R3 = O.extract_features(sd, xyz, 0.05, images[0])
+    assert float((F1.cpu() - R1).abs().max()) < 1e-4 and float((F1 - F0).abs().max()) > 1e-3
+    assert float((F2.cpu() - R2).abs().max()) < 1e-4 and float((F2 - F1).abs().max()) > 1e-3
+    assert float((F3.cpu() - R3).abs().max()) < 1e-4 and not torch.equal(F3, F2)
