@@ -125,6 +125,8 @@ _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
 SIGNATURES = {
     "imf_version": (_I, []),
     "imf_last_error": (C.c_char_p, []),
+    "imf_stream_create": (_P, []),
+    "imf_stream_destroy": (None, [_P]),
     "imf_event_create": (_P, []),
     "imf_event_destroy": (None, [_P]),
     "imf_event_elapsed_ms": (C.c_float, [_P, _P]),

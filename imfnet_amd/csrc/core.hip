@@ -25,6 +25,15 @@ void *imf_event_create(void) {
 void imf_event_destroy(void *ev) {
   if (ev) (void)hipEventDestroy((hipEvent_t)ev);
 }
+/* Streams owned by the library's callers but created here: a framework's stream pool may hand the same stream out
+ * twice (torch.cuda.Stream() wraps around after 32), and imf_fragment_forward needs three DISTINCT ones. */
+void *imf_stream_create(void) {
+  hipStream_t s = nullptr;
+  return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? (void *)s : nullptr;
+}
+void imf_stream_destroy(void *s) {
+  if (s) (void)hipStreamDestroy((hipStream_t)s);
+}
 float imf_event_elapsed_ms(void *b, void *e) {
   float ms = -1.f;
   if (!b || !e || hipEventElapsedTime(&ms, (hipEvent_t)b, (hipEvent_t)e) != hipSuccess) return -1.f;

@@ -18,12 +18,18 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # single-GPU stand-in for a multi-GPU node (tests, tools/emulate_3dmatch.py): IMF_DIST_BACKEND=gloo
+    # IMF_FORCE_DEVICE=0 runs N ranks on one device
+    backend = os.environ.get("IMF_DIST_BACKEND", backend)
+    forced = os.environ.get("IMF_FORCE_DEVICE")
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl" and "IMF_FORCE_DEVICE" not in os.environ:
+        if backend == "nccl" and forced is None:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if forced is not None:
+        local = int(forced)
     return rank, world, local
 
 

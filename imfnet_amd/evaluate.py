@@ -98,8 +98,10 @@ def register_fragment_pair(data_i, data_j, gt_pose, covariance, voxel_size, num_
         trans = run_ransac(frag1_kpts, frag2_kpts, frag1_descs, frag2_descs, voxel_size, ransac_n=3, seed=seed,
                            device=device)
     else:
-        trans = np.linalg.inv(run_ransac(frag2_kpts, frag1_kpts, frag2_descs, frag1_descs, voxel_size, ransac_n=3,
-                                         seed=seed, device=device))
+        t21 = run_ransac(frag2_kpts, frag1_kpts, frag2_descs, frag1_descs, voxel_size, ransac_n=3, seed=seed, device=device)
+        trans = np.linalg.inv(t21) if np.isfinite(t21).all() and abs(np.linalg.det(t21)) > 1e-9 else np.eye(4)
+    if not np.isfinite(trans).all() or abs(np.linalg.det(trans)) < 1e-9:
+        trans = np.eye(4)                       # degenerate winning hypothesis (collinear sample): a failed registration
     es_T = np.linalg.inv(trans)
     accepted = compute_transform_error(gt_pose, covariance, es_T) < 0.2 ** 2
     rr, rre, rte = 0, 0, 0

@@ -163,13 +163,14 @@ def main(argv=None):
     else:
         assert args.seeded_weights is not None, "give --model or --seeded_weights"
         state_dict, config = None, Config()
+    if state_dict is None:
+        torch.manual_seed(args.seeded_weights)            # before construction: every rank must build the same network
     Model = load_model(config.model)
     model = Model(1, config.model_n_out, bn_momentum=0.05, normalize_feature=config.normalize_feature,
                   conv1_kernel_size=config.conv1_kernel_size, D=3, config=config)
     if state_dict is not None:
         model.load_state_dict(state_dict)
     else:
-        torch.manual_seed(args.seeded_weights)
         for m in model.modules():
             if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
                 m.running_var.uniform_(0.5, 1.5)

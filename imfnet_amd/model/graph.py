@@ -109,7 +109,6 @@ class _Bucket:
         self.farena = u8(L.imf_resunet_float_arena_bytes_cap(C.byref(net), rows_c))
         self.out = torch.empty((rows[0], net.out_channels), dtype=torch.float32, device=dev)
         self.events = [L.imf_event_create() for _ in range(11)]
-        self.side, self.imgs = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         io = self.io = FragmentIO()
         io.xyz, io.xyz_is_f64, io.voxel_size = self.xyz.data_ptr(), int(is_f64), float(voxel)
         io.dyn, io.image, io.meta = self.dyn.data_ptr(), self.image.data_ptr(), self.meta.data_ptr()
@@ -121,7 +120,7 @@ class _Bucket:
         io.out = self.out.data_ptr()
         for i, e in enumerate(self.events):
             io.events[i] = e
-        io.side_stream, io.image_stream = self.side.cuda_stream, self.imgs.cuda_stream
+        io.side_stream, io.image_stream = runner.raw_streams(dev)
         io.trace = None
         self.graph = C.c_void_p()
         self.n_nodes = 0
@@ -191,6 +190,7 @@ class FragmentRunner:
         self.grid_words = 0           # largest conv1 bit grid seen
         self.buckets = {}
         self._own = {}
+        self._raw = {}
         # hipGraph replay is opt-in: ROCm 7.2 runs a graph's independent branches back to back (measured 1.77 vs
         # 1.37 ms per fragment pair), the eager capacity-mode call keeps the three streams concurrent
         self.use_graph = bool(os.environ.get("IMFNET_FRAGMENT_GRAPH"))
@@ -215,6 +215,17 @@ class FragmentRunner:
             prev = c
         gw = _grid_up(self.grid_words * 1.5, 2.0, 1 << 18)
         return (npc, tuple(rows), n_items, H, W, gw, float(voxel), bool(is_f64))
+
+    def raw_streams(self, dev):
+        """(side, image) hipStream_t of this device, created through the library: torch's stream pool wraps around
+        after 32 streams and would eventually hand out the main stream again."""
+        s = self._raw.get(dev)
+        if s is None:
+            with torch.cuda.device(dev):
+                s = self._raw[dev] = (self.L.imf_stream_create(), self.L.imf_stream_create())
+            if not (s[0] and s[1]):
+                raise ImfError("could not create the side / image streams")
+        return s
 
     def bucket(self, key, dev, stream=None):
         b = self.buckets.get(key)

@@ -562,6 +562,8 @@ int imf_ransac_registration(const double *src, int64_t n_src, const double *dst,
                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* Measurement helpers (bench.py): HIP events on the caller's stream. */
+void *imf_stream_create(void);     /* non-blocking hipStream_t, distinct from any framework pool stream */
+void imf_stream_destroy(void *stream);
 void *imf_event_create(void);
 void imf_event_destroy(void *ev);
 float imf_event_elapsed_ms(void *ev_begin, void *ev_end);   /* < 0 on error (e.g. not completed) */
