@@ -125,6 +125,13 @@ _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
 SIGNATURES = {
     "imf_version": (_I, []),
     "imf_last_error": (C.c_char_p, []),
+    "imf_ply_vertex_count": (_L, [C.c_char_p]),
+    "imf_ply_read_points": (_L, [C.c_char_p, _P, _L]),
+    "imf_png_info": (_I, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "imf_png_read_f32": (_I, [C.c_char_p, _P, _L, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "imf_resize_bilinear_f32": (_I, [_P, _I, _I, _I, _P, _I, _I, _I]),
+    "imf_npz_write": (_I, [C.c_char_p, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
+                           C.POINTER(C.c_int64), C.POINTER(C.c_void_p), _I]),
     "imf_stream_create": (_P, []),
     "imf_stream_destroy": (None, [_P]),
     "imf_event_create": (_P, []),

@@ -1,0 +1,357 @@
+// Host-side codecs of the batch path (host code only, no kernels): what the reference does with
+// Open3D / matplotlib / OpenCV / numpy around every fragment (scripts/generate_desc.py:83-97,118-123):
+//   imf_ply_read_points   o3d.io.read_point_cloud + np.array(pcd.points)          (:83,102)
+//   imf_png_read_f32      matplotlib.image.imread of a .png: float32 [0,1] HWC     (:92)
+//   imf_resize_bilinear   cv2.resize(INTER_LINEAR) on float images (util/uio.py:33-40)
+//   imf_npz_write         np.savez_compressed(points, xyz, feature)               (:118-123)
+// The python equivalents (dataio.py: a numpy structured read, PIL, torch interpolate, numpy's zlib level 6) capped
+// the CLI at ~40 fragments/s -- a 30th of the GPU's rate -- mostly in the level-6 deflate of ~10 MB per fragment.
+// Here: one pass over the PLY body, an inflate + unfilter PNG decoder, and a ZIP writer that stores the arrays either
+// uncompressed or with a fast raw deflate (zlib level 1); np.load reads both, the arrays are identical.
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace imf {
+namespace {
+
+struct File {
+  FILE *f = nullptr;
+  explicit File(const char *path, const char *mode) { f = fopen(path, mode); }
+  ~File() { if (f) fclose(f); }
+};
+
+int ply_type_size(const char *t, bool &is_float) {
+  is_float = false;
+  if (!strcmp(t, "char") || !strcmp(t, "uchar") || !strcmp(t, "int8") || !strcmp(t, "uint8")) return 1;
+  if (!strcmp(t, "short") || !strcmp(t, "ushort") || !strcmp(t, "int16") || !strcmp(t, "uint16")) return 2;
+  if (!strcmp(t, "int") || !strcmp(t, "uint") || !strcmp(t, "int32") || !strcmp(t, "uint32")) return 4;
+  if (!strcmp(t, "float") || !strcmp(t, "float32")) { is_float = true; return 4; }
+  if (!strcmp(t, "double") || !strcmp(t, "float64")) { is_float = true; return 8; }
+  return 0;
+}
+
+inline uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
+
+inline int paeth(int a, int b, int c) {
+  const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+void put16(std::vector<unsigned char> &v, uint32_t x) { v.push_back(x & 255); v.push_back((x >> 8) & 255); }
+void put32(std::vector<unsigned char> &v, uint32_t x) { put16(v, x & 0xFFFF); put16(v, x >> 16); }
+
+}  // namespace
+}  // namespace imf
+
+using namespace imf;
+
+extern "C" {
+
+/* Vertex count of a PLY file (header only), < 0 on error. */
+int64_t imf_ply_vertex_count(const char *path) {
+  File fh(path, "rb");
+  if (!fh.f) { set_error("imf_ply_vertex_count: cannot open %s", path); return IMF_EINVAL; }
+  char line[512];
+  while (fgets(line, sizeof(line), fh.f)) {
+    long long n;
+    if (sscanf(line, "element vertex %lld", &n) == 1) return n;
+    if (!strncmp(line, "end_header", 10)) break;
+  }
+  set_error("imf_ply_vertex_count: no vertex element in %s", path);
+  return IMF_EINVAL;
+}
+
+/* x, y, z of every vertex as float64 [n,3] (Open3D widens float vertices to double).  ascii, binary_little_endian and
+ * binary_big_endian; any scalar properties beside x/y/z are skipped; list properties in the vertex element are an error.
+ * Returns the number of vertices written (<= capacity) or a negative IMF_E* code. */
+int64_t imf_ply_read_points(const char *path, double *out, int64_t capacity) {
+  IMF_REQUIRE(path && out, "imf_ply_read_points: null pointer");
+  File fh(path, "rb");
+  IMF_REQUIRE(fh.f, "imf_ply_read_points: cannot open %s (%s)", path, strerror(errno));
+  char line[512], a[64], b[64], c[64];
+  IMF_REQUIRE(fgets(line, sizeof(line), fh.f) && !strncmp(line, "ply", 3), "imf_ply_read_points: %s is not a PLY file", path);
+  int fmt = -1;   // 0 ascii, 1 little, 2 big
+  long long n = -1;
+  bool in_vertex = false, header_done = false;
+  struct Prop { int size; bool is_float; int axis; };
+  std::vector<Prop> props;
+  while (fgets(line, sizeof(line), fh.f)) {
+    if (sscanf(line, "format %63s", a) == 1) {
+      fmt = !strcmp(a, "ascii") ? 0 : (!strcmp(a, "binary_little_endian") ? 1 : (!strcmp(a, "binary_big_endian") ? 2 : -1));
+    } else if (sscanf(line, "element %63s %63s", a, b) == 2) {
+      in_vertex = !strcmp(a, "vertex");
+      if (in_vertex) n = atoll(b);
+    } else if (in_vertex && sscanf(line, "property %63s %63s %63s", a, b, c) >= 2) {
+      IMF_REQUIRE(strcmp(a, "list"), "imf_ply_read_points: list property in the vertex element of %s", path);
+      Prop p;
+      p.size = ply_type_size(a, p.is_float);
+      IMF_REQUIRE(p.size > 0, "imf_ply_read_points: unknown property type '%s' in %s", a, path);
+      p.axis = !strcmp(b, "x") ? 0 : (!strcmp(b, "y") ? 1 : (!strcmp(b, "z") ? 2 : -1));
+      props.push_back(p);
+    } else if (!strncmp(line, "end_header", 10)) {
+      header_done = true;
+      break;
+    }
+  }
+  IMF_REQUIRE(header_done && fmt >= 0 && n >= 0, "imf_ply_read_points: malformed header in %s", path);
+  IMF_REQUIRE(n <= capacity, "imf_ply_read_points: %lld vertices exceed the capacity %lld", n, (long long)capacity);
+  int have = 0, stride = 0;
+  for (const Prop &p : props) {
+    if (p.axis >= 0) {
+      have |= 1 << p.axis;
+      IMF_REQUIRE(p.is_float, "imf_ply_read_points: x/y/z must be float or double in %s", path);
+    }
+    stride += p.size;
+  }
+  IMF_REQUIRE(have == 7, "imf_ply_read_points: the vertex element of %s has no x/y/z", path);
+  if (fmt == 0) {
+    for (long long i = 0; i < n; ++i) {
+      for (const Prop &p : props) {
+        double v;
+        IMF_REQUIRE(fscanf(fh.f, "%lf", &v) == 1, "imf_ply_read_points: truncated ascii body in %s", path);
+        if (p.axis >= 0) out[3 * i + p.axis] = v;
+      }
+    }
+    return n;
+  }
+  std::vector<unsigned char> body((size_t)n * stride);
+  IMF_REQUIRE(fread(body.data(), 1, body.size(), fh.f) == body.size(), "imf_ply_read_points: truncated body in %s", path);
+  const bool swap = fmt == 2;
+  int off = 0;
+  for (const Prop &p : props) {
+    if (p.axis >= 0) {
+      const unsigned char *src = body.data() + off;
+      for (long long i = 0; i < n; ++i, src += stride) {
+        unsigned char tmp[8];
+        if (swap) for (int k = 0; k < p.size; ++k) tmp[k] = src[p.size - 1 - k];
+        else memcpy(tmp, src, p.size);
+        if (p.size == 4) { float v; memcpy(&v, tmp, 4); out[3 * i + p.axis] = (double)v; }
+        else { double v; memcpy(&v, tmp, 8); out[3 * i + p.axis] = v; }
+      }
+    }
+    off += p.size;
+  }
+  return n;
+}
+
+/* PNG header: height, width, channels (1, 2, 3 or 4 after palette expansion).  0 on success. */
+int imf_png_info(const char *path, int *h, int *w, int *channels) {
+  IMF_REQUIRE(path && h && w && channels, "imf_png_info: null pointer");
+  File fh(path, "rb");
+  IMF_REQUIRE(fh.f, "imf_png_info: cannot open %s", path);
+  unsigned char hd[33];
+  IMF_REQUIRE(fread(hd, 1, 33, fh.f) == 33 && !memcmp(hd, "\x89PNG\r\n\x1a\n", 8) && !memcmp(hd + 12, "IHDR", 4),
+              "imf_png_info: %s is not a PNG file", path);
+  *w = (int)be32(hd + 16); *h = (int)be32(hd + 20);
+  const int ct = hd[25];
+  *channels = ct == 0 ? 1 : (ct == 2 ? 3 : (ct == 3 ? 3 : (ct == 4 ? 2 : 4)));
+  return IMF_OK;
+}
+
+/* matplotlib.image.imread semantics for .png: float32 in [0,1], [H,W,C] (8-bit samples / 255, 16-bit / 65535; palette
+ * images expanded to RGB).  Non-interlaced files with 8- or 16-bit samples (the data sets' colour images); anything
+ * else returns IMF_EUNSUPPORTED and the caller falls back to its generic decoder. */
+int imf_png_read_f32(const char *path, float *out, int64_t capacity_floats, int *h_out, int *w_out, int *c_out) {
+  IMF_REQUIRE(path && out && h_out && w_out && c_out, "imf_png_read_f32: null pointer");
+  File fh(path, "rb");
+  IMF_REQUIRE(fh.f, "imf_png_read_f32: cannot open %s", path);
+  fseek(fh.f, 0, SEEK_END);
+  const long size = ftell(fh.f);
+  fseek(fh.f, 0, SEEK_SET);
+  std::vector<unsigned char> buf((size_t)size);
+  IMF_REQUIRE(size > 33 && fread(buf.data(), 1, buf.size(), fh.f) == buf.size() && !memcmp(buf.data(), "\x89PNG\r\n\x1a\n", 8),
+              "imf_png_read_f32: %s is not a PNG file", path);
+  int W = 0, H = 0, depth = 0, ct = 0, interlace = 0;
+  std::vector<unsigned char> idat, plte;
+  size_t pos = 8;
+  while (pos + 12 <= buf.size()) {
+    const uint32_t len = be32(&buf[pos]);
+    const unsigned char *type = &buf[pos + 4], *data = &buf[pos + 8];
+    if (pos + 12 + len > buf.size()) break;
+    if (!memcmp(type, "IHDR", 4)) { W = be32(data); H = be32(data + 4); depth = data[8]; ct = data[9]; interlace = data[12]; }
+    else if (!memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
+    else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+    else if (!memcmp(type, "IEND", 4)) break;
+    pos += 12 + len;
+  }
+  if (interlace != 0 || (depth != 8 && depth != 16) || (ct == 3 && depth != 8)) {
+    set_error("imf_png_read_f32: %s: interlaced / sub-byte PNG not handled natively", path);
+    return IMF_EUNSUPPORTED;
+  }
+  const int samples = ct == 0 ? 1 : (ct == 2 ? 3 : (ct == 3 ? 1 : (ct == 4 ? 2 : 4)));
+  const int C = ct == 3 ? 3 : samples;
+  IMF_REQUIRE(W > 0 && H > 0 && (ct == 0 || ct == 2 || ct == 3 || ct == 4 || ct == 6), "imf_png_read_f32: bad IHDR in %s", path);
+  IMF_REQUIRE((int64_t)H * W * C <= capacity_floats, "imf_png_read_f32: %dx%dx%d exceeds the capacity", H, W, C);
+  const int bpp = samples * depth / 8;                         // bytes per pixel
+  const size_t row = (size_t)W * bpp;
+  std::vector<unsigned char> raw((row + 1) * H);
+  uLongf raw_len = (uLongf)raw.size();
+  IMF_REQUIRE(uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) == Z_OK && raw_len == raw.size(),
+              "imf_png_read_f32: corrupt image data in %s", path);
+  std::vector<unsigned char> prev(row, 0), cur(row);
+  for (int y = 0; y < H; ++y) {
+    const unsigned char *src = &raw[(row + 1) * y];
+    const int ft = src[0];
+    ++src;
+    for (size_t i = 0; i < row; ++i) {
+      const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+      int v = src[i];
+      switch (ft) {
+        case 0: break;
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) >> 1; break;
+        case 4: v += paeth(a, b, c); break;
+        default: set_error("imf_png_read_f32: bad filter type in %s", path); return IMF_EINVAL;
+      }
+      cur[i] = (unsigned char)v;
+    }
+    float *dst = out + (size_t)y * W * C;
+    if (ct == 3) {
+      for (int x = 0; x < W; ++x) {
+        const size_t e = (size_t)cur[x] * 3;
+        for (int k = 0; k < 3; ++k) dst[3 * x + k] = e + k < plte.size() ? plte[e + k] / 255.f : 0.f;
+      }
+    } else if (depth == 8) {
+      for (size_t i = 0; i < row; ++i) dst[i] = cur[i] / 255.f;   // a correctly rounded divide, as numpy's
+    } else {
+      for (size_t i = 0; i < (size_t)W * samples; ++i) dst[i] = (float)((cur[2 * i] << 8) | cur[2 * i + 1]) / 65535.f;
+    }
+    prev.swap(cur);
+  }
+  *h_out = H; *w_out = W; *c_out = C;
+  return IMF_OK;
+}
+
+/* cv2.resize(image, (W_out, H_out), INTER_LINEAR) for float images [H,W,C] -> [H_out,W_out,C]: bilinear with
+ * half-pixel centres, edge clamp, no anti-aliasing (util/uio.py:33-40).  chw != 0 writes [C,H_out,W_out] (the
+ * transposes of generate_desc.py:96-97 folded in). */
+int imf_resize_bilinear_f32(const float *in, int H, int W, int C, float *out, int H_out, int W_out, int chw) {
+  IMF_REQUIRE(in && out && H > 0 && W > 0 && C > 0 && H_out > 0 && W_out > 0, "imf_resize_bilinear_f32: bad argument");
+  const float sy = (float)H / H_out, sx = (float)W / W_out;
+  std::vector<int> x0(W_out), x1(W_out);
+  std::vector<float> fx(W_out);
+  for (int x = 0; x < W_out; ++x) {
+    float f = (x + 0.5f) * sx - 0.5f;
+    if (f < 0.f) f = 0.f;
+    int i = (int)f;
+    if (i > W - 1) i = W - 1;
+    x0[x] = i; x1[x] = i + 1 < W ? i + 1 : W - 1; fx[x] = f - (float)i;
+  }
+  for (int y = 0; y < H_out; ++y) {
+    float f = (y + 0.5f) * sy - 0.5f;
+    if (f < 0.f) f = 0.f;
+    int i = (int)f;
+    if (i > H - 1) i = H - 1;
+    const int y1 = i + 1 < H ? i + 1 : H - 1;
+    const float fy = f - (float)i;
+    const float *r0 = in + (size_t)i * W * C, *r1 = in + (size_t)y1 * W * C;
+    for (int x = 0; x < W_out; ++x) {
+      for (int c = 0; c < C; ++c) {
+        const float a = r0[x0[x] * C + c], b = r0[x1[x] * C + c], d = r1[x0[x] * C + c], e = r1[x1[x] * C + c];
+        const float top = a + (b - a) * fx[x], bot = d + (e - d) * fx[x];
+        const float v = top + (bot - top) * fy;
+        if (chw) out[((size_t)c * H_out + y) * W_out + x] = v;
+        else out[((size_t)y * W_out + x) * C + c] = v;
+      }
+    }
+  }
+  return IMF_OK;
+}
+
+/* np.savez / np.savez_compressed replacement: a ZIP archive of .npy members (format 1.0 headers, C order).
+ * names[i]: member name without ".npy"; dtype[i]: numpy descr string ("<f8", "<f4", "<i4", ...); shape: ndim[i] dims each,
+ * concatenated; data[i]: host pointers; level: 0 = stored (np.savez), 1..9 = raw deflate at that zlib level
+ * (np.savez_compressed uses 6; 1 is ~4x faster for a few percent more bytes).  np.load reads either; the arrays are
+ * identical.  Members must stay below 4 GiB (no ZIP64). */
+int imf_npz_write(const char *path, int n_arrays, const char *const *names, const char *const *dtype, const int32_t *ndim,
+                  const int64_t *shape, const void *const *data, int level) {
+  IMF_REQUIRE(path && names && dtype && ndim && shape && data && n_arrays > 0 && level >= 0 && level <= 9,
+              "imf_npz_write: bad argument");
+  File fh(path, "wb");
+  IMF_REQUIRE(fh.f, "imf_npz_write: cannot create %s (%s)", path, strerror(errno));
+  std::vector<unsigned char> central;
+  std::vector<unsigned char> comp;
+  uint32_t offset = 0;
+  const int64_t *sh = shape;
+  for (int i = 0; i < n_arrays; ++i) {
+    const int itemsize = atoi(dtype[i] + 2);
+    IMF_REQUIRE(itemsize > 0 && strlen(dtype[i]) >= 3, "imf_npz_write: dtype '%s'", dtype[i]);
+    size_t count = 1;
+    std::string shp = "(";
+    for (int d = 0; d < ndim[i]; ++d) {
+      count *= (size_t)sh[d];
+      shp += std::to_string((long long)sh[d]) + (ndim[i] == 1 || d + 1 < ndim[i] ? "," : "");
+      if (d + 1 < ndim[i]) shp += " ";
+    }
+    shp += ")";
+    sh += ndim[i];
+    const size_t nbytes = count * (size_t)itemsize;
+    IMF_REQUIRE(nbytes < (1ull << 32) - 256, "imf_npz_write: member %s too large", names[i]);
+    std::string hdr = std::string("{'descr': '") + dtype[i] + "', 'fortran_order': False, 'shape': " + shp + ", }";
+    const size_t unpadded = 10 + hdr.size() + 1;
+    hdr.append((64 - unpadded % 64) % 64, ' ');
+    hdr += '\n';
+    std::vector<unsigned char> npy_head = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+    put16(npy_head, (uint32_t)hdr.size());
+    npy_head.insert(npy_head.end(), hdr.begin(), hdr.end());
+    const uint32_t usize = (uint32_t)(npy_head.size() + nbytes);
+    uLong crc = crc32(0L, Z_NULL, 0);
+    crc = crc32(crc, npy_head.data(), (uInt)npy_head.size());
+    const unsigned char *src = (const unsigned char *)data[i];
+    for (size_t done = 0; done < nbytes;) {               // crc32 takes 32-bit lengths
+      const size_t chunk = nbytes - done < (1u << 30) ? nbytes - done : (1u << 30);
+      crc = crc32(crc, src + done, (uInt)chunk);
+      done += chunk;
+    }
+    uint32_t csize = usize;
+    const unsigned char *payload_head = npy_head.data();
+    if (level > 0) {
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      IMF_REQUIRE(deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK, "imf_npz_write: deflateInit2");
+      comp.resize(deflateBound(&zs, usize) + 64);
+      zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
+      zs.next_in = npy_head.data(); zs.avail_in = (uInt)npy_head.size();
+      int rc = deflate(&zs, Z_NO_FLUSH);
+      zs.next_in = const_cast<unsigned char *>(src); zs.avail_in = (uInt)nbytes;
+      if (rc == Z_OK) rc = deflate(&zs, Z_FINISH);
+      csize = (uint32_t)zs.total_out;
+      deflateEnd(&zs);
+      IMF_REQUIRE(rc == Z_STREAM_END, "imf_npz_write: deflate failed (%d)", rc);
+    }
+    const std::string fname = std::string(names[i]) + ".npy";
+    std::vector<unsigned char> local;
+    put32(local, 0x04034b50); put16(local, 20); put16(local, 0); put16(local, level > 0 ? 8 : 0);
+    put16(local, 0); put16(local, 0x21);                                  // time / date (1980-01-01)
+    put32(local, (uint32_t)crc); put32(local, csize); put32(local, usize);
+    put16(local, (uint32_t)fname.size()); put16(local, 0);
+    local.insert(local.end(), fname.begin(), fname.end());
+    bool ok = fwrite(local.data(), 1, local.size(), fh.f) == local.size();
+    if (level > 0) ok = ok && fwrite(comp.data(), 1, csize, fh.f) == csize;
+    else ok = ok && fwrite(payload_head, 1, npy_head.size(), fh.f) == npy_head.size() && fwrite(src, 1, nbytes, fh.f) == nbytes;
+    IMF_REQUIRE(ok, "imf_npz_write: short write to %s", path);
+    put32(central, 0x02014b50); put16(central, 20); put16(central, 20); put16(central, 0); put16(central, level > 0 ? 8 : 0);
+    put16(central, 0); put16(central, 0x21);
+    put32(central, (uint32_t)crc); put32(central, csize); put32(central, usize);
+    put16(central, (uint32_t)fname.size()); put16(central, 0); put16(central, 0); put16(central, 0); put16(central, 0);
+    put32(central, 0); put32(central, offset);
+    central.insert(central.end(), fname.begin(), fname.end());
+    offset += (uint32_t)local.size() + csize;
+  }
+  std::vector<unsigned char> end;
+  put32(end, 0x06054b50); put16(end, 0); put16(end, 0); put16(end, (uint32_t)n_arrays); put16(end, (uint32_t)n_arrays);
+  put32(end, (uint32_t)central.size()); put32(end, offset); put16(end, 0);
+  IMF_REQUIRE(fwrite(central.data(), 1, central.size(), fh.f) == central.size() && fwrite(end.data(), 1, end.size(), fh.f) == end.size(),
+              "imf_npz_write: short write to %s", path);
+  return IMF_OK;
+}
+
+}  // extern "C"

@@ -16,9 +16,30 @@ _PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int":
               "int32": "i4", "uint32": "u4", "float32": "f4", "float64": "f8"}
 
 
-def read_ply_points(path):
+def _native():
+    from . import _lib
+    return _lib.lib()
+
+
+def read_ply_points(path, out=None):
     """Vertex x,y,z of a PLY file as float64 [N,3] (what np.array(pcd.points) is in the reference:
-    Open3D widens float32 vertices to float64)."""
+    Open3D widens float32 vertices to float64).  Native reader (imf_ply_read_points, csrc/codecs.hip); `out`:
+    optional float64 [cap,3] buffer (e.g. pinned host memory) to read into -- a view of its first N rows is returned."""
+    import ctypes as C
+    L = _native()
+    p = os.fsencode(path)
+    n = L.imf_ply_vertex_count(p)
+    if n < 0:
+        raise ValueError(f"{path}: {L.imf_last_error().decode()}")
+    buf = out if out is not None and out.shape[0] >= n else np.empty((n, 3), dtype=np.float64)
+    got = L.imf_ply_read_points(p, buf.ctypes.data_as(C.c_void_p), buf.shape[0])
+    if got < 0:
+        raise ValueError(f"{path}: {L.imf_last_error().decode()}")
+    return buf[:got]
+
+
+def read_ply_points_numpy(path):
+    """The same in numpy (kept as the independent check of the native reader)."""
     with open(path, "rb") as f:
         if f.readline().strip() != b"ply":
             raise ValueError(f"{path}: not a PLY file")
@@ -58,8 +79,25 @@ def read_image(path):
     """matplotlib.image.imread semantics (generate_desc.py:92): PNG -> float32 in [0,1] (HWC, alpha
     dropped is NOT done by the reference; fixtures are RGB); any other format -> uint8 0..255, which the
     reference then feeds to the network un-normalised (SURVEY App. D.5 -- kept for parity)."""
+    if os.path.splitext(path)[1].lower() == ".png":
+        import ctypes as C
+        L = _native()
+        p = os.fsencode(path)
+        h, w, c = C.c_int(), C.c_int(), C.c_int()
+        if L.imf_png_info(p, C.byref(h), C.byref(w), C.byref(c)) == 0:
+            out = np.empty((h.value, w.value, c.value), dtype=np.float32)
+            rc = L.imf_png_read_f32(p, out.ctypes.data_as(C.c_void_p), out.size, C.byref(h), C.byref(w), C.byref(c))
+            if rc == 0:
+                return out[:, :, 0] if c.value == 1 else out          # matplotlib returns [H,W] for grey images
+    return read_image_pil(path)
+
+
+def read_image_pil(path):
+    """Generic decoder (every format PIL knows): the fallback of read_image and the check of the native PNG path."""
     from PIL import Image
     with Image.open(path) as im:
+        if im.mode == "P":
+            im = im.convert("RGB")
         arr = np.asarray(im)
     if os.path.splitext(path)[1].lower() == ".png":
         return np.divide(arr, 255 if arr.dtype == np.uint8 else 65535, dtype=np.float32)
@@ -81,7 +119,19 @@ def process_image(image, aim_H=480, aim_W=640, mode="resize", clip_mode="center"
         # uint8: 11-bit coefficients, result rounded to the nearest integer (OpenCV resize.cpp, INTER_RESIZE_COEF_BITS = 11;
         # [RECALLED], within 1 LSB of every OpenCV code path).  The reference then casts to float32 0..255.
         return _resize_linear_u8(img, aim_H, aim_W)
-    t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).permute(2, 0, 1)[None]
+    import ctypes as C
+    src = np.ascontiguousarray(img, dtype=np.float32)
+    out = np.empty((aim_H, aim_W, src.shape[2]), dtype=np.float32)
+    rc = _native().imf_resize_bilinear_f32(src.ctypes.data_as(C.c_void_p), H, W, src.shape[2],
+                                           out.ctypes.data_as(C.c_void_p), aim_H, aim_W, 0)
+    if rc != 0:
+        raise ValueError(_native().imf_last_error().decode())
+    return out
+
+
+def process_image_torch(image, aim_H, aim_W):
+    """The same resize through torch (the independent check of the native one)."""
+    t = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).permute(2, 0, 1)[None]
     out = F.interpolate(t, size=(aim_H, aim_W), mode="bilinear", align_corners=False)
     return out[0].permute(1, 2, 0).contiguous().numpy()
 
@@ -116,8 +166,36 @@ def image_to_nchw(image):
     return np.expand_dims(np.transpose(image, (2, 0, 1)), 0)
 
 
+NPZ_LEVEL = int(os.environ.get("IMFNET_NPZ_LEVEL", "1"))
+
+
+def save_npz(path, level=None, **arrays):
+    """np.savez_compressed(path, **arrays) through the native ZIP writer (imf_npz_write): the same members and arrays,
+    deflated at zlib level `level` (default 1: ~4x faster than numpy's 6; 0 = stored like np.savez)."""
+    import ctypes as C
+    if not str(path).endswith(".npz"):
+        path = str(path) + ".npz"
+    names = list(arrays)
+    arrs = [np.ascontiguousarray(arrays[k]) for k in names]
+    for a in arrs:
+        if a.dtype.byteorder == ">" or a.dtype.hasobject or a.dtype.fields is not None:
+            return np.savez_compressed(path, **arrays)        # exotic dtypes: numpy's writer
+    n = len(arrs)
+    c_names = (C.c_char_p * n)(*[k.encode() for k in names])
+    c_dtype = (C.c_char_p * n)(*[a.dtype.str.replace("=", "<").replace("|", "|").encode() for a in arrs])
+    c_ndim = (C.c_int32 * n)(*[a.ndim for a in arrs])
+    dims = [d for a in arrs for d in a.shape]
+    c_shape = (C.c_int64 * max(1, len(dims)))(*dims)
+    c_data = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    L = _native()
+    rc = L.imf_npz_write(os.fsencode(str(path)), n, c_names, c_dtype, c_ndim, c_shape, c_data,
+                         NPZ_LEVEL if level is None else int(level))
+    if rc != 0:
+        raise OSError(L.imf_last_error().decode())
+
+
 def save_descriptors(path, points, xyz_down, feature):
     """generate_desc.py:118-123 -- keys and dtypes consumed by scripts/evaluation_3dmatch.py:129-132."""
     if torch.is_tensor(feature):
         feature = feature.detach().cpu().numpy()
-    np.savez_compressed(path, points=np.asarray(points), xyz=np.asarray(xyz_down), feature=feature)
+    save_npz(path, points=np.asarray(points), xyz=np.asarray(xyz_down), feature=feature)

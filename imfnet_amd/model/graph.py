@@ -250,9 +250,10 @@ class FragmentRunner:
         return own, stream
 
     # -- execution ------------------------------------------------------------------------------------
-    def stage(self, b, xyz, item_starts, image, stream):
+    def stage(self, b, xyz, item_starts, image, stream, dyn_host=None):
         """Copy the inputs into the bucket's static buffers (skipped for tensors that already ARE those buffers)
-        and write the per-fragment scalars."""
+        and write the per-fragment scalars.  `dyn_host`: a pinned int32[16] the caller owns until the copy has run
+        (keeps the call asynchronous; without it the scalars go through a blocking pageable copy)."""
         n = xyz.shape[0]
         with torch.cuda.stream(stream):
             if xyz.data_ptr() != b.xyz.data_ptr():
@@ -260,8 +261,12 @@ class FragmentRunner:
             if image.data_ptr() != b.image.data_ptr():
                 b.image.copy_(torch.as_tensor(image, dtype=torch.float32), non_blocking=True)
             vals = [n, len(item_starts)] + [int(s) for s in item_starts]
-            if vals != b.dyn_values:                  # pageable source: staged by the runtime, safe to run ahead
-                b.dyn.copy_(torch.tensor(vals + [0] * (DYN_WORDS - len(vals)), dtype=torch.int32))
+            if vals != b.dyn_values:
+                if dyn_host is not None:
+                    dyn_host[: len(vals)] = torch.tensor(vals, dtype=torch.int32)
+                    b.dyn.copy_(dyn_host, non_blocking=True)
+                else:                                 # pageable source: staged by the runtime, safe to run ahead
+                    b.dyn.copy_(torch.tensor(vals + [0] * (DYN_WORDS - len(vals)), dtype=torch.int32))
                 b.dyn_values = vals
         return n
 

@@ -561,6 +561,26 @@ int imf_ransac_registration(const double *src, int64_t n_src, const double *dst,
                             int max_iter, uint64_t seed, double *out_T, int32_t *out_meta, double *out_stats,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Host-side codecs of the batch path: HOST pointers, no GPU involved ----------------------
+ * Replace what the reference does around every fragment with Open3D / matplotlib / OpenCV / numpy
+ * (scripts/generate_desc.py:83-97,118-123, util/uio.py:33-40).  All return 0 / a count on success, a negative
+ * IMF_E* code otherwise (imf_last_error). */
+int64_t imf_ply_vertex_count(const char *path);
+/* x,y,z of every vertex as float64 [n,3] = np.array(o3d.io.read_point_cloud(path).points): ascii and both binary
+ * byte orders, other scalar vertex properties skipped.  Returns n. */
+int64_t imf_ply_read_points(const char *path, double *out /* [capacity,3] */, int64_t capacity);
+int imf_png_info(const char *path, int *h, int *w, int *channels);
+/* matplotlib.image.imread of a .png: float32 [H,W,C] in [0,1] (8-bit / 255, 16-bit / 65535, palette -> RGB).
+ * IMF_EUNSUPPORTED for interlaced or sub-byte files (callers fall back to a generic decoder). */
+int imf_png_read_f32(const char *path, float *out, int64_t capacity_floats, int *h, int *w, int *channels);
+/* cv2.resize(INTER_LINEAR) for float images [H,W,C]; chw != 0 writes [C,H_out,W_out] (generate_desc.py:96-97). */
+int imf_resize_bilinear_f32(const float *in, int H, int W, int C, float *out, int H_out, int W_out, int chw);
+/* np.savez (level 0) / np.savez_compressed (level 1..9, raw deflate) of n_arrays C-ordered arrays: names[i] (member
+ * name), dtype[i] (numpy descr, e.g. "<f8"), ndim[i], their dims concatenated in shape, data[i].  np.load reads the
+ * file; the arrays are identical to numpy's own writers'. */
+int imf_npz_write(const char *path, int n_arrays, const char *const *names, const char *const *dtype,
+                  const int32_t *ndim, const int64_t *shape, const void *const *data, int level);
+
 /* Measurement helpers (bench.py): HIP events on the caller's stream. */
 void *imf_stream_create(void);     /* non-blocking hipStream_t, distinct from any framework pool stream */
 void imf_stream_destroy(void *stream);

@@ -226,3 +226,109 @@ def test_conv_refuses_autograd():
     conv = ME.MinkowskiConvolution(32, 32, kernel_size=3, stride=1, dilation=1, bias=False, dimension=3)
     with pytest.raises(ImfError, match="inference-only"):
         conv.run(None)
+
+
+def _write_ply(path, pts, fmt="binary_little_endian", extra=False, dtype="float"):
+    import struct as st
+    n = len(pts)
+    head = f"ply\nformat {fmt} 1.0\ncomment test\nelement vertex {n}\n"
+    if extra:
+        head += "property uchar red\n"
+    head += f"property {dtype} x\nproperty {dtype} y\n"
+    if extra:
+        head += "property float nx\n"
+    head += f"property {dtype} z\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n"
+    with open(path, "wb") as f:
+        f.write(head.encode())
+        end = "<" if fmt != "binary_big_endian" else ">"
+        code = "f" if dtype == "float" else "d"
+        for p in pts:
+            if fmt == "ascii":
+                vals = ([7] if extra else []) + [repr(float(p[0])), repr(float(p[1]))] + ([0.5] if extra else []) + [repr(float(p[2]))]
+                f.write((" ".join(str(v) for v in vals) + "\n").encode())
+            else:
+                if extra:
+                    f.write(st.pack("B", 7))
+                f.write(st.pack(end + code * 2, p[0], p[1]))
+                if extra:
+                    f.write(st.pack(end + "f", 0.5))
+                f.write(st.pack(end + code, p[2]))
+        f.write(b"\x03\x00\x00\x00\x00\x01\x00\x00\x00\x02\x00\x00\x00" if fmt != "ascii" else b"3 0 1 2\n")
+
+
+@pytest.mark.parametrize("fmt", ["binary_little_endian", "binary_big_endian", "ascii"])
+@pytest.mark.parametrize("dtype", ["float", "double"])
+def test_native_ply_reader(tmp_path, clouds, fmt, dtype):
+    """imf_ply_read_points vs the numpy reader on every layout Open3D reads: both byte orders, ascii, float / double
+    coordinates, interleaved extra properties, a face element behind the vertices, empty and missing files."""
+    from imfnet_amd import dataio
+    pts = clouds[0][:997].astype(np.float32 if dtype == "float" else np.float64)
+    for extra in (False, True):
+        path = str(tmp_path / f"c_{extra}.ply")
+        _write_ply(path, pts, fmt, extra, dtype)
+        got = dataio.read_ply_points(path)
+        assert got.dtype == np.float64 and got.shape == (997, 3)
+        assert (got == pts.astype(np.float64)).all() and (got == dataio.read_ply_points_numpy(path)).all()
+    _write_ply(str(tmp_path / "empty.ply"), pts[:0], fmt, False, dtype)
+    assert dataio.read_ply_points(str(tmp_path / "empty.ply")).shape == (0, 3)
+    buf = np.zeros((2000, 3))
+    view = dataio.read_ply_points(str(tmp_path / "c_True.ply"), out=buf)
+    assert view.base is buf and (view == pts.astype(np.float64)).all()
+    with pytest.raises(ValueError):
+        dataio.read_ply_points(str(tmp_path / "missing.ply"))
+
+
+def test_native_png_reader_and_resize(tmp_path):
+    """imf_png_read_f32 == matplotlib's imread semantics as PIL decodes them (8/16-bit, RGB / RGBA / grey / palette, every
+    scan-line filter via real image content), interlaced files fall back; imf_resize_bilinear_f32 == the torch bilinear."""
+    from PIL import Image
+    from imfnet_amd import dataio
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:96, 0:128]
+    smooth = np.stack([(yy * 2 + xx) % 256, (xx * 3) % 256, (yy * xx) % 256], -1).astype(np.uint8)
+    noisy = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    cases = {"rgb_smooth": Image.fromarray(smooth), "rgb_noise": Image.fromarray(noisy),
+             "rgba": Image.fromarray(np.concatenate([smooth, noisy[:, :, :1]], -1), "RGBA"),
+             "grey": Image.fromarray(smooth[:, :, 0], "L"), "palette": Image.fromarray(smooth).convert("P"),
+             "grey16": Image.fromarray((smooth[:, :, 0].astype(np.uint16) * 257), "I;16")}
+    for name, im in cases.items():
+        path = str(tmp_path / f"{name}.png")
+        im.save(path, optimize=(name == "rgb_smooth"))
+        got, ref = dataio.read_image(path), dataio.read_image_pil(path)
+        assert got.dtype == np.float32 and got.shape == ref.shape, name
+        assert (got == ref).all(), name
+    img = dataio.read_image(str(tmp_path / "rgb_noise.png"))
+    small = dataio.process_image(img, aim_H=24, aim_W=32)
+    assert small.shape == (24, 32, 3) and np.abs(small - dataio.process_image_torch(img, 24, 32)).max() < 2e-6
+    odd = dataio.process_image(img, aim_H=50, aim_W=70)
+    assert np.abs(odd - dataio.process_image_torch(img, 50, 70)).max() < 2e-6
+    up = dataio.process_image(img[:10, :12], aim_H=33, aim_W=40)
+    assert np.abs(up - dataio.process_image_torch(img[:10, :12], 33, 40)).max() < 2e-6
+
+
+@pytest.mark.parametrize("level", [0, 1, 6])
+def test_native_npz_writer(tmp_path, level):
+    """imf_npz_write: np.load returns exactly the arrays np.savez_compressed would have stored (keys, dtypes, shapes,
+    values), for the descriptor-file layout and edge shapes (empty, 1-D, scalar-like, non-contiguous input)."""
+    from imfnet_amd import dataio
+    rng = np.random.default_rng(1)
+    arrays = dict(points=rng.normal(size=(5001, 3)), xyz=rng.normal(size=(777, 3)),
+                  feature=rng.normal(size=(777, 32)).astype(np.float32), idx=np.arange(13, dtype=np.int32),
+                  empty=np.zeros((0, 32), np.float32), strided=rng.normal(size=(50, 8))[:, ::2])
+    path = tmp_path / f"d{level}.npz"
+    dataio.save_npz(str(path), level=level, **arrays)
+    z = np.load(path)
+    assert sorted(z.files) == sorted(arrays)
+    for k, a in arrays.items():
+        assert z[k].dtype == a.dtype and z[k].shape == a.shape and (z[k] == a).all(), k
+    ref = tmp_path / "ref.npz"
+    np.savez_compressed(ref, **arrays)
+    if level == 0:
+        assert os.path.getsize(path) > sum(a.nbytes for a in arrays.values())
+    else:
+        assert os.path.getsize(path) < 1.25 * os.path.getsize(ref)
+    import zipfile
+    assert zipfile.ZipFile(path).testzip() is None                        # CRCs and sizes are consistent
+    dataio.save_descriptors(str(tmp_path / "frag.npz"), arrays["points"], arrays["xyz"], arrays["feature"])
+    z = np.load(tmp_path / "frag.npz")
+    assert sorted(z.files) == ["feature", "points", "xyz"] and z["points"].dtype == np.float64
