@@ -1245,6 +1245,9 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   p.split_target = split_target();
   IMF_REQUIRE(!a->n_out_dev || a->variant == 6, "imf_spconv_fwd: n_out_dev (capacity mode) needs variant 6");
   p.err = a->dyn_err;
+  // XCD-contiguous tile order: measured SLOWER (pair step 1.53 vs 1.38 ms; round 2) -- opt-in for experiments only
+  static const int xcd = getenv("IMF_H3_XCD") ? 1 : 0;
+  p.no_xcd_swizzle = !xcd;
   IMF_REQUIRE(!p.dyn_split_kvol || (!p.tickets && a->split_k >= 1), "imf_spconv_fwd: dyn_split_kvol needs an explicit split_k cover and no tickets");
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;

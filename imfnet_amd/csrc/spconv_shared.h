@@ -36,6 +36,7 @@ struct ConvParams {
   int dyn_split_kvol;       // third argument of the split rule (active offsets per tile); 0 = gridDim.z is the split
   int slots_extra;          // slots the rulebook lays out beyond roundup64(rows): 0, or 512 for transposed maps
   int split_min_blocks, split_target;
+  int no_xcd_swizzle;       // A/B switch (env IMF_H3_NO_XCD): plain blockIdx.x -> tile order
   int32_t *err;             // flag word (optional): 16 = the rule wanted more partitions than the launch covers
                             // (capacity mode); 32 = an output value left the f16 range (|y| >= 65504 or NaN): the
                             // next split-f16 convolution would turn it into inf -- see IMF_FLAG_RANGE
