@@ -83,7 +83,7 @@ def pmc_traffic(kernel):
     else:
         return None, "no PMC profile committed"
     ks = json.load(open(path))["kernels"]
-    key = "imf::" + kernel.replace(",", ", ")
+    key = "imf::" + kernel
     if key not in ks:
         return None, f"{key} not in {os.path.basename(path)}"
     v = ks[key]

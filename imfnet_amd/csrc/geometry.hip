@@ -42,27 +42,44 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
                 uint64_t *keys, int32_t *vals, uint32_t capmask, int32_t *slot_of, int32_t *err) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (dyn) {
-    if (i >= min((int64_t)dyn[0], n)) return;
+    n = min((int64_t)dyn[0], n);
     const int nb = min(max(dyn[1], 1), IMF_MAX_BATCH);
     for (int b = 1; b < nb; ++b) batch += (i >= dyn[2 + b]) ? 1 : 0;
   } else {
-    if (i >= n) return;
     for (int b = 1; b < bs.nb; ++b) batch += (i >= bs.start[b]) ? 1 : 0;   // items are contiguous point ranges
   }
-  // util/misc.py:82 -- np.floor(xyz / voxel_size) in float64 (IEEE division, exact floor)
-  double fx = floor((double)xyz[3 * i + 0] / voxel);
-  double fy = floor((double)xyz[3 * i + 1] / voxel);
-  double fz = floor((double)xyz[3 * i + 2] / voxel);
-  bool ok = fx >= -kCoordLim && fx < kCoordLim && fy >= -kCoordLim && fy < kCoordLim &&
-            fz >= -kCoordLim && fz < kCoordLim;   // also false for NaN
-  if (!ok) {
-    atomicOr(err, 1);
-    fx = fy = fz = 0.0;
+  const bool valid = i < n;
+  uint64_t key = kEmptyKey;
+  if (valid) {
+    // util/misc.py:82 -- np.floor(xyz / voxel_size) in float64 (IEEE division, exact floor)
+    double fx = floor((double)xyz[3 * i + 0] / voxel);
+    double fy = floor((double)xyz[3 * i + 1] / voxel);
+    double fz = floor((double)xyz[3 * i + 2] / voxel);
+    bool ok = fx >= -kCoordLim && fx < kCoordLim && fy >= -kCoordLim && fy < kCoordLim &&
+              fz >= -kCoordLim && fz < kCoordLim;   // also false for NaN
+    if (!ok) {
+      atomicOr(err, 1);
+      fx = fy = fz = 0.0;
+    }
+    key = pack_key(batch, (int)fx, (int)fy, (int)fz);
   }
-  uint64_t key = pack_key(batch, (int)fx, (int)fy, (int)fz);
-  uint32_t s = hash_insert(keys, capmask, key);
-  atomicMin(vals + s, (int32_t)i);
-  slot_of[i] = (int32_t)s;
+  // Scan-ordered clouds put consecutive points into the same voxel (~5 points per 2.5 cm voxel): only the first lane
+  // of every run of equal keys inside the wavefront touches the table (one atomicCAS + one atomicMin per run instead
+  // of per point); its slot is handed to the followers.  The leader carries the run's smallest point index, so the
+  // table ends up exactly as with one insert per point.
+  const int lane = threadIdx.x & 63;
+  const uint64_t prev = __shfl_up(key, 1, 64);
+  const bool leader = valid && (lane == 0 || key != prev);
+  uint32_t s = 0;
+  if (leader) {
+    s = hash_insert(keys, capmask, key);
+    atomicMin(vals + s, (int32_t)i);
+  }
+  const unsigned long long lead_mask = __ballot(leader);
+  const unsigned long long below = lead_mask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  const int src = below ? 63 - __builtin_clzll(below) : lane;
+  s = __shfl((int)s, src, 64);
+  if (valid) slot_of[i] = (int32_t)s;
 }
 
 __global__ void __launch_bounds__(256)

@@ -313,6 +313,7 @@ int imf_image_branch(const imf_image_desc *net, const float *image, int B, int H
     a.scale = c.scale; a.shift = c.shift; a.residual = residual; a.relu = c.relu; a.out = out;
     a.variant = c.variant; a.split_k = 0;
     a.dyn_err = c.variant == 6 ? flags : nullptr;
+    a.kernel_tag = 1;
     a.workspace = p.splitk; a.workspace_bytes = p.splitk_bytes;
     return imf_spconv_fwd(&a, st);
   };

@@ -1271,7 +1271,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
       p.tail_split = ts;
       grid.x = (unsigned)(p.tail_begin + tail_tiles * ts);
     }
-    launch_spconv_h3(p, grid, CB, st);
+    launch_spconv_h3(p, grid, CB, st, a->kernel_tag);
   } else if ((a->variant == 4 || a->variant == 5) && !simple) {
     const int RBv = a->variant == 4 ? 2 : 1;
     dim3 g4((unsigned)div_up(a->n_slots / 16, 4 * RBv), grid.y, grid.z);

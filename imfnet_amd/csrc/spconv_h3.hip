@@ -106,7 +106,10 @@ __device__ __forceinline__ void split8(const float4 &x0, const float4 &x1, f16x8
 #define IMF_STAMP(i) do { } while (0)
 #endif
 
-template <int CO_BLK>
+// USE tags the launch for profilers only (same code): 0 = the 23 sparse convolutions of the ResUNet, 1 = the dense
+// image-branch convolutions that run on this kernel over static pixel tables (csrc/image.hip) -- so that a kernel
+// trace's per-symbol averages can be compared with bench.py's roofline block, which counts the sparse launches.
+template <int CO_BLK, int USE>
 __global__ void __launch_bounds__(256, 4)   // 4 workgroups per CU: <= 128 registers per lane
 k_spconv_h3(const ConvParams p) {
   constexpr int SUB_F4 = 2 * CO_BLK * 64;            // float4 per (k, cc) sub-stage: 512 or 256
@@ -383,9 +386,14 @@ k_spconv_h3(const ConvParams p) {
   }
 }
 
-void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st) {
-  if (co_blk == 4) k_spconv_h3<4><<<grid, 256, 0, st>>>(p);
-  else             k_spconv_h3<2><<<grid, 256, 0, st>>>(p);
+void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use) {
+  if (use == 1) {
+    if (co_blk == 4) k_spconv_h3<4, 1><<<grid, 256, 0, st>>>(p);
+    else             k_spconv_h3<2, 1><<<grid, 256, 0, st>>>(p);
+  } else {
+    if (co_blk == 4) k_spconv_h3<4, 0><<<grid, 256, 0, st>>>(p);
+    else             k_spconv_h3<2, 0><<<grid, 256, 0, st>>>(p);
+  }
 }
 
 }  // namespace imf

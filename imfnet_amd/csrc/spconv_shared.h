@@ -186,6 +186,6 @@ __device__ __forceinline__ void fused_reduce_tile(const ConvParams &p, int S, lo
 constexpr int kKCache = 28;   // active offsets cached per workgroup (kvol <= 27 uses the pipelined kernels)
 
 // spconv_h3.hip: variant 6 (split-f16 MFMA); grid = (tiles, cout / (16 CB), split)
-void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st);
+void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use = 0);
 
 }  // namespace imf

@@ -379,7 +379,7 @@ def pack_weights(kernel, out=None, split16=False):
 
 def conv_kernel_name(variant, cin, cout):
     if variant == 6:
-        return f"k_spconv_h3<{4 if cout % 64 == 0 else 2}>"
+        return f"k_spconv_h3<{4 if cout % 64 == 0 else 2}, 0>"
     return f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>"
 
 
