@@ -244,7 +244,7 @@ def main():
                          "as one hipGraph replay; exact: count readback + native executor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-fragment / end-to-end / fp32-MFMA legs")
-    ap.add_argument("--trace-every", type=int, default=5,
+    ap.add_argument("--trace-every", type=int, default=10,
                     help="record the per-launch HIP events of the roofline measurement on every n-th timed step "
                          "(eager launches with two event records per convolution instead of the graph replay)")
     args = ap.parse_args()

@@ -264,8 +264,11 @@ size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split);
  *           ME.MinkowskiBatchNorm (eval), MEF.relu, residual `out += residual`
  *           (residual_block.py:50), ME.cat (resunet.py:197,208,219), `final` bias and the
  *           L2 normalisation (resunet.py:228-233) fused as prologue / epilogue.
- * out[o] = epilogue( sum_k in[nbr[k][o]] @ W[k] ), fp32 MFMA (v_mfma_f32_16x16x4_f32: exact f32
- * FMA chain, ordered by k then input channel => deterministic). */
+ * out[o] = epilogue( sum_k in[nbr[k][o]] @ W[k] ).  args->variant picks the arithmetic: 6 (what the model layers
+ * use) = fp32 operands split into f16 hi + lo halves, three v_mfma_f32_16x16x32_f16 per 32 channels with fp32
+ * accumulation (fp32-class accuracy; inputs must stay below 65 504, see dyn_err / IMF_FLAG_RANGE); 0 = fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32, an exact f32 FMA chain).  Either way the sum order per output element is fixed (k
+ * ascending, then input channel) => deterministic. */
 int imf_spconv_fwd(const imf_conv_args *args /* [host] */, void *stream);
 
 /* First-layer convolution for a small number of input channels (cin <= 4, e.g. the all-ones
