@@ -93,3 +93,42 @@ def test_large_fragment_200k_voxels(clouds, images, seeded_sd):
     assert (xd == xyz[inds]).all()
     Fr = O.resunet_forward(seeded_sd, coords, images[0], geometry=OC.Geometry(coords))
     assert (F.cpu() - Fr).abs().max() < 1e-4
+
+
+def kitti_like_cloud(n_points=2_000_000, seed=0):
+    """seeded union of 64 random planar patches in a 120 m cube, 2 cm jitter (LiDAR-like surfaces
+    at KITTI extents), tuned to ~200 k voxels at 0.3 m."""
+    rng = np.random.default_rng(seed)
+    per = n_points // 64
+    parts = []
+    for _ in range(64):
+        c = rng.uniform(-60, 60, 3)
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        v = np.cross(u, rng.normal(size=3)); v /= np.linalg.norm(v)
+        ext = rng.uniform(5, 12, 2)
+        ab = rng.uniform(-1, 1, (per, 2)) * ext
+        parts.append(c + ab[:, :1] * u + ab[:, 1:] * v + rng.normal(0, 0.02, (per, 3)))
+    return np.clip(np.concatenate(parts, 0), -60, 60)
+
+
+def test_kitti_like_fragment_voxel_30cm(seeded_sd):
+    """BASELINE.json configs[4]: KITTI extents, voxel 0.3 m (config_kitti.py:118), ~200 k voxels, random 120x160 image.
+    Exact voxel set / order vs the C oracle, descriptors vs the oracle to 1e-4; second call through the capacity-mode
+    runner bit-identical."""
+    import imf_oracle_cbind as OC
+    from imfnet_amd.extract import extract_features
+    from imfnet_amd.model import load_model
+    xyz = kitti_like_cloud()
+    img = np.random.default_rng(0).random((1, 3, 120, 160)).astype(np.float32)
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.eval().cuda()
+    with torch.no_grad():
+        xd, F = extract_features(m, xyz, voxel_size=0.3, device=torch.device("cuda:0"), skip_check=True, image=img)
+        xd2, F2 = extract_features(m, xyz, voxel_size=0.3, device=torch.device("cuda:0"), skip_check=True, image=img)
+    coords, inds = OC.voxelize(xyz, 0.3)
+    assert 120_000 < len(coords) < 400_000 and F.shape == (len(coords), 32)
+    assert (xd == xyz[inds]).all() and (xd2 == xd).all() and torch.equal(F, F2)
+    assert m.fragment_runner().stats["eager"] + m.fragment_runner().stats["graph"] >= 1
+    Fr = O.resunet_forward(seeded_sd, coords, img, geometry=OC.Geometry(coords))
+    assert (F.cpu() - Fr).abs().max() < 1e-4
