@@ -1,0 +1,84 @@
+// A C-level client of libimfnet_hip.so: no Python, no torch -- only include/imfnet_hip.h and the HIP runtime for
+// device memory.  It voxelises a synthetic cloud, builds the k=3 rulebook and runs one fused sparse convolution with
+// all-ones features and weights, whose exact result is known: out[row][c] = 32 * (number of occupied neighbours).
+// Exit code 0 = every check passed.  Built by __graft_entry__.build(), run by tests/test_gpu_cabi_driver.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <set>
+#include <tuple>
+#include <vector>
+
+#include "imfnet_hip.h"
+
+#define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
+#define IMF(x) do { int rc_ = (x); if (rc_ != 0) { printf("%s failed: %s\n", #x, imf_last_error()); return 3; } } while (0)
+
+template <typename T> static T *dev(size_t n) { T *p = nullptr; if (hipMalloc((void **)&p, n * sizeof(T) + 256) != hipSuccess) return nullptr; return p; }
+
+int main() {
+  printf("imf_version %d\n", imf_version());
+  // a 20 x 20 x 3 slab of voxels at 5 cm, 4 points per voxel (duplicates exercise the first-occurrence rule)
+  const double voxel = 0.05;
+  std::vector<double> xyz;
+  for (int rep = 0; rep < 4; ++rep)
+    for (int x = 0; x < 20; ++x) for (int y = 0; y < 20; ++y) for (int z = 0; z < 3; ++z) {
+      xyz.push_back((x - 10 + 0.1 + 0.2 * rep) * voxel); xyz.push_back((y - 10 + 0.3) * voxel); xyz.push_back((z + 0.5) * voxel);
+    }
+  const int64_t n = (int64_t)xyz.size() / 3;
+  const int64_t cap = imf_hash_capacity(n);
+  double *d_xyz = dev<double>(3 * n);
+  int32_t *coords = dev<int32_t>(4 * n), *first = dev<int32_t>(n), *meta = dev<int32_t>(2), *vals = dev<int32_t>(cap);
+  uint64_t *keys = dev<uint64_t>(cap);
+  void *ws = dev<char>(imf_unique_workspace_bytes(n));
+  HIP(hipMemcpy(d_xyz, xyz.data(), xyz.size() * 8, hipMemcpyHostToDevice));
+  HIP(hipMemset(meta, 0, 8));
+  IMF(imf_voxelize(d_xyz, 1, n, voxel, 0, coords, first, meta, keys, vals, cap, ws, meta + 1, nullptr));
+  int32_t h_meta[2];
+  HIP(hipMemcpy(h_meta, meta, 8, hipMemcpyDeviceToHost));
+  const int64_t m = h_meta[0];
+  if (m != 1200 || h_meta[1] != 0) { printf("voxel count %lld (expected 1200), err %d\n", (long long)m, h_meta[1]); return 4; }
+  std::vector<int32_t> h_coords(4 * m), h_first(m);
+  HIP(hipMemcpy(h_coords.data(), coords, 16 * m, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(h_first.data(), first, 4 * m, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < m; ++i)
+    if (h_first[i] != i) { printf("first-occurrence order broken at row %lld\n", (long long)i); return 5; }   // rep 0 comes first
+  // rulebook of the 3x3x3 stride-1 convolution + one fused convolution (variant 0: fp32 MFMA, exact on small integers)
+  const int64_t slots = imf_rulebook_slots(m);
+  int32_t *tile_rows = dev<int32_t>(slots), *nbr = dev<int32_t>(27 * slots);
+  uint32_t *mask = dev<uint32_t>(slots / IMF_TILE_ROWS * IMF_MASK_WORDS);
+  IMF(imf_rulebook_conv(keys, vals, cap, coords, m, 1, 3, tile_rows, nbr, mask, nullptr));
+  const int cin = 32, cout = 32;
+  std::vector<float> ones((size_t)27 * cin * cout, 1.f), feat((size_t)m * cin, 1.f);
+  float *d_w = dev<float>(ones.size()), *d_wp = dev<float>(imf_packed_weight_floats(27, cin, cout)), *d_f = dev<float>(feat.size()),
+        *d_out = dev<float>((size_t)m * cout);
+  HIP(hipMemcpy(d_w, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d_f, feat.data(), feat.size() * 4, hipMemcpyHostToDevice));
+  IMF(imf_pack_weights(d_w, 27, cin, cout, d_wp, nullptr));
+  imf_conv_args a;
+  memset(&a, 0, sizeof(a));
+  a.in_a = d_f; a.c_a = cin; a.w_packed = d_wp; a.kvol = 27; a.cout = cout;
+  a.tile_rows = tile_rows; a.nbr = nbr; a.tile_mask = mask; a.n_slots = slots; a.n_out = m;
+  a.relu = 1; a.out = d_out; a.split_k = 1; a.variant = 0;
+  IMF(imf_spconv_fwd(&a, nullptr));
+  HIP(hipDeviceSynchronize());
+  std::vector<float> out((size_t)m * cout);
+  HIP(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+  std::set<std::tuple<int, int, int>> occ;
+  for (int64_t i = 0; i < m; ++i) occ.insert({h_coords[4 * i + 1], h_coords[4 * i + 2], h_coords[4 * i + 3]});
+  for (int64_t i = 0; i < m; ++i) {
+    int cnt = 0;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx)
+      cnt += (int)occ.count({h_coords[4 * i + 1] + dx, h_coords[4 * i + 2] + dy, h_coords[4 * i + 3] + dz});
+    for (int c = 0; c < cout; ++c)
+      if (out[i * cout + c] != (float)(cnt * cin)) { printf("row %lld col %d: %g != %d\n", (long long)i, c, out[i * cout + c], cnt * cin); return 6; }
+  }
+  // a bad argument is reported, not executed
+  a.cout = 33;
+  if (imf_spconv_fwd(&a, nullptr) != IMF_EINVAL || !strstr(imf_last_error(), "cout")) { printf("argument check missing\n"); return 7; }
+  printf("C ABI driver OK: %lld points -> %lld voxels, conv exact on %lld rows\n", (long long)n, (long long)m, (long long)m);
+  return 0;
+}
