@@ -94,14 +94,17 @@ def pmc_traffic(kernel):
 
 
 def cpu_baseline(xyz, img, voxel, sd, seconds_budget=12.0):
-    """The oracle (C hash-map geometry + torch-CPU gather-GEMM-scatter convolutions =
-    MinkowskiEngine's CPU algorithm restated; dense parts are the torch-CPU ops the reference itself
-    would run) timed on this box's host cores over a bounded sample of the same workload.  torch's
-    intra-op pool does not scale to all cores of a large host on these small GEMMs (256 threads are
-    6x SLOWER than 16 on the EPYC 9575F GPU box), so the thread count is picked by a short probe and
-    reported as `cores`; the single-thread rate is reported beside it ("1 thread and all cores")."""
+    """The oracle timed on this box's host cores over a bounded sample of the same workload: C hash-map geometry
+    (MinkowskiEngine's CPU coordinate-map algorithm restated) + the convolutions either as the C / OpenMP twin
+    `imf_cpu_spconv_fwd` (output-stationary gather-FMA) or as torch-CPU per-offset gather-GEMM-scatter
+    (ME's CPU algorithm) -- whichever is faster here is `value`, the other is reported beside it; dense parts
+    (image trunk, attention) are the torch-CPU ops the reference itself would run.  Thread counts are picked by a short
+    probe (torch's intra-op pool does not scale to all cores of a large host: 256 threads are 6x SLOWER than 16 on the
+    EPYC GPU box) and reported as `cores`; the single-thread rate of the faster implementation is reported too
+    ("1 thread and all cores")."""
     import imf_oracle as O
     import imf_oracle_cbind as OC
+    ncpu = os.cpu_count() or 1
 
     def once():
         t0 = time.perf_counter()
@@ -110,35 +113,42 @@ def cpu_baseline(xyz, img, voxel, sd, seconds_budget=12.0):
         F = O.resunet_forward(sd, coords, img, geometry=geom)
         return time.perf_counter() - t0, F.shape[0]
 
-    ncpu = os.cpu_count() or 1
-    best_nt, best_t = 1, float("inf")
-    for nt in sorted({min(ncpu, c) for c in (8, 16, 32)}):
-        torch.set_num_threads(nt)
-        os.environ["OMP_NUM_THREADS"] = str(nt)
-        once()                                         # warm-up (page-in, thread pools)
-        dt, _ = once()
-        if dt < best_t:
-            best_nt, best_t = nt, dt
-    torch.set_num_threads(best_nt)
-    os.environ["OMP_NUM_THREADS"] = str(best_nt)
+    def set_threads(impl, nt):
+        O.SPCONV_IMPL = impl
+        torch.set_num_threads(min(nt, 32) if impl == "c" else nt)     # dense parts: torch's pool stays small
+        OC.set_threads(nt)
+
+    best = {}
+    for impl, cands in (("c", (16, 32, 64, 128, 256)), ("torch", (8, 16, 32))):
+        for nt in sorted({min(ncpu, c) for c in cands}):
+            set_threads(impl, nt)
+            once()                                     # warm-up (page-in, thread pools)
+            dt, _ = once()
+            if impl not in best or dt < best[impl][1]:
+                best[impl] = (nt, dt)
+    impl = min(best, key=lambda k: best[k][1])
+    other = "torch" if impl == "c" else "c"
+    set_threads(impl, best[impl][0])
     times, m, spent = [], 0, 0.0
     while spent < seconds_budget and len(times) < 12:
         dt, m = once()
         times.append(dt)
         spent += dt
     med = statistics.median(times)
-    torch.set_num_threads(1)                           # one thread: one run (a few seconds)
-    os.environ["OMP_NUM_THREADS"] = "1"
+    set_threads(impl, 1)                               # one thread: one run
     one_t, _ = once()
-    torch.set_num_threads(best_nt)
-    os.environ["OMP_NUM_THREADS"] = str(best_nt)
-    return {"value": round(m / med, 1), "unit": "descriptors/s", "cores": best_nt, "kind": "port",
+    set_threads("torch", 16)
+    O.SPCONV_IMPL = "torch"
+    names = {"c": "C / OpenMP twin imf_cpu_spconv_fwd (output-stationary gather-FMA)",
+             "torch": "torch-CPU per-offset gather-GEMM-scatter"}
+    return {"value": round(m / med, 1), "unit": "descriptors/s", "cores": best[impl][0], "kind": "port",
             "value_1_thread": round(m / one_t, 1),
+            "convolutions": names[impl],
+            "other_implementation": {"convolutions": names[other], "value": round(m / best[other][1], 1), "cores": best[other][0]},
             "sample": f"the same fragment (M={m}) end to end on the host, median of {len(times)} runs "
-                      f"({med * 1e3:.0f} ms each), {best_nt} threads (best of 8/16/32 on a {ncpu}-cpu host; one run "
-                      f"on 1 thread: {one_t * 1e3:.0f} ms): "
-                      f"C hash-map voxelise/pyramid/rulebooks (OpenMP) + torch-CPU per-offset "
-                      f"gather-GEMM-scatter convolutions, image encoder and attention"}
+                      f"({med * 1e3:.0f} ms each), {best[impl][0]} threads (best of a probe on a {ncpu}-cpu host; one run "
+                      f"on 1 thread: {one_t * 1e3:.0f} ms): C hash-map voxelise / pyramid / rulebooks (OpenMP) + the "
+                      f"convolutions as {names[impl]} + torch-CPU image encoder and attention"}
 
 
 def self_launch(args):

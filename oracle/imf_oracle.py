@@ -155,8 +155,14 @@ class Geometry:
 # gather -> GEMM -> scatter-add, fp32)
 # --------------------------------------------------------------------------
 
+SPCONV_IMPL = "torch"      # "c": route every convolution through the C / OpenMP twin (imf_oracle_cbind.spconv)
+
+
 def spconv(feat, kernel, nbr):
     """out[o] = sum_k feat[nbr[o,k]] @ kernel[k]; kernel [K,Cin,Cout] or [Cin,Cout]."""
+    if SPCONV_IMPL == "c":
+        import imf_oracle_cbind as OC
+        return OC.spconv(feat, kernel, nbr)
     feat = torch.as_tensor(feat, dtype=torch.float32)
     kernel = torch.as_tensor(kernel, dtype=torch.float32)
     if kernel.dim() == 2:

@@ -129,3 +129,33 @@ int orc_rulebook(const int32_t *in4, int64_t n_in, const int32_t *out4, int64_t 
   table_free(&t);
   return 0;
 }
+
+/* ---- CPU twin of imf_spconv_fwd (SURVEY 8b B3 "imf_cpu_*"; TEST INFRASTRUCTURE / reported CPU baseline only) ----------
+ * out[o] = sum_k in[nbr[o][k]] @ W[k]  (model/resunet.py:168-226 convolutions; nbr row-major [n_out][kvol], -1 = no input
+ * at that offset, the oracle's layout).  Output-stationary, OpenMP over blocks of output rows, the inner loop over the
+ * output channels vectorises; k ascending then input channel = the GPU kernels' summation order. */
+void imf_cpu_spconv_fwd(const float *in, int cin, const float *w, int kvol, int cout, const int32_t *nbr, int64_t n_out,
+                        float *out) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t o = 0; o < n_out; ++o) {
+    float acc[512];
+    for (int c = 0; c < cout; ++c) acc[c] = 0.f;
+    for (int k = 0; k < kvol; ++k) {
+      const int32_t i = nbr ? nbr[o * kvol + k] : (int32_t)o;
+      if (i < 0) continue;
+      const float *x = in + (int64_t)i * cin;
+      const float *wk = w + (int64_t)k * cin * cout;
+      for (int ci = 0; ci < cin; ++ci) {
+        const float a = x[ci];
+        const float *wr = wk + (int64_t)ci * cout;
+        for (int c = 0; c < cout; ++c) acc[c] += a * wr[c];
+      }
+    }
+    float *dst = out + o * cout;
+    for (int c = 0; c < cout; ++c) dst[c] = acc[c];
+  }
+}
+
+#include <omp.h>
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_max_threads(void) { return omp_get_max_threads(); }

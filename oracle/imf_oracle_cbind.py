@@ -22,6 +22,8 @@ def lib():
         L.orc_voxelize.restype, L.orc_voxelize.argtypes = L64, [P, L64, D, I, P, P]
         L.orc_downsample.restype, L.orc_downsample.argtypes = L64, [P, L64, I, P, P]
         L.orc_rulebook.restype, L.orc_rulebook.argtypes = I, [P, L64, P, L64, I, I, I, P]
+        L.imf_cpu_spconv_fwd.restype, L.imf_cpu_spconv_fwd.argtypes = None, [P, I, P, I, I, P, L64, P]
+        L.orc_set_threads.restype, L.orc_set_threads.argtypes = None, [I]
         _lib = L
     return _lib
 
@@ -78,3 +80,29 @@ class Geometry:
         self.k3 = [rulebook(L[i], L[i], 1 << i, 3) for i in range(4)]
         self.down = [rulebook(L[i], L[i + 1], 1 << i, 3) for i in range(3)]
         self.up = [rulebook_transpose(L[i + 1], L[i], 1 << i, 3) for i in range(3)]
+
+
+def spconv(feat, kernel, nbr):
+    """The C / OpenMP twin of the sparse convolution (imf_cpu_spconv_fwd): same contract as imf_oracle.spconv."""
+    import torch
+    f = np.ascontiguousarray(torch.as_tensor(feat, dtype=torch.float32).numpy())
+    w = np.ascontiguousarray(torch.as_tensor(kernel, dtype=torch.float32).numpy())
+    if w.ndim == 2:
+        w = w[None]
+    kvol, cin, cout = w.shape
+    assert cout <= 512 and f.shape[1] == cin
+    if nbr is None:
+        n_out, nb = f.shape[0], None
+    else:
+        nb = np.ascontiguousarray(np.asarray(nbr), dtype=np.int32)
+        n_out = nb.shape[0]
+        assert nb.shape[1] == kvol
+    out = np.empty((n_out, cout), np.float32)
+    lib().imf_cpu_spconv_fwd(f.ctypes.data, cin, w.ctypes.data, kvol, cout, None if nb is None else nb.ctypes.data, n_out,
+                             out.ctypes.data)
+    return torch.from_numpy(out)
+
+
+def set_threads(n):
+    """OpenMP threads of the C restatement (geometry + convolution twin)."""
+    lib().orc_set_threads(int(n))

@@ -186,3 +186,29 @@ def test_ransac_restatement_recovers_known_motion():
     # no hypothesis can survive when every correspondence is wrong by metres
     T0, it0, inl0, *_ = O.ransac_registration(src, dst + 50 * rng.standard_normal((n, 3)), corres, 3, 0.075, 0.9, 2000, seed=3)
     assert it0 == -1 and inl0 == 0 and (T0 == np.eye(4)).all()
+
+
+def test_cpu_conv_twin_matches_the_torch_restatement(clouds):
+    """imf_cpu_spconv_fwd (C / OpenMP, the reported CPU baseline's convolution) == the torch gather-GEMM-scatter
+    restatement, for k3, k1 (no table) and a strided map, and through the whole network."""
+    import imf_oracle_cbind as OC
+    xyz = clouds[0][::5].astype(np.float64)
+    coords, _ = OC.voxelize(xyz, 0.05)
+    g = OC.Geometry(coords)
+    gen = torch.Generator().manual_seed(0)
+    for nbr, cin, cout, kvol in ((g.k3[0], 32, 64, 27), (None, 96, 64, 1), (g.down[0], 32, 64, 27)):
+        n_in = len(g.levels[0])
+        f = torch.randn(n_in, cin, generator=gen)
+        w = torch.randn(kvol, cin, cout, generator=gen) * 0.1
+        ref = O.spconv(f, w if kvol > 1 else w[0], nbr)
+        got = OC.spconv(f, w if kvol > 1 else w[0], nbr)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    sd = O.seeded_state_dict(seed=0, with_unused_image_layers=True)
+    img = np.random.default_rng(0).random((1, 3, 120, 160)).astype(np.float32)
+    F_t = O.resunet_forward(sd, coords, img, geometry=g)
+    O.SPCONV_IMPL = "c"
+    try:
+        F_c = O.resunet_forward(sd, coords, img, geometry=g)
+    finally:
+        O.SPCONV_IMPL = "torch"
+    assert float((F_t - F_c).abs().max()) < 2e-6
