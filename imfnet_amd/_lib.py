@@ -125,6 +125,8 @@ _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
 SIGNATURES = {
     "imf_version": (_I, []),
     "imf_last_error": (C.c_char_p, []),
+    "imf_spconv_wgrad_workspace_bytes": (_Z, [_L, _I, _I, _I]),
+    "imf_spconv_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _L, _L, _I, _P, _P, _Z, _P]),
     "imf_ply_vertex_count": (_L, [C.c_char_p]),
     "imf_ply_read_points": (_L, [C.c_char_p, _P, _L]),
     "imf_png_info": (_I, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

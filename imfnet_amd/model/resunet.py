@@ -330,8 +330,8 @@ class ResUNet2(ME.MinkowskiNetwork):
 
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x, image):
-        if not self._can_fuse():
-            return self.forward_layers(x, image)
+        if not self._can_fuse() or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return self.forward_layers(x, image)          # training mode, or fine-tuning with frozen statistics
         if self._pending_image is None:
             self._refresh()
         bn = self._bn()

@@ -263,10 +263,11 @@ class _ConvBase(nn.Module):
 
     def run(self, x, in_b=None, scale=None, shift=None, residual=None, relu=False, l2norm=False):
         """Fused convolution on raw feature matrices; returns (features, output tensor stride)."""
-        if torch.is_grad_enabled() and self.kernel.requires_grad:
-            # the kernels have no backward: fail loudly instead of silently cutting the graph at every convolution
-            raise ImfError("imfnet_amd is inference-only (no sparse-convolution backward): run under torch.no_grad() "
-                           "or model.requires_grad_(False)")
+        if torch.is_grad_enabled() and (self.kernel.requires_grad or x.F.requires_grad):
+            # the FUSED call has no backward (its epilogue folds BatchNorm / ReLU / residual): fail loudly instead of
+            # silently cutting the graph.  Differentiable path: forward() -> autograd.SparseConvFunction.
+            raise ImfError("the fused convolution call is inference-only: use the module's forward() under autograd "
+                           "(model.forward_layers), or run under torch.no_grad()")
         rb, ts_out = self.rulebook(x)
         feat = x.F
         cin = feat.shape[1] + (0 if in_b is None else in_b.shape[1])
@@ -287,6 +288,13 @@ class _ConvBase(nn.Module):
         return out, ts_out
 
     def forward(self, x):
+        if torch.is_grad_enabled() and (self.kernel.requires_grad or x.F.requires_grad):
+            from .autograd import SparseConvFunction                      # training: differentiable convolution
+            _, ts_out = self.rulebook(x)
+            out = SparseConvFunction.apply(x.F, self.kernel, self, x)
+            if self.bias is not None:
+                out = out + self.bias
+            return x._like(out, ts_out)
         out, ts_out = self.run(x)
         return x._like(out, ts_out)
 

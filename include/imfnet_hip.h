@@ -566,6 +566,19 @@ int imf_ransac_registration(const double *src, int64_t n_src, const double *dst,
                             int max_iter, uint64_t seed, double *out_T, int32_t *out_meta, double *out_stats,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Training backward of the sparse convolution (last item) ---------------------------------------
+ * Replaces: the backward of ME.MinkowskiConvolution / ConvolutionTranspose under loss.backward(), lib/trainer.py:495-569.
+ * The INPUT gradient is imf_spconv_fwd itself over the opposite kernel map with transposed weights
+ * (imfnet_amd/autograd.py: same map with W[K-1-k]^T at stride 1, the transposed map for a strided convolution, the
+ * strided map for a transposed one).  The WEIGHT gradient is this entry point:
+ *     dw[k][ci][co] = sum over the pairs (i, o) of offset k of  in[i][ci] * grad_out[o][co]
+ * over the same rulebook the forward used (tile_rows / nbr as in imf_conv_args; nbr NULL = identity when kvol == 1).
+ * Any cin, cout >= 1.  Deterministic (chunk partials summed in order).  workspace: imf_spconv_wgrad_workspace_bytes. */
+size_t imf_spconv_wgrad_workspace_bytes(int64_t n_slots, int kvol, int cin, int cout);
+int imf_spconv_wgrad(const float *in, int cin, const float *grad_out, int cout, const int32_t *tile_rows,
+                     const int32_t *nbr, int64_t n_slots, int64_t n_out, int kvol, float *dw /* [kvol][cin][cout] */,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- Host-side codecs of the batch path: HOST pointers, no GPU involved ----------------------
  * Replace what the reference does around every fragment with Open3D / matplotlib / OpenCV / numpy
  * (scripts/generate_desc.py:83-97,118-123, util/uio.py:33-40).  All return 0 / a count on success, a negative

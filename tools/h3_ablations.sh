@@ -2,7 +2,7 @@
 # Compile-time ablations of the split-f16 conv (timing only, results are wrong): one library per mask.
 # usage (here): tools/h3_ablations.sh build "0 1 2 4 8 ..."   then on the GPU box: tools/h3_ablations.sh run "..."
 cd "$(dirname "$0")/.."
-SRCS=$(cd imfnet_amd/csrc && ls core.hip geometry.hip spconv.hip spconv_h3.hip fusion.hip image.hip matching.hip keypoints.hip ransac.hip executor.hip codecs.hip | sed 's#^#imfnet_amd/csrc/#')
+SRCS=$(cd imfnet_amd/csrc && ls core.hip geometry.hip spconv.hip spconv_h3.hip fusion.hip image.hip matching.hip keypoints.hip ransac.hip executor.hip codecs.hip backward.hip | sed 's#^#imfnet_amd/csrc/#')
 if [ "$1" = build ]; then
   mkdir -p imfnet_amd/_abl
   for m in $2; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function -DIMF_H3_ABL=$m $SRCS -o imfnet_amd/_abl/lib_$m.so -lz & done; wait
