@@ -158,13 +158,16 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
         got = _extract_with_runner(runner, xyz, voxel_size, device, image)
         if got is not None:
             return got
-    out = _extract_exact(model, runner, xyz, feats, voxel_size, device, image)
-    if hasattr(model, "take_flags") and model.take_flags(device) & FLAG_RANGE:
-        # an activation left the f16 range of the split-f16 convolutions (it would have become inf): the
-        # fragment is redone on the true-fp32 matrix instructions -- slower, never silently wrong
-        import warnings
-        warnings.warn("imfnet_amd: activation outside the f16 range; fragment recomputed with fp32 MFMA (variant 0)")
-        out = model.forward_fp32(lambda: _extract_exact(model, None, xyz, feats, voxel_size, device, image))
+    # descriptor extraction is inference: with is_eval (the reference's callers all sit under torch.no_grad())
+    # no autograd graph is recorded, so the packed-plan forward runs instead of the per-layer training path
+    with torch.set_grad_enabled(torch.is_grad_enabled() and not is_eval):
+        out = _extract_exact(model, runner, xyz, feats, voxel_size, device, image)
+        if hasattr(model, "take_flags") and model.take_flags(device) & FLAG_RANGE:
+            # an activation left the f16 range of the split-f16 convolutions (it would have become inf): the
+            # fragment is redone on the true-fp32 matrix instructions -- slower, never silently wrong
+            import warnings
+            warnings.warn("imfnet_amd: activation outside the f16 range; fragment recomputed with fp32 MFMA (variant 0)")
+            out = model.forward_fp32(lambda: _extract_exact(model, None, xyz, feats, voxel_size, device, image))
     return out
 
 
@@ -212,7 +215,8 @@ def extract_features_batch(model, xyz_list, voxel_size, device, images):
     if img is None:
         img = torch.as_tensor(images, dtype=torch.float32, device=device)
     stensor, inds = sparse_tensor_from_points(None, voxel_size, device, geometry=fut)
-    F = model(stensor, img).F
+    with torch.no_grad():
+        F = model(stensor, img).F
     sel = fut.xyz[inds.long()].cpu().numpy().astype(np.float64)
     items = stensor.coordinate_manager.level(1).items
     return [(sel[r0:r0 + rn], F[r0:r0 + rn]) for r0, rn in items]
