@@ -185,7 +185,6 @@ SIGNATURES = {
     "imf_pack_weights_split16": (_I, [_P, _I, _I, _I, _P, _P]),
     "imf_spconv_auto_split": (_I, [_L, _I, _I]),
     "imf_spconv_max_split": (_I, [_I, _I]),
-    "imf_spconv_lds_resident": (_I, [C.POINTER(ConvArgs)]),
     "imf_spconv_occupancy": (_I, [_I, _I, _I]),
     "imf_spconv_workspace_bytes": (_Z, [_L, _I, _I]),
     "imf_spconv_fwd": (_I, [C.POINTER(ConvArgs), _P]),

@@ -1206,15 +1206,6 @@ size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split) {
   return (size_t)8 * (size_t)(n_tiles % 256) * IMF_TILE_ROWS * (size_t)cout * sizeof(float);
 }
 
-int imf_spconv_lds_resident(const imf_conv_args *a) {
-  if (!a || a->variant != 6 || a->kvol < 1 || a->kvol >= kKCache) return 0;
-  ConvParams p{};
-  p.c_a = a->c_a; p.c_b = a->c_b; p.cout = a->cout; p.kvol = a->kvol;
-  p.nbr = a->nbr; p.tile_mask = a->tile_mask; p.n_slots = a->n_slots; p.tickets = a->tickets;
-  const int split = a->split_k > 0 ? a->split_k : imf_spconv_auto_split(a->n_slots, a->cout, a->kvol);
-  return spconv_h3_lds_applies(p, split) ? 1 : 0;
-}
-
 int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   IMF_REQUIRE(a, "imf_spconv_fwd: null args");
   IMF_REQUIRE(a->in_a && a->w_packed && a->out, "imf_spconv_fwd: null pointer");
@@ -1280,12 +1271,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
       p.tail_split = ts;
       grid.x = (unsigned)(p.tail_begin + tail_tiles * ts);
     }
-    if (spconv_h3_lds_applies(p, split)) {
-      const int rc = launch_spconv_h3_lds(p, st, a->kernel_tag);
-      if (rc != IMF_OK) return rc;
-    } else {
-      launch_spconv_h3(p, grid, CB, st, a->kernel_tag);
-    }
+    launch_spconv_h3(p, grid, CB, st, a->kernel_tag);
   } else if ((a->variant == 4 || a->variant == 5) && !simple) {
     const int RBv = a->variant == 4 ? 2 : 1;
     dim3 g4((unsigned)div_up(a->n_slots / 16, 4 * RBv), grid.y, grid.z);

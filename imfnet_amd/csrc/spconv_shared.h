@@ -187,8 +187,5 @@ constexpr int kKCache = 28;   // active offsets cached per workgroup (kvol <= 27
 
 // spconv_h3.hip: variant 6 (split-f16 MFMA); grid = (tiles, cout / (16 CB), split)
 void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use = 0);
-// spconv_lds.hip: variant 6 with the whole 32 -> 32 kernel resident in LDS, one persistent workgroup per CU
-bool spconv_h3_lds_applies(const ConvParams &p, int split);
-int launch_spconv_h3_lds(const ConvParams &p, hipStream_t st, int use = 0);
 
 }  // namespace imf

@@ -383,9 +383,6 @@ def conv_kernel_name(variant, cin, cout):
     return f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>"
 
 
-LAST_LDS_RESIDENT = False      # did the last spconv() call run the LDS-resident kernel (csrc/spconv_lds.hip)?
-
-
 def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual=None,
            relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False, flags=None):
     """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd.  `flags`: optional int32[1] device word that
@@ -429,8 +426,6 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     if TRACE is not None:
         ev = _Ev()
         a.ev_begin, a.ev_end = ev.begin, ev.end
-    global LAST_LDS_RESIDENT
-    LAST_LDS_RESIDENT = bool(L.imf_spconv_lds_resident(C.byref(a)))
     check(L.imf_spconv_fwd(C.byref(a), _stream()), "imf_spconv_fwd")
     if ev is not None:
         cin = a.c_a + a.c_b

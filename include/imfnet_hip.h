@@ -255,10 +255,6 @@ typedef struct imf_conv_args {
  * kernel that also applies the epilogue. */
 int imf_spconv_auto_split(int64_t n_slots, int cout, int kvol);
 int imf_spconv_max_split(int cout, int kvol);   /* largest value the rule returns for any row count */
-/* 1 when imf_spconv_fwd serves these arguments with the LDS-resident kernel (csrc/spconv_lds.hip: variant 6,
- * 32 -> 32 channels, <= 27 offsets, no split, >= 512 tiles; env IMF_NO_LDS_CONV turns it off), else 0.  Same
- * results bit for bit either way -- the query exists so that tests and profiles can tell which kernel ran. */
-int imf_spconv_lds_resident(const imf_conv_args *a);
 /* Tuning aid: resident workgroups per CU reported by the runtime for kernel `variant`. */
 int imf_spconv_occupancy(int variant, int co_blk, int j);
 size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split);

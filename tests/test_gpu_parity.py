@@ -538,37 +538,3 @@ def test_native_batched_pair_matches_single_fragments(model, clouds, images, mon
                                      skip_check=True, image=torch.as_tensor(imgs3[k:k + 1]))
             assert (out3[k][0] == xd).all() and (out3[k][1] - F).abs().max() < 2e-6
 
-
-def test_spconv_lds_resident_kernel_is_bit_identical(ops, clouds, monkeypatch):
-    """32 -> 32 layers on >= 512 tiles run with the whole kernel resident in LDS (csrc/spconv_lds.hip): same bits as
-    the streaming kernel (IMF_NO_LDS_CONV=1), fp32-class error against the fp64 oracle, every epilogue."""
-    from imfnet_amd import ops as OPS
-    xyz64 = clouds[0].astype(np.float64)
-    cm = _build_levels(ops, ops.voxelize(torch.as_tensor(xyz64).to(DEV), 0.025))
-    g = O.Geometry(O.voxelize(xyz64, 0.025)[0])
-    rb, nbr_ref = cm.conv_rulebook(1, 3, 1), g.k3[0]
-    n = len(g.levels[0])
-    assert rb.n_slots // 64 >= 512
-    f, w = _rand((n, 32), 60), _rand((27, 32, 32), 61, 0.05)
-    sc, sh, res = _rand((32,), 62).abs() + 0.5, _rand((32,), 63), _rand((n, 32), 64)
-    wp = ops.pack_weights(w.to(DEV), split16=True)
-    dev = lambda t: t.to(DEV)   # noqa: E731
-    cases = [dict(), dict(scale=dev(sc), shift=dev(sh), residual=dev(res), relu=True), dict(shift=dev(sh), l2norm=True)]
-    got = []
-    for kw in cases:
-        got.append(ops.spconv(dev(f), wp, 32, rb, variant=6, **kw))
-        assert OPS.LAST_LDS_RESIDENT
-        assert torch.equal(got[-1], ops.spconv(dev(f), wp, 32, rb, variant=6, **kw))
-    monkeypatch.setenv("IMF_NO_LDS_CONV", "1")
-    for kw, a in zip(cases, got):
-        b = ops.spconv(dev(f), wp, 32, rb, variant=6, **kw)
-        assert not OPS.LAST_LDS_RESIDENT
-        assert torch.equal(a, b)
-    monkeypatch.delenv("IMF_NO_LDS_CONV")
-    ref64 = O.spconv_f64(f, w, nbr_ref)
-    bound = O.spconv_f64(f.abs(), w.abs(), nbr_ref) * 2e-6 + 1e-7
-    assert ((got[0].cpu().double() - ref64).abs() <= bound).all()
-    assert (got[1].cpu().double() - torch.relu(ref64 * sc + sh + res)).abs().max() < 2e-5
-    # a split launch or another channel count stays on the streaming kernel
-    ops.spconv(dev(f), wp, 32, rb, variant=6, split_k=3)
-    assert not OPS.LAST_LDS_RESIDENT

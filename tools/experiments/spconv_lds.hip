@@ -1,3 +1,9 @@
+// EXPERIMENT -- not part of the library build (round 2; see DESIGN.md section 6 "what the counters say").
+// Result: 45.9 us per 32->32 level-0 layer, the same as the streaming kernel k_spconv_h3<2> (43-45 us) -- so neither
+// the per-stage barriers nor the weight re-reads set that kernel's time.  Ablations of THIS kernel (tools/kernel_ab.sh,
+// -DIMF_LDS_ABL=..): no MFMA 30.8 us, no gathers 27.8 us, no split 44.0 us, no epilogue 41.2 us, random rows instead
+// of the neighbour table 74.5 us; prefetch depth 2 / 4 / 8: 45.9 / 45.9 / 51.9 us; XCD-contiguous blocks on/off: same.
+// Kept as a record; to try it again add it to SRCS and call launch_spconv_h3_lds from imf_spconv_fwd.
 // Sparse convolution, variant 6, for the layers whose WHOLE split-f16 kernel fits the LDS of a CU:
 // 32 -> 32 channels, up to 27 offsets = 27 x 4 KiB = 108 KiB of the 160 KiB.
 //
@@ -13,6 +19,10 @@
 // exact zeros here and are skipped there).  Same epilogue (spconv_shared.h).
 #include "spconv_shared.h"
 
+#ifndef IMF_LDS_ABL
+#define IMF_LDS_ABL 0   // timing experiments only (tools/lds_ablations.sh): 1 no MFMA, 2 no split, 4 no gathers, 8 no index loads, 16 no LDS reads, 32 no epilogue
+#endif
+
 namespace imf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -21,7 +31,10 @@ namespace {
 
 constexpr int kLdsKvol = 27;
 constexpr int kLdsWaves = 16;
-constexpr int kDepth = 4;            // row gathers in flight per wavefront
+#ifndef IMF_LDS_DEPTH
+#define IMF_LDS_DEPTH 4
+#endif
+constexpr int kDepth = IMF_LDS_DEPTH;   // row gathers in flight per wavefront
 
 __device__ __forceinline__ void split8(const float4 &x0, const float4 &x1, f16x8 &hi, f16x8 &lo) {
   const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -49,14 +62,37 @@ k_spconv_h3_lds(const ConvParams p) {
         auto_split_rule(slots_act, p.cout, p.dyn_split_kvol, p.split_min_blocks, p.split_target) > 1)
       atomicOr(p.err, 16);                           // the exact path would have split this launch: flagged
   }
-  const int n_blk = (int)(slots_act / 16);           // 16-row blocks
-  const int first = blockIdx.x * kLdsWaves + wave, step = gridDim.x * kLdsWaves;
-  if (blockIdx.x * kLdsWaves >= n_blk) return;
+  int n_blk = (int)(slots_act / 16);                 // 16-row blocks
+  int first = blockIdx.x * kLdsWaves + wave, step = gridDim.x * kLdsWaves, blk0 = 0;
+  if (!p.no_xcd_swizzle && (gridDim.x & 7) == 0) {
+    // Workgroup b runs on XCD b % 8, and every XCD has its own 4 MiB L2.  Rows are ordered by voxel key, so a
+    // contiguous eighth of the row blocks gathers (mostly) from a contiguous eighth of the input matrix: XCD x
+    // takes blocks [x n/8, (x+1) n/8) and its 32 workgroups interleave inside that range.
+    const int xcd = blockIdx.x & 7, per = ((n_blk + 31) / 32) * 4;      // tile-aligned share
+    blk0 = xcd * per;
+    n_blk = n_blk < blk0 + per ? n_blk : blk0 + per;
+    first = blk0 + (blockIdx.x >> 3) * kLdsWaves + wave;
+    step = (gridDim.x >> 3) * kLdsWaves;
+    if (blk0 + (int)(blockIdx.x >> 3) * kLdsWaves >= n_blk) return;
+  } else if (blockIdx.x * kLdsWaves >= n_blk) {
+    return;
+  }
 
   {
     const float4 *src = reinterpret_cast<const float4 *>(p.w_packed);
     const int total = p.kvol * 256;
-    for (int i = tid; i < total; i += 64 * kLdsWaves) wl[i] = src[i];
+    constexpr int kPer = (kLdsKvol * 256 + 64 * kLdsWaves - 1) / (64 * kLdsWaves);   // 7: all loads in flight together
+    float4 v[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = tid + i * 64 * kLdsWaves;
+      v[i] = e < total ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = tid + i * 64 * kLdsWaves;
+      if (e < total) wl[e] = v[i];
+    }
   }
   __syncthreads();
   const float un = p.w_unscale ? *p.w_unscale : 1.f;
@@ -75,7 +111,9 @@ k_spconv_h3_lds(const ConvParams p) {
 #pragma unroll
     for (int k = 0; k < kLdsKvol; ++k) {
       int irow = -1;
-      if (k < p.kvol && ((mask >> k) & 1u)) irow = p.nbr[(long long)k * p.n_slots + slot];
+      if (IMF_LDS_ABL & 8) {
+        if (k < p.kvol && ((mask >> k) & 1u)) irow = (int)((slot * 2654435761u + k * 40503u) % (unsigned)p.n_out);
+      } else if (k < p.kvol && ((mask >> k) & 1u)) irow = p.nbr[(long long)k * p.n_slots + slot];
       // a row without an input at this offset reads beyond the 2 GiB window: zeros, no branch
       voff[k] = irow >= 0 ? (unsigned)irow * 128u + 32u * q4 : 0x80000000u;
     }
@@ -85,17 +123,37 @@ k_spconv_h3_lds(const ConvParams p) {
 #pragma unroll
     for (int k = 0; k < kLdsKvol + kDepth - 1; ++k) {
       if (k < kLdsKvol) {
+        if (IMF_LDS_ABL & 4) {
+          a[k % kDepth][0] = make_float4(__uint_as_float(voff[k]), 1.f, 2.f, 3.f);
+          a[k % kDepth][1] = make_float4(__uint_as_float(voff[k] + 1u), 1.f, 2.f, 3.f);
+        } else {
         a[k % kDepth][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[k], 0, 0));
         a[k % kDepth][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[k] + 16u, 0, 0));
+        }
       }
       const int c = k - (kDepth - 1);
       if (c < 0) continue;
       if (__ballot(voff[c] != 0x80000000u) == 0ull) continue;   // nothing under this offset for the 16 rows
       f16x8 ah, al;
-      split8(a[c % kDepth][0], a[c % kDepth][1], ah, al);
+      if (IMF_LDS_ABL & 2) {
+        ah = __builtin_bit_cast(f16x8, a[c % kDepth][0]);
+        al = __builtin_bit_cast(f16x8, a[c % kDepth][1]);
+      } else {
+        split8(a[c % kDepth][0], a[c % kDepth][1], ah, al);
+      }
       const float4 *wk = wl + c * 256 + lane;
-      const f16x8 bh0 = *reinterpret_cast<const f16x8 *>(wk), bl0 = *reinterpret_cast<const f16x8 *>(wk + 64);
-      const f16x8 bh1 = *reinterpret_cast<const f16x8 *>(wk + 128), bl1 = *reinterpret_cast<const f16x8 *>(wk + 192);
+      f16x8 bh0, bl0, bh1, bl1;
+      if (IMF_LDS_ABL & 16) {
+        bh0 = bl0 = bh1 = bl1 = __builtin_bit_cast(f16x8, make_float4(un, (float)c, un, un));
+      } else {
+        bh0 = *reinterpret_cast<const f16x8 *>(wk), bl0 = *reinterpret_cast<const f16x8 *>(wk + 64);
+        bh1 = *reinterpret_cast<const f16x8 *>(wk + 128), bl1 = *reinterpret_cast<const f16x8 *>(wk + 192);
+      }
+      if (IMF_LDS_ABL & 1) {   // keep the operands alive
+        acc[0][0] += (float)bh0[0] + (float)bl0[1] + (float)ah[0] + (float)al[1];
+        acc[1][0] += (float)bh1[0] + (float)bl1[1] + (float)ah[2] + (float)al[3];
+        continue;
+      }
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, acc[1], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, acc[0], 0, 0, 0);
@@ -103,7 +161,11 @@ k_spconv_h3_lds(const ConvParams p) {
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[1], 0, 0, 0);
     }
-    conv_epilogue<2>(p, acc, tile, 0, sub, r16, q4, un);
+    if (IMF_LDS_ABL & 32) {
+      if (acc[0][0] + acc[1][1] == 12345.f) p.out[slot] = acc[0][2];
+    } else {
+      conv_epilogue<2>(p, acc, tile, 0, sub, r16, q4, un);
+    }
   }
 }
 

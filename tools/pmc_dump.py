@@ -1,24 +1,19 @@
 #!/usr/bin/env python3
-"""Average PMC counter values per kernel symbol from rocprofv3 rocpd databases.
-usage: pmc_dump.py <substring of kernel name> <db> [<db> ...]"""
+"""Average per launch of every counter in a rocprofv3 --pmc database, for the kernels whose name matches a regex.
+usage: pmc_dump.py <results.db> <kernel regex>"""
 import collections
-import glob
+import re
 import sqlite3
 import sys
 
-sub = sys.argv[1]
-for pat in sys.argv[2:]:
-    for db in sorted(glob.glob(pat, recursive=True)):
-        cur = sqlite3.connect(db).cursor()
-        try:
-            rows = cur.execute("select name, counter_name, dispatch_id, sum(counter_value) from pmc_events "
-                               "group by name, counter_name, dispatch_id").fetchall()
-        except sqlite3.Error as e:
-            print(db, "->", e)
-            continue
-        agg = collections.defaultdict(list)
-        for name, cn, _, v in rows:
-            if sub in name:
-                agg[(name.split("(")[0].replace("void ", ""), cn)].append(v)
-        for (k, cn), v in sorted(agg.items()):
-            print(f"{k:40s} {cn:34s} n={len(v):3d} avg={sum(v) / len(v):16.1f}")
+cur = sqlite3.connect(sys.argv[1]).cursor()
+rows = cur.execute("select name, counter_name, dispatch_id, sum(counter_value) from pmc_events "
+                   "group by name, counter_name, dispatch_id").fetchall()
+agg = collections.defaultdict(list)
+pat = re.compile(sys.argv[2])
+for name, counter, _, v in rows:
+    short = name.split("(")[0].replace("void ", "")
+    if pat.search(short):
+        agg[(short, counter)].append(v)
+for (k, c), v in sorted(agg.items()):
+    print(f"{k:40s} {c:36s} n={len(v):4d} avg={sum(v) / len(v):16.1f}")
