@@ -361,7 +361,7 @@ def conv_variant_for(kvol):
 
 def pack_weights(kernel, out=None, split16=False):
     """ME kernel tensor [kvol,cin,cout] (or [cin,cout]) -> MFMA fragment-major image: fp32 B
-    fragments (variants 0-5) or, with split16, the hi/lo f16 fragments of variant 6 (same size)."""
+    fragments (variants 0 and 1) or, with split16, the hi/lo f16 fragments of variant 6 (same size)."""
     k = kernel.detach()
     if k.dim() == 2:
         k = k.unsqueeze(0)

@@ -206,10 +206,9 @@ typedef struct imf_conv_args {
   int32_t l2norm;         /* y /= ||y||_2 over the row (requires cout <= 64)                      */
   float *out;             /* [n_out, cout]                                                        */
   int32_t split_k;        /* 0 = choose automatically; >= 1 = number of kernel-offset partitions  */
-  int32_t variant;        /* 0 = pipelined workgroup kernel; 1 = simple reference kernel;
-                             2 = wave-autonomous kernel with per-offset row compaction;
-                             3 = 128-row workgroup kernel with per-offset row compaction;
-                             4 / 5 = barrier-free register kernel, 32 / 16 rows per wavefront;
+  int32_t variant;        /* 0 = pipelined workgroup kernel on the fp32 MFMA; 1 = the same arithmetic without the
+                             pipeline (simple reference kernel; any kvol); 2..5 = retired round-1 experiments
+                             (tools/experiments/spconv_variants.hip), rejected with IMF_ERR_INVALID;
                              6 = variant 0's pipeline on the f16 matrix pipe with split operands
                                  (w_packed from imf_pack_weights_split16; kvol <= 27; |input| < 65504;
                                  in_a / in_b smaller than 2 GiB each: raw-buffer addressing) */

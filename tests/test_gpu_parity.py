@@ -172,8 +172,8 @@ def _rb_and_ref(cm, g, which):
     return cm.conv_rulebook(1, 1, 1), None, len(g.levels[0])
 
 
-@pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple", "wave", "wave_split3", "c", "c_split3",
-                                  "reg2", "reg1", "reg2_split3", "h3", "h3_split1", "h3_split5", "h3_split5_fused"])
+@pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple",
+                                  "h3", "h3_split1", "h3_split5", "h3_split5_fused"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
     """Plain convolution (no epilogue) vs the oracle; error measured against an fp64 evaluation and
@@ -185,13 +185,10 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
     w = _rand((kvol, ca + cb, cout), 12, 1.0 / np.sqrt(kvol * (ca + cb)))
     kw = {"auto": {}, "split1": {"split_k": 1}, "split5": {"split_k": 5}, "simple": {"variant": 1},
           "split5_fused": {"split_k": 5, "fused_reduce": True},
-          "wave": {"variant": 2, "split_k": 1}, "wave_split3": {"variant": 2, "split_k": 3},
-          "c": {"variant": 3, "split_k": 1}, "c_split3": {"variant": 3, "split_k": 3},
-          "reg2": {"variant": 4, "split_k": 1}, "reg1": {"variant": 5, "split_k": 1},
-          "reg2_split3": {"variant": 4, "split_k": 3}, "h3": {"variant": 6},
+          "h3": {"variant": 6},
           "h3_split1": {"variant": 6, "split_k": 1}, "h3_split5": {"variant": 6, "split_k": 5},
           "h3_split5_fused": {"variant": 6, "split_k": 5, "fused_reduce": True}}[mode]
-    if mode in ("split5", "split5_fused", "wave_split3", "c_split3", "reg2_split3", "h3_split5", "h3_split5_fused") and kvol == 1:
+    if mode in ("split5", "split5_fused", "h3_split5", "h3_split5_fused") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")
     out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV), split16=mode.startswith("h3")), cout, rb,
                      in_b=None if fb is None else fb.to(DEV), **kw).cpu()
@@ -218,14 +215,11 @@ def test_spconv_epilogues(ops, geom_s5):
     assert (got - torch.relu(base * sc + sh + res)).abs().max() < 5e-5
     ref = base + sh
     ref = ref / ref.norm(dim=1, keepdim=True)
-    for kw in ({}, {"split_k": 3}, {"variant": 1}, {"variant": 2, "split_k": 1}, {"variant": 2, "split_k": 2},
-               {"variant": 3, "split_k": 1}, {"variant": 3, "split_k": 2}, {"variant": 4, "split_k": 1},
-               {"variant": 5, "split_k": 2}):
+    for kw in ({}, {"split_k": 3}, {"variant": 1}):
         got = ops.spconv(f.to(DEV), wp, 32, rb, shift=sh.to(DEV), l2norm=True, **kw).cpu()
         assert (got - ref).abs().max() < 5e-6
         assert torch.allclose(got.norm(dim=1), torch.ones(n), atol=1e-5)
-    for kw in ({"split_k": 4}, {"variant": 2, "split_k": 1}, {"variant": 3, "split_k": 1}, {"variant": 4},
-               {"variant": 5, "split_k": 1}):
+    for kw in ({"split_k": 4}, {"variant": 1}):
         got = ops.spconv(f.to(DEV), wp, 32, rb, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV),
                          relu=True, **kw).cpu()
         assert (got - torch.relu(base * sc + sh + res)).abs().max() < 5e-5
@@ -282,8 +276,7 @@ def test_spconv_deterministic(ops, geom_s5):
     rb = cm.conv_rulebook(1, 3, 1)
     f = _rand((len(g.levels[0]), 64), 30).to(DEV)
     wp = ops.pack_weights(_rand((27, 64, 64), 31, 0.03).to(DEV))
-    for kw in ({}, {"split_k": 4}, {"variant": 2, "split_k": 1}, {"variant": 3, "split_k": 1}, {"variant": 3},
-               {"variant": 4}, {"variant": 5}):
+    for kw in ({}, {"split_k": 4}, {"variant": 1}):
         a = ops.spconv(f, wp, 64, rb, **kw)
         b = ops.spconv(f, wp, 64, rb, **kw)
         assert torch.equal(a, b)
@@ -354,6 +347,10 @@ def test_spconv_argument_errors(ops, geom_s5):
         ops.spconv(f, torch.zeros(27 * 48 * 32, device=DEV), 32, rb)        # cin % 32 != 0
     with pytest.raises(ImfError):
         ops.spconv(f[:, :32].contiguous(), torch.zeros(5, device=DEV), 32, rb)   # wrong weight size
+    wp = ops.pack_weights(torch.zeros(27, 32, 32, device=DEV))
+    for retired in (2, 3, 4, 5):                                             # round-1 experiments, no longer built
+        with pytest.raises(ImfError):
+            ops.spconv(f[:, :32].contiguous(), wp, 32, rb, variant=retired)
 
 
 # ------------------------------------------------------------------ whole model
