@@ -677,6 +677,9 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   const bool simple = a->variant != 6 && (a->variant == 1 || a->kvol >= kKCache || (a->c_b > 0 && a->c_a % (16 * J) != 0));
   IMF_REQUIRE(a->variant != 6 || a->kvol < kKCache,
               "imf_spconv_fwd: variant 6 (split-f16 weights) needs kvol <= %d", kKCache - 1);
+  IMF_REQUIRE(a->variant != 6 || (a->kvol * (cin / 32) < kSubTab && a->c_a <= 1024 && a->c_b <= 1024),
+              "imf_spconv_fwd: variant 6 needs kvol * cin / 32 < %d and <= 1024 channels per source (kvol=%d cin=%d): use variant 0",
+              kSubTab, a->kvol, cin);
   int split = simple ? 1 : (a->split_k > 0 ? a->split_k : imf_spconv_auto_split(a->n_slots, a->cout, a->kvol));
   IMF_REQUIRE(split >= 1 && split <= 32, "imf_spconv_fwd: split_k=%d", split);
   if (split > 1)

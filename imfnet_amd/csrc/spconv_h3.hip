@@ -13,7 +13,7 @@
 // Work decomposition is the one of variant 0 (spconv.hip): 64-row rulebook tile x 32/64-wide output
 // slab x a partition of the tile's active offsets; 16 KiB weight stages double-buffered in LDS with
 // register prefetch; A gathered straight from the input rows (lane l: 8 consecutive channels
-// 32cc + 8(l>>4).. of row nbr[k][l&15], split to hi/lo in registers).
+// 32cc + 4(l>>4).. and 32cc + 16 + 4(l>>4).. of row nbr[k][l&15], split to hi/lo in registers).
 #include "spconv_shared.h"
 
 #ifndef IMF_H3_ABL
@@ -25,7 +25,9 @@ namespace imf {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Packed image (same size as the fp32 one: two halves per weight):
-//   [y][k][cc][q = 2 cb + h][lane][t],  ci = 32 cc + 8 (lane>>4) + t,  co = y CW + 16 cb + (lane&15),
+//   [y][k][cc][q = 2 cb + h][lane][t],  ci = 32 cc + 16 (t>>2) + 4 (lane>>4) + (t&3),  co = y CW + 16 cb + (lane&15),
+//   (the contraction index of the MFMA is free to permute: lane group q holds channels 4q..4q+3 and 16+4q..16+4q+3 so that
+//   each of the two 16-byte gathers of a row is one contiguous 64-byte segment across the four lanes of that row)
 //   h = 0: hi halves, h = 1: lo halves; one (q, lane) entry = 8 halves = one float4.
 // max |w| of the kernel as float bits (non-negative floats order like unsigned integers)
 __global__ void __launch_bounds__(256)
@@ -75,7 +77,7 @@ k_pack_weights_h3(const float *__restrict__ w, int kvol, int cin, int cout, _Flo
   const int cc = r % ncc; r /= ncc;
   const int k = r % kvol; r /= kvol;
   const int y = (int)r;
-  const int ci = cc * 32 + 8 * (lane >> 4) + t;
+  const int ci = cc * 32 + 16 * (t >> 2) + 4 * (lane >> 4) + (t & 3);
   const int co = y * CW + 16 * cb + (lane & 15);
   const float v = ldexpf(w[((long long)k * cin + ci) * cout + co], shift);
   const _Float16 hi = (_Float16)v;
@@ -106,17 +108,30 @@ __device__ __forceinline__ void split8(const float4 &x0, const float4 &x1, f16x8
 #define IMF_STAMP(i) do { } while (0)
 #endif
 
+// Sub-stage table entry (one per (offset ordinal jk, input-channel chunk cc) of the partition, built once per
+// workgroup): weight sub-stage index k * ncc + cc | jk << 9 | source B? << 14 | chunk index inside its source << 15.
+// The main loop reads ONE word per sub-stage and derives every address from it with a handful of scalar ops -- the
+// previous formulation advanced (jk, cc) with compare/select chains and re-derived the source, the stride and the
+// row offset per sub-stage (~100 bookkeeping instructions per 24 MFMAs; counters and ablations in
+// profiles/r02_pmc_conv_counters.txt showed the kernel issue-bound on exactly those).
+constexpr int kDummyJk = kKCache - 1;        // neighbour-table row that is always "no input" (kvol < kKCache)
+constexpr unsigned kNoRow = 0x00FFFFFFu;     // 24-bit row index of a missing input: kNoRow * stride lands beyond the
+                                             // buffer window for every stride that is a multiple of 128 bytes
+
 // USE tags the launch for profilers only (same code): 0 = the 23 sparse convolutions of the ResUNet, 1 = the dense
 // image-branch convolutions that run on this kernel over static pixel tables (csrc/image.hip) -- so that a kernel
 // trace's per-symbol averages can be compared with bench.py's roofline block, which counts the sparse launches.
-template <int CO_BLK, int USE>
+// CAT: the input is the channel concatenation of two matrices (in_a | in_b), else in_a alone.
+template <int CO_BLK, int USE, bool CAT>
 __global__ void __launch_bounds__(256, 4)   // 4 workgroups per CU: <= 128 registers per lane
 k_spconv_h3(const ConvParams p) {
   constexpr int SUB_F4 = 2 * CO_BLK * 64;            // float4 per (k, cc) sub-stage: 512 or 256
+  constexpr int SUB_SHIFT = CO_BLK == 4 ? 13 : 12;   // log2(bytes per sub-stage)
   constexpr int KG = 1024 / SUB_F4;                  // sub-stages per 16 KiB macro stage: 2 or 4
   constexpr int QPS = SUB_F4 / 256;                  // float4 per thread per sub-stage: 2 or 1
   __shared__ float4 wlds[2][1024];
-  __shared__ int nbr_lds[kKCache][IMF_TILE_ROWS];
+  __shared__ unsigned nbr_lds[kKCache][IMF_TILE_ROWS];
+  __shared__ unsigned stab[kSubTab];
   __shared__ int klist[kKCache];
 
   // XCD-contiguous tile order (opt-in, IMF_H3_XCD=1): workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2,
@@ -162,7 +177,7 @@ k_spconv_h3(const ConvParams p) {
   }
   const int y = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
-  const int cin = p.c_a + p.c_b;
+  const int cin = p.c_a + (CAT ? p.c_b : 0);
   const int ncc = cin / 32;
 
   IMF_STAMP(0);
@@ -192,7 +207,11 @@ k_spconv_h3(const ConvParams p) {
   }
   __syncthreads();
   IMF_STAMP(1);
-  // the tile's slice of the neighbour table: all loads in flight together, then the LDS stores
+  const int n_sub = nk * ncc;
+  const int n_macro = (n_sub + KG - 1) / KG;
+  // the tile's slice of the neighbour table (all loads in flight together, then the LDS stores) as 24-bit row
+  // indices, and the sub-stage table; both padded so that the main loop needs no bounds checks: entries past the
+  // partition point at the all-missing row kDummyJk and at weight sub-stage 0, i.e. they add exact zeros
   const long long tile_slot0 = (long long)tile * IMF_TILE_ROWS;
   {
     constexpr int kPer = (kKCache * IMF_TILE_ROWS + 255) / 256;   // 7
@@ -204,10 +223,22 @@ k_spconv_h3(const ConvParams p) {
       if (j < nk)
         v[i] = p.nbr ? p.nbr[(long long)klist[j] * p.n_slots + tile_slot0 + r] : row_of_slot(p, tile_slot0 + r);
     }
+    if (tid < kSubTab) {
+      unsigned e = (unsigned)kDummyJk << 9;
+      if (tid < n_sub) {
+        const int jk = tid / ncc, cc = tid - jk * ncc;
+        const int ch0 = cc * 32;
+        const bool second = CAT && ch0 >= p.c_a;       // a chunk never straddles the sources: c_a % 32 == 0 (host-checked)
+        const int cch = second ? (ch0 - p.c_a) >> 5 : cc;
+        e = (unsigned)(klist[jk] * ncc + cc) | ((unsigned)jk << 9) | ((second ? 1u : 0u) << 14) | ((unsigned)cch << 15);
+      }
+      stab[tid] = e;
+    }
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       const int e = tid + 256 * i, j = e >> 6, r = e & 63;
-      if (j < nk) nbr_lds[j][r] = v[i];
+      if (j < nk) nbr_lds[j][r] = v[i] >= 0 ? (unsigned)v[i] : kNoRow;
+      else if (j == kDummyJk) nbr_lds[j][r] = kNoRow;
     }
   }
   __syncthreads();
@@ -217,56 +248,56 @@ k_spconv_h3(const ConvParams p) {
 #pragma unroll
   for (int cb = 0; cb < CO_BLK; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int n_sub = nk * ncc;
-  const int n_macro = (n_sub + KG - 1) / KG;
-
   // prefetch registers: named scalars for the weight quads (an array would land in scratch)
   float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, w3 = w0;
   float4 a_next[KG][2] = {};
 
-  // The (offset, input row) of a sub-stage come from LDS; they are looked up one macro stage before
-  // the loads that use them are issued, so the prefetch never waits on an LDS round trip, and the
-  // (offset ordinal, channel chunk) pair is advanced incrementally (no division in the loop).
-  int lk_t = 0, lk_jk = 0, lk_cc = 0;
-  int k_nx[KG], irow_nx[KG], cc_nx[KG];
-#define IMF_LOOKUP()                                                                               \
+  // Raw buffer loads (SGPR base + 32-bit offsets): no 64-bit address arithmetic, and a row without an input at this
+  // offset (kNoRow) gets an offset beyond the buffer window, which the hardware reads as zeros -- no branch, no zero
+  // fill.  Window = 2 GiB - 4 KiB: kNoRow * stride mod 2^32 is >= 0x7FFFFD80 for every stride = 128 m, m <= 8.
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.w_packed), (short)0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.in_a), (short)0, 0x7FFFF000, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(CAT ? p.in_b : p.in_a), (short)0, 0x7FFFF000, 0x00020000);
+  const unsigned stride_a = (unsigned)p.c_a * 4u, stride_b = (unsigned)(CAT ? p.c_b : p.c_a) * 4u;
+  const unsigned lane_base = 16u * q4;
+  const unsigned row_byte = (unsigned)(wave * 16 + r16) * 4u;
+  const unsigned woff0 = (unsigned)tid * 16u;
+  const unsigned wslab = (unsigned)((long long)y * p.kvol * ncc * SUB_F4 * 16);     // bytes (image < 2 GiB)
+
+  // Software pipeline of the bookkeeping: the table word of a sub-stage is read three macro stages ahead, its input
+  // row two ahead, the global loads are issued one ahead -- nothing in the loop waits on an LDS round trip.
+  unsigned e_b[KG], e_c[KG], e_d[KG], irow_b[KG], irow_c[KG];
+#define IMF_READ_E(dst, stage)                                                                     \
   {                                                                                                \
     _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                              \
-      const bool live = lk_t < n_sub;                                                              \
-      const int jk = live ? lk_jk : 0;                                                             \
-      k_nx[g] = klist[jk];                                                                         \
-      irow_nx[g] = live ? nbr_lds[jk][wave * 16 + r16] : -1;                                       \
-      cc_nx[g] = live ? lk_cc : 0;                                                                 \
-      ++lk_t;                                                                                      \
-      if (++lk_cc == ncc) { lk_cc = 0; ++lk_jk; }                                                  \
+      const int t = (stage) * KG + g;                                                              \
+      dst[g] = stab[t < kSubTab - 1 ? t : kSubTab - 1];                                            \
     }                                                                                              \
   }
-
-  // prefetch of the macro stage looked up last: weights -> w0..w3, A fragments -> a_next.
-  // Raw buffer loads (SGPR base + 32-bit offsets): no 64-bit address arithmetic, and a row without an
-  // input at this offset gets an offset beyond the 2 GiB window, which the hardware reads as zeros --
-  // no branch, no zero fill.  The loop was issue-bound on exactly that scalar/vector bookkeeping.
-  const unsigned woff0 = (unsigned)tid * 16u;
-  const long long wslab = (long long)y * p.kvol * ncc * SUB_F4 * 16;     // bytes
-#define IMF_PREFETCH(n)                                                                           \
+#define IMF_READ_ROW(dst, e)                                                                       \
+  {                                                                                                \
+    _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                              \
+      const unsigned jk256 = ((unsigned)__builtin_amdgcn_readfirstlane((int)e[g]) >> 1) & (31u << 8); \
+      dst[g] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(&nbr_lds[0][0]) + jk256 + row_byte); \
+    }                                                                                              \
+  }
+  // global loads of one macro stage: weights -> w0..w3, A fragments -> a_next
+#define IMF_PREFETCH(e, irow)                                                                      \
   {                                                                                                \
     unsigned wso[KG];                                                                              \
     _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                              \
-      const int k = __builtin_amdgcn_readfirstlane(k_nx[g]);                                       \
-      const int cc = cc_nx[g];                                                                     \
-      wso[g] = (unsigned)(wslab + ((long long)k * ncc + cc) * (SUB_F4 * 16));                      \
-      const int irow = irow_nx[g];                                                                 \
-      /* a chunk never straddles the two cat sources: c_a % 32 == 0 (host-checked) */               \
-      const int ch0 = cc * 32;                                                                     \
-      const bool first = ch0 < p.c_a;                                                              \
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(                         \
-          const_cast<float *>(first ? p.in_a : p.in_b), (short)0, 0x7FFFFFFF, 0x00020000);         \
-      const unsigned stride = (unsigned)(first ? p.c_a : p.c_b) * 4u;                              \
-      const unsigned voff = irow >= 0 ? (unsigned)irow * stride + 32u * q4 : 0x80000000u;          \
-      const int soff = (first ? ch0 : ch0 - p.c_a) * 4;                                            \
+      const unsigned ee = (unsigned)__builtin_amdgcn_readfirstlane((int)e[g]);                     \
+      wso[g] = wslab + ((ee & 511u) << SUB_SHIFT);                                                 \
+      const bool second = CAT && ((ee >> 14) & 1u);                                                \
+      const unsigned soff = (ee >> 15) << 7;                                                       \
+      const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                      \
+      const unsigned voff = __umul24(irow[g], second ? stride_b : stride_a) + lane_base;           \
       if (!(IMF_H3_ABL & 4)) {                                                                     \
-      a_next[g][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));      \
-      a_next[g][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16u, soff, 0)); \
+      a_next[g][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));       \
+      a_next[g][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 64u, soff, 0)); \
       } else { a_next[g][0].x += (float)voff + (float)soff; }                                      \
     }                                                                                              \
     if (IMF_H3_ABL & 8) { w0.x += (float)wso[0]; w1.x += (float)wso[KG - 1]; } else {             \
@@ -276,14 +307,13 @@ k_spconv_h3(const ConvParams p) {
     w3 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff0 + (3 % QPS) * 4096u, wso[3 / QPS], 0)); \
     }                                                                                              \
   }
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(p.w_packed), (short)0, 0x7FFFFFFF, 0x00020000);
 
-  IMF_LOOKUP()
-  if (n_macro > 0) {
-    IMF_PREFETCH(0)
-    IMF_LOOKUP()
-  }
+  IMF_READ_E(e_b, 0)
+  IMF_READ_E(e_c, 1)
+  IMF_READ_E(e_d, 2)
+  IMF_READ_ROW(irow_b, e_b)
+  IMF_READ_ROW(irow_c, e_c)
+  if (n_macro > 0) IMF_PREFETCH(e_b, irow_b)
   IMF_STAMP(3);
 #pragma unroll 1
   for (int n = 0; n < n_macro; ++n) {
@@ -308,10 +338,12 @@ k_spconv_h3(const ConvParams p) {
     IMF_STAMP(9 + 4 * n);
     if (!(IMF_H3_ABL & 64)) __syncthreads();   // stage n visible; every wave is past its reads of this buffer (stage n-2)
     IMF_STAMP(10 + 4 * n);
-    if (n + 1 < n_macro) {
-      IMF_PREFETCH(n + 1)
-      IMF_LOOKUP()
-    }
+    // stage n+1: loads (rows looked up last iteration); stage n+2: rows; stage n+3: table words
+#pragma unroll
+    for (int g = 0; g < KG; ++g) { e_b[g] = e_c[g]; irow_b[g] = irow_c[g]; e_c[g] = e_d[g]; }
+    if (n + 1 < n_macro) IMF_PREFETCH(e_b, irow_b)
+    IMF_READ_ROW(irow_c, e_c)
+    IMF_READ_E(e_d, n + 3)
     IMF_STAMP(11 + 4 * n);
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
@@ -345,7 +377,8 @@ k_spconv_h3(const ConvParams p) {
     }
   }
 #undef IMF_PREFETCH
-#undef IMF_LOOKUP
+#undef IMF_READ_ROW
+#undef IMF_READ_E
   IMF_STAMP(4);
 
   if (S == 1) {
@@ -387,12 +420,15 @@ k_spconv_h3(const ConvParams p) {
 }
 
 void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use) {
-  if (use == 1) {
-    if (co_blk == 4) k_spconv_h3<4, 1><<<grid, 256, 0, st>>>(p);
-    else             k_spconv_h3<2, 1><<<grid, 256, 0, st>>>(p);
+  if (p.c_b > 0) {        // two-source input (decoder skip connections)
+    if (co_blk == 4) k_spconv_h3<4, 0, true><<<grid, 256, 0, st>>>(p);
+    else             k_spconv_h3<2, 0, true><<<grid, 256, 0, st>>>(p);
+  } else if (use == 1) {
+    if (co_blk == 4) k_spconv_h3<4, 1, false><<<grid, 256, 0, st>>>(p);
+    else             k_spconv_h3<2, 1, false><<<grid, 256, 0, st>>>(p);
   } else {
-    if (co_blk == 4) k_spconv_h3<4, 0><<<grid, 256, 0, st>>>(p);
-    else             k_spconv_h3<2, 0><<<grid, 256, 0, st>>>(p);
+    if (co_blk == 4) k_spconv_h3<4, 0, false><<<grid, 256, 0, st>>>(p);
+    else             k_spconv_h3<2, 0, false><<<grid, 256, 0, st>>>(p);
   }
 }
 

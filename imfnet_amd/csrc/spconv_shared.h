@@ -184,6 +184,7 @@ __device__ __forceinline__ void fused_reduce_tile(const ConvParams &p, int S, lo
 }
 
 constexpr int kKCache = 28;   // active offsets cached per workgroup (kvol <= 27 uses the pipelined kernels)
+constexpr int kSubTab = 27 * 8 + 8;   // variant 6: sub-stage table entries per workgroup; kvol * cin / 32 must stay below it
 
 // spconv_h3.hip: variant 6 (split-f16 MFMA); grid = (tiles, cout / (16 CB), split)
 void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use = 0);

@@ -240,10 +240,10 @@ def test_spconv_split16_variant(ops, geom_s5):
         assert unscale > 0 and np.log2(unscale) == round(np.log2(unscale))          # a power of two
         assert 2.0 ** 13 <= float(ws.abs().max()) / unscale < 2.0 ** 14
         img = full[:27 * 64 * 32].view(torch.float16)
-        # [y][k][cc][q = 2 cb + h][lane][t]: ci = 32 cc + 8 (lane >> 4) + t, co = 16 cb + (lane & 15)
-        v = img.view(1, 27, 2, 2, 2, 4, 16, 8).double()             # y k cc cb h g c t
-        rec = (v[:, :, :, :, 0] + v[:, :, :, :, 1])[0]              # k cc cb g c t
-        rec = rec.permute(0, 1, 3, 5, 2, 4).reshape(27, 64, 32) * unscale   # k (cc g t) (cb c)
+        # [y][k][cc][q = 2 cb + h][lane][t]: ci = 32 cc + 16 (t >> 2) + 4 (lane >> 4) + (t & 3), co = 16 cb + (lane & 15)
+        v = img.view(1, 27, 2, 2, 2, 4, 16, 2, 4).double()          # y k cc cb h g c th tl
+        rec = (v[:, :, :, :, 0] + v[:, :, :, :, 1])[0]              # k cc cb g c th tl
+        rec = rec.permute(0, 1, 5, 3, 6, 2, 4).reshape(27, 64, 32) * unscale   # k (cc th g tl) (cb c)
         # hi + lo carries >= 21 bits of every weight down to 2^-17 of the largest one (lo stays a normal f16)
         assert ((rec - ws.double()).abs() <= ws.abs().double() * 2.0 ** -21 + float(ws.abs().max()) * 2.0 ** -39).all()
     f = _rand((n, 64), 41)
