@@ -1,0 +1,307 @@
+// Sparse convolution, variant 6, second implementation: both operands go global -> LDS directly
+// (`buffer_load_dwordx4 ... lds`, no VGPR destination); same arithmetic as k_spconv_h3, bit for bit.
+//
+// Why (round 2; tools/ubench/gather_shape.hip, profiles/r02_gather_shape.txt): k_spconv_h3 is bound by the
+// vector-memory RETURN path of the CU, not by L2 / HBM, the matrix pipe or instruction issue.  Per wavefront and
+// 16 KiB stage it issues four row gathers in MFMA-fragment shape (lane l: row l & 15, 16-byte piece l >> 4) and four
+// contiguous 1 KiB weight loads, all into VGPRs.  Measured per wave-level load and CU on L2-resident data:
+//   fragment-shaped gather -> VGPRs      31 cycles (52 % of the rows present)
+//   contiguous 1 KiB block -> VGPRs      28 cycles
+//   either of them          -> LDS       15 cycles
+// i.e. 16 wavefronts x (4 x 31 + 4 x 28) = 3.8 k cycles per CU and stage round, against 1.5 k cycles of MFMA
+// issue per SIMD -- the measured stage period is 3.2 k.  The same bytes cost half when their destination is LDS.
+//
+// So here a sub-stage (one kernel offset x 32 input channels) is staged as
+//   W: the 8 / 4 KiB B-fragment block of the packed image, copied verbatim (thread t: 16 bytes at 16 t), and
+//   A: per wavefront its 16 gathered rows x 128 bytes as two lane-linear 1 KiB images; four consecutive lanes
+//      fetch one contiguous 64-byte run of ONE row (image i holds the 16-byte pieces 4i .. 4i+3),
+// both by LDS-DMA into one of two buffers, one sub-stage ahead of the MFMAs; the only wait is the
+// `s_waitcnt vmcnt(0)` of the per-sub-stage barrier.  The MFMA A fragment (lane l: row l & 15, pieces l >> 4 and
+// 4 + (l >> 4)) is read back with two ds_read_b128.  LDS-DMA images are lane-linear (no padding possible), so the
+// writer lane of (row r, piece q) is 4 r + (q ^ f(r >> 2)), f = {0, 3, 2, 1}: conflict-free for the hardware's
+// ds_read_b128 lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...; MI355X_MICROARCH.md, LDS).  A row
+// without an input reads beyond the buffer window, which an LDS-destination load turns into zeros like a VGPR one
+// (checked on the hardware by the micro-benchmark).  Everything lives in ONE __shared__ array: with a second
+// object hipcc 7.2 drains the DMA queue before every ds_read.
+//
+// Not covered here (launch_spconv_h3 keeps them on k_spconv_h3): the in-launch split-K combine (tickets), the
+// balanced tail, the s_memtime stamps.
+#include "spconv_shared.h"
+
+namespace imf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace {
+
+constexpr int kDummyJk = kKCache - 1;        // neighbour-table row that is always "no input"
+constexpr unsigned kNoRow = 0x00FFFFFFu;     // see spconv_h3.hip
+
+__device__ __forceinline__ void split8(const float4 &x0, const float4 &x1, f16x8 &hi, f16x8 &lo) {
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const _Float16 h = (_Float16)v[t];
+    hi[t] = h;
+    lo[t] = (_Float16)(v[t] - (float)h);
+  }
+}
+
+}  // namespace
+
+// NB = LDS buffers per workgroup = sub-stages in flight + 1.  NB 2 (40 KiB, four workgroups per CU) for launches that
+// fill the chip several times over; NB 4 (72 KiB, two per CU, three sub-stages in flight) for the coarse levels, whose
+// few workgroups cannot hide the ~2 k-cycle DMA latency behind each other (launch_spconv_g picks).
+template <int CO_BLK, int USE, bool CAT, int NB>
+__global__ void __launch_bounds__(256, NB == 2 ? 4 : 2)
+k_spconv_g(const ConvParams p) {
+  constexpr int SUB_F4 = 2 * CO_BLK * 64;            // float4 of weights per sub-stage: 512 or 256
+  constexpr int SUB_SHIFT = CO_BLK == 4 ? 13 : 12;   // log2(bytes per weight sub-stage)
+  constexpr int QPS = SUB_F4 / 256;                  // weight DMAs per thread per sub-stage: 2 or 1
+  constexpr int BUF_F4 = SUB_F4 + 4 * 128;           // + four wavefronts x 2 KiB of gathered rows
+  constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
+  constexpr int TAB_F4 = (kSubTab + 3) / 4;
+  constexpr int KL_F4 = (kKCache + 3) / 4;
+  constexpr int D = NB - 1;                          // sub-stages in flight
+  constexpr int PER = QPS + 2;                       // DMA instructions per thread and sub-stage
+  __shared__ float4 smem[NB * BUF_F4 + NBR_F4 + TAB_F4 + KL_F4];
+  unsigned *const nbr_lds = reinterpret_cast<unsigned *>(smem + NB * BUF_F4);            // [kKCache][64]
+  unsigned *const stab = reinterpret_cast<unsigned *>(smem + NB * BUF_F4 + NBR_F4);       // [kSubTab]
+  int *const klist = reinterpret_cast<int *>(smem + NB * BUF_F4 + NBR_F4 + TAB_F4);       // [kKCache]
+
+  int tile = blockIdx.x, z = blockIdx.z, S = gridDim.z;
+  if (!p.no_xcd_swizzle) {   // opt-in XCD-contiguous tile order, as in k_spconv_h3
+    const int nx = gridDim.x;
+    const int off = (int)(((long long)nx * (blockIdx.y + (long long)gridDim.y * blockIdx.z)) & 7);
+    const int x = (tile + off) & 7;
+    int start = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int first = (q - off) & 7;
+      const int cnt = first < nx ? (nx - first + 7) >> 3 : 0;
+      if (q < x) start += cnt;
+    }
+    tile = start + ((tile - ((x - off) & 7)) >> 3);
+  }
+  if (p.n_out_dev) {   // capacity mode: padding tiles leave; the split is the rule applied to the actual rows
+    const long long slots_act = conv_slots(p, conv_rows(p));
+    if ((long long)tile * IMF_TILE_ROWS >= slots_act) return;
+    if (p.dyn_split_kvol) {
+      S = auto_split_rule(slots_act, p.cout, p.dyn_split_kvol, p.split_min_blocks, p.split_target);
+      if (S > (int)gridDim.z) {
+        if (p.err && blockIdx.x == 0 && blockIdx.y == 0 && z == 0 && threadIdx.x == 0) atomicOr(p.err, 16);
+        S = gridDim.z;
+      }
+      if (z >= S) return;
+    }
+  }
+  const int y = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cin = p.c_a + (CAT ? p.c_b : 0);
+  const int ncc = cin / 32;
+
+  uint32_t mask[IMF_MASK_WORDS] = {1u, 0u, 0u, 0u};
+  if (p.tile_mask) {
+#pragma unroll
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) mask[w] = p.tile_mask[tile * IMF_MASK_WORDS + w];
+  }
+  const int total = __builtin_popcount(mask[0]) + __builtin_popcount(mask[1]) +
+                    __builtin_popcount(mask[2]) + __builtin_popcount(mask[3]);
+  if (total == 0 && S == 1) return;                  // padding tile
+  const int lo = (int)((long long)z * total / S), hi = (int)((long long)(z + 1) * total / S);
+  const int nk = hi - lo;
+
+  if (tid < 32 * IMF_MASK_WORDS) {   // offset list of this partition (lane k owns offset k)
+    const int w = tid >> 5, b = tid & 31;
+    const uint32_t mw = w == 0 ? mask[0] : (w == 1 ? mask[1] : (w == 2 ? mask[2] : mask[3]));
+    if ((mw >> b) & 1u) {
+      int ord = __builtin_popcount(mw & ((1u << b) - 1u));
+#pragma unroll
+      for (int v = 0; v < IMF_MASK_WORDS; ++v)
+        if (v < w) ord += __builtin_popcount(mask[v]);
+      if (ord >= lo && ord < hi) klist[ord - lo] = tid;
+    }
+  }
+  __syncthreads();
+  const int n_sub = nk * ncc;
+  const long long tile_slot0 = (long long)tile * IMF_TILE_ROWS;
+  {   // the tile's slice of the neighbour table as 24-bit row indices, and the sub-stage table (spconv_h3.hip).
+      // The loads are unconditional (clamped offset index) and sit outside any per-element branch: a
+      // "load or constant" select per element makes hipcc 7.2 branch around every load and wait for each one --
+      // seven dependent memory round trips per workgroup instead of one.
+    constexpr int kPer = (kKCache * IMF_TILE_ROWS + 255) / 256;   // 7
+    int v[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) v[i] = -1;
+    if (p.nbr) {
+      if (nk > 0) {
+        const int32_t *const src = p.nbr + tile_slot0 + lane;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+          const int j = wave + 4 * i;
+          v[i] = src[(long long)klist[j < nk ? j : 0] * p.n_slots];
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i)
+          if (wave + 4 * i >= nk) v[i] = -1;
+      }
+    } else if (tid < IMF_TILE_ROWS && nk > 0) {   // kvol == 1: the slot's own row
+      v[0] = row_of_slot(p, tile_slot0 + tid);
+    }
+    if (tid < kSubTab) {
+      unsigned e = (unsigned)kDummyJk << 9;
+      if (tid < n_sub) {
+        const int jk = tid / ncc, cc = tid - jk * ncc;
+        const int ch0 = cc * 32;
+        const bool second = CAT && ch0 >= p.c_a;
+        const int cch = second ? (ch0 - p.c_a) >> 5 : cc;
+        e = (unsigned)(klist[jk] * ncc + cc) | ((unsigned)jk << 9) | ((second ? 1u : 0u) << 14) | ((unsigned)cch << 15);
+      }
+      stab[tid] = e;
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int j = wave + 4 * i;
+      if (j < nk) nbr_lds[j * IMF_TILE_ROWS + lane] = v[i] >= 0 ? (unsigned)v[i] : kNoRow;
+      else if (j == kDummyJk) nbr_lds[j * IMF_TILE_ROWS + lane] = kNoRow;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[CO_BLK];
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.w_packed), (short)0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.in_a), (short)0, 0x7FFFF000, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(CAT ? p.in_b : p.in_a), (short)0, 0x7FFFF000, 0x00020000);
+  const unsigned stride_a = (unsigned)p.c_a * 4u, stride_b = (unsigned)(CAT ? p.c_b : p.c_a) * 4u;
+  const unsigned woff0 = (unsigned)tid * 16u;
+  const unsigned wslab = (unsigned)((long long)y * p.kvol * ncc * SUB_F4 * 16);     // bytes (image < 2 GiB)
+  // writer role of the lane in the row gather: row lane >> 2 of the wavefront's 16, piece (lane & 3) ^ f(row >> 2)
+  const int row_w = lane >> 2;
+  const unsigned piece_w = (unsigned)((lane & 3) ^ ((4 - (row_w >> 2)) & 3));
+  const unsigned wr_byte = 16u * piece_w;
+  const unsigned row_byte = (unsigned)(wave * 16 + row_w) * 4u;
+  // reader role: MFMA A fragment, row r16, pieces q4 and 4 + q4
+  const int rd_slot = 4 * r16 + (q4 ^ ((4 - (r16 >> 2)) & 3));
+
+#define IMF_READ_E(t) stab[(t) < kSubTab - 1 ? (t) : kSubTab - 1]
+#define IMF_READ_ROW(e)                                                                                          \
+  (*reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(nbr_lds) +                                  \
+                                       ((((unsigned)__builtin_amdgcn_readfirstlane((int)(e))) >> 1) & (31u << 8)) + row_byte))
+  // LDS-DMA of one sub-stage into buffer `b`: weights verbatim, the wavefront's 16 rows as two 1 KiB images
+#define IMF_DMA(e, irow, b)                                                                                      \
+  {                                                                                                              \
+    const unsigned ee = (unsigned)__builtin_amdgcn_readfirstlane((int)(e));                                      \
+    const unsigned wso = wslab + ((ee & 511u) << SUB_SHIFT);                                                     \
+    float4 *const wb = smem + (b) * BUF_F4;                                                                      \
+    _Pragma("unroll") for (int j = 0; j < QPS; ++j)                                                              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wb + j * 256 + wave * 64), 16,              \
+                                                 woff0 + (unsigned)j * 4096u, wso, 0, 0);                        \
+    const bool second = CAT && ((ee >> 14) & 1u);                                                                \
+    const unsigned soff = (ee >> 15) << 7;                                                                       \
+    const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                      \
+    const unsigned voff = __umul24((irow), second ? stride_b : stride_a) + wr_byte;                              \
+    float4 *const ab = wb + SUB_F4 + wave * 128;                                                                 \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)ab, 16, voff, soff, 0, 0);                          \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(ab + 64), 16, voff + 64u, soff, 0, 0);             \
+  }
+
+  // Ring of NB buffers, D = NB - 1 sub-stages in flight.  Bookkeeping runs ahead of the DMA: the table word of
+  // sub-stage t + D + 2 and the input row of t + D + 1 are read in iteration t, the DMA of t + D is issued in it.
+  // Waits are counted by hand (the compiler does not order ds_reads after LDS-DMAs, and __syncthreads() would
+  // drain the whole queue): vmcnt(PER (D - 1)) leaves the D - 1 younger sub-stages in flight across the barrier.
+  unsigned e_b, e_c = IMF_READ_E(D), e_d = IMF_READ_E(D + 1);
+  unsigned irow_b, irow_c = IMF_READ_ROW(e_c);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (d < n_sub) {
+      const unsigned e0 = IMF_READ_E(d);
+      const unsigned irow0 = IMF_READ_ROW(e0);
+      IMF_DMA(e0, irow0, d)
+    }
+  }
+  int slot_rd = 0, slot_wr = D;   // t % NB and (t + D) % NB
+#pragma unroll 1
+  for (int t = 0; t < n_sub; ++t) {
+    // sub-stage t has landed (this thread's part, then -- barrier -- everyone's); every wavefront is past its reads
+    // of buffer (t - 1) % NB, which the DMA below refills
+    if (n_sub - 1 - t >= D - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER * (D - 1)) : "memory");
+    else                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    e_b = e_c; irow_b = irow_c; e_c = e_d;
+    if (t + D < n_sub) IMF_DMA(e_b, irow_b, slot_wr)
+    irow_c = IMF_READ_ROW(e_c);
+    e_d = IMF_READ_E(t + D + 2);
+    const float4 *const wbuf = smem + slot_rd * BUF_F4;
+    const float4 *const abuf = wbuf + SUB_F4 + wave * 128;
+    slot_rd = slot_rd + 1 == NB ? 0 : slot_rd + 1;
+    slot_wr = slot_wr + 1 == NB ? 0 : slot_wr + 1;
+    f16x8 ah, al;
+    split8(abuf[rd_slot], abuf[64 + rd_slot], ah, al);
+    f16x8 bh[CO_BLK], bl[CO_BLK];
+#pragma unroll
+    for (int cb = 0; cb < CO_BLK; ++cb) {
+      bh[cb] = *reinterpret_cast<const f16x8 *>(&wbuf[(2 * cb) * 64 + lane]);
+      bl[cb] = *reinterpret_cast<const f16x8 *>(&wbuf[(2 * cb + 1) * 64 + lane]);
+    }
+    // same order as k_spconv_h3: small terms first, consecutive MFMAs on different accumulators
+#pragma unroll
+    for (int cb = 0; cb < CO_BLK; ++cb)
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+    for (int cb = 0; cb < CO_BLK; ++cb)
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+    for (int cb = 0; cb < CO_BLK; ++cb)
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[cb], acc[cb], 0, 0, 0);
+  }
+#undef IMF_DMA
+#undef IMF_READ_ROW
+#undef IMF_READ_E
+
+  if (S == 1) {
+    conv_epilogue<CO_BLK>(p, acc, tile, y, wave, r16, q4, p.w_unscale ? *p.w_unscale : 1.f);
+  } else {   // raw partial sums, slot-major (k_spconv_reduce finishes)
+    const int CW = 16 * CO_BLK;
+#pragma unroll
+    for (int cb = 0; cb < CO_BLK; ++cb) {
+      const int col = y * CW + cb * 16 + r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long slot = tile_slot0 + wave * 16 + q4 * 4 + r;
+        p.partial[((long long)z * p.n_slots + slot) * p.cout + col] = acc[cb][r];
+      }
+    }
+  }
+}
+
+void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use) {
+  // deep ring (NB 4, two workgroups per CU) when the whole launch is resident at once that way (<= 512 workgroups);
+  // measured (tools/layer_times.py): 438 unsplit workgroups of a pair's stride-2 level 43 -> 33 us, but 544 workgroups
+  // 28 -> 33 us (a second round of 32), and every launch that fills the chip is faster with four workgroups per CU
+  static const int nb_env = getenv("IMF_G_NB") ? atoi(getenv("IMF_G_NB")) : 0;
+  static const int nb_wgs = getenv("IMF_G_NB_WGS") ? atoi(getenv("IMF_G_NB_WGS")) : 512;
+  const long long wgs = (long long)grid.x * grid.y * grid.z;
+  const bool deep = nb_env ? nb_env >= 4 : wgs <= nb_wgs;
+#define IMF_G_LAUNCH(CB, USE, CAT)                                              \
+  do {                                                                          \
+    if (deep) k_spconv_g<CB, USE, CAT, 4><<<grid, 256, 0, st>>>(p);             \
+    else      k_spconv_g<CB, USE, CAT, 2><<<grid, 256, 0, st>>>(p);             \
+  } while (0)
+  if (p.c_b > 0) {        // two-source input (decoder skip connections)
+    if (co_blk == 4) IMF_G_LAUNCH(4, 0, true); else IMF_G_LAUNCH(2, 0, true);
+  } else if (use == 1) {
+    if (co_blk == 4) IMF_G_LAUNCH(4, 1, false); else IMF_G_LAUNCH(2, 1, false);
+  } else {
+    if (co_blk == 4) IMF_G_LAUNCH(4, 0, false); else IMF_G_LAUNCH(2, 0, false);
+  }
+#undef IMF_G_LAUNCH
+}
+
+}  // namespace imf

@@ -214,14 +214,27 @@ k_spconv_h3(const ConvParams p) {
   // partition point at the all-missing row kDummyJk and at weight sub-stage 0, i.e. they add exact zeros
   const long long tile_slot0 = (long long)tile * IMF_TILE_ROWS;
   {
+    // (the loads are unconditional -- clamped offset index -- and outside any per-element branch: with a
+    // "load or constant" select per element hipcc 7.2 branched around every load and waited for each one, seven
+    // dependent memory round trips per workgroup instead of one; found in the ISA in round 2)
     constexpr int kPer = (kKCache * IMF_TILE_ROWS + 255) / 256;   // 7
     int v[kPer];
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-      const int e = tid + 256 * i, j = e >> 6, r = e & 63;
-      v[i] = -1;
-      if (j < nk)
-        v[i] = p.nbr ? p.nbr[(long long)klist[j] * p.n_slots + tile_slot0 + r] : row_of_slot(p, tile_slot0 + r);
+    for (int i = 0; i < kPer; ++i) v[i] = -1;
+    if (p.nbr) {
+      if (nk > 0) {
+        const int32_t *const src = p.nbr + tile_slot0 + lane;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+          const int j = wave + 4 * i;
+          v[i] = src[(long long)klist[j < nk ? j : 0] * p.n_slots];
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i)
+          if (wave + 4 * i >= nk) v[i] = -1;
+      }
+    } else if (tid < IMF_TILE_ROWS && nk > 0) {   // kvol == 1: the slot's own row
+      v[0] = row_of_slot(p, tile_slot0 + tid);
     }
     if (tid < kSubTab) {
       unsigned e = (unsigned)kDummyJk << 9;
@@ -236,9 +249,9 @@ k_spconv_h3(const ConvParams p) {
     }
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
-      const int e = tid + 256 * i, j = e >> 6, r = e & 63;
-      if (j < nk) nbr_lds[j][r] = v[i] >= 0 ? (unsigned)v[i] : kNoRow;
-      else if (j == kDummyJk) nbr_lds[j][r] = kNoRow;
+      const int j = wave + 4 * i;
+      if (j < nk) nbr_lds[j][lane] = v[i] >= 0 ? (unsigned)v[i] : kNoRow;
+      else if (j == kDummyJk) nbr_lds[j][lane] = kNoRow;
     }
   }
   __syncthreads();
@@ -420,6 +433,17 @@ k_spconv_h3(const ConvParams p) {
 }
 
 void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use) {
+  // Default implementation since round 2: k_spconv_g (spconv_g.hip), both operands by LDS-DMA -- same sums bit for
+  // bit.  This register-staged kernel stays for the in-launch combine (tickets), the balanced tail and the stamps
+  // build, and as the A/B partner: kernel_tag bit 1 per call, IMF_H3_GLDS=0 for the whole process.
+#ifndef IMF_H3_STAMPS
+  static const int dma_env = getenv("IMF_H3_GLDS") ? atoi(getenv("IMF_H3_GLDS")) : 1;
+  if (dma_env && !(use & 2) && !p.tickets && p.tail_split <= 1) {
+    launch_spconv_g(p, grid, co_blk, st, use & 1);
+    return;
+  }
+#endif
+  use &= 1;
   if (p.c_b > 0) {        // two-source input (decoder skip connections)
     if (co_blk == 4) k_spconv_h3<4, 0, true><<<grid, 256, 0, st>>>(p);
     else             k_spconv_h3<2, 0, true><<<grid, 256, 0, st>>>(p);

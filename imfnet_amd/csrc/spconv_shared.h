@@ -188,5 +188,7 @@ constexpr int kSubTab = 27 * 8 + 8;   // variant 6: sub-stage table entries per 
 
 // spconv_h3.hip: variant 6 (split-f16 MFMA); grid = (tiles, cout / (16 CB), split)
 void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use = 0);
+// spconv_g.hip: the same arithmetic with both operands staged by LDS-DMA (default; launch_spconv_h3 dispatches)
+void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use = 0);
 
 }  // namespace imf

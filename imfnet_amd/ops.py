@@ -377,16 +377,23 @@ def pack_weights(kernel, out=None, split16=False):
     return packed
 
 
-def conv_kernel_name(variant, cin, cout):
+# variant 6 runs k_spconv_g (operands staged by LDS-DMA, csrc/spconv_g.hip) unless IMF_H3_GLDS=0 or the call asks
+# for the register-staged k_spconv_h3 (`staging="regs"`, kernel_tag bit 1); the two agree bit for bit
+H3_DMA = int(os.environ.get("IMF_H3_GLDS", "1")) != 0
+
+
+def conv_kernel_name(variant, cin, cout, staging=None):
     if variant == 6:
-        return f"k_spconv_h3<{4 if cout % 64 == 0 else 2}, 0>"
+        dma = H3_DMA if staging is None else staging == "dma"
+        return f"k_spconv_{'g' if dma else 'h3'}<{4 if cout % 64 == 0 else 2}, 0>"
     return f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>"
 
 
 def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual=None,
-           relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False, flags=None):
+           relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False, flags=None, staging=None):
     """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd.  `flags`: optional int32[1] device word that
-    receives IMF_FLAG_RANGE (32) when an output is NaN or >= 65504 in magnitude."""
+    receives IMF_FLAG_RANGE (32) when an output is NaN or >= 65504 in magnitude.  `staging` (variant 6): None = the
+    library default (LDS-DMA kernel), "regs" = the register-staged kernel (A/B and bit-identity tests)."""
     _req(in_a, torch.float32, "in_a", 2)
     if in_b is not None:
         _req(in_b, torch.float32, "in_b", 2)
@@ -407,6 +414,9 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
         split = 1
     a.split_k, a.variant = split, int(variant)
     a.dyn_err = None if flags is None else flags.data_ptr()
+    if staging not in (None, "dma", "regs"):
+        raise ImfError(f"spconv: staging={staging!r}")
+    a.kernel_tag = 2 if staging == "regs" else 0
     ws = None
     nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)   # split-K partials / balanced-tail partials
     if nbytes:
@@ -429,7 +439,7 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     check(L.imf_spconv_fwd(C.byref(a), _stream()), "imf_spconv_fwd")
     if ev is not None:
         cin = a.c_a + a.c_b
-        TRACE.append(dict(kernel=conv_kernel_name(variant, cin, cout),
+        TRACE.append(dict(kernel=conv_kernel_name(variant, cin, cout, "regs" if (staging == "regs" or fused_reduce) else None),
                           kvol=rb.kvol, cin=cin, cout=cout, rb=rb, split=split, ev=ev))
     return out
 

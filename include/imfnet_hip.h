@@ -231,8 +231,11 @@ typedef struct imf_conv_args {
    * imf_rulebook_transpose's parity classes, else 0). */
   const int32_t *n_out_dev;
   int32_t dyn_split_kvol, slots_extra;
-  int32_t kernel_tag;     /* profiling label only: variant 6 launches with tag 1 run the identical kernel under a second
-                             symbol (k_spconv_h3<.., 1>: the image branch's dense convolutions) */
+  int32_t kernel_tag;     /* variant 6 only.  bit 0: profiling label -- the identical kernel under a second symbol
+                             (k_spconv_g<.., 1>: the image branch's dense convolutions).  bit 1: run the register-staged
+                             implementation k_spconv_h3 (csrc/spconv_h3.hip) instead of the default k_spconv_g
+                             (csrc/spconv_g.hip: both operands global -> LDS by DMA); same sums bit for bit, kept for A/B
+                             and selected automatically with `tickets`.  Process-wide: env IMF_H3_GLDS=0 */
   int32_t *dyn_err;       /* optional device flag word (any mode): IMF_FLAG_SPLIT_COVER when the rule asks for more
                              partitions than split_k covers; IMF_FLAG_RANGE when an OUTPUT value is NaN or |y| >= 65504,
                              i.e. cannot be an operand of a following variant-6 convolution */

@@ -173,7 +173,7 @@ def _rb_and_ref(cm, g, which):
 
 
 @pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple",
-                                  "h3", "h3_split1", "h3_split5", "h3_split5_fused"])
+                                  "h3", "h3_split1", "h3_split5", "h3_split5_fused", "h3_regs", "h3_regs_split5"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
     """Plain convolution (no epilogue) vs the oracle; error measured against an fp64 evaluation and
@@ -187,8 +187,11 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
           "split5_fused": {"split_k": 5, "fused_reduce": True},
           "h3": {"variant": 6},
           "h3_split1": {"variant": 6, "split_k": 1}, "h3_split5": {"variant": 6, "split_k": 5},
-          "h3_split5_fused": {"variant": 6, "split_k": 5, "fused_reduce": True}}[mode]
-    if mode in ("split5", "split5_fused", "h3_split5", "h3_split5_fused") and kvol == 1:
+          "h3_split5_fused": {"variant": 6, "split_k": 5, "fused_reduce": True},
+          # variant 6 defaults to the LDS-DMA kernel (k_spconv_g); "regs" = the register-staged k_spconv_h3
+          "h3_regs": {"variant": 6, "staging": "regs"},
+          "h3_regs_split5": {"variant": 6, "split_k": 5, "staging": "regs"}}[mode]
+    if mode in ("split5", "split5_fused", "h3_split5", "h3_split5_fused", "h3_regs_split5") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")
     out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV), split16=mode.startswith("h3")), cout, rb,
                      in_b=None if fb is None else fb.to(DEV), **kw).cpu()
@@ -200,6 +203,30 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
     assert out.shape == ref32.shape
     assert ((out.double() - ref64).abs() <= bound).all()
     assert (out - ref32).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
+def test_spconv_dma_staging_is_bit_identical(ops, geom_s5, ca, cb, cout, which):
+    """k_spconv_g (both operands global -> LDS by DMA, the default of variant 6) forms exactly the sums of the
+    register-staged k_spconv_h3: same MFMA sequence per (row block, offset, channel chunk) -- every shape of the
+    network, unsplit, split and with the fused epilogue."""
+    cm, g = geom_s5
+    rb, nbr_ref, n_in = _rb_and_ref(cm, g, which)
+    kvol = 1 if nbr_ref is None else nbr_ref.shape[1]
+    fa, fb = _rand((n_in, ca), 50).to(DEV), (_rand((n_in, cb), 51).to(DEV) if cb else None)
+    wp = ops.pack_weights(_rand((kvol, ca + cb, cout), 52, 1.0 / np.sqrt(kvol * (ca + cb))).to(DEV), split16=True)
+    sc, sh = (_rand((cout,), 53).abs() + 0.5).to(DEV), _rand((cout,), 54).to(DEV)
+    res = _rand((rb.n_out, cout), 55).to(DEV)
+    for kw in ({}, {"split_k": 1}, {"split_k": 4}, {"split_k": 1, "scale": sc, "shift": sh, "residual": res, "relu": True},
+               {"scale": sc, "shift": sh, "relu": True}):
+        if kvol == 1 and kw.get("split_k", 0) > 1:
+            continue
+        a = ops.spconv(fa, wp, cout, rb, in_b=fb, variant=6, staging="dma", **kw)
+        b = ops.spconv(fa, wp, cout, rb, in_b=fb, variant=6, staging="regs", **kw)
+        assert torch.equal(a, b), (kw.keys(), float((a - b).abs().max()))
+    if cout <= 64:
+        a = ops.spconv(fa, wp, cout, rb, in_b=fb, variant=6, shift=sh, l2norm=True, staging="dma")
+        assert torch.equal(a, ops.spconv(fa, wp, cout, rb, in_b=fb, variant=6, shift=sh, l2norm=True, staging="regs"))
 
 
 def test_spconv_epilogues(ops, geom_s5):
