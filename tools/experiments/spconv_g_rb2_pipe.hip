@@ -1,3 +1,10 @@
+// EXPERIMENT -- not part of the library build (round 2).  csrc/spconv_g.hip as it stood with two more schedules:
+//   RB 2  (launch option IMF_G_RB=2): two 64-row tiles per workgroup, each wavefront two row blocks per B-fragment
+//         read.  Bit-identical; isolated (tools/conv_iso.py, pair): 64 -> 64 @ 103 k rows 90.0 -> 96.6 us, 32 -> 32
+//         37.0 -> 42.9, transposed maps 37.9 -> 50.3 / 35.3 -> 58.7 us (union of two parity classes' offsets).
+//   PIPE  (IMF_G_PIPE=1): LDS -> VGPR fragment reads of sub-stage t + 1 issued between the MFMA groups of sub-stage t
+//         (121 VGPRs).  Bit-identical; 64 -> 64 @ 103 k rows 92.8 -> 97.6 us, 51 k rows 48.4 -> 54.2 us.
+// Neither the LDS read volume nor its latency alone sets the kernel time; see DESIGN.md section 4c.
 // Sparse convolution, variant 6, second implementation: both operands go global -> LDS directly
 // (`buffer_load_dwordx4 ... lds`, no VGPR destination); same arithmetic as k_spconv_h3, bit for bit.
 //
@@ -77,13 +84,14 @@ __device__ __forceinline__ f16x8 lds_read_f16x8(const float4 *__restrict__ src) 
 // active offsets (an offset outside it reads as "no input" for that tile's rows), and every accumulator sees the same
 // MFMA sequence as in k_spconv_h3.
 //
-// Two further schedules were built on this kernel, measured bit-identical and SLOWER, and live in
-// tools/experiments/spconv_g_rb2_pipe.hip: RB 2 as a launch option (64 -> 64 at 103 k rows 93 -> 97 us; the transposed
-// maps up to 1.6x slower: only two workgroups fit a CU) and register double-buffering of the LDS -> VGPR fragment reads
-// (93 -> 98 us at 121 VGPRs).  Only RB 1 is instantiated here.
-template <int CO_BLK, int USE, bool CAT, int NB, int RB>
+// PIPE (NB 2, RB 1): register double-buffering of the LDS -> VGPR fragment reads.  After the barrier of step t the
+// wavefront issues the DMA of sub-stage t + 2 and the ds_reads of sub-stage t + 1, then runs the MFMAs of sub-stage t
+// from registers loaded one step earlier -- the LDS read latency (the largest single cost left, see RB above) hides
+// behind the matrix pipe, and the DMA has two steps to land with only two buffers.
+template <int CO_BLK, int USE, bool CAT, int NB, int RB, int PIPE>
 __global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? 4 : 2)
 k_spconv_g(const ConvParams p) {
+  static_assert(!PIPE || (NB == 2 && RB == 1), "PIPE is the NB 2 / RB 1 schedule");
   constexpr int ROWS = IMF_TILE_ROWS * RB;           // output rows per workgroup
   constexpr int SUB_F4 = 2 * CO_BLK * 64;            // float4 of weights per sub-stage: 512 or 256
   constexpr int SUB_SHIFT = CO_BLK == 4 ? 13 : 12;   // log2(bytes per weight sub-stage)
@@ -270,6 +278,85 @@ k_spconv_g(const ConvParams p) {
     }                                                                                                            \
   }
 
+  if constexpr (PIPE != 0) {
+    // Operands of the current sub-stage live in registers; those of the next one are read from LDS in two instalments
+    // placed between the MFMA groups so that at most one extra set of hi fragments is live (bl is refilled in place
+    // after its last use, the raw A pieces replace ah / al after theirs) -- 4 wavefronts per SIMD need <= 128 VGPRs.
+    f16x8 bh_x[CO_BLK], bh_y[CO_BLK], bl[CO_BLK], ah, al;
+    float4 an0, an1;
+    // the DMA of the next sub-stage to issue uses (e_n, irow_n); the table runs two words ahead of it
+#define IMF_ISSUE(buf)                                                                                           \
+  {                                                                                                              \
+    IMF_DMA(e_n, irow_n, buf)                                                                                    \
+    e_n = e_n1; irow_n = irow_n1; e_n1 = e_n2;                                                                   \
+    IMF_READ_ROWS(irow_n1, e_n1)                                                                                 \
+    e_n2 = IMF_READ_E(tab_next); ++tab_next;                                                                     \
+  }
+#define IMF_STEP_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define IMF_READ_A_BH(bh, buf)                                                                                   \
+  {                                                                                                              \
+    const float4 *const wbuf_ = smem + (buf) * BUF_F4;                                                           \
+    an0 = lds_read16(&wbuf_[SUB_F4 + wave * AW_F4 + rd_slot]);                                                   \
+    an1 = lds_read16(&wbuf_[SUB_F4 + wave * AW_F4 + 64 + rd_slot]);                                              \
+    _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                                        \
+        bh[cb] = lds_read_f16x8(&wbuf_[(2 * cb) * 64 + lane]);                                                   \
+  }
+#define IMF_READ_BL(buf)                                                                                         \
+  {                                                                                                              \
+    const float4 *const wbuf_ = smem + (buf) * BUF_F4;                                                           \
+    _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                                        \
+        bl[cb] = lds_read_f16x8(&wbuf_[(2 * cb + 1) * 64 + lane]);                                               \
+  }
+    // one step: MFMAs of sub-stage t from (ah, al, bh_cur, bl); if there is a sub-stage t + 1 (in buffer nbuf,
+    // landed by the barrier), read it into (an*, bh_nxt, bl) on the way and issue the DMA of t + 2 into buffer cbuf
+#define IMF_STEP(bh_cur, bh_nxt, cbuf, nbuf)                                                                     \
+  {                                                                                                              \
+    const bool more_ = t + 1 < n_sub;                                                                            \
+    if (more_) {                                                                                                 \
+      IMF_STEP_BARRIER();                                                                                        \
+      if (t + 2 < n_sub) IMF_ISSUE(cbuf)                                                                         \
+      IMF_READ_A_BH(bh_nxt, nbuf)                                                                                \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                                        \
+        acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh_cur[cb], acc[0][cb], 0, 0, 0);                \
+    _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                                        \
+        acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[cb], acc[0][cb], 0, 0, 0);                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (more_) IMF_READ_BL(nbuf)                                                                                 \
+    _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                                        \
+        acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh_cur[cb], acc[0][cb], 0, 0, 0);                \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (more_) split8(an0, an1, ah, al);                                                                         \
+  }
+    if (n_sub > 0) {
+      unsigned e_n = IMF_READ_E(0), e_n1 = IMF_READ_E(1), e_n2 = IMF_READ_E(2);
+      int tab_next = 3;
+      Rows irow_n, irow_n1;
+      IMF_READ_ROWS(irow_n, e_n)
+      IMF_READ_ROWS(irow_n1, e_n1)
+      IMF_ISSUE(0)                                   // sub-stage 0
+      IMF_STEP_BARRIER();
+      if (n_sub > 1) IMF_ISSUE(1)                    // sub-stage 1
+      IMF_READ_A_BH(bh_x, 0)
+      IMF_READ_BL(0)
+      split8(an0, an1, ah, al);
+      int b0 = 0, b1 = 1;   // run-time buffer indices on purpose: with compile-time LDS addresses hipcc 7.2 waits
+                            // vmcnt(0) before every ds_read that follows a DMA issue (it cannot tell the buffers apart)
+#pragma unroll 1
+      for (int t = 0; t < n_sub; ++t) {
+        IMF_STEP(bh_x, bh_y, b0, b1)
+        if (++t >= n_sub) break;
+        IMF_STEP(bh_y, bh_x, b1, b0)
+        asm volatile("" : "+s"(b0), "+s"(b1));
+      }
+    }
+#undef IMF_STEP
+#undef IMF_READ_BL
+#undef IMF_READ_A_BH
+#undef IMF_STEP_BARRIER
+#undef IMF_ISSUE
+  } else {
   // Ring of NB buffers, D = NB - 1 sub-stages in flight.  Bookkeeping runs ahead of the DMA: the table word of
   // sub-stage t + D + 2 and the input rows of t + D + 1 are read in iteration t, the DMA of t + D is issued in it.
   // Waits are counted by hand (the compiler does not order ds_reads after LDS-DMAs, and __syncthreads() would
@@ -348,6 +435,7 @@ k_spconv_g(const ConvParams p) {
       for (int cb = 0; cb < CO_BLK; ++cb)
         acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bh[cb], acc[b][cb], 0, 0, 0);
   }
+  }   // !PIPE
 #undef IMF_DMA
 #undef IMF_READ_ROWS
 #undef IMF_READ_E
@@ -380,17 +468,25 @@ k_spconv_g(const ConvParams p) {
 }
 
 void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use) {
-  // deep ring (NB 4, two workgroups per CU) when the whole launch is resident at once that way (<= 512 workgroups);
+  // RB 2 (two tiles per workgroup, half the LDS fragment reads per row) for the launches with plenty of tiles; deep
+  // ring (NB 4, two workgroups per CU) when the whole launch is resident at once that way (<= 512 workgroups):
   // measured (tools/layer_times.py): 438 unsplit workgroups of a pair's stride-2 level 43 -> 33 us, but 544 workgroups
   // 28 -> 33 us (a second round of 32), and every launch that fills the chip is faster with four workgroups per CU
   static const int nb_env = getenv("IMF_G_NB") ? atoi(getenv("IMF_G_NB")) : 0;
   static const int nb_wgs = getenv("IMF_G_NB_WGS") ? atoi(getenv("IMF_G_NB_WGS")) : 512;
-  const long long wgs = (long long)grid.x * grid.y * grid.z;
-  const bool deep = nb_env ? nb_env >= 4 : wgs <= nb_wgs;
+  static const int rb_env = getenv("IMF_G_RB") ? atoi(getenv("IMF_G_RB")) : 0;
+  static const int rb_tiles = getenv("IMF_G_RB_TILES") ? atoi(getenv("IMF_G_RB_TILES")) : (1 << 30);   // measured slower everywhere: off
+  const long long wgs1 = (long long)grid.x * grid.y * grid.z;
+  const bool two = rb_env ? rb_env >= 2 : (long long)grid.x * grid.y * grid.z >= rb_tiles;
+  const bool deep = !two && (nb_env ? nb_env >= 4 : wgs1 <= nb_wgs);
+  static const int pipe = getenv("IMF_G_PIPE") ? atoi(getenv("IMF_G_PIPE")) : 1;
+  if (two) grid.x = (grid.x + 1) / 2;
 #define IMF_G_LAUNCH(CB, USE, CAT)                                              \
   do {                                                                          \
-    if (deep) k_spconv_g<CB, USE, CAT, 4, 1><<<grid, 256, 0, st>>>(p);          \
-    else      k_spconv_g<CB, USE, CAT, 2, 1><<<grid, 256, 0, st>>>(p);          \
+    if (two)       k_spconv_g<CB, USE, CAT, 2, 2, 0><<<grid, 256, 0, st>>>(p);  \
+    else if (deep) k_spconv_g<CB, USE, CAT, 4, 1, 0><<<grid, 256, 0, st>>>(p);  \
+    else if (pipe) k_spconv_g<CB, USE, CAT, 2, 1, 1><<<grid, 256, 0, st>>>(p);  \
+    else           k_spconv_g<CB, USE, CAT, 2, 1, 0><<<grid, 256, 0, st>>>(p);  \
   } while (0)
   if (p.c_b > 0) {        // two-source input (decoder skip connections)
     if (co_blk == 4) IMF_G_LAUNCH(4, 0, true); else IMF_G_LAUNCH(2, 0, true);
