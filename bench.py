@@ -83,14 +83,19 @@ def pmc_traffic(kernel):
     else:
         return None, "no PMC profile committed"
     ks = json.load(open(path))["kernels"]
+    # `kernel` names a template FAMILY (k_spconv_g<4, 0> = every (CAT, NB, RB) instance of the 64-column sparse
+    # launches, which is what the live timing above groups too): launch-weighted average over its symbols
     key = "imf::" + kernel
-    if key not in ks:
+    fam = [v for k, v in ks.items() if k == key or k.startswith(key[:-1] + ",")]
+    if not fam:
         return None, f"{key} not in {os.path.basename(path)}"
-    v = ks[key]
-    return v["hbm_bytes_fetch_x2"], (f"bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (raw FETCH {v['fetch_bytes_raw']} B, "
-                                     f"WRITE {v['write_bytes']} B, L2 hit {v['l2_hit_rate']}) from "
-                                     f"profiles/{os.path.basename(path)}; below the algorithmic bytes because "
-                                     f"feature rows are re-gathered from L2 / Infinity Cache, not HBM")
+    n = sum(v["launches"] for v in fam)
+    avg = lambda f: sum(v[f] * v["launches"] for v in fam) / n
+    hit = sum(v["l2_hit_rate"] * v["launches"] for v in fam) / n
+    return int(avg("hbm_bytes_fetch_x2")), (f"bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (raw FETCH {int(avg('fetch_bytes_raw'))} B, "
+                                            f"WRITE {int(avg('write_bytes'))} B, L2 hit {hit:.4f}; {n} launches of {len(fam)} "
+                                            f"symbol(s) of the family) from profiles/{os.path.basename(path)}; below the algorithmic "
+                                            f"bytes because feature rows are re-gathered from L2 / Infinity Cache, not HBM")
 
 
 def cpu_baseline(xyz, img, voxel, sd, seconds_budget=12.0):

@@ -385,7 +385,17 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
   // 28 -> 33 us (a second round of 32), and every launch that fills the chip is faster with four workgroups per CU
   static const int nb_env = getenv("IMF_G_NB") ? atoi(getenv("IMF_G_NB")) : 0;
   static const int nb_wgs = getenv("IMF_G_NB_WGS") ? atoi(getenv("IMF_G_NB_WGS")) : 512;
-  const long long wgs = (long long)grid.x * grid.y * grid.z;
+  long long wgs = (long long)grid.x * grid.y * grid.z;
+  if (p.n_out_dev) {
+    // capacity mode: the grid covers a capacity and the largest split, the working workgroups are decided on the
+    // device.  Estimate them the way the buckets are sized (rows ~ capacity / 1.2; model/graph.py) -- a wrong guess
+    // costs time only, both ring depths form the same sums.
+    const long long tiles = grid.x > 1 ? (long long)(grid.x / 1.2) : 1;
+    const int s_est = p.dyn_split_kvol ? auto_split_rule(tiles * IMF_TILE_ROWS, p.cout, p.dyn_split_kvol,
+                                                         p.split_min_blocks, p.split_target)
+                                       : (int)grid.z;
+    wgs = tiles * grid.y * (s_est < (int)grid.z ? s_est : (int)grid.z);
+  }
   const bool deep = nb_env ? nb_env >= 4 : wgs <= nb_wgs;
 #define IMF_G_LAUNCH(CB, USE, CAT)                                              \
   do {                                                                          \

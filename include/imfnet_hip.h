@@ -209,7 +209,8 @@ typedef struct imf_conv_args {
   int32_t variant;        /* 0 = pipelined workgroup kernel on the fp32 MFMA; 1 = the same arithmetic without the
                              pipeline (simple reference kernel; any kvol); 2..5 = retired round-1 experiments
                              (tools/experiments/spconv_variants.hip), rejected with IMF_ERR_INVALID;
-                             6 = variant 0's pipeline on the f16 matrix pipe with split operands
+                             6 = fp32-class arithmetic on the f16 matrix pipe with split operands, both operands staged
+                                 global -> LDS by DMA (k_spconv_g; see kernel_tag for the register-staged twin)
                                  (w_packed from imf_pack_weights_split16; kvol <= 27; |input| < 65504;
                                  in_a / in_b smaller than 2 GiB each: raw-buffer addressing) */
   void *workspace;        /* split-K partial sums (NULL allowed iff split_k resolves to 1); with split 1 and
