@@ -539,20 +539,48 @@ k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_
   float *W_l = lds_f + kBitsRows * kBitsLda;             // [128][COUT], rows >= kvol are zero
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const long long v0 = (long long)blockIdx.x * kBitsRows;
-  for (int i = tid; i < 128 * COUT; i += 256) W_l[i] = i < kvol * COUT ? w[i] : 0.f;
+  // weights as float4 (kvol * COUT is a multiple of 4), zero rows up to 128
+  for (int i = tid; i < 32 * COUT; i += 256)
+    reinterpret_cast<float4 *>(W_l)[i] = 4 * i < kvol * COUT ? reinterpret_cast<const float4 *>(w)[i]
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = tid; i < kBitsRows * kBitsLda; i += 256) A_l[i] = 0.f;
   __syncthreads();
+  // Occupancy windows: one item = (voxel, dy, dz) -> ksize bits along x.  Two phases with every load of a phase in
+  // flight together (coordinates, then grid words): as a per-item loop this was ~12 dependent memory round trips
+  // per workgroup (coordinate -> grid row, six to seven items per thread) and set the kernel's time.
   const int r = ksize >> 1, nyz = ksize * ksize;
-  for (int it = tid; it < kBitsRows * nyz; it += 256) {
+  constexpr int kItems = (kBitsRows * 25 + 255) / 256;   // 7 (ksize 5); ksize 3 uses 3 of them
+  const int n_items = kBitsRows * nyz;
+  int4 c[kItems];
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    const int it = tid + 256 * j;
+    const int v = (it < n_items ? it : 0) / nyz;
+    const long long row = v0 + v < n ? v0 + v : n - 1;     // clamped: the load is unconditional
+    c[j] = reinterpret_cast<const int4 *>(coords)[row];
+  }
+  uint32_t w0[kItems], w1[kItems];
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    const int it = tid + 256 * j;
+    const int itc = it < n_items ? it : 0;
+    const int v = itc / nyz, yz = itc - v * nyz;
+    const int dy = yz % ksize - r, dz = yz / ksize - r;
+    const uint32_t *row = grid + grid_row(g, c[j].x, c[j].z + dy, c[j].w + dz);
+    const int bx = c[j].y - r - g.x0;                      // first bit of the window, >= 0 by construction
+    const int wi = bx >> 5, sh = bx & 31;
+    w0[j] = row[wi];
+    w1[j] = row[sh + ksize > 32 ? wi + 1 : wi];            // second word only when the window straddles
+  }
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    const int it = tid + 256 * j;
+    if (it >= n_items) continue;
     const int v = it / nyz, yz = it - v * nyz;
     if (v0 + v >= n) continue;
-    const int4 c = reinterpret_cast<const int4 *>(coords)[v0 + v];
-    const int dy = yz % ksize - r, dz = yz / ksize - r;
-    const uint32_t *row = grid + grid_row(g, c.x, c.z + dy, c.w + dz);
-    const int bx = c.y - r - g.x0;                       // first bit of the window, >= 0 by construction
-    const int wi = bx >> 5, sh = bx & 31;
-    uint32_t bits = row[wi] >> sh;
-    if (sh + ksize > 32) bits |= row[wi + 1] << (32 - sh);
+    const int sh = (c[j].y - r - g.x0) & 31;
+    uint32_t bits = w0[j] >> sh;
+    if (sh + ksize > 32) bits |= w1[j] << (32 - sh);
     float *dst = A_l + v * kBitsLda + yz * ksize;
     for (int dx = 0; dx < ksize; ++dx) dst[dx] = (bits >> dx) & 1u ? 1.f : 0.f;
   }
