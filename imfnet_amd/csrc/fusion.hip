@@ -393,10 +393,17 @@ int imf_fusion_attention_dyn(const float *x, int64_t n_cap, const int32_t *n_dev
   p.partial = (float *)workspace;
   p.n_dev = n_dev; p.starts_dev = item_starts_dev; p.err = err; p.hs_override = fusion_hs_override();
   hipStream_t st = (hipStream_t)stream;
-  // every variant is issued; on the device exactly one of them finds its slice count selected
+  // every variant the rule can return for ANY row count up to the capacity is issued (fusion_slices_rule: <= 64 blocks
+  // -> 4, <= 128 -> 2, <= 256 -> 4, more -> 1); on the device exactly one of them finds its slice count selected
+  const long long blocks_cap = (n_cap + kFRows - 1) / kFRows;
   int rc;
-  if ((rc = launch_fusion<1>(p, st))) return rc;
-  if ((rc = launch_fusion<2>(p, st))) return rc;
+  if (p.hs_override) {
+    if (p.hs_override == 1) return launch_fusion<1>(p, st);
+    if (p.hs_override == 2) return launch_fusion<2>(p, st);
+    return launch_fusion<4>(p, st);
+  }
+  if (blocks_cap > 256 && (rc = launch_fusion<1>(p, st))) return rc;
+  if (blocks_cap > 64 && (rc = launch_fusion<2>(p, st))) return rc;
   return launch_fusion<4>(p, st);
 }
 
