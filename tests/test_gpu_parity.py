@@ -229,6 +229,27 @@ def test_spconv_dma_staging_is_bit_identical(ops, geom_s5, ca, cb, cout, which):
         assert torch.equal(a, ops.spconv(fa, wp, cout, rb, in_b=fb, variant=6, shift=sh, l2norm=True, staging="regs"))
 
 
+def test_spconv_dma_staging_is_bit_identical_large(ops, clouds):
+    """The same on a chip-filling geometry (the fixture fragment x1.7 at 2.5 cm: ~51 k voxels, 800 tiles): launches of
+    more than 512 workgroups take the 2-deep buffer ring (four workgroups per CU), smaller ones the 4-deep ring -- the
+    small geometry above only ever sees the latter.  No oracle here (too slow at this size): dma == regs bit for bit."""
+    xyz = clouds[0].astype(np.float64) * 1.7
+    cm = _build_levels(ops, ops.voxelize(torch.as_tensor(xyz).to(DEV), 0.025))
+    n0 = cm.level(1).n
+    assert n0 > 40_000
+    for ca, cb, cout, rb, n_in in ((32, 0, 32, cm.conv_rulebook(1, 3, 1), n0), (64, 0, 64, cm.conv_rulebook(1, 3, 1), n0),
+                                   (64, 64, 64, cm.transpose_rulebook(2, 3, 2), cm.level(2).n),
+                                   (64, 32, 64, cm.conv_rulebook(1, 1, 1), n0)):
+        assert rb.n_slots // 64 * max(1, cout // 64) > 512          # the chip-filling path
+        fa, fb = _rand((n_in, ca), 60).to(DEV), (_rand((n_in, cb), 61).to(DEV) if cb else None)
+        wp = ops.pack_weights(_rand((rb.kvol, ca + cb, cout), 62, 0.05).to(DEV), split16=True)
+        sc, sh = (_rand((cout,), 63).abs() + 0.5).to(DEV), _rand((cout,), 64).to(DEV)
+        for kw in ({"split_k": 1}, {"split_k": 1, "scale": sc, "shift": sh, "relu": True}):
+            a = ops.spconv(fa, wp, cout, rb, in_b=fb, variant=6, staging="dma", **kw)
+            b = ops.spconv(fa, wp, cout, rb, in_b=fb, variant=6, staging="regs", **kw)
+            assert torch.equal(a, b), (ca, cb, cout, float((a - b).abs().max()))
+
+
 def test_spconv_epilogues(ops, geom_s5):
     cm, g = geom_s5
     rb, nbr_ref = cm.conv_rulebook(1, 3, 1), g.k3[0]
