@@ -30,7 +30,8 @@
 
 #ifndef IMF_G_ABL
 #define IMF_G_ABL 0   // timing experiments only (wrong results): 4 no row gathers, 8 no weight copies, 1 no MFMAs, 2 no hi/lo split,
-                      // 16 no main loop at all, 32 no LDS fragment reads, 64 no barrier, 128 no prologue table loads, 256 no output stores
+                      // 16 no main loop at all, 32 no LDS fragment reads, 64 no barrier, 128 no prologue table loads, 256 no output stores,
+                      // 512 every gather folded onto the first 1024 rows (all L2 / L1 hits)
 #endif
 
 namespace imf {
@@ -263,7 +264,8 @@ k_spconv_g(const ConvParams p) {
     float4 *const ab = wb + SUB_F4 + wave * AW_F4;                                                               \
     if (!(ABL & 4)) {                                                                                            \
     _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) {                                                          \
-      const unsigned voff = __umul24((rows).r[b_], second ? stride_b : stride_a) + wr_byte;                      \
+      const unsigned rr_ = (ABL & 512) && (rows).r[b_] != kNoRow ? ((rows).r[b_] & 1023u) : (rows).r[b_];        \
+      const unsigned voff = __umul24(rr_, second ? stride_b : stride_a) + wr_byte;                               \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(ab + 128 * b_), 16, voff, soff, 0, 0);           \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(ab + 128 * b_ + 64), 16, voff + 64u, soff, 0, 0); \
     }                                                                                                            \
