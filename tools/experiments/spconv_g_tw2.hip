@@ -1,3 +1,9 @@
+// EXPERIMENT -- not part of the library build (round 2).  csrc/spconv_g.hip with template parameter TW = tiles per
+// workgroup by way of more wavefronts (TW 2: 512 threads, eight wavefronts, two 64-row tiles sharing one weight block;
+// launch option IMF_G_TW=2).  Motivation: the in-kernel stamps (tools/conv_stamps_g.py) show a wavefront spending a
+// third of each sub-stage issuing its four DMA instructions, half of which copy weights that the co-resident
+// workgroups copy as well.  Bit-identical (parity tests green under IMF_G_TW=2); isolated (tools/conv_iso.py, pair):
+// 64 -> 64 @ 103 k rows 91.4 -> 99.0 us, 32 -> 32 36.9 -> 42.6, transposed maps 38.1 -> 45.1 / 25.2 -> 36.6 us.
 // Sparse convolution, variant 6, second implementation: both operands go global -> LDS directly
 // (`buffer_load_dwordx4 ... lds`, no VGPR destination); same arithmetic as k_spconv_h3, bit for bit.
 //
@@ -92,18 +98,25 @@ __device__ __forceinline__ f16x8 lds_read_f16x8(const float4 *__restrict__ src) 
 // Two further schedules were built on this kernel, measured bit-identical and SLOWER, and live in
 // tools/experiments/spconv_g_rb2_pipe.hip: RB 2 as a launch option (64 -> 64 at 103 k rows 93 -> 97 us; the transposed
 // maps up to 1.6x slower: only two workgroups fit a CU) and register double-buffering of the LDS -> VGPR fragment reads
-// (93 -> 98 us at 121 VGPRs).  A third one, eight-wavefront workgroups sharing one weight block between two tiles (DMA
-// instructions per row -25 % at the same 16 wavefronts per CU; tools/experiments/spconv_g_tw2.hip), was bit-identical
-// and slower too (91 -> 99 us).  Only RB 1 with four wavefronts is instantiated here.
-template <int CO_BLK, int USE, bool CAT, int NB, int RB>
-__global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? 4 : 2)
+// (93 -> 98 us at 121 VGPRs).  Only RB 1 is instantiated here.
+//
+// TW = 64-row tiles per workgroup by way of MORE WAVEFRONTS (4 TW of them, 256 TW threads): the in-kernel stamps
+// (tools/conv_stamps_g.py) show a wavefront spending a third of every sub-stage issuing its four DMA instructions --
+// the address path of the vector-memory unit is the most loaded unit once the data no longer returns to VGPRs -- and
+// half of those instructions copy weights that the co-resident workgroups of the CU copy as well.  TW 2 shares one
+// weight block between eight wavefronts (DMA instructions per row -25 %) at the same 16 wavefronts per CU.
+template <int CO_BLK, int USE, bool CAT, int NB, int RB, int TW>
+__global__ void __launch_bounds__(256 * TW, (NB == 2 && RB == 1) ? (TW == 1 ? 4 : 2) : (TW == 1 ? 2 : 1))
 k_spconv_g(const ConvParams p) {
-  constexpr int ROWS = IMF_TILE_ROWS * RB;           // output rows per workgroup
+  static_assert(TW == 1 || (NB == 2 && RB == 1), "TW 2 is the NB 2 / RB 1 schedule");
+  constexpr int NT = RB * TW;                        // tiles per workgroup
+  constexpr int THREADS = 256 * TW;
+  constexpr int ROWS = IMF_TILE_ROWS * NT;           // output rows per workgroup
   constexpr int SUB_F4 = 2 * CO_BLK * 64;            // float4 of weights per sub-stage: 512 or 256
   constexpr int SUB_SHIFT = CO_BLK == 4 ? 13 : 12;   // log2(bytes per weight sub-stage)
-  constexpr int QPS = SUB_F4 / 256;                  // weight DMAs per thread per sub-stage: 2 or 1
+  constexpr int QPS = (SUB_F4 + THREADS - 1) / THREADS;   // weight DMAs per thread per sub-stage: 2 or 1 (TW 2: some wavefronts 0)
   constexpr int AW_F4 = 128 * RB;                    // gathered rows per wavefront and sub-stage: RB x 2 KiB
-  constexpr int BUF_F4 = SUB_F4 + 4 * AW_F4;
+  constexpr int BUF_F4 = SUB_F4 + 4 * TW * AW_F4;
   constexpr int NBR_F4 = kKCache * ROWS / 4;
   constexpr int TAB_F4 = (kSubTab + 3) / 4;
   constexpr int KL_F4 = (kKCache + 3) / 4;
@@ -129,7 +142,7 @@ k_spconv_g(const ConvParams p) {
     }
     super = start + ((super - ((x - off) & 7)) >> 3);
   }
-  const int tile0 = super * RB;
+  const int tile0 = super * NT;
   long long slots_act = p.n_slots;
   if (p.n_out_dev) {   // capacity mode: padding tiles leave; the split is the rule applied to the actual rows
     slots_act = conv_slots(p, conv_rows(p));
@@ -152,12 +165,12 @@ k_spconv_g(const ConvParams p) {
 
   // Per tile: its active offsets (kvol <= 27: one mask word) and, of those, the ones of partition z -- `sel`.
   // The workgroup walks the union of the tiles' selections in ascending order.
-  bool valid[RB];
-  uint32_t sel[RB];
-  int total[RB];
+  bool valid[NT];
+  uint32_t sel[NT];
+  int total[NT];
   uint32_t uni = 0u;
 #pragma unroll
-  for (int b = 0; b < RB; ++b) {
+  for (int b = 0; b < NT; ++b) {
     valid[b] = (long long)(tile0 + b) * IMF_TILE_ROWS < slots_act;
     uint32_t m = 0u;
     if (valid[b]) m = p.tile_mask ? p.tile_mask[(tile0 + b) * IMF_MASK_WORDS] : 1u;
@@ -171,7 +184,7 @@ k_spconv_g(const ConvParams p) {
   }
   bool any_out = S > 1;
 #pragma unroll
-  for (int b = 0; b < RB; ++b) any_out |= total[b] > 0;
+  for (int b = 0; b < NT; ++b) any_out |= total[b] > 0;
   if (!any_out) return;                              // padding tiles only
   const int nk = __builtin_popcount(uni);
   if (tid < 32 && ((uni >> tid) & 1u)) klist[__builtin_popcount(uni & ((1u << tid) - 1u))] = tid;
@@ -181,12 +194,12 @@ k_spconv_g(const ConvParams p) {
       // The loads are unconditional (clamped offset index, clamped tile) and sit outside any per-element branch: a
       // "load or constant" select per element makes hipcc 7.2 branch around every load and wait for each one --
       // seven dependent memory round trips per workgroup instead of one.
-    constexpr int kPer = kKCache * ROWS / 256;       // 7 / 14
-    constexpr int JSTEP = 256 / ROWS;                // offsets covered per pass of the 256 threads: 4 / 2
+    constexpr int kPer = kKCache * ROWS / THREADS;   // 7 / 14
+    constexpr int JSTEP = THREADS / ROWS;            // offsets covered per pass of the workgroup's threads: 4 / 2
     const int srow = tid & (ROWS - 1), j0 = tid / ROWS;
     const int b_of = srow >> 6;                      // tile of this thread's row
-    const bool vb = RB == 1 ? valid[0] : (b_of ? valid[RB - 1] : valid[0]);
-    const uint32_t sb = RB == 1 ? sel[0] : (b_of ? sel[RB - 1] : sel[0]);
+    const bool vb = NT == 1 ? valid[0] : (b_of ? valid[NT - 1] : valid[0]);
+    const uint32_t sb = NT == 1 ? sel[0] : (b_of ? sel[NT - 1] : sel[0]);
     const long long slot = (long long)(tile0 + (vb ? b_of : 0)) * IMF_TILE_ROWS + (srow & 63);
     int v[kPer];
 #pragma unroll
@@ -269,8 +282,9 @@ k_spconv_g(const ConvParams p) {
     float4 *const wb = smem + (b) * BUF_F4;                                                                      \
     if (!(ABL & 8)) {                                                                                            \
     _Pragma("unroll") for (int j = 0; j < QPS; ++j)                                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wb + j * 256 + wave * 64), 16,              \
-                                                 woff0 + (unsigned)j * 4096u, wso, 0, 0);                        \
+      if (j * THREADS + wave * 64 < SUB_F4)                                                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wb + j * THREADS + wave * 64), 16,          \
+                                                 woff0 + (unsigned)(j * THREADS * 16), wso, 0, 0);               \
     }                                                                                                            \
     const bool second = CAT && ((ee >> 14) & 1u);                                                                \
     const unsigned soff = (ee >> 15) << 7;                                                                       \
@@ -382,10 +396,10 @@ k_spconv_g(const ConvParams p) {
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
     const int blk = RB * wave + b;                   // 16-row block of the workgroup
-    const int tb = blk >> 2;                         // tile of the block (0 .. RB - 1)
+    const int tb = blk >> 2;                         // tile of the block (0 .. NT - 1)
     const int tile = tile0 + tb, wv = blk & 3;
-    const bool vt = RB == 1 ? valid[0] : (tb ? valid[RB - 1] : valid[0]);
-    const int tt = RB == 1 ? total[0] : (tb ? total[RB - 1] : total[0]);
+    const bool vt = NT == 1 ? valid[0] : (tb ? valid[NT - 1] : valid[0]);
+    const int tt = NT == 1 ? total[0] : (tb ? total[NT - 1] : total[0]);
     if (!vt) continue;
     if (S == 1) {
       if (tt > 0) conv_epilogue<CO_BLK>(p, acc[b], tile, y, wv, r16, q4, p.w_unscale ? *p.w_unscale : 1.f);
@@ -411,6 +425,8 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
   // 28 -> 33 us (a second round of 32), and every launch that fills the chip is faster with four workgroups per CU
   static const int nb_env = getenv("IMF_G_NB") ? atoi(getenv("IMF_G_NB")) : 0;
   static const int nb_wgs = getenv("IMF_G_NB_WGS") ? atoi(getenv("IMF_G_NB_WGS")) : 512;
+  static const int tw_env = getenv("IMF_G_TW") ? atoi(getenv("IMF_G_TW")) : 0;
+  static const int tw_tiles = getenv("IMF_G_TW_TILES") ? atoi(getenv("IMF_G_TW_TILES")) : (1 << 30);
   long long wgs = (long long)grid.x * grid.y * grid.z;
   if (p.n_out_dev) {
     // capacity mode: the grid covers a capacity and the largest split, the working workgroups are decided on the
@@ -423,10 +439,13 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
     wgs = tiles * grid.y * (s_est < (int)grid.z ? s_est : (int)grid.z);
   }
   const bool deep = nb_env ? nb_env >= 4 : wgs <= nb_wgs;
-#define IMF_G_LAUNCH(CB, USE, CAT)                                              \
-  do {                                                                          \
-    if (deep) k_spconv_g<CB, USE, CAT, 4, 1><<<grid, 256, 0, st>>>(p);          \
-    else      k_spconv_g<CB, USE, CAT, 2, 1><<<grid, 256, 0, st>>>(p);          \
+  const bool two = !deep && (tw_env ? tw_env >= 2 : (long long)grid.x >= tw_tiles);
+  if (two) grid.x = (grid.x + 1) / 2;
+#define IMF_G_LAUNCH(CB, USE, CAT)                                                 \
+  do {                                                                             \
+    if (two)       k_spconv_g<CB, USE, CAT, 2, 1, 2><<<grid, 512, 0, st>>>(p);     \
+    else if (deep) k_spconv_g<CB, USE, CAT, 4, 1, 1><<<grid, 256, 0, st>>>(p);     \
+    else           k_spconv_g<CB, USE, CAT, 2, 1, 1><<<grid, 256, 0, st>>>(p);     \
   } while (0)
   if (p.c_b > 0) {        // two-source input (decoder skip connections)
     if (co_blk == 4) IMF_G_LAUNCH(4, 0, true); else IMF_G_LAUNCH(2, 0, true);
