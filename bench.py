@@ -254,14 +254,20 @@ def main():
     ap.add_argument("--batch", type=int, default=2, choices=(1, 2),
                     help="fragments per forward: 2 = the in-tree fragment PAIR (cloud_bin_0 + cloud_bin_1, one image "
                          "each) as ONE batched sparse tensor, the batched call of model/resunet.py:241-250")
-    ap.add_argument("--mode", default="capacity", choices=("capacity", "graph", "exact"),
+    ap.add_argument("--mode", default="auto", choices=("auto", "capacity", "graph", "exact"),
                     help="capacity: imf_fragment_forward per step (device-side counts, no host readback); graph: the same "
-                         "as one hipGraph replay; exact: count readback + native executor")
+                         "as one hipGraph replay; auto (default): both are timed after the clocks have settled and the faster "
+                         "one runs the timed region (config.capacity_mode.picked says which); exact: count readback + native "
+                         "executor")
+    ap.add_argument("--repeats", type=int, default=9,
+                    help="the timed region (exactly --steps steps between barrier + synchronize) is repeated this many times; "
+                         "ms_per_step / value are the MEDIAN repeat, min and max are reported beside it")
+    ap.add_argument("--settle-ms", type=float, default=600.0,
+                    help="untimed steps run for at least this long before the first timed region (clock / power settle)")
+    ap.add_argument("--trace-steps", type=int, default=3,
+                    help="steps AFTER the timed regions that carry HIP events around every convolution (live roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-fragment / end-to-end / fp32-MFMA legs")
-    ap.add_argument("--trace-every", type=int, default=10,
-                    help="record the per-launch HIP events of the roofline measurement on every n-th timed step "
-                         "(eager launches with two event records per convolution instead of the graph replay)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -298,63 +304,104 @@ def main():
     sync = torch.cuda.synchronize
     graph_info = None
     with torch.no_grad():
-        dyn = args.mode in ("capacity", "graph")
+        dyn = args.mode != "exact"
         F_exact = wl.prepare_graph().clone() if dyn else None
+        step = (lambda tl=None: wl.graph_step(tl)) if dyn else (lambda tl=None: wl.exact_step())
         if dyn:
             wl.runner.use_graph = args.mode == "graph"
-        step = (lambda tl=None: wl.graph_step(tl)) if dyn else (lambda tl=None: wl.exact_step())
         for _ in range(args.warmup):
             out = step()
         sync()
+
+        # clock / power settle: untimed steps for >= --settle-ms (the first tens of ms after start-up run at other
+        # clocks than the steady state: r02's driver line was a 28 ms sample taken 7 ms after the warm-up)
+        settle_steps, t_s = 0, time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+            for _ in range(10):
+                out = step()
+            sync()
+            settle_steps += 10
+
+        picked = {"mode": args.mode}
+        if args.mode == "auto":                           # eager capacity-mode launches vs ONE hipGraph replay: measure, pick
+            probe = {}
+            for rnd in range(2):                          # interleaved rounds; the capture happens in round 0's warm-up
+                for name, ug in (("capacity", False), ("graph", True)):
+                    wl.runner.use_graph = ug
+                    for _ in range(3):
+                        step()
+                    probe.setdefault(name, []).append(timed(step, max(10, args.steps), sync) * 1e3)
+            best = min(probe, key=lambda k: min(probe[k]))
+            wl.runner.use_graph = best == "graph"
+            picked = {"mode": "auto", "picked": best,
+                      "probe_ms_per_step": {k: [round(v, 4) for v in vs] for k, vs in probe.items()}}
+            for _ in range(3):
+                out = step()
+            sync()
+        run_mode = picked.get("picked", args.mode)
+
         if dyn:
+            out = step()
+            sync()
             assert out.flags == 0, f"capacity flags {out.flags}"
             M = out.counts[0]
             F_ref = out.F.clone()
             same = bool(torch.equal(F_ref, F_exact))
             assert float((F_ref - F_exact).abs().max()) < 1e-5, "graph path differs from the exact path"
-            graph_info = {"hipgraph_replay": bool(wl.bucket.graph), "graph_nodes": wl.bucket.n_nodes,
+            graph_info = {"hipgraph_replay": bool(wl.runner.use_graph), "graph_nodes": wl.bucket.n_nodes,
                           "equals_exact_path_bitwise": same, "host_readbacks_per_step": 0,
-                          "capacities": {"points": wl.bucket.caps.n_points, "rows": list(wl.bucket.caps.rows)}}
+                          "capacities": {"points": wl.bucket.caps.n_points, "rows": list(wl.bucket.caps.rows)},
+                          **picked}
         else:
+            out = step()
+            sync()
             M = out.shape[0]
             F_ref = out.clone()
 
-        trace_all = []
-        barrier()
-        sync()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            traced = (i % args.trace_every == 0)
-            if dyn:
-                out = step(trace_all if traced else None)
-            else:
-                ops.TRACE = trace_all if traced else None
+        # ---- the timed regions: EXACTLY --steps steps each, barrier + synchronize on both sides, nothing else inside
+        # (no event records, no readbacks).  Fragments are independent units: no data-path collective (each rank
+        # would write its own <frag>.npz; the optional --gather of generate_desc is not the path).
+        rep = []
+        for _ in range(max(1, args.repeats)):
+            barrier()
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
                 out = step()
-        ops.TRACE = None
-        # fragments are independent units: no data-path collective inside the timed region (each
-        # rank would write its own <frag>.npz; the optional --gather of generate_desc is not the path)
-        sync()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        trace = trace_all
+            sync()
+            barrier()
+            rep.append(time.perf_counter() - t0)
         F_last = out.F if dyn else out
 
         # every step recomputes the same input: the last timed step must reproduce the warm-up step bit for bit
         drift = float((F_last - F_ref).abs().max())
         assert drift < 1e-5, f"descriptors of the last timed step differ from the warm-up step by {drift}"
         bit_reproducible = drift == 0.0
-        if graph_info is not None:
-            graph_info["traced_steps_in_timed_region"] = len(range(0, args.steps, args.trace_every))
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        # ---- live roofline: --trace-steps further steps, in situ (all three streams), HIP events around every
+        # convolution on its launch stream -- AFTER the timed regions
+        trace_all = []
+        traced_steps = max(1, args.trace_steps)
+        for i in range(traced_steps):
+            if dyn:
+                step(trace_all)
+            else:
+                ops.TRACE = trace_all
+                step()
+        ops.TRACE = None
+        sync()
+        trace = trace_all
+
+    t = torch.tensor(rep, dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per repeat: the slowest rank
         m = torch.tensor([M], dtype=torch.int64, device=dev)
         dist.all_reduce(m, op=dist.ReduceOp.SUM)
         total_m = int(m.item())
     else:
         total_m = M
-    elapsed = float(t.item())
+    rep = sorted(float(v) for v in t.tolist())
+    elapsed = rep[len(rep) // 2] if len(rep) % 2 else 0.5 * (rep[len(rep) // 2 - 1] + rep[len(rep) // 2])
 
     if rank == 0:
         # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
@@ -377,7 +424,6 @@ def main():
         dom = max(groups, key=lambda k: groups[k]["ms"])
         g = groups[dom]
         achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
-        traced_steps = len(range(0, args.steps, args.trace_every))
         conv_ms = sum(v["ms"] for v in groups.values()) / traced_steps
         traffic, traffic_note = pmc_traffic(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -388,7 +434,8 @@ def main():
                     "algorithmic_bytes_per_launch": g["bytes"] // g["n"],
                     "achieved_tflops_useful": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2),
                     "all_sparse_conv_ms_per_step": round(conv_ms, 3),
-                    "timing": "HIP events around each launch, in situ (other streams' kernels of the same step overlap)"}
+                    "timing": "HIP events around each launch on its launch stream, in situ (other streams' kernels of the same "
+                              "step overlap), %d steps after the timed regions" % traced_steps}
         extras = {}
         with torch.no_grad():
             if dyn and world == 1:
@@ -416,6 +463,13 @@ def main():
             "value": round(total_m * args.steps / elapsed, 1),
             "unit": "descriptors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "timing": {"repeats": len(rep), "statistic": "median over the repeats of one timed region = exactly --steps steps "
+                                                        "between barrier + synchronize (max over ranks per repeat)",
+                       "ms_per_step_min": round(rep[0] / args.steps * 1e3, 4),
+                       "ms_per_step_max": round(rep[-1] / args.steps * 1e3, 4),
+                       "ms_per_step_all": [round(v / args.steps * 1e3, 4) for v in rep],
+                       "settle_steps": settle_steps, "settle_ms": args.settle_ms,
+                       "traced_steps_in_timed_region": 0},
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": ("synthetic (reference fixture fragment%s scaled x%.2f, seeded random weights)"
                      % (" PAIR cloud_bin_0 + cloud_bin_1" if args.batch == 2 else " cloud_bin_0", args.scale)),
@@ -432,9 +486,9 @@ def main():
                        "execution": {"capacity": "one imf_fragment_forward call per step in capacity mode: device-side row counts, "
                                                  "no host readback, launches issued natively on three streams",
                                      "graph": "one hipGraph replay per step of imf_fragment_forward in capacity mode",
-                                     "exact": "exact mode: row-count readback + native executor (imf_resunet_forward)"}[args.mode],
+                                     "exact": "exact mode: row-count readback + native executor (imf_resunet_forward)"}[run_mode],
                        "capacity_mode": graph_info,
-                       "image_branch": model.image_branch_mode if args.mode == "exact" else "native-hip (csrc/image.hip)",
+                       "image_branch": model.image_branch_mode if not dyn else wl.runner.image_branch_mode,
                        "conv_arithmetic": ("fp32 operands split into f16 hi+lo (weights pre-scaled by a power of two), "
                                            "3x v_mfma_f32_16x16x32_f16 with fp32 accumulation (fp32-class: max |dF| 3e-7 vs "
                                            "an fp64-accumulated network)" if ops.CONV_VARIANT == 6 else "fp32 MFMA"),

@@ -444,20 +444,24 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   IMF_REQUIRE(fio->tokens_padded % 64 == 0 && fio->tokens_padded >= ntok && fio->tokens_padded <= 320,
               "imf_fragment_forward: tokens_padded=%d for %d tokens", fio->tokens_padded, ntok);
 
+  // The meta block (row counts, flag words) is reset on the main stream BEFORE the image stream forks: the image branch
+  // ORs IMF_FLAG_RANGE into meta[1], which must not race with that reset.
+  PyramidBuild pb;
+  int rc = pyramid_prepare(pb, fio->xyz, fio->xyz_is_f64, caps->n_points, fio->voxel_size, 0, nullptr, 1, 4, fio->pyramid_arena,
+                           fio->pyramid_arena_bytes, fio->meta, fio->levels, fio->dyn, caps->rows);
+  if (rc) return rc;
+  if ((rc = pyramid_init(pb, main))) return rc;
+
   // image branch on its own stream, forked from and later joined to the main one (events 9 / 10)
   IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[9], main));
   IMF_CHECK_HIP(hipStreamWaitEvent(imgs, (hipEvent_t)fio->events[9], 0));
-  int rc = imf_image_branch(img, fio->image, caps->n_items, caps->img_h, caps->img_w, fio->image_ws, fio->image_ws_bytes,
-                            nullptr, fio->kt_packed, fio->v_packed, fio->tokens_padded, fio->meta + 1, imgs);
+  rc = imf_image_branch(img, fio->image, caps->n_items, caps->img_h, caps->img_w, fio->image_ws, fio->image_ws_bytes,
+                        nullptr, fio->kt_packed, fio->v_packed, fio->tokens_padded, fio->meta + 1, imgs);
   if (rc) return rc;
   IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[10], imgs));
 
   // level 0 of the pyramid on the main stream (conv1 needs it first); the coarse levels go to the side stream
-  PyramidBuild pb;
-  rc = pyramid_prepare(pb, fio->xyz, fio->xyz_is_f64, caps->n_points, fio->voxel_size, 0, nullptr, 1, 4, fio->pyramid_arena,
-                       fio->pyramid_arena_bytes, fio->meta, fio->levels, fio->dyn, caps->rows);
-  if (rc) return rc;
-  if ((rc = pyramid_level0(pb, main))) return rc;
+  if ((rc = pyramid_level0(pb, main, false))) return rc;
 
   imf_resunet_io io;
   memset(&io, 0, sizeof(io));

@@ -574,13 +574,22 @@ int pyramid_prepare(PyramidBuild &b, const void *xyz, int xyz_is_f64, int64_t n,
   return IMF_OK;
 }
 
-int pyramid_level0(const PyramidBuild &b, hipStream_t st) {
-  const BatchStarts &bs = *reinterpret_cast<const BatchStarts *>(b.batch_starts);
+int pyramid_init(const PyramidBuild &b, hipStream_t st) {
   imf_level *lv = b.levels;
   int64_t nb = div_up(b.n_keys, 256 * 4);
   nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
   k_init_tables2<<<(unsigned)nb, 256, 0, st>>>(lv[0].keys, b.n_keys, lv[0].vals, b.n_vals, b.n_levels, b.meta, b.n_meta);
   IMF_CHECK_LAUNCH("k_init_tables2");
+  return IMF_OK;
+}
+
+int pyramid_level0(const PyramidBuild &b, hipStream_t st, bool init) {
+  const BatchStarts &bs = *reinterpret_cast<const BatchStarts *>(b.batch_starts);
+  imf_level *lv = b.levels;
+  if (init) {
+    const int rc = pyramid_init(b, st);
+    if (rc) return rc;
+  }
   const int nblk = (int)div_up(b.n, 256);
   if (b.xyz_is_f64)
     k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,

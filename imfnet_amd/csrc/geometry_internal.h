@@ -25,7 +25,9 @@ struct PyramidBuild {
 int pyramid_prepare(PyramidBuild &b, const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
                     const int64_t *item_starts, int n_items, int n_levels, void *arena, size_t arena_bytes,
                     int32_t *meta, imf_level *levels_out, const int32_t *dyn, const int64_t *row_caps);
-int pyramid_level0(const PyramidBuild &b, hipStream_t st);
+// hash tables empty, meta block (counts, flag words, bounding box, item starts) reset -- the first launch of level 0
+int pyramid_init(const PyramidBuild &b, hipStream_t st);
+int pyramid_level0(const PyramidBuild &b, hipStream_t st, bool init = true);
 int pyramid_coarse_level(const PyramidBuild &b, int l, hipStream_t st);
 int pyramid_item_starts(const PyramidBuild &b, hipStream_t st, int l_begin, int l_end);
 

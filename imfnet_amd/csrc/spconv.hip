@@ -718,7 +718,6 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
                a->nbr, a->tile_mask, (long long)a->n_slots, (long long)a->n_out, a->scale, a->shift,
                a->residual, a->relu, a->l2norm, a->out, (float *)a->workspace,
                ((a->variant == 0 && !simple) || a->variant == 6) ? a->tickets : nullptr, 0};
-  if (const char *e = getenv("IMF_ABLATE")) p.ablate = atoi(e);
   p.tail_begin = p.tail_split = 0;
   p.w_unscale = a->variant == 6 ? a->w_packed + (long long)a->kvol * cin * a->cout + 1 : nullptr;
   p.n_out_dev = a->n_out_dev;

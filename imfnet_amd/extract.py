@@ -15,6 +15,16 @@ from . import sparse as ME
 from ._lib import FLAG_RANGE, ImfError
 
 
+def _cuda_device(device):
+    """torch.device with an explicit index (`cuda` -> `cuda:<current>`): per-device state is keyed by it."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise ImfError('imfnet_amd runs on the GPU only; there is no CPU fallback')
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    return device
+
+
 def _as_device_points(xyz, device):
     if torch.is_tensor(xyz):
         t = xyz
@@ -140,9 +150,7 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
                 raise ValueError('Invalid normal. Normal must range from [-1, 1]')
     if device is None:
         device = torch.device('cuda:0')
-    device = torch.device(device)
-    if device.type != 'cuda':
-        raise ImfError('imfnet_amd runs on the GPU only; there is no CPU fallback')
+    device = _cuda_device(device)
 
     feats = []
     if rgb is not None:
@@ -204,19 +212,26 @@ def extract_features_batch(model, xyz_list, voxel_size, device, images):
     reference's model accepts, model/resunet.py:241-250).  xyz_list: point arrays; images: [B,3,H,W].
     Returns [(xyz_down float64 [M_b,3], F_b device view [M_b,32])] in input order.  Small fragments share
     the per-forward fixed costs (about 0.5 ms of launch-latency-bound coarse layers) this way."""
-    device = torch.device(device)
-    if device.type != 'cuda':
-        raise ImfError('imfnet_amd runs on the GPU only; there is no CPU fallback')
+    device = _cuda_device(device)
     if model.training:
         model.eval()
-    fut = start_geometry(list(xyz_list), voxel_size, device)
-    start = getattr(model, "start_image_branch", None)
-    img = start(images, device=device) if start is not None else torch.as_tensor(images, dtype=torch.float32, device=device)
-    if img is None:
-        img = torch.as_tensor(images, dtype=torch.float32, device=device)
-    stensor, inds = sparse_tensor_from_points(None, voxel_size, device, geometry=fut)
-    with torch.no_grad():
-        F = model(stensor, img).F
+
+    def run():
+        fut = start_geometry(list(xyz_list), voxel_size, device)
+        start = getattr(model, "start_image_branch", None)
+        img = start(images, device=device) if start is not None else None
+        if img is None:
+            img = torch.as_tensor(images, dtype=torch.float32, device=device)
+        stensor, inds = sparse_tensor_from_points(None, voxel_size, device, geometry=fut)
+        with torch.no_grad():
+            F = model(stensor, img).F
+        return fut, stensor, inds, F
+
+    fut, stensor, inds, F = run()
+    if hasattr(model, "take_flags") and model.take_flags(device) & FLAG_RANGE:   # as in extract_features: never silently wrong
+        import warnings
+        warnings.warn("imfnet_amd: activation outside the f16 range; batch recomputed with fp32 MFMA (variant 0)")
+        fut, stensor, inds, F = model.forward_fp32(run)
     sel = fut.xyz[inds.long()].cpu().numpy().astype(np.float64)
     items = stensor.coordinate_manager.level(1).items
     return [(sel[r0:r0 + rn], F[r0:r0 + rn]) for r0, rn in items]

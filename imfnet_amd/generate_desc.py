@@ -134,6 +134,12 @@ def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, devic
         top_up(False)
         n = xyz.shape[0]
         key = runner.caps_for(n, 1, int(slot.image.shape[2]), int(slot.image.shape[3]), voxel_size, True)
+        if key is None:                                     # no capacities known (e.g. the bit grid never fitted): exact path
+            redo.append(job)
+            slots.put(slot)
+            if not inflight:
+                top_up(True)
+            continue
         b = runner.bucket(key, device, stream)
         slot.fit(n, b.caps.rows[0], b.out.shape[1])
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -194,11 +200,11 @@ def extract_features_batch(model, config, source_path, target_path, voxel_size, 
     runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
     if runner is not None and workers > 0 and not (gather and world > 1) and len(mine) > 1:
         # first fragment on the exact path (teaches the runner the voxel-per-point ratios), the rest pipelined
-        jobs = [frags[i] for i in mine]
+        pending = [frags[i] for i in mine]
         t_all = []
-        head, tail = jobs[:1], jobs[1:]
-        while head:
-            scene, fi = head.pop()
+
+        def run_exact(job):
+            scene, fi = job
             xyz, image = load_fragment(fi, config)
             torch.cuda.synchronize(device)
             t0 = time.time()
@@ -209,10 +215,16 @@ def extract_features_batch(model, config, source_path, target_path, voxel_size, 
             out_dir = os.path.join(target_path, os.path.basename(scene), "seq-01")
             ensure_dir(out_dir)
             save_descriptors(os.path.join(out_dir, os.path.basename(fi).replace(".ply", ".npz")), xyz, xyz_down, feature)
-            if not head and tail and runner.ratios is not None:
-                t_pipe, head = _batch_pipelined(model, runner, config, tail, target_path, voxel_size, device, workers)
-                t_all += t_pipe
-                tail = []
+
+        run_exact(pending.pop(0))
+        # re-fetched AFTER the head fragment: an fp32 recompute or a refresh rebuilds the plans the runner points into
+        runner = model.fragment_runner()
+        if runner is not None and runner.ratios is not None and runner.grid_words > 0:
+            t_pipe, redo = _batch_pipelined(model, runner, config, pending, target_path, voxel_size, device, workers)
+            t_all += t_pipe
+            pending = redo                                  # flagged fragments (capacity / f16 range): exact path
+        for job in pending:                                 # also everything, when the runner turned out unusable
+            run_exact(job)
         return t_all, len(frags)
     loader = ThreadPoolExecutor(max_workers=workers) if workers > 0 else None
     writer = ThreadPoolExecutor(max_workers=workers) if workers > 0 else None

@@ -180,12 +180,16 @@ class FragmentRunner:
             model._plan = FusedPlan(model)
         if model._native_plan is None:
             model._native_plan = NativePlan(model, model._plan)
+        # the descriptors below hold raw pointers into these plans' packed weights: keep them alive with the runner
+        self._plans = (model._plan, model._native_plan)
         self.net_desc = model._native_plan.desc
         self.img_plan = model._native_image()
         fw = model._fusion_weights()
         self.supported = bool(self.img_plan.supported and self.img_plan.with_kv and fw.supported and
                               model._plan.small_first and model.conv1.in_channels == 1 and
                               all(c.variant == 6 for c in self.net_desc.conv if c.w_packed))
+        # imf_fragment_forward calls imf_image_branch (csrc/image.hip) itself: a runner exists only when that plan is usable
+        self.image_branch_mode = "native-hip (csrc/image.hip, inside imf_fragment_forward)" if self.supported else None
         self.ratios = None            # max rows_l / n_points seen (4 levels)
         self.grid_words = 0           # largest conv1 bit grid seen
         self.buckets = {}

@@ -148,6 +148,8 @@ class ResUNet2(ME.MinkowskiNetwork):
         return super().train(mode)
 
     # ---- image branch: independent of the sparse encoder until the bottleneck ------------------
+    _warned_grad = False
+
     def _image_branch(self, image):
         """Image encoder + the context half of the cross attention (LayerNorm + K/V projection of
         the image tokens): everything that depends on the image only."""
@@ -229,6 +231,7 @@ class ResUNet2(ME.MinkowskiNetwork):
     def flag_word(self, device):
         """Device int32[1] the kernels OR IMF_FLAG_RANGE (32) into when an activation that feeds a split-f16
         convolution is NaN or >= 65504 in magnitude (it would become inf as an f16 operand)."""
+        device = _norm_device(device)
         w = self._flag_words.get(device)
         if w is None:
             w = self._flag_words[device] = torch.zeros(1, dtype=torch.int32, device=device)
@@ -236,7 +239,7 @@ class ResUNet2(ME.MinkowskiNetwork):
 
     def take_flags(self, device):
         """Read and clear the flag word (one 4-byte readback: synchronises with the current stream)."""
-        w = self._flag_words.get(device)
+        w = self._flag_words.get(_norm_device(device))
         if w is None:
             return 0
         v = int(w.item())
@@ -303,20 +306,16 @@ class ResUNet2(ME.MinkowskiNetwork):
     def _capture_image_graph(self, image, side):
         if os.environ.get("IMFNET_NO_GRAPH"):
             return False
-        try:
-            static_in = image.clone()
-            for _ in range(3):                           # warm-up: MIOpen / hipBLASLt pick their kernels
-                self._image_branch(static_in)
-            side.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                outs = self._image_branch(static_in)
-            return graph, static_in, outs
-        except Exception as e:                           # noqa: BLE001 -- fall back to eager launches
-            import warnings
-            warnings.warn(f"imfnet_amd: image-branch hipGraph capture failed ({e}); running eagerly")
-            torch.cuda.synchronize()
-            return False
+        # diagnostic path (IMFNET_TORCH_IMAGE=1; the default image branch is csrc/image.hip): a failed capture raises --
+        # nothing here falls back silently; IMFNET_NO_GRAPH=1 asks for eager launches explicitly
+        static_in = image.clone()
+        for _ in range(3):                               # warm-up: MIOpen / hipBLASLt pick their kernels
+            self._image_branch(static_in)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            outs = self._image_branch(static_in)
+        return graph, static_in, outs
 
     def _bn(self):
         if self._folded is None:
@@ -331,6 +330,12 @@ class ResUNet2(ME.MinkowskiNetwork):
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x, image):
         if not self._can_fuse() or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            if self._can_fuse() and not ResUNet2._warned_grad:
+                ResUNet2._warned_grad = True
+                import warnings
+                warnings.warn("imfnet_amd: eval-mode forward called with autograd enabled and trainable parameters: running "
+                              "the per-layer training path (10-100x slower than the fused inference plan); wrap the call in "
+                              "torch.no_grad() for descriptor extraction")
             return self.forward_layers(x, image)          # training mode, or fine-tuning with frozen statistics
         if self._pending_image is None:
             self._refresh()
@@ -445,6 +450,14 @@ class ResUNet2(ME.MinkowskiNetwork):
             parts.append(self.attention_fusion(tokens[b:b + 1], queries_encoder=F[start:start + n].unsqueeze(0))[0])
             start += n
         return torch.cat(parts, dim=0)
+
+
+def _norm_device(device):
+    """`cuda` and `cuda:<current>` are the same device but different dict keys: always carry the index."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
 
 
 def _variant(name, base, **attrs):
