@@ -80,7 +80,8 @@ class NetTrace(C.Structure):
     """struct imf_net_trace."""
     _fields_ = [("ev_begin", C.c_void_p), ("ev_end", C.c_void_p), ("nbr", C.c_void_p), ("kvol", C.c_int32),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("split", C.c_int32), ("n_slots", C.c_int64),
-                ("n_out", C.c_int64), ("launched", C.c_int32), ("level", C.c_int32), ("slots_extra", C.c_int32)]
+                ("n_out", C.c_int64), ("launched", C.c_int32), ("level", C.c_int32), ("slots_extra", C.c_int32),
+                ("kernel_tag", C.c_int32)]
 
 
 class ResunetIO(C.Structure):
@@ -146,6 +147,7 @@ SIGNATURES = {
     "imf_select_keypoints": (_I, [_P, _L, _P, _L, _D, _P, _P, _P, _Z, _P]),
     "imf_resunet_int_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64), _P]),
     "imf_resunet_float_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64)]),
+    "imf_resunet_conv_kernel_tag": (_I, [_I, _I, _I, _I]),
     "imf_resunet_forward": (_I, [C.POINTER(ResunetDesc), C.POINTER(ResunetIO)]),
     "imf_resunet_int_arena_bytes_cap": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64), _Z]),
     "imf_resunet_float_arena_bytes_cap": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64)]),

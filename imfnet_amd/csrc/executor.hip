@@ -67,14 +67,6 @@ Sizes sizes_of(const imf_resunet_desc *net, const int64_t *n) {
   return s;
 }
 
-// Capacity mode: the device picks the split from the actual rows; the launch covers what the rule returns for a
-// quarter of the capacity (fewer rows than that are flagged and the caller redoes the fragment exactly).
-int split_cover(int64_t n_slots, int cout, int kvol) {
-  int64_t q = n_slots / 4 / IMF_TILE_ROWS * IMF_TILE_ROWS;
-  if (q < IMF_TILE_ROWS) q = IMF_TILE_ROWS;
-  return imf_spconv_auto_split(q, cout, kvol);
-}
-
 size_t rb_words(int64_t n_slots, int kvol) {
   return (size_t)n_slots + (size_t)kvol * n_slots + (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS;
 }
@@ -109,9 +101,9 @@ size_t float_arena_bytes(const Sizes &s, bool dyn) {
   for (int i = 0; i < NBUF; ++i) total += (cnt[i] + 63) / 64 * 64;
   // largest split-K workspace of any launch (same rule as imf_spconv_fwd's automatic split)
   size_t ws = 0;
-  auto consider = [&](int64_t n_slots, int cout, int max_active) {
-    const int sp = dyn ? split_cover(n_slots, cout, max_active) : imf_spconv_auto_split(n_slots, cout, max_active);
-    const size_t need = imf_spconv_workspace_bytes(n_slots, cout, sp) / 4;
+  auto consider = [&](int64_t n_slots, int cout, int max_active) {   // unsplit launches: the optional balanced tail only
+    (void)max_active;
+    const size_t need = imf_spconv_workspace_bytes(n_slots, cout, 1) / 4;
     ws = ws > need ? ws : need;
   };
   for (int i = 0; i < 4; ++i) {
@@ -141,6 +133,13 @@ constexpr int kMetaStarts = 16;                     // meta[16 + IMF_MAX_BATCH *
 using namespace imf;
 
 extern "C" {
+
+int imf_resunet_conv_kernel_tag(int level, int kvol, int cout, int variant) {
+  if (variant != 6 || kvol <= 1 || cout % 64 != 0 || level <= 0) return 0;
+  // measured on the S50k pair / single fragment (profiles/r03_conv_isolated.txt): level 1 (438 / 219 tiles) is fastest
+  // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
+  return level == 1 ? 8 : 4;
+}
 
 size_t imf_resunet_int_arena_bytes(const imf_resunet_desc *net, const int64_t *n, const int32_t *bbox) {
   if (!net || !n) return 0;
@@ -378,16 +377,11 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
       a.n_out_dev = meta + 2 * rb.level;
       a.slots_extra = rb.slots_extra;
       a.dyn_err = err;
-      if (c.kvol == 1) {
-        a.split_k = 1;
-      } else {
-        a.dyn_split_kvol = rb.max_active;
-        a.split_k = split_cover(rb.n_slots, c.cout, rb.max_active);
-      }
-    } else {
-      const int split = imf_spconv_auto_split(rb.n_slots, c.cout, rb.max_active);
-      a.split_k = c.kvol == 1 ? 1 : split;
     }
+    // one workgroup (or its wavefronts) owns a tile for all kernel offsets: no split-K partitions, no reduce launch, and
+    // the kernel is a function of the level only -- both modes form the same sums
+    a.split_k = 1;
+    a.kernel_tag = imf_resunet_conv_kernel_tag(rb.level, c.kvol, c.cout, c.variant);
     a.variant = c.variant;
     a.workspace = ws; a.workspace_bytes = ws_bytes;   // split-K partials or the balanced tail's
     if (io->trace) {
@@ -395,7 +389,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
       a.ev_begin = t.ev_begin; a.ev_end = t.ev_end;
       t.nbr = rb.nbr; t.kvol = c.kvol; t.cin = c.cin; t.cout = c.cout; t.split = a.split_k;
       t.n_slots = rb.n_slots; t.n_out = rb.n_out; t.launched = 1;
-      t.level = rb.level; t.slots_extra = rb.slots_extra;
+      t.level = rb.level; t.slots_extra = rb.slots_extra; t.kernel_tag = a.kernel_tag;
     }
     return imf_spconv_fwd(&a, main);
   };

@@ -708,7 +708,15 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   IMF_REQUIRE(a->variant != 6 || (a->kvol * (cin / 32) < kSubTab && a->c_a <= 1024 && a->c_b <= 1024),
               "imf_spconv_fwd: variant 6 needs kvol * cin / 32 < %d and <= 1024 channels per source (kvol=%d cin=%d): use variant 0",
               kSubTab, a->kvol, cin);
-  int split = simple ? 1 : (a->split_k > 0 ? a->split_k : imf_spconv_auto_split(a->n_slots, a->cout, a->kvol));
+  // variant 6, kernel_tag bits 2 / 3: the wave-split kernel (spconv_w.hip) with 8 / 4 wavefronts per workgroup -- the
+  // whole tile in one workgroup, no split-K partitions, no reduce launch
+  const int wsplit = a->variant == 6 ? ((a->kernel_tag & 4) ? 8 : ((a->kernel_tag & 8) ? 4 : 0)) : 0;
+  if (wsplit) {
+    IMF_REQUIRE(a->kvol > 1 && a->nbr && a->tile_mask && a->cout % 64 == 0,
+                "imf_spconv_fwd: the wave-split kernel needs kvol > 1 and cout %% 64 == 0 (kvol=%d cout=%d)", a->kvol, a->cout);
+    IMF_REQUIRE(a->split_k <= 1 && !a->tickets, "imf_spconv_fwd: the wave-split kernel takes no split_k / tickets");
+  }
+  int split = (simple || wsplit) ? 1 : (a->split_k > 0 ? a->split_k : imf_spconv_auto_split(a->n_slots, a->cout, a->kvol));
   IMF_REQUIRE(split >= 1 && split <= 32, "imf_spconv_fwd: split_k=%d", split);
   if (split > 1)
     IMF_REQUIRE(a->workspace && a->workspace_bytes >= imf_spconv_workspace_bytes(a->n_slots, a->cout, split),
@@ -721,7 +729,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   p.tail_begin = p.tail_split = 0;
   p.w_unscale = a->variant == 6 ? a->w_packed + (long long)a->kvol * cin * a->cout + 1 : nullptr;
   p.n_out_dev = a->n_out_dev;
-  p.dyn_split_kvol = a->n_out_dev ? a->dyn_split_kvol : 0;
+  p.dyn_split_kvol = (a->n_out_dev && !wsplit) ? a->dyn_split_kvol : 0;
   p.slots_extra = a->slots_extra;
   p.split_min_blocks = split_min_blocks();
   p.split_target = split_target();
@@ -734,7 +742,9 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
-  if (a->variant == 6) {
+  if (wsplit) {
+    launch_spconv_w(p, grid.x, wsplit, st);
+  } else if (a->variant == 6) {
     // Balanced tail: with >= 2 full rounds of workgroups per CU and a partial last round (801 tiles on
     // 256 CUs: 33 CUs get a 4th tile and set the kernel time), the tail tiles are split over their
     // offsets so every CU receives the same work.  Needs a little workspace; skipped without it.

@@ -191,4 +191,8 @@ void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st
 // spconv_g.hip: the same arithmetic with both operands staged by LDS-DMA (default; launch_spconv_h3 dispatches)
 void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use = 0);
 
+// spconv_w.hip: variant 6 for the coarse levels -- one workgroup per (tile, 64-column slab), the tile's sub-stages split
+// over its `waves` (8 or 4) wavefronts, partial tiles combined through LDS, epilogue in the same launch
+void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t st);
+
 }  // namespace imf

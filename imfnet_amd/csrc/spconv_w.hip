@@ -1,0 +1,299 @@
+// Sparse convolution, variant 6, third implementation: the "wave-split" kernel for the levels that cannot fill the
+// chip with 64-row tiles (tensor stride >= 2: a few hundred tiles or fewer).
+//
+// Why (round 3).  k_spconv_g gives such a level its parallelism by splitting a tile's kernel offsets over up to eight
+// WORKGROUPS (split-K): every partition pays the launch prologue, writes a 64 x 64 slab of raw partial sums to HBM, and
+// a second launch (k_spconv_reduce) adds the slabs and applies the epilogue.  Measured on the pair's stride-4 / 8
+// levels (profiles/r02_kernel_stats.txt): 19-36 us per convolution + 6-8 us of reduce + a kernel boundary, of which
+// the data path is < 15 % (profiles/r02_conv_dma_ablations.txt) -- and inside a partition the four wavefronts share
+// the weight block of a sub-stage, so each sub-stage costs a workgroup barrier for 12 MFMAs per wavefront and every
+// wavefront re-reads the whole 8 KiB B block from LDS.
+//
+// Here ONE workgroup owns a (64-row tile, 64-column slab) for ALL of its kernel offsets, and the split runs over its
+// W wavefronts instead: the tile's sub-stage list (active offset x 32-channel chunk, ascending) is cut into W
+// contiguous ranges, wavefront w walks range w for all 64 rows x 64 columns (16 accumulators).  Consequences:
+//   * a wavefront's operands are private: its own 8 KiB row image (64 gathered rows x 128 B) and 8 KiB weight block per
+//     sub-stage, fetched by LDS-DMA into its own 16 KiB of LDS -- no workgroup barrier in the main loop, only the
+//     wavefront's own `s_waitcnt vmcnt(0)`;
+//   * one read of the B fragments feeds four row blocks: 16 ds_read_b128 per 48 MFMAs instead of 10 per 12;
+//   * the LDS buffer is single: once the 16 fragments of sub-stage t sit in registers the DMA of t + 1 is issued into the
+//     same 16 KiB and lands under the 48 MFMAs of t (registers are the second buffer);
+//   * the W partial tiles meet in LDS (the staging area, reused), are added in wavefront order by all threads, and the
+//     epilogue (BatchNorm scale / shift, residual, ReLU, range flag, L2 norm) runs in the same launch: no partial sums
+//     in HBM, no reduce launch, no kernel boundary.
+// The partition depends on the tile's own active-offset list and on W only -- not on the row count, the grid or the
+// capacity -- so a tile's sums are the same in every launch that contains it (exact mode == capacity mode bit for bit
+// with no device-side split rule).  W is part of the arithmetic (the ranges), so it is the CALLER's static choice
+// (imf_conv_args.kernel_tag), never a function of the row count.
+//
+// Operand layout, MFMA sequence per (row block, column block, sub-stage) and the weight image are k_spconv_g's
+// (csrc/spconv_g.hip): DMA row images with the conflict-free lane swizzle, `lo*hi, hi*lo, hi*hi` per 32 channels.
+#include "spconv_shared.h"
+
+namespace imf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace {
+
+constexpr int kDummyJkW = kKCache - 1;        // neighbour-table row that is always "no input"
+constexpr unsigned kNoRowW = 0x00FFFFFFu;     // 24-bit row index whose byte offset falls outside the buffer window
+
+__device__ __forceinline__ void w_split8(const float4 &x0, const float4 &x1, f16x8 &hi, f16x8 &lo) {
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const _Float16 h = (_Float16)v[t];
+    hi[t] = h;
+    lo[t] = (_Float16)(v[t] - (float)h);
+  }
+}
+
+// fragment reads behind __restrict__ parameters (alias-scope metadata): see spconv_g.hip
+__device__ __forceinline__ float4 w_lds16(const float4 *__restrict__ src) { return *src; }
+__device__ __forceinline__ f16x8 w_lds_f16x8(const float4 *__restrict__ src) {
+  return *reinterpret_cast<const f16x8 *>(src);
+}
+__device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) { return *src; }
+
+}  // namespace
+
+template <bool CAT, int W>
+__global__ void __launch_bounds__(64 * W, 2)
+k_spconv_w(const ConvParams p) {
+  constexpr int NT = 64 * W;
+  constexpr int REG_F4 = 1024;                       // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512
+  constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
+  constexpr int TAB_F4 = (kSubTab + 3) / 4;
+  constexpr int KL_F4 = (kKCache + 3) / 4;
+  __shared__ float4 smem[W * REG_F4 + NBR_F4 + TAB_F4 + KL_F4];
+  unsigned *const nbr_lds = reinterpret_cast<unsigned *>(smem + W * REG_F4);              // [kKCache][64]
+  unsigned *const stab = reinterpret_cast<unsigned *>(smem + W * REG_F4 + NBR_F4);        // [kSubTab]
+  int *const klist = reinterpret_cast<int *>(smem + W * REG_F4 + NBR_F4 + TAB_F4);        // [kKCache]
+
+  const int tile = blockIdx.x, y = blockIdx.y;
+  long long slots_act = p.n_slots;
+  if (p.n_out_dev) {                                 // capacity mode: tiles beyond the actual rows leave
+    slots_act = conv_slots(p, conv_rows(p));
+    if ((long long)tile * IMF_TILE_ROWS >= slots_act) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cin = p.c_a + (CAT ? p.c_b : 0);
+  const int ncc = cin / 32;
+
+  const uint32_t m = p.tile_mask[tile * IMF_MASK_WORDS];
+  const int nk = __builtin_popcount(m);
+  if (nk == 0) return;                               // padding tile
+  if (tid < 32 && ((m >> tid) & 1u)) klist[__builtin_popcount(m & ((1u << tid) - 1u))] = tid;
+  __syncthreads();
+  const int n_sub = nk * ncc;
+  {   // the tile's slice of the neighbour table (24-bit row indices) and the sub-stage table; unconditional loads
+    constexpr int JSTEP = NT / IMF_TILE_ROWS;        // offsets covered per pass of the workgroup: 8 / 4
+    constexpr int kPer = (kKCache + JSTEP - 1) / JSTEP;
+    const int srow = tid & 63, j0 = tid >> 6;
+    const long long slot = (long long)tile * IMF_TILE_ROWS + srow;
+    const int32_t *const src = p.nbr + slot;
+    int v[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int j = j0 + JSTEP * i;
+      v[i] = src[(long long)klist[j < nk ? j : 0] * p.n_slots];
+    }
+    if (tid < kSubTab) {
+      unsigned e = (unsigned)kDummyJkW << 9;
+      if (tid < n_sub) {
+        const int jk = tid / ncc, cc = tid - jk * ncc;
+        const int ch0 = cc * 32;
+        const bool second = CAT && ch0 >= p.c_a;
+        const int cch = second ? (ch0 - p.c_a) >> 5 : cc;
+        e = (unsigned)(klist[jk] * ncc + cc) | ((unsigned)jk << 9) | ((second ? 1u : 0u) << 14) | ((unsigned)cch << 15);
+      }
+      stab[tid] = e;
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int j = j0 + JSTEP * i;
+      if (j < nk) nbr_lds[j * IMF_TILE_ROWS + srow] = v[i] >= 0 ? (unsigned)v[i] : kNoRowW;
+      else if (j == kDummyJkW) nbr_lds[j * IMF_TILE_ROWS + srow] = kNoRowW;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[b][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.w_packed), (short)0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.in_a), (short)0, 0x7FFFF000, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(CAT ? p.in_b : p.in_a), (short)0, 0x7FFFF000, 0x00020000);
+  const unsigned stride_a = (unsigned)p.c_a * 4u, stride_b = (unsigned)(CAT ? p.c_b : p.c_a) * 4u;
+  const unsigned wslab = (unsigned)((long long)y * p.kvol * ncc * 512 * 16);       // bytes (image < 2 GiB)
+  const unsigned woff = (unsigned)lane * 16u;
+  // writer role of the lane in a 16-row block's gather: row lane >> 2, piece (lane & 3) ^ f(row >> 2)   (spconv_g.hip)
+  const int row_w = lane >> 2;
+  const unsigned wr_byte = 16u * (unsigned)((lane & 3) ^ ((4 - (row_w >> 2)) & 3));
+  // reader role: MFMA A fragment, row r16, pieces q4 and 4 + q4
+  const int rd_slot = 4 * r16 + (q4 ^ ((4 - (r16 >> 2)) & 3));
+  float4 *const areg = smem + wave * REG_F4;         // rows: block b at + 128 b (two 1 KiB images)
+  float4 *const wreg = areg + 512;                   // weights: fragment (2 cb + {hi, lo}) at + 64 (2 cb + h)
+
+  struct Rows { unsigned r[4]; };
+#define IMF_W_ROWS(dst, e)                                                                                         \
+  {                                                                                                                \
+    const unsigned *const base_ = nbr_lds + ((((unsigned)(e)) >> 9) & 31u) * IMF_TILE_ROWS + row_w;                \
+    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) (dst).r[b_] = w_lds_u32(base_ + 16 * b_);                                 \
+  }
+  // LDS-DMA of one sub-stage into the wavefront's region: 8 KiB of weights verbatim, 64 rows x 128 B as 8 images
+#define IMF_W_DMA(e, rows)                                                                                         \
+  {                                                                                                                \
+    const unsigned ee = (unsigned)(e);                                                                             \
+    const unsigned wso = wslab + ((ee & 511u) << 13);                                                              \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wreg + 64 * j), 16, woff + 1024u * j, wso, 0, 0); \
+    const bool second = CAT && ((ee >> 14) & 1u);                                                                  \
+    const unsigned soff = (ee >> 15) << 7;                                                                         \
+    const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                        \
+    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) {                                                             \
+      const unsigned voff = __umul24((rows).r[b_], second ? stride_b : stride_a) + wr_byte;                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(areg + 128 * b_), 16, voff, soff, 0, 0);           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(areg + 128 * b_ + 64), 16, voff + 64u, soff, 0, 0); \
+    }                                                                                                              \
+  }
+
+  // this wavefront's range of the tile's sub-stages
+  const int t0 = (int)((long long)wave * n_sub / W), t1 = (int)((long long)(wave + 1) * n_sub / W);
+  unsigned e_cur = 0, e_nxt = 0;
+  Rows rows_nxt;
+  if (t0 < t1) {
+    e_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t0]));
+    Rows rows0;
+    IMF_W_ROWS(rows0, e_cur)
+    IMF_W_DMA(e_cur, rows0)
+    e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t0 + 1 < kSubTab ? t0 + 1 : kSubTab - 1]));
+    IMF_W_ROWS(rows_nxt, e_nxt)
+  }
+#pragma unroll 1
+  for (int t = t0; t < t1; ++t) {
+    // sub-stage t has landed: the region is private, the wavefront's own counter is the only wait
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float4 a0[4], a1[4];
+    f16x8 bh[4], bl[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      a0[b] = w_lds16(&areg[128 * b + rd_slot]);
+      a1[b] = w_lds16(&areg[128 * b + 64 + rd_slot]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      bh[cb] = w_lds_f16x8(&wreg[(2 * cb) * 64 + lane]);
+      bl[cb] = w_lds_f16x8(&wreg[(2 * cb + 1) * 64 + lane]);
+    }
+    // every fragment is in registers before the region is refilled
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t + 1 < t1) {
+      IMF_W_DMA(e_nxt, rows_nxt)                      // lands under the 48 MFMAs below
+      e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 2 < kSubTab ? t + 2 : kSubTab - 1]));
+      IMF_W_ROWS(rows_nxt, e_nxt)
+    }
+    f16x8 ah[4], al[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) w_split8(a0[b], a1[b], ah[b], al[b]);
+    // per accumulator: lo*hi, hi*lo, hi*hi (k_spconv_g's order); consecutive MFMAs on different accumulators
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b], bh[cb], acc[b][cb], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bl[cb], acc[b][cb], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bh[cb], acc[b][cb], 0, 0, 0);
+  }
+#undef IMF_W_DMA
+#undef IMF_W_ROWS
+
+  // ---- the W partial tiles meet in LDS (each wavefront's own 16 KiB: its DMAs have all landed and been read) ----
+  // element (row, col) of wavefront w at float index  w * 4096 + row * 64 + (((col >> 2) ^ f(row)) << 2) + (col & 3),
+  // f(row) = 4 * ((row >> 2) & 1): conflict-free for the ds_write_b32 of the accumulator layout and the ds_read_b128 below
+  {
+    float *const mine = reinterpret_cast<float *>(areg);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * b + 4 * q4 + r, col = 16 * cb + r16;
+          mine[row * 64 + ((((col >> 2) ^ (((row >> 2) & 1) << 2))) << 2) + (col & 3)] = acc[b][cb][r];
+        }
+  }
+  __syncthreads();
+  constexpr int PT = 1024 / NT;                      // float4 per thread: 2 (W 8) / 4 (W 4)
+  const float un = p.w_unscale ? *p.w_unscale : 1.f;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int idx = i * NT + tid, row = idx >> 4, c4 = idx & 15;
+    const int col = y * 64 + 4 * c4;
+    const int phys = row * 16 + (c4 ^ (((row >> 2) & 1) << 2));
+    float4 s = w_lds16(&smem[phys]);
+#pragma unroll
+    for (int w = 1; w < W; ++w) {                    // wavefront order: fixed, deterministic
+      const float4 v = w_lds16(&smem[w * REG_F4 + phys]);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int orow = row_of_slot(p, (long long)tile * IMF_TILE_ROWS + row);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + col);
+    if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + col);
+    s.x = (s.x * un) * sc.x + sh.x; s.y = (s.y * un) * sc.y + sh.y;
+    s.z = (s.z * un) * sc.z + sh.z; s.w = (s.w * un) * sc.w + sh.w;
+    if (p.residual && orow >= 0) {
+      const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (long long)orow * p.cout + col);
+      s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
+    }
+    if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    if (p.err) {                                     // range guard for the consumer's f16 operands
+      const bool bad = orow >= 0 && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) ||
+                                     out_of_f16_range(s.w));
+      if (__ballot(bad) != 0ull && lane == 0) atomicOr(p.err, 32);
+    }
+    if (p.l2norm) {                                  // cout == 64: the row is these 16 consecutive lanes
+      float ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
+      ss += __shfl_xor(ss, 8, 64);
+      const float nrm = sqrtf(ss);
+      s.x /= nrm; s.y /= nrm; s.z /= nrm; s.w /= nrm;   // no eps: resunet.py:230
+    }
+    if (orow >= 0) *reinterpret_cast<float4 *>(p.out + (long long)orow * p.cout + col) = s;
+  }
+}
+
+// grid = (tiles, cout / 64); `waves` = 8 (512 threads, one workgroup per CU) or 4 (256 threads, two per CU)
+void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t st) {
+  const dim3 grid(tiles, (unsigned)(p.cout / 64), 1);
+  const bool cat = p.c_b > 0;
+  if (waves == 8) {
+    if (cat) k_spconv_w<true, 8><<<grid, 512, 0, st>>>(p);
+    else     k_spconv_w<false, 8><<<grid, 512, 0, st>>>(p);
+  } else {
+    if (cat) k_spconv_w<true, 4><<<grid, 256, 0, st>>>(p);
+    else     k_spconv_w<false, 4><<<grid, 256, 0, st>>>(p);
+  }
+}
+
+}  // namespace imf

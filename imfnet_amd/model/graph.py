@@ -314,7 +314,8 @@ class FragmentRunner:
                     continue
                 rb = _RB(t.n_slots, t.n_out, t.kvol, t.kvol)
                 rb.nbr = t.nbr or 0
-                trace_list.append(dict(kernel=ops.conv_kernel_name(self.net_desc.conv[i].variant, t.cin, t.cout),
+                trace_list.append(dict(kernel=ops.conv_kernel_name(self.net_desc.conv[i].variant, t.cin, t.cout,
+                                                                   kernel_tag=t.kernel_tag),
                                        kvol=t.kvol, cin=t.cin, cout=t.cout, rb=rb, split=t.split, ev=e,
                                        name=NativePlan.ORDER[i], arena=arena, res=res, level=t.level,
                                        slots_extra=t.slots_extra))

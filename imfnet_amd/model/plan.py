@@ -27,7 +27,7 @@ def _stream():
 
 class _RB:
     """Rulebook living inside the plan's int32 arena (raw device addresses)."""
-    __slots__ = ("tile_rows", "nbr", "tile_mask", "n_slots", "n_out", "kvol", "max_active")
+    __slots__ = ("tile_rows", "nbr", "tile_mask", "n_slots", "n_out", "kvol", "max_active", "level")
 
     def count_pairs(self, arena, valid_slots=None, rows=None):
         """Valid (input,output) pairs -- bench.py's algorithmic-bytes accounting, outside timing.  Capacity mode:
@@ -40,9 +40,10 @@ class _RB:
             tab = tab[:, :valid_slots]
         return int((tab >= 0).sum().item())
 
-    def __init__(self, n_slots, n_out, kvol, max_active):
+    def __init__(self, n_slots, n_out, kvol, max_active, level=0):
         self.tile_rows = self.nbr = self.tile_mask = 0
         self.n_slots, self.n_out, self.kvol, self.max_active = n_slots, n_out, kvol, max_active
+        self.level = level                            # pyramid level of the OUTPUT rows (picks the kernel)
 
     def words(self):
         return self.n_slots + self.kvol * self.n_slots + self.n_slots // TILE_ROWS * MASK_WORDS
@@ -104,8 +105,6 @@ class FusedPlan:
         conv_args("final", m.final, l2norm=bool(m.normalize_feature))
         self.first_ksize = m.conv1.kernel_size
         self._trace_arena = None
-        self._tickets = 0
-        self.fused_reduce = False
         self._side = {}
 
     # -------------------------------------------------------------------------------------------
@@ -121,10 +120,12 @@ class FusedPlan:
         a.n_slots, a.n_out = rb.n_slots, rb.n_out
         a.residual = residual or None
         a.out = out
-        split = self.L.imf_spconv_auto_split(rb.n_slots, a.cout, rb.max_active)
+        # the executors' static kernel policy (csrc/executor.hip): a function of the output level only, never split-K
+        split = 1
         a.split_k = split
+        a.kernel_tag = self.L.imf_resunet_conv_kernel_tag(rb.level, a.kvol, a.cout, a.variant)
         a.workspace, a.workspace_bytes = (ws[0] or None, ws[1])
-        a.tickets = (self._tickets or None) if (split > 1 and self.fused_reduce) else None
+        a.tickets = None
         a.dyn_err = self._flags if (a.variant == 6 and not a.l2norm) else None
         ev = None
         if ops.TRACE is not None:
@@ -135,7 +136,7 @@ class FusedPlan:
         check(self.L.imf_spconv_fwd(C.byref(a), _stream()), f"imf_spconv_fwd[{name}]")
         if ev is not None:
             cin = c_a + c_b
-            ops.TRACE.append(dict(kernel=ops.conv_kernel_name(a.variant, cin, a.cout),
+            ops.TRACE.append(dict(kernel=ops.conv_kernel_name(a.variant, cin, a.cout, kernel_tag=a.kernel_tag),
                                   kvol=rb.kvol, cin=cin, cout=a.cout, rb=rb, split=split, ev=ev, name=name,
                                   arena=self._trace_arena))
 
@@ -154,9 +155,9 @@ class FusedPlan:
         # ---- rulebooks: one int32 arena ------------------------------------------------------
         slots = [L.imf_rulebook_slots(k) for k in n]
         rb_first = _RB(slots[0], n[0], self.first_ksize ** 3, self.first_ksize ** 3)
-        rb_k3 = [_RB(slots[i], n[i], 27, 27) for i in range(4)]
-        rb_dn = [_RB(slots[i + 1], n[i + 1], 27, 27) for i in range(3)]
-        rb_up = [_RB(L.imf_rulebook_transpose_slots(n[i]), n[i], 27, 8) for i in range(3)]
+        rb_k3 = [_RB(slots[i], n[i], 27, 27, level=i) for i in range(4)]
+        rb_dn = [_RB(slots[i + 1], n[i + 1], 27, 27, level=i + 1) for i in range(3)]
+        rb_up = [_RB(L.imf_rulebook_transpose_slots(n[i]), n[i], 27, 8, level=i) for i in range(3)]
         rb_id = _RB(slots[0], n[0], 1, 1)
         all_rb = ([] if self.small_first else [rb_first]) + rb_k3 + rb_dn + rb_up
         words = sum(r.words() for r in all_rb) + 16 * 3
@@ -240,19 +241,10 @@ class FusedPlan:
             for sfx in "abc":
                 sizes[f"d{i}{sfx}"] = n[i] * dec_ch[i]
         sizes["head"] = n[0] * T[1]
-        ws_floats, n_tickets = 0, 0
+        ws_floats = 0
         for name, rb, *_ in sched:
             cout = self.convs[name][0].cout
-            sp = L.imf_spconv_auto_split(rb.n_slots, cout, rb.max_active)
-            ws_floats = max(ws_floats, L.imf_spconv_workspace_bytes(rb.n_slots, cout, sp) // 4)
-            if sp > 1:
-                n_tickets = max(n_tickets, rb.n_slots // TILE_ROWS * max(1, cout // 32))
-        # arrival counters of the optional in-kernel split-K combine (measured SLOWER on MI355X than
-        # the second launch: every partition pays an agent-scope release = L2 write-back; 1.91 vs
-        # 1.60 ms/fragment), zeroed once per fragment and left zero by every launch
-        if self.fused_reduce:
-            tickets = torch.zeros(max(1, n_tickets), dtype=torch.int32, device=dev)
-            self._tickets = tickets.data_ptr()
+            ws_floats = max(ws_floats, L.imf_spconv_workspace_bytes(rb.n_slots, cout, 1) // 4)
         farena = torch.empty(sum(sizes.values()) + ws_floats, dtype=torch.float32, device=dev)
         base, off, addr, foff = farena.data_ptr(), 0, {}, {}
         for name, cnt in sizes.items():
@@ -416,7 +408,8 @@ class NativePlan:
                     continue
                 rb = _RB(t.n_slots, t.n_out, t.kvol, t.kvol)
                 rb.nbr = t.nbr or 0
-                ops.TRACE.append(dict(kernel=ops.conv_kernel_name(d.conv[i].variant, t.cin, t.cout), kvol=t.kvol,
+                ops.TRACE.append(dict(kernel=ops.conv_kernel_name(d.conv[i].variant, t.cin, t.cout, kernel_tag=t.kernel_tag),
+                                      kvol=t.kvol,
                                       cin=t.cin, cout=t.cout, rb=rb, split=t.split, ev=e, name=self.ORDER[i],
                                       arena=iarena.view(torch.int32)))
         return F

@@ -382,7 +382,9 @@ def pack_weights(kernel, out=None, split16=False):
 H3_DMA = int(os.environ.get("IMF_H3_GLDS", "1")) != 0
 
 
-def conv_kernel_name(variant, cin, cout, staging=None):
+def conv_kernel_name(variant, cin, cout, staging=None, kernel_tag=0):
+    if variant == 6 and (kernel_tag & 12 or staging in ("wave8", "wave4")):
+        return f"k_spconv_w<{8 if (kernel_tag & 4 or staging == 'wave8') else 4}>"
     if variant == 6:
         dma = H3_DMA if staging is None else staging == "dma"
         return f"k_spconv_{'g' if dma else 'h3'}<{4 if cout % 64 == 0 else 2}, 0>"
@@ -393,7 +395,8 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
            relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False, flags=None, staging=None):
     """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd.  `flags`: optional int32[1] device word that
     receives IMF_FLAG_RANGE (32) when an output is NaN or >= 65504 in magnitude.  `staging` (variant 6): None = the
-    library default (LDS-DMA kernel), "regs" = the register-staged kernel (A/B and bit-identity tests)."""
+    library default (LDS-DMA kernel), "regs" = the register-staged kernel (A/B and bit-identity tests), "wave8" /
+    "wave4" = the wave-split kernel for coarse levels (csrc/spconv_w.hip; kvol > 1, cout % 64 == 0, no split-K)."""
     _req(in_a, torch.float32, "in_a", 2)
     if in_b is not None:
         _req(in_b, torch.float32, "in_b", 2)
@@ -410,13 +413,13 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     a.out = out.data_ptr()
     L = _lib.lib()
     split = 1 if variant == 1 else (int(split_k) if split_k else L.imf_spconv_auto_split(rb.n_slots, cout, rb.max_active))
-    if rb.kvol == 1:
+    if rb.kvol == 1 or staging in ("wave8", "wave4"):
         split = 1
     a.split_k, a.variant = split, int(variant)
     a.dyn_err = None if flags is None else flags.data_ptr()
-    if staging not in (None, "dma", "regs"):
+    if staging not in (None, "dma", "regs", "wave8", "wave4"):
         raise ImfError(f"spconv: staging={staging!r}")
-    a.kernel_tag = 2 if staging == "regs" else 0
+    a.kernel_tag = {"regs": 2, "wave8": 4, "wave4": 8}.get(staging, 0)
     ws = None
     nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)   # split-K partials / balanced-tail partials
     if nbytes:
@@ -439,7 +442,7 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     check(L.imf_spconv_fwd(C.byref(a), _stream()), "imf_spconv_fwd")
     if ev is not None:
         cin = a.c_a + a.c_b
-        TRACE.append(dict(kernel=conv_kernel_name(variant, cin, cout, "regs" if (staging == "regs" or fused_reduce) else None),
+        TRACE.append(dict(kernel=conv_kernel_name(variant, cin, cout, "regs" if (staging == "regs" or fused_reduce) else staging),
                           kvol=rb.kvol, cin=cin, cout=cout, rb=rb, split=split, ev=ev))
     return out
 

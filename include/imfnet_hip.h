@@ -236,7 +236,14 @@ typedef struct imf_conv_args {
                              (k_spconv_g<.., 1>: the image branch's dense convolutions).  bit 1: run the register-staged
                              implementation k_spconv_h3 (csrc/spconv_h3.hip) instead of the default k_spconv_g
                              (csrc/spconv_g.hip: both operands global -> LDS by DMA); same sums bit for bit, kept for A/B
-                             and selected automatically with `tickets`.  Process-wide: env IMF_H3_GLDS=0 */
+                             and selected automatically with `tickets`.  Process-wide: env IMF_H3_GLDS=0.
+                             bit 2 (4) / bit 3 (8): the wave-split kernel k_spconv_w (csrc/spconv_w.hip) with 8 / 4
+                             wavefronts per workgroup -- for levels of a few hundred 64-row tiles or fewer: one workgroup
+                             owns a (tile, 64-column slab) for all kernel offsets, its wavefronts split the tile's
+                             (offset, 32-channel chunk) list into contiguous ranges and combine their partial tiles through
+                             LDS in wavefront order, epilogue in the same launch.  Needs kvol > 1, cout % 64 == 0,
+                             split_k <= 1.  The wavefront count is part of the summation order (deterministic; a tile's
+                             sums do not depend on the row count, so exact and capacity mode agree bit for bit) */
   int32_t *dyn_err;       /* optional device flag word (any mode): IMF_FLAG_SPLIT_COVER when the rule asks for more
                              partitions than split_k covers; IMF_FLAG_RANGE when an OUTPUT value is NaN or |y| >= 65504,
                              i.e. cannot be an operand of a following variant-6 convolution */
@@ -423,7 +430,19 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
   int64_t n_slots, n_out;
   int32_t launched;
   int32_t level, slots_extra;          /* out: pyramid level of the output rows; rulebook slots beyond roundup64(rows) */
+  int32_t kernel_tag;                  /* out: imf_conv_args.kernel_tag of the launch (imf_resunet_conv_kernel_tag) */
 } imf_net_trace;
+
+/* Which variant-6 kernel the ResUNet executors (imf_resunet_forward, imf_fragment_forward and the Python plan that
+ * mirrors them) use for a convolution whose OUTPUT rows live on pyramid level `level` (0 = tensor stride 1):
+ * the value for imf_conv_args.kernel_tag.  Level 0 (thousands of 64-row tiles): k_spconv_g, unsplit.  Level 1: the
+ * wave-split kernel with 4 wavefronts per workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4).  The
+ * choice is a function of the LEVEL only -- never of the row count -- so exact mode, capacity mode and a graph replay
+ * form every sum in the same order (bit-identical descriptors) without a device-side split rule; no executor launch
+ * uses split-K partitions or the k_spconv_reduce pass any more.  0 for shapes the wave-split kernel does not serve
+ * (kvol == 1, cout % 64 != 0, variant != 6).  Replaces: the implicit per-layer algorithm choice inside
+ * ME.MinkowskiConvolution (model/resunet.py:168-226). */
+int imf_resunet_conv_kernel_tag(int level, int kvol, int cout, int variant);
 
 typedef struct imf_resunet_io {        /* per fragment */
   imf_level level[4];                  /* tensor strides 1, 2, 4, 8 (imf_pyramid_build) */

@@ -173,7 +173,8 @@ def _rb_and_ref(cm, g, which):
 
 
 @pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple",
-                                  "h3", "h3_split1", "h3_split5", "h3_split5_fused", "h3_regs", "h3_regs_split5"])
+                                  "h3", "h3_split1", "h3_split5", "h3_split5_fused", "h3_regs", "h3_regs_split5",
+                                  "h3_wave8", "h3_wave4"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
     """Plain convolution (no epilogue) vs the oracle; error measured against an fp64 evaluation and
@@ -190,7 +191,11 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
           "h3_split5_fused": {"variant": 6, "split_k": 5, "fused_reduce": True},
           # variant 6 defaults to the LDS-DMA kernel (k_spconv_g); "regs" = the register-staged k_spconv_h3
           "h3_regs": {"variant": 6, "staging": "regs"},
-          "h3_regs_split5": {"variant": 6, "split_k": 5, "staging": "regs"}}[mode]
+          "h3_regs_split5": {"variant": 6, "split_k": 5, "staging": "regs"},
+          # the wave-split kernel of the coarse levels (csrc/spconv_w.hip): whole tile per workgroup, 8 / 4 wavefronts
+          "h3_wave8": {"variant": 6, "staging": "wave8"}, "h3_wave4": {"variant": 6, "staging": "wave4"}}[mode]
+    if mode in ("h3_wave8", "h3_wave4") and (kvol == 1 or cout % 64):
+        pytest.skip("the wave-split kernel covers kvol > 1 and cout % 64 == 0")
     if mode in ("split5", "split5_fused", "h3_split5", "h3_split5_fused", "h3_regs_split5") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")
     out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV), split16=mode.startswith("h3")), cout, rb,
@@ -271,6 +276,44 @@ def test_spconv_epilogues(ops, geom_s5):
         got = ops.spconv(f.to(DEV), wp, 32, rb, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV),
                          relu=True, **kw).cpu()
         assert (got - torch.relu(base * sc + sh + res)).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("staging", ["wave8", "wave4"])
+def test_spconv_wave_kernel_epilogues(ops, geom_s5, staging):
+    """k_spconv_w (one workgroup per tile, sub-stages split over its wavefronts, partial tiles combined in LDS): the
+    in-launch epilogue (scale / shift / residual / ReLU, L2 norm), the two-source input and the transposed map against
+    the oracle; run-to-run bit reproducibility; and agreement with the unsplit k_spconv_g within fp32 roundoff."""
+    cm, g = geom_s5
+    for which, ca, cb, cout in ((("k3", 1), 64, 0, 64), (("up", 1), 128, 128, 64), (("down", 1), 64, 0, 128)):
+        rb, nbr_ref, n_in = _rb_and_ref(cm, g, which)
+        fa, fb = _rand((n_in, ca), 70), (_rand((n_in, cb), 71) if cb else None)
+        w = _rand((27, ca + cb, cout), 72, 1.0 / np.sqrt(27 * (ca + cb)))
+        sc, sh, res = _rand((cout,), 73).abs() + 0.5, _rand((cout,), 74), _rand((rb.n_out, cout), 75)
+        wp = ops.pack_weights(w.to(DEV), split16=True)
+        fin = fa if fb is None else torch.cat([fa, fb], 1)
+        base = O.spconv_f64(fin, w, nbr_ref)
+        kw = dict(in_b=None if fb is None else fb.to(DEV), variant=6)
+        got = ops.spconv(fa.to(DEV), wp, cout, rb, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True,
+                         staging=staging, **kw)
+        assert (got.cpu().double() - torch.relu(base * sc + sh + res)).abs().max() < 2e-5
+        again = ops.spconv(fa.to(DEV), wp, cout, rb, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True,
+                           staging=staging, **kw)
+        assert torch.equal(got, again)
+        unsplit = ops.spconv(fa.to(DEV), wp, cout, rb, scale=sc.to(DEV), shift=sh.to(DEV), residual=res.to(DEV), relu=True,
+                             split_k=1, **kw)
+        assert (got - unsplit).abs().max() < 2e-5
+        if cout == 64:
+            ref = base + sh
+            ref = ref / ref.norm(dim=1, keepdim=True)
+            got = ops.spconv(fa.to(DEV), wp, cout, rb, shift=sh.to(DEV), l2norm=True, staging=staging, **kw).cpu()
+            assert (got.double() - ref).abs().max() < 2e-6
+        flags = torch.zeros(1, dtype=torch.int32, device=DEV)          # range guard: raised by the in-launch epilogue
+        ops.spconv(fa.to(DEV) * 3e5, wp, cout, rb, staging=staging, flags=flags, **kw)
+        assert int(flags.item()) & 32
+    with pytest.raises(Exception):                                     # 32 output channels: not served
+        rb = cm.conv_rulebook(1, 3, 1)
+        ops.spconv(_rand((len(g.levels[0]), 32), 76).to(DEV), ops.pack_weights(_rand((27, 32, 32), 77).to(DEV), split16=True),
+                   32, rb, variant=6, staging=staging)
 
 
 def test_spconv_split16_variant(ops, geom_s5):

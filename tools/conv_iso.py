@@ -1,6 +1,7 @@
 """Isolated timing of the network's sparse-convolution shapes (nothing else on the GPU): each shape is launched
 REPS times back to back on one stream and timed with one event pair (main kernel + split-K reduce).
-usage: [BATCH=2] [IMF_LIB=...] conv_iso.py [staging]      staging: dma (default) | regs"""
+usage: [BATCH=2] [IMF_LIB=...] conv_iso.py [staging ...]      staging: dma (default) | regs | wave8 | wave4
+Several stagings print one column each (a shape a staging does not serve prints "-")."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -8,7 +9,7 @@ import numpy as np, torch
 from imfnet_amd import ops
 from imfnet_amd import sparse as ME
 from bench import load_workload, load_pair
-staging = sys.argv[1] if len(sys.argv) > 1 else None
+stagings = sys.argv[1:] or [None]
 REPS = 20
 dev = torch.device("cuda:0")
 xyz, img, voxel = load_workload(1.7, 0.025)
@@ -39,17 +40,23 @@ for name, ca, cb, cout, kind, i in SHAPES:
     w = ops.pack_weights((torch.randn(rb.kvol, ca + cb, cout, generator=g) * 0.05).to(dev), split16=True)
     sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
     out = torch.empty(rb.n_out, cout, device=dev)
-    kw = dict(in_b=fb, scale=sc, shift=sh, relu=True, variant=6, out=out, staging=staging)
-    for _ in range(3):
-        ops.spconv(fa, w, cout, rb, **kw)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(REPS):
-        ops.spconv(fa, w, cout, rb, **kw)
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / REPS
+    cols = []
+    for staging in stagings:
+        if staging in ("wave8", "wave4") and (rb.kvol == 1 or cout % 64):
+            cols.append(None)
+            continue
+        kw = dict(in_b=fb, scale=sc, shift=sh, relu=True, variant=6, out=out, staging=staging)
+        for _ in range(3):
+            ops.spconv(fa, w, cout, rb, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REPS):
+            ops.spconv(fa, w, cout, rb, **kw)
+        e1.record(); torch.cuda.synchronize()
+        cols.append(e0.elapsed_time(e1) * 1e3 / REPS)
     split = ops._lib.lib().imf_spconv_auto_split(rb.n_slots, cout, rb.max_active) if rb.kvol > 1 else 1
-    tot += us
-    print("%-10s k=%2d %3d->%3d slots=%6d split=%d  %7.1f us" % (name, rb.kvol, ca + cb, cout, rb.n_slots, split, us))
-print("sum: %.1f us" % tot)
+    tot = [a + (b if b is not None else cols[0]) for a, b in zip(tot if isinstance(tot, list) else [0.0] * len(cols), cols)]
+    print("%-10s k=%2d %3d->%3d slots=%6d split=%d  " % (name, rb.kvol, ca + cb, cout, rb.n_slots, split) +
+          "  ".join("%7.1f us" % c if c is not None else "      -   " for c in cols))
+print("sum (missing = first column):  " + "  ".join("%7.1f us" % t for t in tot) + "   [" + ", ".join(str(s) for s in stagings) + "]")
