@@ -37,7 +37,7 @@ class ConvArgs(C.Structure):
         ("tickets", C.c_void_p),
         ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p),
         ("n_out_dev", C.c_void_p), ("dyn_split_kvol", C.c_int32), ("slots_extra", C.c_int32),
-        ("kernel_tag", C.c_int32), ("dyn_err", C.c_void_p),
+        ("kernel_tag", C.c_int32), ("dyn_err", C.c_void_p), ("geglu", C.c_int32),
     ]
 
 

@@ -1,13 +1,20 @@
 // Bottleneck fusion block (model/attention_fusion.py:132-154 with depth 0, one head):
 //   x  = Attn(LN(x), ctx = LN(img tokens)) + x        q: 256->128, softmax over the image tokens, out 128->256
 //   x  = FF(LN(x)) + x                                 256 -> 2 x 1024 (GEGLU, exact-erf GELU) -> 256
-// as ONE kernel.  In PyTorch this is 15 launches of ~5 us each on 1 k rows (launch-latency bound,
-// 0.12 ms per fragment); here a workgroup of 8 wavefronts owns 16 point rows, keeps every
-// intermediate (LN, q, scores, probabilities, attention output, hidden) in LDS and walks the six
-// GEMMs on fp32 MFMA with the N dimension split over the waves.  All weight matrices -- and the
-// image-dependent K^T / V, packed once per fragment on the image-branch stream -- are in the same
-// fragment-major layout as the convolution weights (imf_pack_weights with kvol = 1), so every B
-// fragment is one coalesced float4 per lane.  Deterministic (fixed summation order), fp32 throughout.
+// In PyTorch this is 15 launches of ~5 us each on 1 k rows.  Round 3 runs it as THREE launches:
+//   k_fusion_attn   the attention half (16 % of the FLOPs): a workgroup of 8 wavefronts owns 16 point rows, keeps LN, q,
+//                   scores, probabilities and the attention output in LDS and walks its four GEMMs on fp32 MFMA with the
+//                   N dimension split over the waves; writes y and LN2(y)
+//   k_spconv_g      g = GEGLU(LN2(y) W1^T + b1): a Linear layer is a 1x1x1 convolution over the rows -- the sparse
+//                   convolution kernel with a GEGLU epilogue (spconv_shared.h), 34 x 32 workgroups for a pair
+//   k_spconv_w      z = g W2^T + b2 + y: the wave-split kernel, K = 1024 over 8 wavefronts, bias + residual epilogue
+// The feed-forward (84 % of the FLOPs) thus runs on the split-f16 matrix pipe with weights staged through LDS by DMA,
+// parallel over (row tile, column slab) with full K per accumulator -- no hidden-dimension split over workgroups, no
+// partial sums, no reduce pass, no row-count-dependent variant choice.  Rounds 1-2 ran the whole block as one fp32-MFMA
+// kernel whose 16-row workgroups each streamed all 3.5 MB of weights from L2 (114 us for a pair).
+// The attention weight matrices -- and the image-dependent K^T / V, packed once per fragment on the image-branch
+// stream -- are in the fragment-major layout of imf_pack_weights (kvol = 1); W1 / W2 are imf_pack_weights_split16
+// images.  Deterministic (fixed summation order), fp32-class arithmetic throughout.
 #include <stdlib.h>
 #include <string.h>
 
@@ -30,28 +37,15 @@ struct FusionParams {
   const float *ktp_b[IMF_MAX_BATCH], *vp_b[IMF_MAX_BATCH];   // packed K^T [kFQ x tokp] and V [tokp x kFQ] per item
   int ntok, tokp;            // valid tokens, padded to a multiple of 64
   float scale;
-  const float *ln1g, *ln1b, *wq, *wo, *bo, *ln2g, *ln2b, *w1, *b1, *w2, *b2;
-  float *out;
-  float *partial;   // [HS][n][256] when the GEGLU hidden dimension is split over gridDim.y (HS > 1)
+  const float *ln1g, *ln1b, *wq, *wo, *bo, *ln2g, *ln2b;
+  float *y, *n2;             // out: y = Attn(LN(x)) + x and LN2(y), [n, 256] each (the feed-forward's residual and input)
   // Capacity mode: n is a capacity; the row count and every item's first row are read from the device (meta
-  // block of imf_pyramid_build: count of the stride-8 level, its item-start words).  The launcher issues every
-  // hidden-split variant and each one runs only if the rule picks it for the ACTUAL rows (same sums as exact-size).
+  // block of imf_pyramid_build: count of the stride-8 level, its item-start words).
   const int32_t *n_dev, *starts_dev;
   int32_t *err;
-  int hs_override;
 };
 
-// slices of the hidden dimension: fill ~256 CUs, one workgroup each
-__host__ __device__ inline int fusion_slices_rule(long long n, int hs_override) {
-  if (hs_override) return hs_override;
-  const long long blocks = (n + 15) / 16;
-  // measured: 68 blocks x 2 = 136 workgroups beat x4 = 272 (> 256 CUs); a pair's 136 blocks: x4 (two co-resident
-  // 79 KB workgroups per CU) = x1 > x2
-  return blocks <= 64 ? 4 : (blocks <= 128 ? 2 : (blocks <= 256 ? 4 : 1));   // measured: 272 workgroups on 256 CUs lose to 136
-}
-
 // rows [row0, row_end) of batch item `item`; false = nothing to do for this workgroup
-template <int HS>
 __device__ __forceinline__ bool fusion_item_rows(const FusionParams &p, int item, long long &row0, long long &row_end) {
   if (!p.n_dev) {
     row0 = p.row0[item];
@@ -60,11 +54,10 @@ __device__ __forceinline__ bool fusion_item_rows(const FusionParams &p, int item
   }
   long long n = *p.n_dev;
   n = n < p.n ? n : p.n;
-  if (fusion_slices_rule(n, p.hs_override) != HS) return false;
   const int s0 = p.starts_dev[item];
   const int s1 = item + 1 < p.n_items ? p.starts_dev[item + 1] : (int)n;
   if (s0 < 0 || s1 < s0) {          // an item without rows: flagged, as the exact-size path raises
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(p.err, 8);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(p.err, 8);
     return false;
   }
   row0 = s0;
@@ -138,29 +131,22 @@ __device__ __forceinline__ void layer_norm_row(const float *src, float *dst, con
 
 constexpr int kLdX = kFD + 4;       // 260: (row * lda) % 64 == 4 * row -> conflict-free ds_read_b128 of A
 constexpr int kLdQ = kFQ + 4;       // 132
-template <int HS> constexpr int ld_g() { return kFH / HS + 4; }   // 1028 / 516 / 260
 constexpr int kMaxTokP = 320;
 constexpr int kLdS = kMaxTokP + 4;  // 324
 
-// HS = number of slices of the GEGLU hidden dimension (gridDim.y): with ~1 k rows a 16-row workgroup
-// per row block fills only 68 of 256 CUs and each one streams all 3.6 MB of weights; with HS = 4 every
-// workgroup repeats the (cheap) attention part, takes a quarter of W1 / W2 and writes a partial z that
-// k_fusion_reduce sums in a fixed order.
-template <int HS>
+// The attention half: y = to_out(softmax(to_q(LN1(x)) K^T * scale) V) + x, and n2 = LN2(y) for the feed-forward.
+// 16 rows per workgroup of 8 wavefronts; every intermediate lives in LDS; exact fp32 MFMA (16 % of the block's FLOPs).
 __global__ void __launch_bounds__(512)
-k_fusion_attention(const FusionParams p) {
-  constexpr int kLdG = ld_g<HS>();
-  const int hs = blockIdx.y;
+k_fusion_attn(const FusionParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *X = lds;                          // [16][260]  x, later y
   float *N = X + kFRows * kLdX;            // [16][260]  LN(x), later LN(y)
   float *S = N + kFRows * kLdX;            // [16][324]  scores -> probabilities
   float *Q = S + kFRows * kLdS;            // [16][132]  q, later attention output
-  float *G = Q + kFRows * kLdQ;            // [16][1028] GEGLU hidden
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
   const int item = blockIdx.z;
   long long row0, row_end;
-  if (!fusion_item_rows<HS>(p, item, row0, row_end)) return;
+  if (!fusion_item_rows(p, item, row0, row_end)) return;
   row0 += (long long)blockIdx.x * kFRows;
   if (row0 >= row_end) return;                                      // grid.x covers the largest item
   const float *ktp = p.ktp_b[item], *vp = p.vp_b[item];
@@ -250,111 +236,67 @@ k_fusion_attention(const FusionParams p) {
   }
   __syncthreads();
   for (int rr = 0; rr < 2; ++rr) layer_norm_row(X + (2 * wave + rr) * kLdX, N + (2 * wave + rr) * kLdX, p.ln2g, p.ln2b, lane);
-  __syncthreads();
-
-  // ---- GEGLU: h = LN(y) W1^T + b1 (2048 wide); g = h[:1024] * gelu(h[1024:]) ---------------------
-  // this workgroup's hidden slice is [hs * 1024/HS, +1024/HS); wave w owns 128/HS of its columns:
-  // value blocks vb0 .. and gate blocks 64 + vb0 ..
-  constexpr int VB = 8 / HS;                 // value blocks per wave: 8, 4 or 2
-  constexpr int PASS = VB > 4 ? 2 : 1;       // at most 4 value + 4 gate accumulators at a time
-  constexpr int VP = VB / PASS;
-  for (int half = 0; half < PASS; ++half) {
-    f32x4 acc[2 * VP];
-#pragma unroll
-    for (int i = 0; i < 2 * VP; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int lb0 = VB * wave + VP * half;                  // first local value block
-    const int c0 = hs * (64 / HS) + lb0;                    // ... and its global index
-    int cb[2 * VP];
-#pragma unroll
-    for (int i = 0; i < VP; ++i) {
-      cb[i] = c0 + i;
-      cb[VP + i] = 64 + c0 + i;
-    }
-    gemm16<2 * VP, (VP == 4 ? 2 : 4)>(acc, N, kLdX, kFD, p.w1, cb, lane);
-#pragma unroll
-    for (int i = 0; i < VP; ++i) {
-      const int col = (c0 + i) * 16 + r16, lcol = (lb0 + i) * 16 + r16;
-      const float bv = p.b1[col], bg = p.b1[kFH + col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float val = acc[i][r] + bv, gate = acc[VP + i][r] + bg;
-        G[(4 * q4 + r) * kLdG + lcol] = val * (0.5f * gate * (1.f + erff(gate * 0.70710678118654752f)));
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- z = g W2^T + b2 + y : K = 1024 / HS of this slice, N = 256 -> 2 column blocks per wave ---------
-  {
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    const int cb[2] = {2 * wave, 2 * wave + 1};
-    gemm16<2, 8>(acc, G, kLdG, kFH / HS, p.w2, cb, lane, kFH, hs * (kFH / HS / 16));
-    float *dst = HS == 1 ? p.out : p.partial + (long long)hs * p.n * kFD;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int col = cb[i] * 16 + r16;
-      const float bias = p.b2[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long row = row0 + 4 * q4 + r;
-        if (row < row_end) {
-          float v = acc[i][r];
-          if (hs == 0) v += bias + X[(4 * q4 + r) * kLdX + col];   // bias and residual enter once
-          if (HS == 1 && p.err && !(fabsf(v) < 65504.f)) atomicOr(p.err, 32);   // f16 range of the next convolution
-          dst[row * kFD + col] = v;
-        }
-      }
+  // ---- y and LN2(y) to HBM (wave w wrote rows 2w, 2w+1 of N itself; X was completed before the barrier above) ----
+  for (int rr = 0; rr < 2; ++rr) {
+    const int r = 2 * wave + rr;
+    if (row0 + r < row_end) {
+      const float4 yv = *reinterpret_cast<const float4 *>(X + r * kLdX + 4 * lane);
+      const float4 nv = *reinterpret_cast<const float4 *>(N + r * kLdX + 4 * lane);
+      // n2 feeds a split-f16 GEMM: f16 range guard (LayerNorm output: only a degenerate gain / bias can trip it)
+      if (p.err && (!(fabsf(nv.x) < 65504.f) || !(fabsf(nv.y) < 65504.f) || !(fabsf(nv.z) < 65504.f) || !(fabsf(nv.w) < 65504.f)))
+        atomicOr(p.err, 32);
+      *reinterpret_cast<float4 *>(p.y + (row0 + r) * kFD + 4 * lane) = yv;
+      *reinterpret_cast<float4 *>(p.n2 + (row0 + r) * kFD + 4 * lane) = nv;
     }
   }
 }
 
-// out = sum over the HS partial slices, ascending (deterministic)
-__global__ void __launch_bounds__(256) k_fusion_reduce(const float *__restrict__ partial, long long n4, int hs,
-                                                       float *__restrict__ out, const int32_t *__restrict__ n_dev,
-                                                       int hs_override, int32_t *err) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long stride4 = n4;
-  if (n_dev) {   // capacity mode: n4 is the capacity (and the slice stride); only the variant the rule picks runs
-    const long long n = *n_dev;
-    if (fusion_slices_rule(n, hs_override) != hs) return;
-    n4 = n * (kFD / 4) < n4 ? n * (kFD / 4) : n4;
-  }
-  if (i >= n4) return;
-  float4 s = reinterpret_cast<const float4 *>(partial)[i];
-  for (int h = 1; h < hs; ++h) {
-    const float4 v = reinterpret_cast<const float4 *>(partial)[(long long)h * stride4 + i];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
-  if (err && (!(fabsf(s.x) < 65504.f) || !(fabsf(s.y) < 65504.f) || !(fabsf(s.z) < 65504.f) || !(fabsf(s.w) < 65504.f)))
-    atomicOr(err, 32);
-  reinterpret_cast<float4 *>(out)[i] = s;
-}
-
-template <int HS>
-static int launch_fusion(const FusionParams &p, hipStream_t st) {
-  const size_t lds = (size_t)kFRows * (2 * kLdX + kLdS + kLdQ + ld_g<HS>()) * sizeof(float);
+static int launch_attn(const FusionParams &p, hipStream_t st) {
+  const size_t lds = (size_t)kFRows * (2 * kLdX + kLdS + kLdQ) * sizeof(float);
   static bool attr_set = false;   // idempotent; a benign race at worst sets it twice
   if (!attr_set) {
-    IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_fusion_attention<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_fusion_attn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   long long max_rows = p.n_dev ? p.n : 0;
   for (int b = 0; b < p.n_items; ++b) max_rows = p.rows[b] > max_rows ? p.rows[b] : max_rows;
-  k_fusion_attention<HS><<<dim3((unsigned)div_up(max_rows, kFRows), HS, p.n_items), 512, lds, st>>>(p);
-  IMF_CHECK_LAUNCH("k_fusion_attention");
-  if (HS > 1) {
-    const long long n4 = p.n * kFD / 4;
-    k_fusion_reduce<<<(unsigned)div_up(n4, 256), 256, 0, st>>>(p.partial, n4, HS, p.out, p.n_dev, p.hs_override, p.err);
-    IMF_CHECK_LAUNCH("k_fusion_reduce");
-  }
+  k_fusion_attn<<<dim3((unsigned)div_up(max_rows, kFRows), 1, p.n_items), 512, lds, st>>>(p);
+  IMF_CHECK_LAUNCH("k_fusion_attn");
   return IMF_OK;
 }
 
-static int fusion_hs_override() {
-  static const int v = getenv("IMF_FUSION_SLICES") ? (atoi(getenv("IMF_FUSION_SLICES")) == 4 ? 4 : (atoi(getenv("IMF_FUSION_SLICES")) == 2 ? 2 : 1)) : 0;
-  return v;
+// workspace: y [n,256] | n2 [n,256] | g [n,1024]
+constexpr size_t kWsFloatsPerRow = 2 * kFD + kFH;
+
+// The feed-forward half on the convolution kernels (a Linear layer is a 1x1x1 convolution over the rows):
+//   g = GEGLU(n2 W1^T + b1)   k_spconv_g, 64-column slabs [32 values | 32 gates], GEGLU epilogue      (84 % of the
+//   z = g W2^T + b2 + y       k_spconv_w, 8 wavefronts split K = 1024, bias + residual epilogue        block's FLOPs)
+// both on the split-f16 matrix pipe (fp32-class arithmetic, spconv_g.hip) with weights staged through LDS by DMA.
+static int run_feed_forward(const imf_fusion_weights *w, long long n, const int32_t *n_dev, float *ws, float *out,
+                            int32_t *err, hipStream_t st) {
+  float *y = ws, *n2 = ws + (size_t)n * kFD, *g = ws + (size_t)n * 2 * kFD;
+  const long long slots = (n + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
+  imf_conv_args a;
+  memset(&a, 0, sizeof(a));
+  a.in_a = n2; a.c_a = kFD; a.w_packed = w->w1_p; a.kvol = 1; a.cout = 2 * kFH;
+  a.n_slots = slots; a.n_out = n; a.shift = w->b1; a.out = g; a.split_k = 1; a.variant = 6; a.geglu = 1;
+  a.n_out_dev = n_dev; a.dyn_err = err;
+  int rc = imf_spconv_fwd(&a, st);
+  if (rc) return rc;
+  memset(&a, 0, sizeof(a));
+  a.in_a = g; a.c_a = kFH; a.w_packed = w->w2_p; a.kvol = 1; a.cout = kFD;
+  a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = 6;
+  a.kernel_tag = 4;                                  // wave-split, 8 wavefronts: K = 1024 is 32 sub-stages per tile
+  a.n_out_dev = n_dev; a.dyn_err = err;              // z feeds conv4_tr (split-f16): range guard
+  return imf_spconv_fwd(&a, st);
 }
-static int fusion_slices(int64_t n) { return fusion_slices_rule(n, fusion_hs_override()); }
+
+static void fill_params(FusionParams &p, const float *x, const imf_fusion_weights *w, int n_tokens, int tokens_padded,
+                        float scale, float *ws, long long n) {
+  p.x = x; p.n = n; p.ntok = n_tokens; p.tokp = tokens_padded; p.scale = scale;
+  p.ln1g = w->ln1_g; p.ln1b = w->ln1_b; p.wq = w->wq_p; p.wo = w->wo_p; p.bo = w->bo; p.ln2g = w->ln2_g; p.ln2b = w->ln2_b;
+  p.y = ws; p.n2 = ws + (size_t)n * kFD;
+}
 
 }  // namespace imf
 
@@ -362,12 +304,8 @@ using namespace imf;
 
 extern "C" {
 
-size_t imf_fusion_workspace_bytes(int64_t n) {
-  const int hs = fusion_slices(n);
-  return hs > 1 ? (size_t)hs * (size_t)n * kFD * sizeof(float) : 0;
-}
-
-size_t imf_fusion_workspace_bytes_cap(int64_t n_cap) { return (size_t)4 * (size_t)n_cap * kFD * sizeof(float); }
+size_t imf_fusion_workspace_bytes(int64_t n) { return (size_t)n * kWsFloatsPerRow * sizeof(float); }
+size_t imf_fusion_workspace_bytes_cap(int64_t n_cap) { return imf_fusion_workspace_bytes(n_cap); }
 
 int imf_fusion_attention_dyn(const float *x, int64_t n_cap, const int32_t *n_dev, const int32_t *item_starts_dev,
                              int n_items, int32_t *err, const float *const *kt_packed, const float *const *v_packed,
@@ -378,8 +316,8 @@ int imf_fusion_attention_dyn(const float *x, int64_t n_cap, const int32_t *n_dev
   IMF_REQUIRE(n_items >= 1 && n_items <= IMF_MAX_BATCH && n_cap > 0, "imf_fusion_attention_dyn: n_items=%d", n_items);
   IMF_REQUIRE(tokens_padded % 64 == 0 && tokens_padded <= kMaxTokP && n_tokens > 0 && n_tokens <= tokens_padded,
               "imf_fusion_attention_dyn: tokens=%d padded=%d", n_tokens, tokens_padded);
-  IMF_REQUIRE(workspace_bytes >= imf_fusion_workspace_bytes_cap(n_cap), "imf_fusion_attention_dyn: needs %zu workspace bytes",
-              imf_fusion_workspace_bytes_cap(n_cap));
+  IMF_REQUIRE(workspace_bytes >= imf_fusion_workspace_bytes_cap(n_cap) && ((uintptr_t)workspace & 15) == 0,
+              "imf_fusion_attention_dyn: needs %zu workspace bytes, 16-byte aligned", imf_fusion_workspace_bytes_cap(n_cap));
   FusionParams p;
   memset(&p, 0, sizeof(p));
   for (int b = 0; b < n_items; ++b) {
@@ -387,24 +325,13 @@ int imf_fusion_attention_dyn(const float *x, int64_t n_cap, const int32_t *n_dev
     p.ktp_b[b] = kt_packed[b];
     p.vp_b[b] = v_packed[b];
   }
-  p.x = x; p.n = n_cap; p.n_items = n_items; p.ntok = n_tokens; p.tokp = tokens_padded; p.scale = scale;
-  p.ln1g = w->ln1_g; p.ln1b = w->ln1_b; p.wq = w->wq_p; p.wo = w->wo_p; p.bo = w->bo; p.ln2g = w->ln2_g;
-  p.ln2b = w->ln2_b; p.w1 = w->w1_p; p.b1 = w->b1; p.w2 = w->w2_p; p.b2 = w->b2; p.out = out;
-  p.partial = (float *)workspace;
-  p.n_dev = n_dev; p.starts_dev = item_starts_dev; p.err = err; p.hs_override = fusion_hs_override();
+  fill_params(p, x, w, n_tokens, tokens_padded, scale, (float *)workspace, n_cap);
+  p.n_items = n_items;
+  p.n_dev = n_dev; p.starts_dev = item_starts_dev; p.err = err;
   hipStream_t st = (hipStream_t)stream;
-  // every variant the rule can return for ANY row count up to the capacity is issued (fusion_slices_rule: <= 64 blocks
-  // -> 4, <= 128 -> 2, <= 256 -> 4, more -> 1); on the device exactly one of them finds its slice count selected
-  const long long blocks_cap = (n_cap + kFRows - 1) / kFRows;
-  int rc;
-  if (p.hs_override) {
-    if (p.hs_override == 1) return launch_fusion<1>(p, st);
-    if (p.hs_override == 2) return launch_fusion<2>(p, st);
-    return launch_fusion<4>(p, st);
-  }
-  if (blocks_cap > 256 && (rc = launch_fusion<1>(p, st))) return rc;
-  if (blocks_cap > 64 && (rc = launch_fusion<2>(p, st))) return rc;
-  return launch_fusion<4>(p, st);
+  int rc = launch_attn(p, st);
+  if (rc) return rc;
+  return run_feed_forward(w, n_cap, n_dev, (float *)workspace, out, err, st);
 }
 
 int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
@@ -436,18 +363,15 @@ int imf_fusion_attention_batched_flags(const float *x, int n_items, const int64_
     p.vp_b[b] = v_packed[b];
     n = n > item_row0[b] + item_rows[b] ? n : item_row0[b] + item_rows[b];
   }
-  const int hs = fusion_slices(n);
-  IMF_REQUIRE(hs == 1 || (workspace && workspace_bytes >= imf_fusion_workspace_bytes(n)),
-              "imf_fusion_attention: needs %zu workspace bytes", imf_fusion_workspace_bytes(n));
-  p.x = x; p.n = n; p.n_items = n_items; p.ntok = n_tokens; p.tokp = tokens_padded; p.scale = scale;
-  p.ln1g = w->ln1_g; p.ln1b = w->ln1_b; p.wq = w->wq_p; p.wo = w->wo_p; p.bo = w->bo; p.ln2g = w->ln2_g;
-  p.ln2b = w->ln2_b; p.w1 = w->w1_p; p.b1 = w->b1; p.w2 = w->w2_p; p.b2 = w->b2; p.out = out;
-  p.partial = (float *)workspace;
+  IMF_REQUIRE(workspace && workspace_bytes >= imf_fusion_workspace_bytes(n) && ((uintptr_t)workspace & 15) == 0,
+              "imf_fusion_attention: needs %zu workspace bytes, 16-byte aligned", imf_fusion_workspace_bytes(n));
+  fill_params(p, x, w, n_tokens, tokens_padded, scale, (float *)workspace, n);
+  p.n_items = n_items;
   p.err = flags;
   hipStream_t st = (hipStream_t)stream;
-  if (hs == 4) return launch_fusion<4>(p, st);
-  if (hs == 2) return launch_fusion<2>(p, st);
-  return launch_fusion<1>(p, st);
+  int rc = launch_attn(p, st);
+  if (rc) return rc;
+  return run_feed_forward(w, n, nullptr, (float *)workspace, out, flags, st);
 }
 
 int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed, int n_tokens,

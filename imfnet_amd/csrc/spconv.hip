@@ -712,8 +712,9 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   // whole tile in one workgroup, no split-K partitions, no reduce launch
   const int wsplit = a->variant == 6 ? ((a->kernel_tag & 4) ? 8 : ((a->kernel_tag & 8) ? 4 : 0)) : 0;
   if (wsplit) {
-    IMF_REQUIRE(a->kvol > 1 && a->nbr && a->tile_mask && a->cout % 64 == 0,
-                "imf_spconv_fwd: the wave-split kernel needs kvol > 1 and cout %% 64 == 0 (kvol=%d cout=%d)", a->kvol, a->cout);
+    IMF_REQUIRE(a->cout % 64 == 0 && (a->kvol > 1 || cin >= 256),
+                "imf_spconv_fwd: the wave-split kernel needs cout %% 64 == 0 and kvol > 1 or cin >= 256 (kvol=%d cin=%d cout=%d)",
+                a->kvol, cin, a->cout);
     IMF_REQUIRE(a->split_k <= 1 && !a->tickets, "imf_spconv_fwd: the wave-split kernel takes no split_k / tickets");
   }
   int split = (simple || wsplit) ? 1 : (a->split_k > 0 ? a->split_k : imf_spconv_auto_split(a->n_slots, a->cout, a->kvol));
@@ -735,6 +736,10 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   p.split_target = split_target();
   IMF_REQUIRE(!a->n_out_dev || a->variant == 6, "imf_spconv_fwd: n_out_dev (capacity mode) needs variant 6");
   p.err = a->dyn_err;
+  p.geglu = a->geglu;
+  IMF_REQUIRE(!a->geglu || (a->variant == 6 && !wsplit && a->kvol == 1 && a->cout % 64 == 0 && split == 1 && !a->scale &&
+                            !a->residual && !a->relu && !a->l2norm && !(a->kernel_tag & 2)),
+              "imf_spconv_fwd: geglu needs variant 6 (k_spconv_g), kvol 1, cout %% 64 == 0 and no other epilogue");
   // XCD-contiguous tile order: measured SLOWER (pair step 1.53 vs 1.38 ms; round 2) -- opt-in for experiments only
   static const int xcd = getenv("IMF_H3_XCD") ? 1 : 0;
   p.no_xcd_swizzle = !xcd;

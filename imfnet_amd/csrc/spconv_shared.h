@@ -37,6 +37,10 @@ struct ConvParams {
   int slots_extra;          // slots the rulebook lays out beyond roundup64(rows): 0, or 512 for transposed maps
   int split_min_blocks, split_target;
   int no_xcd_swizzle;       // A/B switch (env IMF_H3_NO_XCD): plain blockIdx.x -> tile order
+  int geglu;                // epilogue of the fusion block's first feed-forward GEMM (variant 6, 64-column slabs, unsplit): the
+                            // packed columns of slab y are [32 values | 32 gates] of hidden units 32 y .. 32 y + 31; the output
+                            // is [n_out, cout / 2]: out = (v + shift_v) * gelu(g + shift_g), exact-erf GELU
+                            // (model/attention_fusion.py:20-23 GEGLU)
   int32_t *err;             // flag word (optional): 16 = the rule wanted more partitions than the launch covers
                             // (capacity mode); 32 = an output value left the f16 range (|y| >= 65504 or NaN): the
                             // next split-f16 convolution would turn it into inf -- see IMF_FLAG_RANGE
@@ -95,6 +99,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     orow[r] = row_of_slot(p, (long long)tile * IMF_TILE_ROWS + wave * 16 + q4 * 4 + r);
+
+  if (CO_BLK == 4 && p.geglu) {   // column blocks 0, 1: values; 2, 3: the gates of the same hidden units
+    const int half = p.cout / 2;
+    bool bad = false;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int pc = y * CW + cb * 16 + r16;               // packed column of the value; its gate sits 32 further
+      const float bv = p.shift ? p.shift[pc] : 0.f, bg = p.shift ? p.shift[pc + 32] : 0.f;
+      const int oc = y * 32 + cb * 16 + r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float val = acc[cb][r] * unscale + bv, gate = acc[(cb + 2) % CO_BLK][r] * unscale + bg;
+        const float g = val * (0.5f * gate * (1.f + erff(gate * 0.70710678118654752f)));
+        bad |= orow[r] >= 0 && out_of_f16_range(g);
+        if (orow[r] >= 0) p.out[(long long)orow[r] * half + oc] = g;
+      }
+    }
+    if (p.err && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(p.err, 32);
+    return;
+  }
 
   float v[CO_BLK][4];
 #pragma unroll

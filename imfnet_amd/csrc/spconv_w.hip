@@ -83,7 +83,7 @@ k_spconv_w(const ConvParams p) {
   const int cin = p.c_a + (CAT ? p.c_b : 0);
   const int ncc = cin / 32;
 
-  const uint32_t m = p.tile_mask[tile * IMF_MASK_WORDS];
+  const uint32_t m = p.tile_mask ? p.tile_mask[tile * IMF_MASK_WORDS] : 1u;      // kvol == 1: offset 0, every tile
   const int nk = __builtin_popcount(m);
   if (nk == 0) return;                               // padding tile
   if (tid < 32 && ((m >> tid) & 1u)) klist[__builtin_popcount(m & ((1u << tid) - 1u))] = tid;
@@ -94,12 +94,17 @@ k_spconv_w(const ConvParams p) {
     constexpr int kPer = (kKCache + JSTEP - 1) / JSTEP;
     const int srow = tid & 63, j0 = tid >> 6;
     const long long slot = (long long)tile * IMF_TILE_ROWS + srow;
-    const int32_t *const src = p.nbr + slot;
     int v[kPer];
+    if (p.nbr) {
+      const int32_t *const src = p.nbr + slot;
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-      const int j = j0 + JSTEP * i;
-      v[i] = src[(long long)klist[j < nk ? j : 0] * p.n_slots];
+      for (int i = 0; i < kPer; ++i) {
+        const int j = j0 + JSTEP * i;
+        v[i] = src[(long long)klist[j < nk ? j : 0] * p.n_slots];
+      }
+    } else {                                         // kvol == 1 (a pointwise layer): the slot's own row
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) v[i] = row_of_slot(p, slot);
     }
     if (tid < kSubTab) {
       unsigned e = (unsigned)kDummyJkW << 9;

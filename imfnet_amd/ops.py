@@ -515,10 +515,17 @@ class FusionKernelWeights:
         if not self.supported:
             return
         f = lambda t: t.detach().float().contiguous()                     # noqa: E731
+        # feed-forward on the split-f16 convolution kernels (include/imfnet_hip.h, imf_fusion_weights): W1^T with its
+        # columns interleaved per 64-column slab as [32 values | 32 gates] (GEGLU epilogue), b1 likewise
+        H = self.hidden
+        j = torch.arange(H // 32).view(-1, 1, 1) * 32
+        c = torch.arange(32).view(1, 1, -1)
+        perm = (j + c + torch.tensor([0, H]).view(1, 2, 1)).reshape(-1).to(ff[0].weight.device)   # packed col -> torch row
+        w1t = f(ff[0].weight)[perm].t().contiguous()                       # [256, 2048], packed column order
         self.t = dict(ln1_g=f(blk0.norm.weight), ln1_b=f(blk0.norm.bias), wq_p=pack_weights(f(att.to_q.weight).t()),
                       wo_p=pack_weights(f(att.to_out.weight).t()), bo=f(att.to_out.bias), ln2_g=f(blk1.norm.weight),
-                      ln2_b=f(blk1.norm.bias), w1_p=pack_weights(f(ff[0].weight).t()), b1=f(ff[0].bias),
-                      w2_p=pack_weights(f(ff[2].weight).t()), b2=f(ff[2].bias))
+                      ln2_b=f(blk1.norm.bias), w1_p=pack_weights(w1t, split16=True), b1=f(ff[0].bias)[perm].contiguous(),
+                      w2_p=pack_weights(f(ff[2].weight).t(), split16=True), b2=f(ff[2].bias))
         self.c = FusionWeights(**{k: v.data_ptr() for k, v in self.t.items()})
 
 
@@ -543,7 +550,7 @@ def fusion_attention_batched(x, items, kt_packed, v_packed, n_tokens, tokens_pad
 
 
 def fusion_attention(x, kt_packed, v_packed, n_tokens, tokens_padded, fw, out=None):
-    """x [n,256] -> [n,256]: imf_fusion_attention (one kernel for attention + GEGLU feed-forward)."""
+    """x [n,256] -> [n,256]: imf_fusion_attention (attention kernel + the two feed-forward GEMMs on the conv kernels)."""
     _req(x, torch.float32, "x", 2)
     if out is None:
         out = torch.empty_like(x)

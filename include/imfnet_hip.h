@@ -247,6 +247,11 @@ typedef struct imf_conv_args {
   int32_t *dyn_err;       /* optional device flag word (any mode): IMF_FLAG_SPLIT_COVER when the rule asks for more
                              partitions than split_k covers; IMF_FLAG_RANGE when an OUTPUT value is NaN or |y| >= 65504,
                              i.e. cannot be an operand of a following variant-6 convolution */
+  int32_t geglu;          /* variant 6, kvol == 1, cout % 64 == 0, unsplit, no scale / residual / relu / l2norm: GEGLU
+                             epilogue of the fusion block's feed-forward (model/attention_fusion.py:20-23,56-63).  The
+                             weight image's columns are arranged per 64-column slab y as [32 values | 32 gates] of hidden
+                             units 32 y .. 32 y + 31 (shift likewise); out is [n_out, cout / 2]:
+                             out[r][32 y + c] = (acc_v + shift_v) * gelu(acc_g + shift_g), exact-erf GELU */
 } imf_conv_args;
 
 /* Flag bits the kernels OR into a caller-provided device word (imf_conv_args.dyn_err, imf_resunet_io.flags, meta[1]
@@ -324,15 +329,20 @@ int imf_conv_first_bitgrid_dyn(const int32_t *coords, int64_t n_cap, const int32
  * Replaces: ResUNet2.transformer + AttentionFusion.forward (model/resunet.py:237-273,
  *           model/attention_fusion.py:65-95,132-154) for the N stride-8 point rows x [n,256]:
  *   x = to_out(softmax(to_q(LN(x)) K^T * scale) V) + x ;  x = W2(GEGLU(W1 LN(x))) + x
- * Every matrix is given in the fragment-major layout of imf_pack_weights(kvol = 1) applied to the
- * TRANSPOSED torch Linear weight ([in, out]): wq_p [256->128], wo_p [128->256], w1_p [256->2048],
- * w2_p [1024->256]; kt_packed = pack(K^T [128, tokens_padded]), v_packed = pack(V [tokens_padded, 128])
- * with K, V = chunks of to_kv(LN(image tokens)), zero-padded to tokens_padded (multiple of 64, <= 320). */
+ * The attention matrices are given in the fragment-major layout of imf_pack_weights(kvol = 1) applied to the
+ * TRANSPOSED torch Linear weight ([in, out]): wq_p [256->128], wo_p [128->256]; kt_packed = pack(K^T [128,
+ * tokens_padded]), v_packed = pack(V [tokens_padded, 128]) with K, V = chunks of to_kv(LN(image tokens)), zero-padded
+ * to tokens_padded (multiple of 64, <= 320).  The feed-forward runs on imf_spconv_fwd's split-f16 kernels (a Linear
+ * layer is a 1x1x1 convolution over the rows), so its matrices are imf_pack_weights_split16 images:
+ *   w1_p  [1][256][2048] = W1^T with the output columns re-ordered for imf_conv_args.geglu: packed column
+ *         64 j + c      (c < 32) = value column 32 j + c        (torch row 32 j + c of ff[0].weight)
+ *         64 j + 32 + c          = gate column 1024 + 32 j + c  (the second chunk of GEGLU's `chunk(2, dim=-1)`)
+ *   b1    [2048] in the same packed order;  w2_p [1][1024][256] = W2^T;  b2 [256].
+ * workspace: imf_fusion_workspace_bytes(n) bytes, 16-byte aligned (y, LN2(y) and the GEGLU hidden, 6 KB per row). */
 typedef struct imf_fusion_weights {
   const float *ln1_g, *ln1_b, *wq_p, *wo_p, *bo, *ln2_g, *ln2_b, *w1_p, *b1, *w2_p, *b2;
 } imf_fusion_weights;
-/* Workspace for the hidden-dimension split the library applies to small n (so that ~1 k rows still fill
- * the chip): imf_fusion_workspace_bytes(n) bytes of device memory (0 when no split is used). */
+/* Workspace of the block's three launches (attention half -> GEGLU GEMM -> output GEMM): 6 KB per row. */
 size_t imf_fusion_workspace_bytes(int64_t n);
 int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed,
                          int n_tokens, int tokens_padded, const imf_fusion_weights *w /* [host] */,
@@ -394,8 +404,8 @@ int imf_fusion_attention_batched_flags(const float *x, int n_items, const int64_
                                        int tokens_padded, const imf_fusion_weights *w /* [host] */, float scale,
                                        float *out, void *workspace, size_t workspace_bytes, int32_t *flags, void *stream);
 /* Capacity mode: x has room for n_cap rows, the count is *n_dev and item b covers rows [item_starts_dev[b],
- * item_starts_dev[b+1]) (the last one up to the count); an item without rows raises bit 3 (value 8) of *err.  All
- * three hidden-split variants are launched and the one the rule picks for the actual rows does the work.
+ * item_starts_dev[b+1]) (the last one up to the count); an item without rows raises bit 3 (value 8) of *err.  The same
+ * three launches as the exact-size call (grids sized for the capacity, surplus tiles exit at once): bit-identical.
  * workspace: imf_fusion_workspace_bytes_cap(n_cap). */
 size_t imf_fusion_workspace_bytes_cap(int64_t n_cap);
 int imf_fusion_attention_dyn(const float *x, int64_t n_cap, const int32_t *n_dev, const int32_t *item_starts_dev,

@@ -10,7 +10,7 @@ sd = O.seeded_state_dict(0, with_unused_image_layers=True)
 model = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
 model.load_state_dict(sd); model = model.eval().to(dev)
 fw = model._fusion_weights()
-for n in (413, 1076, 4400):
+for n in (413, 1076, 2176, 4400):
     x = torch.randn(n, 256, device=dev); kv = torch.randn(300, 256, device=dev)
     kt = torch.zeros(128, 320, device=dev); kt[:, :300] = kv[:, :128].t()
     vp = torch.zeros(320, 128, device=dev); vp[:300] = kv[:, 128:]
