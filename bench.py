@@ -434,6 +434,9 @@ def main():
                     "algorithmic_bytes_per_launch": g["bytes"] // g["n"],
                     "achieved_tflops_useful": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2),
                     "all_sparse_conv_ms_per_step": round(conv_ms, 3),
+                    "per_kernel": {k: {"launches_per_step": v["n"] // traced_steps, "avg_launch_us": round(v["ms"] * 1e3 / v["n"], 2),
+                                       "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                   for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
                     "timing": "HIP events around each launch on its launch stream, in situ (other streams' kernels of the same "
                               "step overlap), %d steps after the timed regions" % traced_steps}
         extras = {}
@@ -523,7 +526,8 @@ def extra_legs(O, model, dev, args, sync):
     xyz_host = xyz1.astype(np.float64)
     def e2e():
         xd, F = extract_features(model, xyz_host, voxel_size=voxel, device=dev, skip_check=True, image=img1)
-        return xd, F.cpu().numpy()
+        Fh = getattr(F, "host", None)                 # the descriptors as they came back with the counts (pinned block)
+        return xd, (Fh if Fh is not None else F.cpu().numpy())
     for _ in range(3):
         xd, Fh = e2e()
     t0 = time.perf_counter()
@@ -533,9 +537,28 @@ def extra_legs(O, model, dev, args, sync):
     dt = (time.perf_counter() - t0) / n_it
     out["e2e_extract_features"] = {"descriptors_per_s": round(Fh.shape[0] / dt, 1), "ms_per_fragment": round(dt * 1e3, 3),
                                    "span": "extract_features(host float64 points [%d,3] + host image) -> xyz_down on the host, "
-                                           "F synchronised and copied to the host (PCIe both ways, pageable memory), "
-                                           "one fragment at a time, synchronous" % len(xyz_host),
+                                           "and F on the host (PCIe both ways: one pinned H2D block scalars | image | points, one "
+                                           "pinned D2H block counts | xyz_down | F -- F.host of the returned tensor), one "
+                                           "fragment at a time, synchronous" % len(xyz_host),
                                    "runner": dict(model.fragment_runner().stats) if model.fragment_runner() else None}
+
+    from imfnet_amd.extract import extract_features_stream
+    def frags(k):
+        for _ in range(k):
+            yield xyz_host, img1
+    for _ in extract_features_stream(model, frags(6), voxel, dev):
+        pass
+    sync()
+    t0 = time.perf_counter()
+    n_it = 40
+    m_tot = 0
+    for xd, Fh in extract_features_stream(model, frags(n_it), voxel, dev, copy=False):
+        m_tot += Fh.shape[0]
+    dt = (time.perf_counter() - t0) / n_it
+    out["e2e_extract_features_stream"] = {"descriptors_per_s": round(m_tot / n_it / dt, 1), "ms_per_fragment": round(dt * 1e3, 3),
+                                          "span": "the same span over a stream of %d host fragments through extract_features_stream: "
+                                                  "pinned staging, H2D / D2H on copy streams under the neighbouring fragments' "
+                                                  "kernels, xyz_down and F delivered as host arrays (views of the pinned slots, copy=False), in order" % n_it}
 
     pts2, imgs2 = load_pair(args.scale)
     wl2 = Workload(model, dev, pts2, imgs2, voxel)

@@ -41,9 +41,22 @@ class ConvArgs(C.Structure):
     ]
 
 
+class HeadArgs(C.Structure):
+    """struct imf_head_args (include/imfnet_hip.h)."""
+    _fields_ = [
+        ("in_a", C.c_void_p), ("in_b", C.c_void_p), ("c_a", C.c_int32), ("c_b", C.c_int32),
+        ("w1_packed", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p),
+        ("relu1", C.c_int32), ("c_mid", C.c_int32),
+        ("w2_packed", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
+        ("l2norm", C.c_int32), ("c_out", C.c_int32),
+        ("n", C.c_int64), ("n_dev", C.c_void_p), ("out", C.c_void_p), ("flags", C.c_void_p),
+        ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p),
+    ]
+
+
 class LevelDesc(C.Structure):
     """struct imf_level (include/imfnet_hip.h)."""
-    _fields_ = [("coords", C.c_void_p), ("keys", C.c_void_p), ("vals", C.c_void_p),
+    _fields_ = [("coords", C.c_void_p), ("table", C.c_void_p),
                 ("capacity", C.c_int64), ("first_idx", C.c_void_p), ("cap_rows", C.c_int64),
                 ("tensor_stride", C.c_int32)]
 
@@ -161,26 +174,27 @@ SIGNATURES = {
     "imf_graph_destroy": (None, [_P]),
     "imf_pyramid_arena_bytes_caps": (_Z, [_L, _I, C.POINTER(C.c_int64)]),
     "imf_pyramid_build_dyn": (_I, [_P, _I, _P, _L, C.POINTER(C.c_int64), _D, _I, _P, _Z, _P, C.POINTER(LevelDesc), _P]),
-    "imf_rulebook_conv_dyn": (_I, [_P, _P, _L, _P, _L, _P, _I, _I, _P, _P, _P, _P]),
-    "imf_rulebook_transpose_dyn": (_I, [_P, _P, _L, _P, _L, _P, _I, _I, _P, _P, _P, _L, _P, _P]),
+    "imf_rulebook_conv_dyn": (_I, [_P, _L, _P, _L, _P, _I, _I, _P, _P, _P, _P]),
+    "imf_rulebook_transpose_dyn": (_I, [_P, _L, _P, _L, _P, _I, _I, _P, _P, _P, _L, _P, _P]),
     "imf_conv_first_bitgrid_dyn": (_I, [_P, _L, _P, _P, _P, _I, _P, _Z, _P, _I, _P, _P, _I, _P, _P]),
     "imf_fusion_workspace_bytes_cap": (_Z, [_L]),
     "imf_fusion_attention_dyn": (_I, [_P, _L, _P, _P, _I, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _I,
                                       C.POINTER(FusionWeights), C.c_float, _P, _P, _Z, _P]),
     "imf_ransac_workspace_bytes": (_Z, [_I]),
     "imf_ransac_registration": (_I, [_P, _L, _P, _L, _P, _I, _D, _D, _I, C.c_uint64, _P, _P, _P, _P, _Z, _P]),
+    "imf_gather_points": (_I, [_P, _I, _P, _P, _L, _P, _P]),
     "imf_hash_capacity": (_L, [_L]),
     "imf_unique_workspace_bytes": (_Z, [_L]),
-    "imf_voxelize": (_I, [_P, _I, _L, _D, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
-    "imf_downsample": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _L, _P, _P]),
+    "imf_voxelize": (_I, [_P, _I, _L, _D, _I, _P, _P, _P, _P, _L, _P, _P, _P]),
+    "imf_downsample": (_I, [_P, _P, _L, _I, _P, _P, _P, _L, _P, _P]),
     "imf_pyramid_arena_bytes": (_Z, [_L, _I]),
     "imf_pyramid_build": (_I, [_P, _I, _L, _D, _I, _I, _P, _Z, _P, C.POINTER(LevelDesc), _P]),
     "imf_pyramid_build_batched": (_I, [_P, _I, _L, _D, C.POINTER(C.c_int64), _I, _I, _P, _Z, _P,
                                        C.POINTER(LevelDesc), _P]),
     "imf_rulebook_slots": (_L, [_L]),
-    "imf_rulebook_conv": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "imf_rulebook_conv": (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P]),
     "imf_rulebook_transpose_slots": (_L, [_L]),
-    "imf_rulebook_transpose": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P]),
+    "imf_rulebook_transpose": (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P]),
     "imf_packed_weight_floats": (_L, [_I, _I, _I]),
     "imf_packed_weight_floats_split16": (_L, [_I, _I, _I]),
     "imf_pack_weights": (_I, [_P, _I, _I, _I, _P, _P]),
@@ -190,6 +204,7 @@ SIGNATURES = {
     "imf_spconv_occupancy": (_I, [_I, _I, _I]),
     "imf_spconv_workspace_bytes": (_Z, [_L, _I, _I]),
     "imf_spconv_fwd": (_I, [C.POINTER(ConvArgs), _P]),
+    "imf_pointwise_head": (_I, [C.POINTER(HeadArgs), _P]),
     "imf_spconv_small_cin": (_I, [_P, _I, _P, _I, _I, _P, _L, _L, _P, _P, _I, _P, _P]),
     "imf_fusion_workspace_bytes": (_Z, [_L]),
     "imf_fusion_attention_batched": (_I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
@@ -206,7 +221,7 @@ SIGNATURES = {
                                                 _Z, _P, _P]),
     "imf_bitgrid_words": (_Z, [_P, _I]),
     "imf_conv_first_bitgrid": (_I, [_P, _L, _P, _I, _P, _Z, _P, _I, _P, _P, _I, _P, _P]),
-    "imf_conv_first_fused": (_I, [_P, _P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P]),
+    "imf_conv_first_fused": (_I, [_P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P]),
 }
 
 _lib = None

@@ -13,6 +13,8 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -25,7 +27,32 @@ struct File {
   FILE *f = nullptr;
   explicit File(const char *path, const char *mode) { f = fopen(path, mode); }
   ~File() { if (f) fclose(f); }
+  bool close() {   // flush + close with the error checked (a full disk shows up here, not in fwrite)
+    if (!f) return false;
+    const bool ok = fflush(f) == 0 && !ferror(f);
+    const bool closed = fclose(f) == 0;
+    f = nullptr;
+    return ok && closed;
+  }
+  long size() {
+    if (fseek(f, 0, SEEK_END) != 0) return -1;
+    const long s = ftell(f);
+    return fseek(f, 0, SEEK_SET) == 0 ? s : -1;
+  }
 };
+
+// Untrusted files: nothing a file says may escape an extern "C" function as a C++ exception (std::terminate).
+template <typename R, typename F>
+R guarded(const char *what, F &&body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    set_error("%s: out of memory (corrupt size field?)", what);
+  } catch (const std::exception &e) {
+    set_error("%s: %s", what, e.what());
+  }
+  return (R)IMF_EINVAL;
+}
 
 int ply_type_size(const char *t, bool &is_float) {
   is_float = false;
@@ -72,6 +99,7 @@ int64_t imf_ply_vertex_count(const char *path) {
  * binary_big_endian; any scalar properties beside x/y/z are skipped; list properties in the vertex element are an error.
  * Returns the number of vertices written (<= capacity) or a negative IMF_E* code. */
 int64_t imf_ply_read_points(const char *path, double *out, int64_t capacity) {
+  return guarded<int64_t>("imf_ply_read_points", [&]() -> int64_t {
   IMF_REQUIRE(path && out, "imf_ply_read_points: null pointer");
   File fh(path, "rb");
   IMF_REQUIRE(fh.f, "imf_ply_read_points: cannot open %s (%s)", path, strerror(errno));
@@ -121,6 +149,12 @@ int64_t imf_ply_read_points(const char *path, double *out, int64_t capacity) {
     }
     return n;
   }
+  {   // the vertex count comes from the file: check it against what the file can hold before allocating
+    const long at = ftell(fh.f), total = fh.size();
+    IMF_REQUIRE(at >= 0 && total >= at && fseek(fh.f, at, SEEK_SET) == 0 && stride > 0 &&
+                    (unsigned long long)n * (unsigned long long)stride <= (unsigned long long)(total - at),
+                "imf_ply_read_points: %s declares %lld vertices of %d bytes but holds %ld body bytes", path, n, stride, total - at);
+  }
   std::vector<unsigned char> body((size_t)n * stride);
   IMF_REQUIRE(fread(body.data(), 1, body.size(), fh.f) == body.size(), "imf_ply_read_points: truncated body in %s", path);
   const bool swap = fmt == 2;
@@ -139,6 +173,7 @@ int64_t imf_ply_read_points(const char *path, double *out, int64_t capacity) {
     off += p.size;
   }
   return n;
+  });
 }
 
 /* PNG header: height, width, channels (1, 2, 3 or 4 after palette expansion).  0 on success. */
@@ -159,30 +194,38 @@ int imf_png_info(const char *path, int *h, int *w, int *channels) {
  * images expanded to RGB).  Non-interlaced files with 8- or 16-bit samples (the data sets' colour images); anything
  * else returns IMF_EUNSUPPORTED and the caller falls back to its generic decoder. */
 int imf_png_read_f32(const char *path, float *out, int64_t capacity_floats, int *h_out, int *w_out, int *c_out) {
+  return guarded<int>("imf_png_read_f32", [&]() -> int {
   IMF_REQUIRE(path && out && h_out && w_out && c_out, "imf_png_read_f32: null pointer");
   File fh(path, "rb");
   IMF_REQUIRE(fh.f, "imf_png_read_f32: cannot open %s", path);
-  fseek(fh.f, 0, SEEK_END);
-  const long size = ftell(fh.f);
-  fseek(fh.f, 0, SEEK_SET);
+  const long size = fh.size();
+  IMF_REQUIRE(size > 33, "imf_png_read_f32: %s is not a PNG file", path);
   std::vector<unsigned char> buf((size_t)size);
-  IMF_REQUIRE(size > 33 && fread(buf.data(), 1, buf.size(), fh.f) == buf.size() && !memcmp(buf.data(), "\x89PNG\r\n\x1a\n", 8),
+  IMF_REQUIRE( fread(buf.data(), 1, buf.size(), fh.f) == buf.size() && !memcmp(buf.data(), "\x89PNG\r\n\x1a\n", 8),
               "imf_png_read_f32: %s is not a PNG file", path);
   int W = 0, H = 0, depth = 0, ct = 0, interlace = 0;
   std::vector<unsigned char> idat, plte;
   size_t pos = 8;
+  bool transparency = false;
   while (pos + 12 <= buf.size()) {
     const uint32_t len = be32(&buf[pos]);
     const unsigned char *type = &buf[pos + 4], *data = &buf[pos + 8];
-    if (pos + 12 + len > buf.size()) break;
-    if (!memcmp(type, "IHDR", 4)) { W = be32(data); H = be32(data + 4); depth = data[8]; ct = data[9]; interlace = data[12]; }
+    if ((unsigned long long)pos + 12 + len > buf.size()) break;
+    if (!memcmp(type, "IHDR", 4)) {
+      IMF_REQUIRE(len >= 13, "imf_png_read_f32: short IHDR chunk in %s", path);
+      W = (int)be32(data); H = (int)be32(data + 4); depth = data[8]; ct = data[9]; interlace = data[12];
+    }
+    else if (!memcmp(type, "tRNS", 4)) transparency = true;
     else if (!memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
     else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
     else if (!memcmp(type, "IEND", 4)) break;
     pos += 12 + len;
   }
-  if (interlace != 0 || (depth != 8 && depth != 16) || (ct == 3 && depth != 8)) {
-    set_error("imf_png_read_f32: %s: interlaced / sub-byte PNG not handled natively", path);
+  // tRNS: matplotlib returns RGBA for such files; 16-bit RGB(A): matplotlib / PIL go through an 8-bit path -- neither is
+  // reproduced here, the caller's generic decoder takes them
+  if (interlace != 0 || (depth != 8 && depth != 16) || (ct == 3 && depth != 8) || transparency ||
+      (depth == 16 && (ct == 2 || ct == 6))) {
+    set_error("imf_png_read_f32: %s: interlaced / sub-byte / tRNS / 16-bit colour PNG not handled natively", path);
     return IMF_EUNSUPPORTED;
   }
   const int samples = ct == 0 ? 1 : (ct == 2 ? 3 : (ct == 3 ? 1 : (ct == 4 ? 2 : 4)));
@@ -191,6 +234,9 @@ int imf_png_read_f32(const char *path, float *out, int64_t capacity_floats, int 
   IMF_REQUIRE((int64_t)H * W * C <= capacity_floats, "imf_png_read_f32: %dx%dx%d exceeds the capacity", H, W, C);
   const int bpp = samples * depth / 8;                         // bytes per pixel
   const size_t row = (size_t)W * bpp;
+  // deflate expands at most ~1032x: a header that promises more pixels than the IDAT stream can hold is corrupt
+  IMF_REQUIRE((unsigned long long)(row + 1) * (unsigned long long)H <= 1040ull * (unsigned long long)idat.size() + 64,
+              "imf_png_read_f32: %s declares %dx%d pixels but holds %zu bytes of image data", path, W, H, idat.size());
   std::vector<unsigned char> raw((row + 1) * H);
   uLongf raw_len = (uLongf)raw.size();
   IMF_REQUIRE(uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) == Z_OK && raw_len == raw.size(),
@@ -228,12 +274,14 @@ int imf_png_read_f32(const char *path, float *out, int64_t capacity_floats, int 
   }
   *h_out = H; *w_out = W; *c_out = C;
   return IMF_OK;
+  });
 }
 
 /* cv2.resize(image, (W_out, H_out), INTER_LINEAR) for float images [H,W,C] -> [H_out,W_out,C]: bilinear with
  * half-pixel centres, edge clamp, no anti-aliasing (util/uio.py:33-40).  chw != 0 writes [C,H_out,W_out] (the
  * transposes of generate_desc.py:96-97 folded in). */
 int imf_resize_bilinear_f32(const float *in, int H, int W, int C, float *out, int H_out, int W_out, int chw) {
+  return guarded<int>("imf_resize_bilinear_f32", [&]() -> int {
   IMF_REQUIRE(in && out && H > 0 && W > 0 && C > 0 && H_out > 0 && W_out > 0, "imf_resize_bilinear_f32: bad argument");
   const float sy = (float)H / H_out, sx = (float)W / W_out;
   std::vector<int> x0(W_out), x1(W_out);
@@ -264,6 +312,7 @@ int imf_resize_bilinear_f32(const float *in, int H, int W, int C, float *out, in
     }
   }
   return IMF_OK;
+  });
 }
 
 /* np.savez / np.savez_compressed replacement: a ZIP archive of .npy members (format 1.0 headers, C order).
@@ -273,6 +322,7 @@ int imf_resize_bilinear_f32(const float *in, int H, int W, int C, float *out, in
  * identical.  Members must stay below 4 GiB (no ZIP64). */
 int imf_npz_write(const char *path, int n_arrays, const char *const *names, const char *const *dtype, const int32_t *ndim,
                   const int64_t *shape, const void *const *data, int level) {
+  return guarded<int>("imf_npz_write", [&]() -> int {
   IMF_REQUIRE(path && names && dtype && ndim && shape && data && n_arrays > 0 && level >= 0 && level <= 9,
               "imf_npz_write: bad argument");
   File fh(path, "wb");
@@ -282,8 +332,12 @@ int imf_npz_write(const char *path, int n_arrays, const char *const *names, cons
   uint32_t offset = 0;
   const int64_t *sh = shape;
   for (int i = 0; i < n_arrays; ++i) {
+    // numeric / bool descrs only ("<f8", "<i4", "|u1", "|b1" ...): the digits are the item size.  Strings ("<U7": 4 bytes
+    // per character, "|S3") and anything else are refused -- the caller writes such arrays with numpy
+    IMF_REQUIRE(dtype[i] && strlen(dtype[i]) >= 3 && strchr("<|=", dtype[i][0]) && strchr("fiub", dtype[i][1]),
+                "imf_npz_write: dtype '%s' (numeric little-endian descrs only)", dtype[i] ? dtype[i] : "(null)");
     const int itemsize = atoi(dtype[i] + 2);
-    IMF_REQUIRE(itemsize > 0 && strlen(dtype[i]) >= 3, "imf_npz_write: dtype '%s'", dtype[i]);
+    IMF_REQUIRE(itemsize == 1 || itemsize == 2 || itemsize == 4 || itemsize == 8, "imf_npz_write: dtype '%s'", dtype[i]);
     size_t count = 1;
     std::string shp = "(";
     for (int d = 0; d < ndim[i]; ++d) {
@@ -351,7 +405,9 @@ int imf_npz_write(const char *path, int n_arrays, const char *const *names, cons
   put32(end, (uint32_t)central.size()); put32(end, offset); put16(end, 0);
   IMF_REQUIRE(fwrite(central.data(), 1, central.size(), fh.f) == central.size() && fwrite(end.data(), 1, end.size(), fh.f) == end.size(),
               "imf_npz_write: short write to %s", path);
+  IMF_REQUIRE(fh.close(), "imf_npz_write: flush / close of %s failed (%s)", path, strerror(errno));
   return IMF_OK;
+  });
 }
 
 }  // extern "C"

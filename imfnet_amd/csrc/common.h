@@ -60,7 +60,19 @@ __device__ __forceinline__ uint32_t hash64(uint64_t k) {
 }
 
 // Returns the slot that holds `key` after the call (inserting it if absent).
-__device__ __forceinline__ uint32_t hash_insert(uint64_t *keys, uint32_t capmask, uint64_t key) {
+__device__ __forceinline__ uint32_t hash_insert(imf_slot *tab, uint32_t capmask, uint64_t key) {
+  uint32_t s = hash64(key) & capmask;
+  while (true) {
+    unsigned long long prev =
+        atomicCAS(reinterpret_cast<unsigned long long *>(&tab[s].key), (unsigned long long)kEmptyKey,
+                  (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) return s;
+    s = (s + 1) & capmask;
+  }
+}
+
+// key-only table (keypoint membership sets)
+__device__ __forceinline__ uint32_t hash_insert_key(uint64_t *keys, uint32_t capmask, uint64_t key) {
   uint32_t s = hash64(key) & capmask;
   while (true) {
     unsigned long long prev =
@@ -71,13 +83,13 @@ __device__ __forceinline__ uint32_t hash_insert(uint64_t *keys, uint32_t capmask
   }
 }
 
-__device__ __forceinline__ int hash_find(const uint64_t *__restrict__ keys,
-                                         const int32_t *__restrict__ vals, uint32_t capmask,
-                                         uint64_t key) {
+// One 16-byte load per probe: key and row of a slot arrive together (a hit costs no second random line).
+__device__ __forceinline__ int hash_find(const imf_slot *__restrict__ tab, uint32_t capmask, uint64_t key) {
   uint32_t s = hash64(key) & capmask;
   while (true) {
-    uint64_t k = keys[s];
-    if (k == key) return vals[s];
+    const uint4 v = *reinterpret_cast<const uint4 *>(tab + s);
+    const uint64_t k = ((uint64_t)v.y << 32) | v.x;
+    if (k == key) return (int)v.z;
     if (k == kEmptyKey) return -1;
     s = (s + 1) & capmask;
   }

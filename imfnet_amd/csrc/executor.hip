@@ -15,10 +15,12 @@
 //             grid and argument is then a function of the capacities only, the whole fragment
 //             (imf_fragment_forward: pyramid + rulebooks + image branch + 23 convolutions + fusion) can be
 //             captured ONCE per capacity bucket as a hipGraph and replayed with no host work but one launch.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
 #include "geometry_internal.h"
+#include "spconv_shared.h"
 
 namespace imf {
 namespace {
@@ -124,6 +126,33 @@ struct Step {   // one fused convolution of the schedule
   int in_a, c_a, out, in_b, c_b, residual;   // buffer ids (-1 none; -2 = io->x; -3 = io->out)
 };
 
+// What imf_fragment_forward hands to imf_resunet_forward through imf_resunet_io::pyramid (internal): the coarse
+// pyramid levels still to be built, and the image branch, to be forked off the main stream after encoder step
+// `fork_after` of the schedule (-1: the caller has forked it already).
+struct FragmentCtx {
+  const PyramidBuild *pb;
+  int fork_after;
+  const imf_image_desc *img;
+  const imf_fragment_caps *caps;
+  imf_fragment_io *fio;
+  hipStream_t imgs;
+};
+
+int fork_image_branch(const FragmentCtx &c, hipStream_t main) {
+  imf_fragment_io *fio = c.fio;
+  IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[9], main));
+  IMF_CHECK_HIP(hipStreamWaitEvent(c.imgs, (hipEvent_t)fio->events[9], 0));
+  // IMF_IMAGE_SKIP=1 (timing experiments only: the fusion then reads the previous fragment's tokens) leaves the branch out
+  static const bool skip = getenv("IMF_IMAGE_SKIP") && atoi(getenv("IMF_IMAGE_SKIP")) != 0;
+  const int rc = skip ? IMF_OK
+                      : imf_image_branch(c.img, fio->image, c.caps->n_items, c.caps->img_h, c.caps->img_w, fio->image_ws,
+                                         fio->image_ws_bytes, nullptr, fio->kt_packed, fio->v_packed, fio->tokens_padded,
+                                         fio->meta + 1, c.imgs);
+  if (rc) return rc;
+  IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[10], c.imgs));
+  return IMF_OK;
+}
+
 constexpr int kMetaBBox = 8;                        // meta[2 * n_levels + 0..7] with n_levels = 4
 constexpr int kMetaStarts = 16;                     // meta[16 + IMF_MAX_BATCH * level + item]
 
@@ -168,9 +197,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   IMF_REQUIRE(net && io, "imf_resunet_forward: null pointer");
   IMF_REQUIRE(io->int_arena && io->float_arena && io->out, "imf_resunet_forward: null arena / out");
   const bool dyn = io->dyn != 0;
-  const PyramidBuild *pyr = (const PyramidBuild *)io->pyramid;   // coarse levels still to build (fragment forward)
+  const FragmentCtx *fctx = (const FragmentCtx *)io->pyramid;    // fragment forward: coarse levels still to build, image branch
+  const PyramidBuild *pyr = fctx ? fctx->pb : nullptr;
   for (int i = 0; i < 4; ++i)
-    IMF_REQUIRE(io->n[i] > 0 && io->level[i].coords && io->level[i].keys && io->level[i].vals,
+    IMF_REQUIRE(io->n[i] > 0 && io->level[i].coords && io->level[i].table,
                 "imf_resunet_forward: level %d missing", i);
   IMF_REQUIRE(net->small_first || io->x, "imf_resunet_forward: input features required");
   IMF_REQUIRE(io->n_items >= 1 && io->n_items <= IMF_MAX_BATCH, "imf_resunet_forward: n_items=%d", io->n_items);
@@ -235,9 +265,9 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   auto build_conv = [&](Rb &rb, int lin, int lout, int ksize, hipStream_t st) -> int {
     const imf_level &in = io->level[lin], &out = io->level[lout];
     if (dyn)
-      return imf_rulebook_conv_dyn(in.keys, in.vals, in.capacity, out.coords, s.n[lout], meta + 2 * lout,
+      return imf_rulebook_conv_dyn(in.table, in.capacity, out.coords, s.n[lout], meta + 2 * lout,
                                    in.tensor_stride, ksize, rb.tile_rows, rb.nbr, rb.tile_mask, st);
-    return imf_rulebook_conv(in.keys, in.vals, in.capacity, out.coords, s.n[lout], in.tensor_stride, ksize,
+    return imf_rulebook_conv(in.table, in.capacity, out.coords, s.n[lout], in.tensor_stride, ksize,
                              rb.tile_rows, rb.nbr, rb.tile_mask, st);
   };
   int ev = 0;
@@ -273,11 +303,11 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   for (int i = 2; i >= 0; --i) {
     const imf_level &co = io->level[i + 1], &fi = io->level[i];
     if (dyn)
-      rc = imf_rulebook_transpose_dyn(co.keys, co.vals, co.capacity, fi.coords, s.n[i], meta + 2 * i, 1 << i, 3,
+      rc = imf_rulebook_transpose_dyn(co.table, co.capacity, fi.coords, s.n[i], meta + 2 * i, 1 << i, 3,
                                       rb_up[i].tile_rows, rb_up[i].nbr, rb_up[i].tile_mask, rb_up[i].n_slots,
                                       counters + 16 * i, side);
     else
-      rc = imf_rulebook_transpose(co.keys, co.vals, co.capacity, fi.coords, s.n[i], 1 << i, 3, rb_up[i].tile_rows,
+      rc = imf_rulebook_transpose(co.table, co.capacity, fi.coords, s.n[i], 1 << i, 3, rb_up[i].tile_rows,
                                   rb_up[i].nbr, rb_up[i].tile_mask, rb_up[i].n_slots, counters + 16 * i, side);
     if (rc) return rc;
     if ((rc = mark(rb_up[i]))) return rc;
@@ -333,7 +363,11 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
 
   // ---- first convolution (Cin <= 4): occupancy bit grid for the all-ones feature, else hash probing --
   if (s.small_first) {
-    if (dyn) {
+    if (dyn && pyr) {   // imf_fragment_forward zeroed the grid before the level-0 pyramid
+      rc = conv_first_bitgrid_dyn_cleared(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
+                                          io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale,
+                                          net->first_shift, 0, buf[ebuf(0, 0)], main);
+    } else if (dyn) {
       rc = imf_conv_first_bitgrid_dyn(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
                                       io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale,
                                       net->first_shift, 0, buf[ebuf(0, 0)], main);
@@ -345,7 +379,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
                                           net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
                                           buf[ebuf(0, 0)], err, main);
       } else {
-        rc = imf_conv_first_fused(io->level[0].keys, io->level[0].vals, io->level[0].capacity, io->level[0].coords,
+        rc = imf_conv_first_fused(io->level[0].table, io->level[0].capacity, io->level[0].coords,
                                   s.n[0], 1, net->first_ksize, io->x_all_ones ? nullptr : io->x, net->in_channels,
                                   net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
                                   buf[ebuf(0, 0)], main);
@@ -394,8 +428,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     return imf_spconv_fwd(&a, main);
   };
 
-  for (int i = 0; i < n_enc; ++i)
+  for (int i = 0; i < n_enc; ++i) {
     if ((rc = launch(sched[i]))) return rc;
+    if (fctx && fctx->fork_after == i && (rc = fork_image_branch(*fctx, main))) return rc;
+  }
 
   // ---- bottleneck fusion (model/resunet.py:237-273) ----------------------------------------------------
   if (io->image_ready) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
@@ -412,8 +448,39 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   if (rc) return rc;
   if (io->fusion_done) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->fusion_done, main));
 
-  for (int i = n_enc; i < n_steps; ++i)
+  // The head (conv1_tr + norm + ReLU + final + L2 norm, model/resunet.py:219-233) as one launch when its shapes are the
+  // ones imf_pointwise_head serves; bit-identical to the two convolution launches (A/B: IMF_HEAD_FUSED=0).
+  static const bool head_env = !(getenv("IMF_HEAD_FUSED") && atoi(getenv("IMF_HEAD_FUSED")) == 0);
+  const imf_net_conv &h1 = net->conv[21], &h2 = net->conv[22];
+  const int head_cin = s.tr[2] + s.ch[1];
+  const bool fused_head = head_env && h1.w_packed && h2.w_packed && h1.variant == 6 && h2.variant == 6 && h1.kvol == 1 &&
+                          h2.kvol == 1 && h1.cout == 64 && h2.cin == 64 && h2.cout == 32 && h1.cin == head_cin &&
+                          s.tr[2] % 32 == 0 && s.ch[1] % 32 == 0 && head_cin >= 64 && head_cin <= 128 && !h1.l2norm &&
+                          (size_t)s.n[0] * (size_t)(s.tr[2] > s.ch[1] ? s.tr[2] : s.ch[1]) * 4 < (1ull << 31);
+  const int n_tail = fused_head ? n_steps - 2 : n_steps;
+  for (int i = n_enc; i < n_tail; ++i)
     if ((rc = launch(sched[i]))) return rc;
+  if (fused_head) {
+    imf_head_args a;
+    memset(&a, 0, sizeof(a));
+    a.in_a = buf[dbuf(0, 2)]; a.c_a = s.tr[2];
+    a.in_b = buf[ebuf(0, 2)]; a.c_b = s.ch[1];
+    a.w1_packed = h1.w_packed; a.scale1 = h1.scale; a.shift1 = h1.shift; a.relu1 = h1.relu; a.c_mid = 64;
+    a.w2_packed = h2.w_packed; a.scale2 = h2.scale; a.shift2 = h2.shift; a.l2norm = h2.l2norm; a.c_out = 32;
+    a.n = s.n[0];
+    a.n_dev = dyn ? meta : nullptr;
+    a.out = io->out;
+    a.flags = err;
+    if (io->trace) {   // one record (conv1_tr's) carries the launch; `final` is marked as not launched
+      imf_net_trace &t = io->trace[21];
+      a.ev_begin = t.ev_begin; a.ev_end = t.ev_end;
+      t.nbr = nullptr; t.kvol = 1; t.cin = h1.cin; t.cout = h1.cout; t.split = 1;
+      t.n_slots = rb_id.n_slots; t.n_out = rb_id.n_out; t.launched = 1;
+      t.level = 0; t.slots_extra = 0; t.kernel_tag = 16;
+      io->trace[22].launched = 0;
+    }
+    if ((rc = imf_pointwise_head(&a, main))) return rc;
+  }
   return IMF_OK;
 }
 
@@ -446,14 +513,25 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   if (rc) return rc;
   if ((rc = pyramid_init(pb, main))) return rc;
 
-  // image branch on its own stream, forked from and later joined to the main one (events 9 / 10)
-  IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[9], main));
-  IMF_CHECK_HIP(hipStreamWaitEvent(imgs, (hipEvent_t)fio->events[9], 0));
-  rc = imf_image_branch(img, fio->image, caps->n_items, caps->img_h, caps->img_w, fio->image_ws, fio->image_ws_bytes,
-                        nullptr, fio->kt_packed, fio->v_packed, fio->tokens_padded, fio->meta + 1, imgs);
-  if (rc) return rc;
-  IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[10], imgs));
+  // image branch on its own stream, forked from and later joined to the main one (events 9 / 10).  Where it forks
+  // (IMF_IMAGE_FORK: -1 = here, ahead of the pyramid; i >= 0 = after encoder step i of the schedule: 1 block1, 2 conv2,
+  // 4 block2, 5 conv3, 7 block3) decides what its ~50 small launches (~0.2 ms as a chain) run beside: it must be done by
+  // the fusion block, and the stride-4 / 8 levels leave CUs idle that the level-0 kernels do not.
+  static const int fork_env = getenv("IMF_IMAGE_FORK") ? atoi(getenv("IMF_IMAGE_FORK")) : -1;
+  FragmentCtx fctx{&pb, fio->serialize ? -1 : fork_env, img, caps, fio, imgs};
+  if (fctx.fork_after < 0 && (rc = fork_image_branch(fctx, main))) return rc;
 
+  // conv1's occupancy bit grid (the int arena's tail, as imf_resunet_forward lays it out) is zeroed here, ahead of the
+  // pyramid, instead of between the pyramid and conv1
+  {
+    IMF_REQUIRE(net->small_first && caps->bitgrid_words > 0 && fio->int_arena, "imf_fragment_forward: needs the occupancy-feature first convolution and a bit-grid capacity");
+    IMF_REQUIRE(fio->int_arena_bytes >= imf_resunet_int_arena_bytes_cap(net, caps->rows, caps->bitgrid_words),
+                "imf_fragment_forward: int arena %zu < %zu bytes", fio->int_arena_bytes,
+                imf_resunet_int_arena_bytes_cap(net, caps->rows, caps->bitgrid_words));
+    int32_t *ibase = (int32_t *)(((uintptr_t)fio->int_arena + 255) & ~(uintptr_t)255);
+    uint32_t *bitgrid = (uint32_t *)(ibase + int_words(sizes_of(net, caps->rows)));
+    IMF_CHECK_HIP(hipMemsetAsync(bitgrid, 0, caps->bitgrid_words * sizeof(uint32_t), main));
+  }
   // level 0 of the pyramid on the main stream (conv1 needs it first); the coarse levels go to the side stream
   if ((rc = pyramid_level0(pb, main, false))) return rc;
 
@@ -478,7 +556,7 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   for (int i = 0; i < 9; ++i) io.events[i] = fio->events[i];
   io.side_stream = side; io.main_stream = main;
   io.trace = fio->trace;
-  io.dyn = 1; io.meta = fio->meta; io.bitgrid_words = caps->bitgrid_words; io.pyramid = &pb;
+  io.dyn = 1; io.meta = fio->meta; io.bitgrid_words = caps->bitgrid_words; io.pyramid = &fctx;
   return imf_resunet_forward(net, &io);
 }
 

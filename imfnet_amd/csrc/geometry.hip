@@ -39,7 +39,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, const BatchStarts bs,
                 const int32_t *__restrict__ dyn,
-                uint64_t *keys, int32_t *vals, uint32_t capmask, int32_t *slot_of, int32_t *err) {
+                imf_slot *tab, uint32_t capmask, int32_t *slot_of, int32_t *err) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (dyn) {
     n = min((int64_t)dyn[0], n);
@@ -72,8 +72,8 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
   const bool leader = valid && (lane == 0 || key != prev);
   uint32_t s = 0;
   if (leader) {
-    s = hash_insert(keys, capmask, key);
-    atomicMin(vals + s, (int32_t)i);
+    s = hash_insert(tab, capmask, key);
+    atomicMin(&tab[s].val, (int32_t)i);
   }
   const unsigned long long lead_mask = __ballot(leader);
   const unsigned long long below = lead_mask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
@@ -84,15 +84,15 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
 
 __global__ void __launch_bounds__(256)
 k_insert_coords(const int32_t *__restrict__ cin, const int32_t *__restrict__ n_dev, int stride,
-                uint64_t *keys, int32_t *vals, uint32_t capmask, int32_t *slot_of) {
+                imf_slot *tab, uint32_t capmask, int32_t *slot_of) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *n_dev) return;
   int4 c = reinterpret_cast<const int4 *>(cin)[i];
   int x = floor_div(c.y, stride) * stride;
   int y = floor_div(c.z, stride) * stride;
   int z = floor_div(c.w, stride) * stride;
-  uint32_t s = hash_insert(keys, capmask, pack_key(c.x, x, y, z));
-  atomicMin(vals + s, (int32_t)i);
+  uint32_t s = hash_insert(tab, capmask, pack_key(c.x, x, y, z));
+  atomicMin(&tab[s].val, (int32_t)i);
   slot_of[i] = (int32_t)s;
 }
 
@@ -106,7 +106,7 @@ __device__ __forceinline__ int block_sum_256(int v, int *lds4) {
 }
 
 __global__ void __launch_bounds__(kScanThreads)
-k_flag_first(int32_t *slot_of, const int32_t *__restrict__ vals, int64_t n_static,
+k_flag_first(int32_t *slot_of, const imf_slot *__restrict__ tab, int64_t n_static,
              const int32_t *__restrict__ n_dev, int32_t *block_sums) {
   __shared__ int lds4[4];
   const int64_t n = n_dev ? min((int64_t)*n_dev, n_static) : n_static;
@@ -117,7 +117,7 @@ k_flag_first(int32_t *slot_of, const int32_t *__restrict__ vals, int64_t n_stati
     int64_t i = base + e;
     if (i < n) {
       int s = slot_of[i];
-      bool first = vals[s] == (int32_t)i;
+      bool first = tab[s].val == (int32_t)i;
       slot_of[i] = first ? s : ~s;
       cnt += first;
     }
@@ -126,50 +126,36 @@ k_flag_first(int32_t *slot_of, const int32_t *__restrict__ vals, int64_t n_stati
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-// ---- K3: exclusive scan of the block counts (one block), total -> m_out ------------------------
-// row_cap > 0: the level holds at most row_cap rows; a larger count is clamped and flagged (bit 1 of err)
-__global__ void __launch_bounds__(256)
-k_scan_block_sums(int32_t *block_sums, int nb, int32_t *m_out, int64_t row_cap = 0, int32_t *err = nullptr) {
-  __shared__ int part[256];
-  const int t = threadIdx.x;
-  const int per = (nb + 255) / 256;
-  const int lo = t * per, hi = min(nb, lo + per);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += block_sums[i];
-  part[t] = s;
-  __syncthreads();
-  // Hillis-Steele inclusive scan over 256 partials
-  for (int o = 1; o < 256; o <<= 1) {
-    int v = (t >= o) ? part[t - o] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int run = part[t] - s;  // exclusive prefix of this thread's chunk
-  for (int i = lo; i < hi; ++i) {
-    int v = block_sums[i];
-    block_sums[i] = run;
-    run += v;
-  }
-  if (t == 255) {
-    int m = part[255];
-    if (row_cap > 0 && m > row_cap) {
-      m = (int)row_cap;
-      if (err) atomicOr(err, 2);
-    }
-    *m_out = m;
-  }
-}
-
-// ---- K4: order-preserving compaction: row r = rank of the first-occurrence point ---------------
+// ---- K3: order-preserving compaction: row r = rank of the first-occurrence point ---------------
+// The exclusive scan of the per-block counts is done here, by every workgroup for itself (it sums the counts of the
+// blocks before it: <= a few thousand ints from L2) -- a single-workgroup scan kernel between K2 and K3 cost a launch
+// and a kernel boundary on the critical path of every level.  The last block writes the level's row count to *m_out.
+// row_cap > 0: the level holds at most row_cap rows; a larger count is clamped and flagged (bit 1 of m_out[1]).
 __global__ void __launch_bounds__(kScanThreads)
-k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ keys, int32_t *vals,
+k_emit_unique(const int32_t *__restrict__ slot_of, imf_slot *tab,
               int64_t n_static, const int32_t *__restrict__ n_dev,
-              const int32_t *__restrict__ block_offs, int32_t *coords_out, int32_t *first_idx,
+              const int32_t *__restrict__ block_sums, int32_t *m_out, int32_t *coords_out, int32_t *first_idx,
               int32_t *bbox, int64_t row_cap = 0) {
-  __shared__ int wsum[4];
+  __shared__ int wsum[4], psum[4];
   const int64_t n = n_dev ? min((int64_t)*n_dev, n_static) : n_static;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int block_off = 0;
+  {
+    int part = 0;
+    for (int i = t; i < (int)blockIdx.x; i += kScanThreads) part += block_sums[i];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if (lane == 0) psum[w] = part;
+    __syncthreads();
+    block_off = psum[0] + psum[1] + psum[2] + psum[3];
+    if (blockIdx.x == gridDim.x - 1 && t == 0) {
+      int m = block_off + block_sums[blockIdx.x];
+      if (row_cap > 0 && m > row_cap) {
+        m = (int)row_cap;
+        atomicOr(m_out + 1, 2);
+      }
+      *m_out = m;
+    }
+  }
   int64_t base = (int64_t)blockIdx.x * kScanTile + t * kScanItems;
   int s[kScanItems];
   int cnt = 0;
@@ -189,16 +175,16 @@ k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ 
   __syncthreads();
   int woff = 0;
   for (int q = 0; q < w; ++q) woff += wsum[q];
-  int r = block_offs[blockIdx.x] + woff + inc - cnt;
+  int r = block_off + woff + inc - cnt;
   int4 lo = make_int4(0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF);
   int4 hi = make_int4(-0x7FFFFFFF - 1, -0x7FFFFFFF - 1, -0x7FFFFFFF - 1, -0x7FFFFFFF - 1);
 #pragma unroll
   for (int e = 0; e < kScanItems; ++e) {
     if (s[e] >= 0 && row_cap > 0 && r >= row_cap) {
-      vals[s[e]] = -1;            // over capacity (flagged by the scan): the voxel has no row
+      tab[s[e]].val = -1;         // over capacity (flagged by the last block): the voxel has no row
       ++r;
     } else if (s[e] >= 0) {
-      uint64_t key = keys[s[e]];
+      uint64_t key = tab[s[e]].key;
       int4 c;
       c.x = (int)(key >> (3 * kCoordBits));
       c.y = ((int)((key >> (2 * kCoordBits)) & 0x3FFFF) << 14) >> 14;   // sign-extend 18 bits
@@ -206,7 +192,7 @@ k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ 
       c.w = ((int)(key & 0x3FFFF) << 14) >> 14;
       reinterpret_cast<int4 *>(coords_out)[r] = c;
       if (first_idx) first_idx[r] = (int32_t)(base + e);
-      vals[s[e]] = r;   // the table now maps voxel -> row
+      tab[s[e]].val = r;   // the table now maps voxel -> row
       ++r;
       lo.x = min(lo.x, c.x); lo.y = min(lo.y, c.y); lo.z = min(lo.z, c.z); lo.w = min(lo.w, c.w);
       hi.x = max(hi.x, c.x); hi.y = max(hi.y, c.y); hi.z = max(hi.z, c.z); hi.w = max(hi.w, c.w);
@@ -241,14 +227,13 @@ k_emit_unique(const int32_t *__restrict__ slot_of, const uint64_t *__restrict__ 
   }
 }
 
-static int run_unique_tail(int32_t *slot_of, int32_t *block_sums, uint64_t *keys, int32_t *vals,
+static int run_unique_tail(int32_t *slot_of, int32_t *block_sums, imf_slot *tab,
                            int64_t n_max, const int32_t *n_dev, int32_t *coords_out,
                            int32_t *first_idx, int32_t *m_out, hipStream_t st, int32_t *bbox = nullptr,
                            int64_t row_cap = 0) {
   const int nb = (int)div_up(n_max, kScanTile);
-  k_flag_first<<<nb, kScanThreads, 0, st>>>(slot_of, vals, n_max, n_dev, block_sums);
-  k_scan_block_sums<<<1, 256, 0, st>>>(block_sums, nb, m_out, row_cap, row_cap > 0 ? m_out + 1 : nullptr);
-  k_emit_unique<<<nb, kScanThreads, 0, st>>>(slot_of, keys, vals, n_max, n_dev, block_sums,
+  k_flag_first<<<nb, kScanThreads, 0, st>>>(slot_of, tab, n_max, n_dev, block_sums);
+  k_emit_unique<<<nb, kScanThreads, 0, st>>>(slot_of, tab, n_max, n_dev, block_sums, m_out,
                                              coords_out, first_idx, bbox, row_cap);
   IMF_CHECK_LAUNCH("unique pipeline");
   return IMF_OK;
@@ -267,7 +252,7 @@ __device__ __forceinline__ void kernel_offset(int k, int ksize, int &dx, int &dy
 // SIGN = +1: in = out + off*ts (conv); SIGN = -1: coarse = fine - off*ts (transposed conv).
 template <int SIGN, bool INDIRECT>
 __global__ void __launch_bounds__(256)
-k_rulebook(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, uint32_t capmask,
+k_rulebook(const imf_slot *__restrict__ tab, uint32_t capmask,
            const int32_t *__restrict__ out_coords, int64_t n_out, const int32_t *__restrict__ n_out_dev, int ts,
            int ksize, int kvol, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,7 +275,7 @@ k_rulebook(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, 
     int dx, dy, dz;
     kernel_offset(k, ksize, dx, dy, dz);
     int x = c.y + SIGN * dx * ts, y = c.z + SIGN * dy * ts, z = c.w + SIGN * dz * ts;
-    if (coord_in_range(x, y, z)) found = hash_find(keys, vals, capmask, pack_key(c.x, x, y, z));
+    if (coord_in_range(x, y, z)) found = hash_find(tab, capmask, pack_key(c.x, x, y, z));
   }
   nbr[idx] = found;
   unsigned long long any = __ballot(found >= 0);
@@ -393,16 +378,25 @@ k_init_transpose(int32_t *counters, int32_t *tile_rows, int64_t n_slots, uint32_
 }
 
 __global__ void __launch_bounds__(256)
-k_init_table(uint64_t *keys, int32_t *vals, int64_t capacity) {
+k_init_table(imf_slot *tab, int64_t capacity) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < capacity) {
-    keys[i] = kEmptyKey;
-    vals[i] = 0x7FFFFFFF;
-  }
+  if (i < capacity) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu, 0u);
 }
 
-static int init_table(uint64_t *keys, int32_t *vals, int64_t capacity, hipStream_t st) {
-  k_init_table<<<(unsigned)div_up(capacity, 256), 256, 0, st>>>(keys, vals, capacity);
+// xyz_down = xyz[inds] on the device (util/misc.py:92 return_coords): one thread per output coordinate
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gather_points(const T *__restrict__ xyz, const int32_t *__restrict__ first_idx, const int32_t *__restrict__ m_dev,
+                int64_t m_cap, double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t m = m_dev ? min((int64_t)*m_dev, m_cap) : m_cap;
+  if (i >= 3 * m) return;
+  const int64_t r = i / 3;
+  out[i] = (double)xyz[3 * (int64_t)first_idx[r] + (i - 3 * r)];
+}
+
+static int init_table(imf_slot *tab, int64_t capacity, hipStream_t st) {
+  k_init_table<<<(unsigned)div_up(capacity, 256), 256, 0, st>>>(tab, capacity);
   IMF_CHECK_LAUNCH("k_init_table");
   return IMF_OK;
 }
@@ -424,9 +418,9 @@ size_t imf_unique_workspace_bytes(int64_t n) {
 }
 
 int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
-                 int32_t *coords, int32_t *first_idx, int32_t *m_out, uint64_t *keys, int32_t *vals,
+                 int32_t *coords, int32_t *first_idx, int32_t *m_out, imf_slot *table,
                  int64_t capacity, void *workspace, int32_t *err_out, void *stream) {
-  IMF_REQUIRE(xyz && coords && first_idx && m_out && keys && vals && workspace && err_out,
+  IMF_REQUIRE(xyz && coords && first_idx && m_out && table && workspace && err_out,
               "imf_voxelize: null pointer");
   IMF_REQUIRE(n > 0 && n < (1ll << 31) - 2048, "imf_voxelize: n=%lld out of range", (long long)n);
   IMF_REQUIRE(voxel_size > 0.0, "imf_voxelize: voxel_size must be > 0");
@@ -436,7 +430,7 @@ int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, 
   hipStream_t st = (hipStream_t)stream;
   int32_t *slot_of = (int32_t *)workspace;
   int32_t *block_sums = slot_of + n;
-  int rc = init_table(keys, vals, capacity, st);
+  int rc = init_table(table, capacity, st);
   if (rc) return rc;
   const int nblk = (int)div_up(n, 256);
   BatchStarts one;
@@ -444,20 +438,20 @@ int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, 
   one.nb = 1;
   if (xyz_is_f64)
     k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index, one, nullptr,
-                                                  keys, vals, (uint32_t)(capacity - 1), slot_of,
+                                                  table, (uint32_t)(capacity - 1), slot_of,
                                                   err_out);
   else
     k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index, one, nullptr,
-                                                 keys, vals, (uint32_t)(capacity - 1), slot_of,
+                                                 table, (uint32_t)(capacity - 1), slot_of,
                                                  err_out);
   IMF_CHECK_LAUNCH("k_insert_points");
-  return run_unique_tail(slot_of, block_sums, keys, vals, n, nullptr, coords, first_idx, m_out, st);
+  return run_unique_tail(slot_of, block_sums, table, n, nullptr, coords, first_idx, m_out, st);
 }
 
 int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_in_max,
-                   int out_stride, int32_t *coords_out, int32_t *m_out, uint64_t *keys,
-                   int32_t *vals, int64_t capacity, void *workspace, void *stream) {
-  IMF_REQUIRE(coords_in && n_in_dev && coords_out && m_out && keys && vals && workspace,
+                   int out_stride, int32_t *coords_out, int32_t *m_out, imf_slot *table,
+                   int64_t capacity, void *workspace, void *stream) {
+  IMF_REQUIRE(coords_in && n_in_dev && coords_out && m_out && table && workspace,
               "imf_downsample: null pointer");
   IMF_REQUIRE(n_in_max > 0 && n_in_max < (1ll << 31) - 2048, "imf_downsample: n out of range");
   IMF_REQUIRE(out_stride >= 1, "imf_downsample: out_stride must be >= 1");
@@ -466,12 +460,12 @@ int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_
   hipStream_t st = (hipStream_t)stream;
   int32_t *slot_of = (int32_t *)workspace;
   int32_t *block_sums = slot_of + n_in_max;
-  int rc = init_table(keys, vals, capacity, st);
+  int rc = init_table(table, capacity, st);
   if (rc) return rc;
   k_insert_coords<<<(int)div_up(n_in_max, 256), 256, 0, st>>>(
-      coords_in, n_in_dev, out_stride, keys, vals, (uint32_t)(capacity - 1), slot_of);
+      coords_in, n_in_dev, out_stride, table, (uint32_t)(capacity - 1), slot_of);
   IMF_CHECK_LAUNCH("k_insert_coords");
-  return run_unique_tail(slot_of, block_sums, keys, vals, n_in_max, n_in_dev, coords_out, nullptr,
+  return run_unique_tail(slot_of, block_sums, table, n_in_max, n_in_dev, coords_out, nullptr,
                          m_out, st);
 }
 
@@ -482,7 +476,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // mode): level l holds at most row_caps[l] rows and its table is sized for the rows that can be INSERTED into
 // it -- n points at level 0, row_caps[l-1] rows above -- so an over-full level can never fill a table.
 struct PyramidLayout {
-  size_t coords_off[8], keys_off[8], vals_off[8];
+  size_t coords_off[8], table_off[8];
   int64_t cap[8], rows[8];
   size_t first_off, slot_off, total;
 };
@@ -495,9 +489,8 @@ static PyramidLayout pyramid_layout(int64_t n, int n_levels, const int64_t *row_
     L.cap[l] = imf_hash_capacity(row_caps && l > 0 ? row_caps[l - 1] : n);
     L.coords_off[l] = p;  p += align_up((size_t)L.rows[l] * 16, 256);
   }
-  // the tables are contiguous (keys of all levels, then vals) so that one launch initialises them
-  for (int l = 0; l < n_levels; ++l) { L.keys_off[l] = p; p += align_up((size_t)L.cap[l] * 8, 256); }
-  for (int l = 0; l < n_levels; ++l) { L.vals_off[l] = p; p += align_up((size_t)L.cap[l] * 4, 256); }
+  // the tables of all levels are contiguous so that one launch initialises them
+  for (int l = 0; l < n_levels; ++l) { L.table_off[l] = p; p += align_up((size_t)L.cap[l] * sizeof(imf_slot), 256); }
   L.first_off = p;  p += align_up((size_t)L.rows[0] * 4, 256);
   L.slot_off = p;   p += align_up(imf_unique_workspace_bytes(n), 256);
   L.total = p;
@@ -514,16 +507,15 @@ size_t imf_pyramid_arena_bytes_caps(int64_t n_points_cap, int n_levels, const in
   return pyramid_layout(n_points_cap, n_levels, row_caps).total;
 }
 
-// keys / vals of all levels are two contiguous regions: one grid-stride launch fills both
+// the tables of all levels are one contiguous region: one grid-stride launch empties them and resets the meta block
 __global__ void __launch_bounds__(256)
-k_init_tables2(uint64_t *keys, int64_t n_keys, int32_t *vals, int64_t n_vals, int n_levels, int32_t *meta,
-               int n_meta) {
+k_init_tables2(imf_slot *tab, int64_t n_slots, int n_levels, int32_t *meta, int n_meta) {
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
   if (i0 < n_meta) meta[i0] = (i0 >= 2 * n_levels && i0 < 2 * n_levels + 8)
                                   ? (i0 < 2 * n_levels + 4 ? 0x7FFFFFFF : -0x7FFFFFFF - 1)    // level-0 bounding box
                                   : (i0 >= 2 * n_levels + 8 ? -1 : 0);                       // item starts / counts
-  for (int64_t i = i0; i < n_keys; i += step) keys[i] = kEmptyKey;
-  for (int64_t i = i0; i < n_vals; i += step) vals[i] = 0x7FFFFFFF;
+  for (int64_t i = i0; i < n_slots; i += step)
+    reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu, 0u);
 }
 
 }  // extern "C"
@@ -554,8 +546,7 @@ int pyramid_prepare(PyramidBuild &b, const void *xyz, int xyz_is_f64, int64_t n,
   for (int l = 0; l < n_levels; ++l) {
     imf_level &L = levels_out[l];
     L.coords = (int32_t *)(base + lay.coords_off[l]);
-    L.keys = (uint64_t *)(base + lay.keys_off[l]);
-    L.vals = (int32_t *)(base + lay.vals_off[l]);
+    L.table = (imf_slot *)(base + lay.table_off[l]);
     L.capacity = lay.cap[l];
     L.first_idx = nullptr;
     L.cap_rows = lay.rows[l];
@@ -569,16 +560,15 @@ int pyramid_prepare(PyramidBuild &b, const void *xyz, int xyz_is_f64, int64_t n,
   b.block_sums = b.slot_of + n;
   b.batched = n_items > 1 || dyn != nullptr;
   b.n_meta = 2 * n_levels + 8 + (b.batched ? IMF_MAX_BATCH * n_levels : 0);
-  b.n_keys = (int64_t)((lay.vals_off[0] - lay.keys_off[0]) / 8);
-  b.n_vals = (int64_t)((lay.first_off - lay.vals_off[0]) / 4);
+  b.n_table_slots = (int64_t)((lay.first_off - lay.table_off[0]) / sizeof(imf_slot));
   return IMF_OK;
 }
 
 int pyramid_init(const PyramidBuild &b, hipStream_t st) {
   imf_level *lv = b.levels;
-  int64_t nb = div_up(b.n_keys, 256 * 4);
+  int64_t nb = div_up(b.n_table_slots, 256 * 4);
   nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
-  k_init_tables2<<<(unsigned)nb, 256, 0, st>>>(lv[0].keys, b.n_keys, lv[0].vals, b.n_vals, b.n_levels, b.meta, b.n_meta);
+  k_init_tables2<<<(unsigned)nb, 256, 0, st>>>(lv[0].table, b.n_table_slots, b.n_levels, b.meta, b.n_meta);
   IMF_CHECK_LAUNCH("k_init_tables2");
   return IMF_OK;
 }
@@ -593,24 +583,24 @@ int pyramid_level0(const PyramidBuild &b, hipStream_t st, bool init) {
   const int nblk = (int)div_up(b.n, 256);
   if (b.xyz_is_f64)
     k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
-                                                  lv[0].keys, lv[0].vals, (uint32_t)(lv[0].capacity - 1), b.slot_of,
+                                                  lv[0].table, (uint32_t)(lv[0].capacity - 1), b.slot_of,
                                                   b.meta + 1);
   else
     k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
-                                                 lv[0].keys, lv[0].vals, (uint32_t)(lv[0].capacity - 1), b.slot_of,
+                                                 lv[0].table, (uint32_t)(lv[0].capacity - 1), b.slot_of,
                                                  b.meta + 1);
   IMF_CHECK_LAUNCH("k_insert_points");
-  return run_unique_tail(b.slot_of, b.block_sums, lv[0].keys, lv[0].vals, b.n, b.dyn, lv[0].coords, lv[0].first_idx,
+  return run_unique_tail(b.slot_of, b.block_sums, lv[0].table, b.n, b.dyn, lv[0].coords, lv[0].first_idx,
                          b.meta, st, b.meta + 2 * b.n_levels, b.row_cap[0]);
 }
 
 int pyramid_coarse_level(const PyramidBuild &b, int l, hipStream_t st) {
   imf_level *lv = b.levels;
   const int64_t n_in = lv[l - 1].cap_rows;
-  k_insert_coords<<<(unsigned)div_up(n_in, 256), 256, 0, st>>>(lv[l - 1].coords, b.meta + 2 * (l - 1), 1 << l, lv[l].keys,
-                                                              lv[l].vals, (uint32_t)(lv[l].capacity - 1), b.slot_of);
+  k_insert_coords<<<(unsigned)div_up(n_in, 256), 256, 0, st>>>(lv[l - 1].coords, b.meta + 2 * (l - 1), 1 << l, lv[l].table,
+                                                              (uint32_t)(lv[l].capacity - 1), b.slot_of);
   IMF_CHECK_LAUNCH("k_insert_coords");
-  return run_unique_tail(b.slot_of, b.block_sums, lv[l].keys, lv[l].vals, n_in, b.meta + 2 * (l - 1), lv[l].coords, nullptr,
+  return run_unique_tail(b.slot_of, b.block_sums, lv[l].table, n_in, b.meta + 2 * (l - 1), lv[l].coords, nullptr,
                          b.meta + 2 * l, st, nullptr, b.row_cap[l]);
 }
 
@@ -672,12 +662,23 @@ int imf_pyramid_build_dyn(const void *xyz, int xyz_is_f64, const int32_t *dyn, i
                             levels_out, stream, dyn, row_caps);
 }
 
+int imf_gather_points(const void *xyz, int xyz_is_f64, const int32_t *first_idx, const int32_t *m_dev, int64_t m_cap,
+                      double *out, void *stream) {
+  IMF_REQUIRE(xyz && first_idx && out && m_cap > 0, "imf_gather_points: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = (unsigned)div_up(3 * m_cap, 256);
+  if (xyz_is_f64) k_gather_points<double><<<nb, 256, 0, st>>>((const double *)xyz, first_idx, m_dev, m_cap, out);
+  else k_gather_points<float><<<nb, 256, 0, st>>>((const float *)xyz, first_idx, m_dev, m_cap, out);
+  IMF_CHECK_LAUNCH("k_gather_points");
+  return IMF_OK;
+}
+
 int64_t imf_rulebook_slots(int64_t n_out) { return div_up(n_out, IMF_TILE_ROWS) * IMF_TILE_ROWS; }
 
-static int rulebook_conv_impl(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+static int rulebook_conv_impl(const imf_slot *in_table, int64_t in_capacity,
                               const int32_t *out_coords, int64_t n_out, const int32_t *n_out_dev, int ts_in, int ksize,
                               int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream) {
-  IMF_REQUIRE(in_keys && in_vals && out_coords && tile_rows && nbr && tile_mask,
+  IMF_REQUIRE(in_table && out_coords && tile_rows && nbr && tile_mask,
               "imf_rulebook_conv: null pointer");
   IMF_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "imf_rulebook_conv: ksize must be 1, 3 or 5");
   IMF_REQUIRE(n_out > 0 && ts_in >= 1, "imf_rulebook_conv: bad n_out / ts_in");
@@ -687,24 +688,24 @@ static int rulebook_conv_impl(const uint64_t *in_keys, const int32_t *in_vals, i
   const int64_t n_slots = imf_rulebook_slots(n_out);
   IMF_CHECK_HIP(hipMemsetAsync(tile_mask, 0, (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS * 4, st));
   k_rulebook<+1, false><<<(unsigned)div_up(n_slots * kvol, 256), 256, 0, st>>>(
-      in_keys, in_vals, (uint32_t)(in_capacity - 1), out_coords, n_out, n_out_dev, ts_in, ksize, kvol,
+      in_table, (uint32_t)(in_capacity - 1), out_coords, n_out, n_out_dev, ts_in, ksize, kvol,
       tile_rows, nbr, tile_mask, n_slots);
   IMF_CHECK_LAUNCH("k_rulebook");
   return IMF_OK;
 }
 
-int imf_rulebook_conv(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+int imf_rulebook_conv(const imf_slot *in_table, int64_t in_capacity,
                       const int32_t *out_coords, int64_t n_out, int ts_in, int ksize,
                       int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream) {
-  return rulebook_conv_impl(in_keys, in_vals, in_capacity, out_coords, n_out, nullptr, ts_in, ksize, tile_rows, nbr,
+  return rulebook_conv_impl(in_table, in_capacity, out_coords, n_out, nullptr, ts_in, ksize, tile_rows, nbr,
                             tile_mask, stream);
 }
 
-int imf_rulebook_conv_dyn(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+int imf_rulebook_conv_dyn(const imf_slot *in_table, int64_t in_capacity,
                           const int32_t *out_coords, int64_t n_out_cap, const int32_t *n_out_dev, int ts_in,
                           int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream) {
   IMF_REQUIRE(n_out_dev, "imf_rulebook_conv_dyn: null pointer");
-  return rulebook_conv_impl(in_keys, in_vals, in_capacity, out_coords, n_out_cap, n_out_dev, ts_in, ksize, tile_rows,
+  return rulebook_conv_impl(in_table, in_capacity, out_coords, n_out_cap, n_out_dev, ts_in, ksize, tile_rows,
                             nbr, tile_mask, stream);
 }
 
@@ -712,11 +713,11 @@ int64_t imf_rulebook_transpose_slots(int64_t n_fine) {
   return (div_up(n_fine, IMF_TILE_ROWS) + 8) * IMF_TILE_ROWS;
 }
 
-static int rulebook_transpose_impl(const uint64_t *coarse_keys, const int32_t *coarse_vals, int64_t coarse_capacity,
+static int rulebook_transpose_impl(const imf_slot *coarse_table, int64_t coarse_capacity,
                                    const int32_t *fine_coords, int64_t n_fine, const int32_t *n_fine_dev, int ts_fine,
                                    int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots,
                                    int32_t *counters, void *stream) {
-  IMF_REQUIRE(coarse_keys && coarse_vals && fine_coords && tile_rows && nbr && tile_mask && counters,
+  IMF_REQUIRE(coarse_table && fine_coords && tile_rows && nbr && tile_mask && counters,
               "imf_rulebook_transpose: null pointer");
   IMF_REQUIRE(ksize == 3, "imf_rulebook_transpose: only kernel_size 3 / stride 2 is supported");
   IMF_REQUIRE(n_fine > 0 && ts_fine >= 1, "imf_rulebook_transpose: bad n_fine / ts_fine");
@@ -732,26 +733,25 @@ static int rulebook_transpose_impl(const uint64_t *coarse_keys, const int32_t *c
   k_class_bases<<<1, 256, 0, st>>>(blockcnt, (int)nb, counters);
   k_class_assign<<<nb, 256, 0, st>>>(fine_coords, n_fine, n_fine_dev, ts_fine, counters, blockcnt, tile_rows);
   k_rulebook<-1, true><<<(unsigned)div_up(n_slots * kvol, 256), 256, 0, st>>>(
-      coarse_keys, coarse_vals, (uint32_t)(coarse_capacity - 1), fine_coords, n_fine, n_fine_dev, ts_fine, ksize,
+      coarse_table, (uint32_t)(coarse_capacity - 1), fine_coords, n_fine, n_fine_dev, ts_fine, ksize,
       kvol, tile_rows, nbr, tile_mask, n_slots);
   IMF_CHECK_LAUNCH("transpose rulebook");
   return IMF_OK;
 }
 
-int imf_rulebook_transpose(const uint64_t *coarse_keys, const int32_t *coarse_vals,
-                           int64_t coarse_capacity, const int32_t *fine_coords, int64_t n_fine,
+int imf_rulebook_transpose(const imf_slot *coarse_table, int64_t coarse_capacity, const int32_t *fine_coords, int64_t n_fine,
                            int ts_fine, int ksize, int32_t *tile_rows, int32_t *nbr,
                            uint32_t *tile_mask, int64_t n_slots, int32_t *counters, void *stream) {
-  return rulebook_transpose_impl(coarse_keys, coarse_vals, coarse_capacity, fine_coords, n_fine, nullptr, ts_fine, ksize,
+  return rulebook_transpose_impl(coarse_table, coarse_capacity, fine_coords, n_fine, nullptr, ts_fine, ksize,
                                  tile_rows, nbr, tile_mask, n_slots, counters, stream);
 }
 
-int imf_rulebook_transpose_dyn(const uint64_t *coarse_keys, const int32_t *coarse_vals, int64_t coarse_capacity,
+int imf_rulebook_transpose_dyn(const imf_slot *coarse_table, int64_t coarse_capacity,
                                const int32_t *fine_coords, int64_t n_fine_cap, const int32_t *n_fine_dev, int ts_fine,
                                int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots,
                                int32_t *counters, void *stream) {
   IMF_REQUIRE(n_fine_dev, "imf_rulebook_transpose_dyn: null pointer");
-  return rulebook_transpose_impl(coarse_keys, coarse_vals, coarse_capacity, fine_coords, n_fine_cap, n_fine_dev, ts_fine,
+  return rulebook_transpose_impl(coarse_table, coarse_capacity, fine_coords, n_fine_cap, n_fine_dev, ts_fine,
                                  ksize, tile_rows, nbr, tile_mask, n_slots, counters, stream);
 }
 

@@ -18,7 +18,7 @@ struct PyramidBuild {
   int64_t row_cap[8];        // 0 = exact-size mode
   int32_t *slot_of, *block_sums;
   bool batched;
-  int64_t n_keys, n_vals;
+  int64_t n_table_slots;     // slots of all levels' tables (one contiguous region)
   alignas(8) char batch_starts[8 * IMF_MAX_BATCH + 16];
 };
 

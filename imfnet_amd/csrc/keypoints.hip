@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_kp_insert(const double *__restrict__ sa
   if (i >= ns) return;
   uint64_t k = fnv_key(samples + 3 * i, voxel);
   if (k == kEmptyKey) k = kEmptyKey - 1;   // 2^-64: keep the sentinel free (probe applies the same map)
-  hash_insert(keys, capmask, k);
+  hash_insert_key(keys, capmask, k);
 }
 
 __device__ __forceinline__ bool set_contains(const uint64_t *__restrict__ keys, uint32_t capmask, uint64_t key) {

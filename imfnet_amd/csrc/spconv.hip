@@ -378,7 +378,7 @@ constexpr int kFirstRows = 32;
 
 template <int COUT>
 __global__ void __launch_bounds__(256)
-k_conv_first_fused(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, uint32_t capmask,
+k_conv_first_fused(const imf_slot *__restrict__ tab, uint32_t capmask,
                    const int32_t *__restrict__ coords, long long n, int ts, int ksize, int kvol,
                    const float *__restrict__ in, int cin, const float *__restrict__ w,
                    const float *__restrict__ scale, const float *__restrict__ shift, int relu,
@@ -390,10 +390,11 @@ k_conv_first_fused(const uint64_t *__restrict__ keys, const int32_t *__restrict_
   for (int i = tid; i < nw; i += 256) wl[i] = w[i];
   const long long row0 = (long long)blockIdx.x * kFirstRows;
   const int r = ksize >> 1;
-  // 16 probes per thread, issued as independent batches: all first-slot key loads, then all value
-  // loads; only a collision (rare: the level-0 table is <= 25 % full) falls back to the probe loop.
+  // 16 probes per thread, issued as one independent batch of 16-byte slot loads (key + row together);
+  // only a collision (rare: the level-0 table is <= 25 % full) falls back to the probe loop.
   constexpr int NP = kFirstRows * 128 / 256;
-  uint64_t want[NP], got[NP];
+  uint64_t want[NP];
+  uint4 got[NP];
   uint32_t hs[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
@@ -412,13 +413,14 @@ k_conv_first_fused(const uint64_t *__restrict__ keys, const int32_t *__restrict_
     }
   }
 #pragma unroll
-  for (int j = 0; j < NP; ++j) got[j] = keys[hs[j]];
+  for (int j = 0; j < NP; ++j) got[j] = *reinterpret_cast<const uint4 *>(tab + hs[j]);
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     int found = -1;
     if (want[j] != kEmptyKey) {
-      if (got[j] == want[j]) found = vals[hs[j]];
-      else if (got[j] != kEmptyKey) found = hash_find(keys, vals, capmask, want[j]);   // collision: slow path
+      const uint64_t k0 = ((uint64_t)got[j].y << 32) | got[j].x;
+      if (k0 == want[j]) found = (int)got[j].z;
+      else if (k0 != kEmptyKey) found = hash_find(tab, capmask, want[j]);   // collision: slow path
     }
     nbr_l[j * 256 + tid] = found;
   }
@@ -816,11 +818,11 @@ int imf_spconv_small_cin(const float *in, int cin, const float *w, int kvol, int
   return IMF_OK;
 }
 
-int imf_conv_first_fused(const uint64_t *keys, const int32_t *vals, int64_t capacity,
+int imf_conv_first_fused(const imf_slot *table, int64_t capacity,
                          const int32_t *coords, int64_t n, int ts, int ksize, const float *in, int cin,
                          const float *w, int cout, const float *scale, const float *shift, int relu,
                          float *out, void *stream) {
-  IMF_REQUIRE(keys && vals && coords && w && out, "imf_conv_first_fused: null pointer");
+  IMF_REQUIRE(table && coords && w && out, "imf_conv_first_fused: null pointer");
   IMF_REQUIRE(ksize == 3 || ksize == 5, "imf_conv_first_fused: ksize must be 3 or 5");
   IMF_REQUIRE(cin >= 1 && cin <= 4, "imf_conv_first_fused: cin=%d not in [1,4]", cin);
   IMF_REQUIRE(cout == 32 || cout == 64, "imf_conv_first_fused: cout=%d not in {32,64}", cout);
@@ -832,10 +834,10 @@ int imf_conv_first_fused(const uint64_t *keys, const int32_t *vals, int64_t capa
   hipStream_t st = (hipStream_t)stream;
   const long long nb = div_up(n, kFirstRows);
   if (cout == 32)
-    k_conv_first_fused<32><<<(unsigned)nb, 256, lds, st>>>(keys, vals, (uint32_t)(capacity - 1), coords, n, ts,
+    k_conv_first_fused<32><<<(unsigned)nb, 256, lds, st>>>(table, (uint32_t)(capacity - 1), coords, n, ts,
                                                           ksize, kvol, in, cin, w, scale, shift, relu, out);
   else
-    k_conv_first_fused<64><<<(unsigned)nb, 256, lds, st>>>(keys, vals, (uint32_t)(capacity - 1), coords, n, ts,
+    k_conv_first_fused<64><<<(unsigned)nb, 256, lds, st>>>(table, (uint32_t)(capacity - 1), coords, n, ts,
                                                           ksize, kvol, in, cin, w, scale, shift, relu, out);
   IMF_CHECK_LAUNCH("k_conv_first_fused");
   return IMF_OK;
@@ -850,7 +852,8 @@ size_t imf_bitgrid_words(const int32_t *bbox, int ksize) {
 
 static int conv_first_bitgrid_impl(const int32_t *coords, int64_t n, const int32_t *bbox, const DynGrid &dg, int ksize,
                                    uint32_t *grid, size_t grid_words, const float *w, int cout,
-                                   const float *scale, const float *shift, int relu, float *out, void *stream) {
+                                   const float *scale, const float *shift, int relu, float *out, void *stream,
+                                   bool grid_is_clear = false) {
   IMF_REQUIRE(coords && grid && w && out, "imf_conv_first_bitgrid: null pointer");
   IMF_REQUIRE(ksize == 3 || ksize == 5, "imf_conv_first_bitgrid: ksize must be 3 or 5");
   IMF_REQUIRE(cout == 32 || cout == 64, "imf_conv_first_bitgrid: cout=%d not in {32,64}", cout);
@@ -862,7 +865,7 @@ static int conv_first_bitgrid_impl(const int32_t *coords, int64_t n, const int32
     IMF_REQUIRE(bbox && grid_desc_from_bbox(bbox, ksize, g, words) && words <= grid_words,
                 "imf_conv_first_bitgrid: bounding box too large for the provided grid");
   hipStream_t st = (hipStream_t)stream;
-  IMF_CHECK_HIP(hipMemsetAsync(grid, 0, words * sizeof(uint32_t), st));
+  if (!grid_is_clear) IMF_CHECK_HIP(hipMemsetAsync(grid, 0, words * sizeof(uint32_t), st));
   k_bitgrid_fill<<<(unsigned)div_up(n, 256), 256, 0, st>>>(coords, n, grid, g, ksize, dg);
   const int kvol = ksize * ksize * ksize;
   const size_t lds = ((size_t)kBitsRows * kBitsLda + 128 * (size_t)cout) * sizeof(float);
@@ -907,3 +910,16 @@ int imf_conv_first_bitgrid_dyn(const int32_t *coords, int64_t n_cap, const int32
 }
 
 }  // extern "C"
+
+namespace imf {
+// imf_conv_first_bitgrid_dyn for a grid the caller has already zeroed (imf_fragment_forward clears it before the
+// level-0 pyramid: one launch and one kernel boundary fewer between the pyramid and conv1)
+int conv_first_bitgrid_dyn_cleared(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
+                                   int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
+                                   const float *scale, const float *shift, int relu, float *out, hipStream_t stream) {
+  IMF_REQUIRE(n_dev && bbox_dev && err && grid_words > 0, "imf_conv_first_bitgrid_dyn: null pointer");
+  DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words};
+  return conv_first_bitgrid_impl(coords, n_cap, nullptr, dg, ksize, grid, grid_words, w, cout, scale, shift, relu, out,
+                                 stream, true);
+}
+}  // namespace imf

@@ -37,6 +37,7 @@ struct ConvParams {
   int slots_extra;          // slots the rulebook lays out beyond roundup64(rows): 0, or 512 for transposed maps
   int split_min_blocks, split_target;
   int no_xcd_swizzle;       // A/B switch (env IMF_H3_NO_XCD): plain blockIdx.x -> tile order
+  int w_xcd;                // k_spconv_w: slab = f(XCD) workgroup order (env IMF_W_XCD)
   int geglu;                // epilogue of the fusion block's first feed-forward GEMM (variant 6, 64-column slabs, unsplit): the
                             // packed columns of slab y are [32 values | 32 gates] of hidden units 32 y .. 32 y + 31; the output
                             // is [n_out, cout / 2]: out = (v + shift_v) * gelu(g + shift_g), exact-erf GELU
@@ -218,5 +219,10 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
 // spconv_w.hip: variant 6 for the coarse levels -- one workgroup per (tile, 64-column slab), the tile's sub-stages split
 // over its `waves` (8 or 4) wavefronts, partial tiles combined through LDS, epilogue in the same launch
 void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t st);
+
+// spconv.hip: imf_conv_first_bitgrid_dyn on a grid the caller already zeroed
+int conv_first_bitgrid_dyn_cleared(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
+                                   int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
+                                   const float *scale, const float *shift, int relu, float *out, hipStream_t stream);
 
 }  // namespace imf

@@ -72,7 +72,16 @@ k_spconv_w(const ConvParams p) {
   unsigned *const stab = reinterpret_cast<unsigned *>(smem + W * REG_F4 + NBR_F4);        // [kSubTab]
   int *const klist = reinterpret_cast<int *>(smem + W * REG_F4 + NBR_F4 + TAB_F4);        // [kKCache]
 
-  const int tile = blockIdx.x, y = blockIdx.y;
+  // XCD-aware (tile, slab) order (p.w_xcd): workgroups go to the 8 XCDs round-robin in launch order, so with the plain
+  // (x = tile, y = slab) order every XCD's 4 MiB L2 sees every slab of the weight image (7 MB for 256 -> 256).  Here the
+  // slab is a function of the XCD (launch index mod 8), each L2 then holds 1 / n_slabs of the weights.
+  int tile = blockIdx.x, y = blockIdx.y;
+  if (p.w_xcd && gridDim.y > 1 && gridDim.y <= 8 && (gridDim.y & (gridDim.y - 1)) == 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, ns = gridDim.y;
+    const unsigned xcd = lin & 7u, j = lin >> 3;
+    y = (int)(xcd % ns);
+    tile = (int)(j * (8u / ns) + xcd / ns);
+  }
   long long slots_act = p.n_slots;
   if (p.n_out_dev) {                                 // capacity mode: tiles beyond the actual rows leave
     slots_act = conv_slots(p, conv_rows(p));
@@ -289,7 +298,10 @@ k_spconv_w(const ConvParams p) {
 }
 
 // grid = (tiles, cout / 64); `waves` = 8 (512 threads, one workgroup per CU) or 4 (256 threads, two per CU)
-void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t st) {
+void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st) {
+  static const int xcd_env = getenv("IMF_W_XCD") ? atoi(getenv("IMF_W_XCD")) : 1;   // measured: pair step 1.092 -> 1.074 ms
+  ConvParams p = p_in;
+  p.w_xcd = xcd_env;
   const dim3 grid(tiles, (unsigned)(p.cout / 64), 1);
   const bool cat = p.c_b > 0;
   if (waves == 8) {

@@ -178,8 +178,8 @@ def save_npz(path, level=None, **arrays):
     names = list(arrays)
     arrs = [np.ascontiguousarray(arrays[k]) for k in names]
     for a in arrs:
-        if a.dtype.byteorder == ">" or a.dtype.hasobject or a.dtype.fields is not None:
-            return np.savez_compressed(path, **arrays)        # exotic dtypes: numpy's writer
+        if a.dtype.byteorder == ">" or a.dtype.hasobject or a.dtype.fields is not None or a.dtype.kind not in "fiub":
+            return np.savez_compressed(path, **arrays)        # strings / exotic dtypes: numpy's writer
     n = len(arrs)
     c_names = (C.c_char_p * n)(*[k.encode() for k in names])
     c_dtype = (C.c_char_p * n)(*[a.dtype.str.replace("=", "<").replace("|", "|").encode() for a in arrs])

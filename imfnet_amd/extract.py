@@ -12,7 +12,8 @@ import torch
 
 from . import ops
 from . import sparse as ME
-from ._lib import FLAG_RANGE, ImfError
+from .model import graph
+from ._lib import FLAG_RANGE, ImfError, check
 
 
 def _cuda_device(device):
@@ -96,6 +97,47 @@ def sparse_tensor_from_points(xyz, voxel_size, device, feats=None, before_sync=N
     return st, inds
 
 
+def _host_inputs(xyz, image):
+    """(points as a host float32 / float64 array, image as a host float32 array), or None when either lives on the GPU."""
+    if (torch.is_tensor(xyz) and xyz.is_cuda) or (torch.is_tensor(image) and image.is_cuda):
+        return None
+    a = xyz.detach().numpy() if torch.is_tensor(xyz) else np.asarray(xyz)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    img = image.detach().numpy() if torch.is_tensor(image) else np.asarray(image)
+    return np.ascontiguousarray(a), np.ascontiguousarray(img, dtype=np.float32)
+
+
+def _submit_host(runner, slot, host_xyz, host_img, voxel_size, device, stream):
+    """Stage one host fragment through `slot` (pinned), launch it in capacity mode and queue the copy back -- ONE
+    host-to-device copy (scalars | image | points) and ONE device-to-host copy (counts | xyz_down | descriptors) per
+    fragment; xyz_down = xyz[inds] is gathered on the device (imf_gather_points).  Asynchronous; `slot.done` marks
+    completion.  Returns (result, views of the slot's pinned blocks) or None when no capacities are known."""
+    n = host_xyz.shape[0]
+    key = runner.caps_for(n, 1, int(host_img.shape[2]), int(host_img.shape[3]), voxel_size, host_xyz.dtype == np.float64)
+    if key is None:
+        return None
+    b = runner.bucket(key, device, stream)
+    v = slot.bind(b)
+    np.copyto(v["xyz"][:n], host_xyz)
+    np.copyto(v["image"], host_img)
+    vals = [n, 1, 0]
+    v["dyn"][:len(vals)] = vals
+    rows = b.caps.rows[0]
+    used_in = b.lay["xyz"] + n * 3 * host_xyz.dtype.itemsize
+    with torch.cuda.stream(stream):
+        b.inbuf[:used_in].copy_(slot.inbuf[:used_in], non_blocking=True)
+    b.dyn_values = vals
+    res = runner.launch(b, n, 1, stream, meta_to=(v["meta"], slot.done))
+    check(runner.L.imf_gather_points(b.xyz.data_ptr(), int(b.xyz.dtype == torch.float64), b.first_idx_view().data_ptr(),
+                                     b.meta.data_ptr(), rows, b.sel.data_ptr(), stream.cuda_stream), "imf_gather_points")
+    with torch.cuda.stream(stream):
+        nb = b.outbuf.numel()
+        slot.outbuf[:nb].copy_(b.outbuf, non_blocking=True)
+        slot.done.record(stream)
+    return res, v
+
+
 def _extract_with_runner(runner, xyz, voxel_size, device, image):
     """extract_features through the capacity-mode graph; None = not applicable / flagged (caller runs the exact path)."""
     n = int(xyz.shape[0])
@@ -103,13 +145,40 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image):
     img = image if torch.is_tensor(image) else torch.as_tensor(np.asarray(image), dtype=torch.float32)
     if img.dim() != 4 or img.shape[0] != 1:
         return None
+    stream, outer = runner._stream_for(device, None)
+    host = _host_inputs(xyz, image)
+    if host is not None:
+        # host arrays (the reference's call, scripts/generate_desc.py:100): pinned staging both ways -- a parallel CPU
+        # copy + asynchronous DMA instead of the runtime's blocking pageable copies; xyz_down = xyz[inds] is gathered on
+        # the device (imf_gather_points) and comes back with the counts
+        slots = runner.host_slots
+        slot = slots[0] if slots else graph.HostSlot()
+        if not slots:
+            slots.append(slot)
+        got = _submit_host(runner, slot, host[0], host[1], voxel_size, device, stream)
+        if got is None:
+            return None
+        res, v = got
+        with torch.cuda.stream(stream):
+            F = res.bucket.out.clone()                # the caller owns its descriptors (the bucket is reused)
+        slot.done.synchronize()
+        if res.flags:                                 # does not fit this bucket: exact path (which re-observes)
+            runner.stats["redone"] += 1
+            if outer is not None:
+                outer.wait_stream(stream)
+            return None
+        m = res.counts[0]
+        sel = v["sel"][:m].copy()
+        if outer is not None:
+            outer.wait_stream(stream)
+        F = F[:m]
+        F.host = v["F"][:m]                           # the same descriptors, already on the host (pinned; valid until the
+        return sel, F                                 # next extract_features call): saves the caller's F.cpu()
     key = runner.caps_for(n, 1, int(img.shape[2]), int(img.shape[3]), voxel_size, is_f64)
     if key is None:
         return None
-    stream, outer = runner._stream_for(device, None)
     b = runner.bucket(key, device, stream)
-    src = xyz if torch.is_tensor(xyz) else torch.from_numpy(np.ascontiguousarray(np.asarray(xyz)))
-    runner.stage(b, src, [0], img, stream)
+    runner.stage(b, xyz, [0], img, stream)
     res = runner.launch(b, n, 1, stream)
     if res.flags:                                     # does not fit this bucket: exact path (which re-observes)
         runner.stats["redone"] += 1
@@ -123,11 +192,82 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image):
             sel = xyz.detach()[inds].cpu().numpy().astype(np.float64)
         else:
             inds_host = inds.cpu().numpy()
-            host = xyz.detach().numpy() if torch.is_tensor(xyz) else np.asarray(xyz)
-            sel = host[inds_host].astype(np.float64, copy=False)
+            host_xyz = xyz.detach().numpy() if torch.is_tensor(xyz) else np.asarray(xyz)
+            sel = host_xyz[inds_host].astype(np.float64, copy=False)
     if outer is not None:
         outer.wait_stream(stream)
     return sel, F
+
+
+def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, copy=True):
+    """`extract_features` over a STREAM of host fragments (SURVEY 8d's span -- host arrays in, descriptors back on the
+    host -- pipelined): yields (xyz_down float64 [M,3], F float32 [M,32] numpy) per fragment, in order.  `fragments`:
+    iterable of (xyz [N,3] host array, image [1,3,H,W] host array).  Up to `depth` fragments are queued on the GPU, so
+    the host's share of fragment i + 1 (pinned staging, ~150 launches) runs under fragment i's kernels; per fragment the
+    stream carries one H2D copy, the forward and one D2H copy.  (Copies on streams of their own -- device mirrors per
+    slot, events both ways -- were measured SLOWER on this stack: 2.0-2.7 vs 1.3 ms per fragment, tools/e2e_probe.py.)
+    copy=True: the arrays of a yield are fresh host copies; copy=False: views of the pinned slot, valid until the NEXT
+    item is requested (a 6.5 MB copy into newly faulted pages costs ~0.3 ms per fragment).  Fragments the capacity mode
+    cannot take (no capacities yet, a flag) go through `extract_features`, in order."""
+    from collections import deque
+    device = _cuda_device(device or 'cuda:0')
+    if model.training:
+        model.eval()
+    runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
+    n_slots = max(1, depth) + 1
+    cache = getattr(runner, "stream_state", None) if runner is not None else None
+    if cache is None or cache[0] != device or len(cache[2]) < n_slots:
+        cache = (device, torch.cuda.Stream(device=device), [graph.HostSlot() for _ in range(n_slots)])
+        if runner is not None:
+            runner.stream_state = cache               # pinned slots are expensive to create: kept with the runner
+    _, stream, slots = cache
+    free = list(slots[:n_slots])
+    inflight = deque()
+    lent = []                                         # the slot whose views the consumer currently holds (copy=False)
+
+    def finish(entry):
+        xyz, image, slot, got = entry
+        while lent:
+            free.append(lent.pop())
+        if got is not None:
+            res, v = got
+            slot.done.synchronize()
+            if not res.flags:
+                m = res.counts[0]
+                if copy:
+                    out = v["sel"][:m].copy(), v["F"][:m].copy()
+                    free.append(slot)
+                else:
+                    out = v["sel"][:m], v["F"][:m]
+                    lent.append(slot)
+                return out
+            runner.stats["redone"] += 1
+        free.append(slot)
+        with torch.no_grad():
+            xd, F = extract_features(model, xyz, voxel_size=voxel_size, device=device, skip_check=True, image=image)
+        return xd, F.cpu().numpy()
+
+    with torch.no_grad():
+        for xyz, image in fragments:
+            host = _host_inputs(xyz, image)
+            if host is None:
+                raise ImfError("extract_features_stream takes host arrays")
+            while len(free) < 2 and inflight:         # one slot stays spare: a lent one comes back at the next finish
+                yield finish(inflight.popleft())
+            slot = free.pop()
+            got = None
+            if runner is not None and runner.ratios is not None:
+                got = _submit_host(runner, slot, host[0], host[1], voxel_size, device, stream)
+            if got is None:                           # teach the runner on the exact path first, in order
+                while inflight:
+                    yield finish(inflight.popleft())
+                yield finish((host[0], host[1], slot, None))
+                runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
+                continue
+            inflight.append((host[0], host[1], slot, got))
+        while inflight:
+            yield finish(inflight.popleft())
+    torch.cuda.current_stream(device).wait_stream(stream)
 
 
 def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=None,

@@ -35,23 +35,25 @@ def _grid_up(v, ratio, lo):
 
 
 class FragmentResult:
-    """Device-side result of one launch; `sync()` reads the counts back (one small pinned D2H + event wait)."""
+    """Device-side result of one launch; `sync()` reads the counts back (one small pinned D2H + event wait).
+    pooled=False: the meta words arrive inside a caller-owned pinned buffer (HostSlot) with the caller's event."""
 
-    def __init__(self, bucket, n_points, n_items, meta_host, done):
+    def __init__(self, bucket, n_points, n_items, meta_host, done, pooled=True):
         self.bucket, self.n_points, self.n_items = bucket, n_points, n_items
-        self._host, self._done, self._meta = meta_host, done, None
+        self._host, self._done, self._meta, self._pooled = meta_host, done, None, pooled
 
     def sync(self):
         if self._meta is None:
             self._done.synchronize()
             self._meta = self._host.numpy().copy()
-            self.bucket.pool.append((self._host, self._done))
+            if self._pooled:
+                self.bucket.pool.append((self._host, self._done))
             self._host = self._done = None
         return self._meta
 
     def __del__(self):
         try:
-            if self._host is not None:                # never read: hand the pair back (reused once its event completed)
+            if self._host is not None and self._pooled:   # never read: hand the pair back (reused once its event completed)
                 self.bucket.pool.append((self._host, self._done))
         except Exception:                             # noqa: BLE001 -- interpreter shutdown
             pass
@@ -84,22 +86,69 @@ class FragmentResult:
         return self.bucket.first_idx_view()[: self.counts[0]]
 
 
+def _pad256(n):
+    return (int(n) + 255) // 256 * 256
+
+
+class HostSlot:
+    """Pinned host staging of one in-flight fragment, laid out like its capacity bucket's two device blocks:
+        in : [dyn scalars | image | points]                      -> ONE host-to-device copy per fragment
+        out: [meta (counts, flags) | xyz_down | descriptors]     <- ONE device-to-host copy per fragment
+    (every hipMemcpyAsync costs the host ~0.1 ms on this stack, whatever its size: tools/e2e_probe.py).  Host arrays are
+    copied in with a plain single-threaded memcpy (np.copyto: 0.13 ms for 6 MB) -- torch's CPU copy_ fans a copy of that
+    size out over its whole thread pool, and waking 128 idle OpenMP threads was measured at 10-30 ms per call."""
+
+    def __init__(self):
+        self.inbuf = self.outbuf = None
+        self.done = torch.cuda.Event()
+        self._views = None
+
+    def bind(self, b):
+        """Views of the pinned blocks in bucket b's layout (blocks grow on demand)."""
+        if self._views is not None and self._views[0] is b:
+            return self._views[1]
+        if self.inbuf is None or self.inbuf.numel() < b.inbuf.numel():
+            self.inbuf = torch.empty(b.inbuf.numel(), dtype=torch.uint8).pin_memory()
+        if self.outbuf is None or self.outbuf.numel() < b.outbuf.numel():
+            self.outbuf = torch.empty(b.outbuf.numel(), dtype=torch.uint8).pin_memory()
+        L, hi, ho = b.lay, self.inbuf.numpy(), self.outbuf.numpy()
+        v = dict(dyn=hi[:4 * DYN_WORDS].view(np.int32),
+                 image=hi[L["img"]:L["img"] + b.image.numel() * 4].view(np.float32).reshape(tuple(b.image.shape)),
+                 xyz=hi[L["xyz"]:L["xyz"] + b.xyz.numel() * b.xyz.element_size()]
+                     .view(np.float64 if b.xyz.dtype == torch.float64 else np.float32).reshape(-1, 3),
+                 meta=self.outbuf[:4 * META_WORDS].view(torch.int32),
+                 sel=ho[L["sel"]:L["sel"] + b.sel.numel() * 8].view(np.float64).reshape(-1, 3),
+                 F=ho[L["F"]:L["F"] + b.out.numel() * 4].view(np.float32).reshape(tuple(b.out.shape)))
+        self._views = (b, v)
+        return v
+
+
 class _Bucket:
     def __init__(self, runner, caps_tuple, dev):
         L = self.L = runner.L
         n_points, rows, n_items, H, W, grid_words, voxel, is_f64 = caps_tuple
         self.key, self.dev = caps_tuple, dev
+        net, img = runner.net_desc, runner.img_plan
         c = self.caps = FragmentCaps()
         c.n_points, c.n_items, c.img_h, c.img_w, c.bitgrid_words = n_points, n_items, H, W, grid_words
         for i in range(4):
             c.rows[i] = rows[i]
-        net, img = runner.net_desc, runner.img_plan
         u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)      # noqa: E731
-        self.xyz = torch.zeros((n_points, 3), dtype=torch.float64 if is_f64 else torch.float32, device=dev)
-        self.image = torch.zeros((n_items, 3, H, W), dtype=torch.float32, device=dev)
-        self.dyn = torch.zeros(DYN_WORDS, dtype=torch.int32, device=dev)
+        # inputs and outputs are views of two contiguous device blocks (see HostSlot): in = dyn | image | points,
+        # out = meta | xyz_down | descriptors
+        isz = 8 if is_f64 else 4
+        lay = self.lay = dict(img=_pad256(4 * DYN_WORDS))
+        lay["xyz"] = lay["img"] + _pad256(n_items * 3 * H * W * 4)
+        lay["sel"] = _pad256(4 * META_WORDS)
+        lay["F"] = lay["sel"] + _pad256(rows[0] * 24)
+        self.inbuf = torch.zeros(lay["xyz"] + _pad256(n_points * 3 * isz), dtype=torch.uint8, device=dev)
+        self.outbuf = torch.zeros(lay["F"] + _pad256(rows[0] * net.out_channels * 4), dtype=torch.uint8, device=dev)
+        self.xyz = self.inbuf[lay["xyz"]:lay["xyz"] + n_points * 3 * isz].view(torch.float64 if is_f64 else torch.float32).view(n_points, 3)
+        self.image = self.inbuf[lay["img"]:lay["img"] + n_items * 3 * H * W * 4].view(torch.float32).view(n_items, 3, H, W)
+        self.dyn = self.inbuf[:4 * DYN_WORDS].view(torch.int32)
         self.dyn_values = None                        # what the device copy currently holds
-        self.meta = torch.zeros(META_WORDS, dtype=torch.int32, device=dev)
+        self.meta = self.outbuf[:4 * META_WORDS].view(torch.int32)
+        self.sel = self.outbuf[lay["sel"]:lay["sel"] + rows[0] * 24].view(torch.float64).view(rows[0], 3)   # xyz[inds]
         self.pool = []                                # (pinned meta copy, event) pairs of finished results
         self.pyr = u8(L.imf_fragment_pyramid_bytes(C.byref(c)))
         ib = img.buffers(dev, n_items, H, W, private=True)
@@ -107,7 +156,7 @@ class _Bucket:
         rows_c = (C.c_int64 * 4)(*rows)
         self.iarena = u8(L.imf_resunet_int_arena_bytes_cap(C.byref(net), rows_c, grid_words))
         self.farena = u8(L.imf_resunet_float_arena_bytes_cap(C.byref(net), rows_c))
-        self.out = torch.empty((rows[0], net.out_channels), dtype=torch.float32, device=dev)
+        self.out = self.outbuf[lay["F"]:lay["F"] + rows[0] * net.out_channels * 4].view(torch.float32).view(rows[0], net.out_channels)
         self.events = [L.imf_event_create() for _ in range(11)]
         io = self.io = FragmentIO()
         io.xyz, io.xyz_is_f64, io.voxel_size = self.xyz.data_ptr(), int(is_f64), float(voxel)
@@ -199,6 +248,8 @@ class FragmentRunner:
         # 1.37 ms per fragment pair), the eager capacity-mode call keeps the three streams concurrent
         self.use_graph = bool(os.environ.get("IMFNET_FRAGMENT_GRAPH"))
         self.stats = dict(graph=0, eager=0, redone=0, captured=0)
+        self.host_slots = []          # pinned staging of the synchronous host-array path (extract.py)
+        self.stream_state = None      # streams + pinned slots of extract_features_stream
 
     # -- capacity policy ----------------------------------------------------------------------------
     def observe(self, n_points, counts, bbox):
@@ -274,7 +325,7 @@ class FragmentRunner:
                 b.dyn_values = vals
         return n
 
-    def launch(self, b, n_points, n_items, stream, trace_list=None):
+    def launch(self, b, n_points, n_items, stream, trace_list=None, meta_to=None):
         """One fragment on `stream`: graph replay (captured on first use) or eager capacity-mode launches (always
         when `trace_list` is given: per-convolution HIP events are appended to it as ops.TRACE records)."""
         from .. import ops
@@ -295,17 +346,20 @@ class FragmentRunner:
                     self.stats["captured"] += 1
                 check(self.L.imf_graph_launch(b.graph, stream.cuda_stream), "imf_graph_launch")
                 self.stats["graph"] += 1
-            host = done = None
-            for i, (h, d) in enumerate(b.pool):       # a pair whose previous copy has landed (never wait here)
-                if d.query():
-                    host, done = b.pool.pop(i)
-                    break
-            if host is None:
-                host, done = torch.zeros(META_WORDS, dtype=torch.int32).pin_memory(), torch.cuda.Event()
-            host.copy_(b.meta, non_blocking=True)
-            done.record(stream)
+            if meta_to is not None:                   # (pinned int32 view, event): the caller's own copy carries the counts
+                host, done = meta_to
+            else:
+                host = done = None
+                for i, (h, d) in enumerate(b.pool):   # a pair whose previous copy has landed (never wait here)
+                    if d.query():
+                        host, done = b.pool.pop(i)
+                        break
+                if host is None:
+                    host, done = torch.zeros(META_WORDS, dtype=torch.int32).pin_memory(), torch.cuda.Event()
+                host.copy_(b.meta, non_blocking=True)
+                done.record(stream)
         b.launches += 1
-        res = FragmentResult(b, n_points, n_items, host, done)
+        res = FragmentResult(b, n_points, n_items, host, done, pooled=meta_to is None)
         if trace_list is not None:
             arena = b.iarena.view(torch.int32)
             for i, e in enumerate(evs):

@@ -176,12 +176,12 @@ class FusedPlan:
         # stream while conv1 / block1 (MFMA-bound, whole GPU) run; each group is joined by an event
         # right before its first use.
         def build_conv(rb, in_lv, out_lv, ksize, stream):
-            check(L.imf_rulebook_conv(in_lv.keys.data_ptr(), in_lv.vals.data_ptr(), in_lv.capacity,
+            check(L.imf_rulebook_conv(in_lv.table.data_ptr(), in_lv.capacity,
                                       out_lv.coords_buf.data_ptr(), out_lv.n, in_lv.ts, ksize, rb.tile_rows,
                                       rb.nbr, rb.tile_mask, stream), "imf_rulebook_conv")
 
         def build_up(i, stream):
-            check(L.imf_rulebook_transpose(lv[i + 1].keys.data_ptr(), lv[i + 1].vals.data_ptr(),
+            check(L.imf_rulebook_transpose(lv[i + 1].table.data_ptr(),
                                            lv[i + 1].capacity, lv[i].coords_buf.data_ptr(), n[i], 1 << i, 3,
                                            rb_up[i].tile_rows, rb_up[i].nbr, rb_up[i].tile_mask,
                                            rb_up[i].n_slots, counters[i], stream), "imf_rulebook_transpose")
@@ -270,7 +270,7 @@ class FusedPlan:
                                                sc.data_ptr(), sh.data_ptr(), 0, addr["e0a"], st),
                       "imf_conv_first_bitgrid")
             else:
-                check(L.imf_conv_first_fused(lv[0].keys.data_ptr(), lv[0].vals.data_ptr(), lv[0].capacity,
+                check(L.imf_conv_first_fused(lv[0].table.data_ptr(), lv[0].capacity,
                                              lv[0].coords_buf.data_ptr(), n[0], 1, self.first_ksize,
                                              None if ones else x.F.data_ptr(), x.F.shape[1],
                                              self.first_kernel.data_ptr(), Ch[1], sc.data_ptr(), sh.data_ptr(),
@@ -356,7 +356,7 @@ class NativePlan:
             side = self._side[dev] = torch.cuda.Stream(device=dev)
         for i, l in enumerate(lv):
             ld = io.level[i]
-            ld.coords, ld.keys, ld.vals = l.coords_buf.data_ptr(), l.keys.data_ptr(), l.vals.data_ptr()
+            ld.coords, ld.table = l.coords_buf.data_ptr(), l.table.data_ptr()
             ld.capacity, ld.tensor_stride = l.capacity, l.ts
             self._n[i] = io.n[i] = l.n
         bbox = getattr(lv[0], "bbox", None)

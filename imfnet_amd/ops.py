@@ -6,7 +6,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, ImfError, LevelDesc, TILE_ROWS, MASK_WORDS, check
+from ._lib import ConvArgs, HeadArgs, ImfError, LevelDesc, TILE_ROWS, MASK_WORDS, check
 
 
 # When set to a list, every sparse-conv launch is bracketed by HIP events recorded on the launch
@@ -56,12 +56,12 @@ def _req(t, dtype, name, ndim=None):
 
 class Level:
     """One coordinate map: rows `coords[:n]` (int32 (b,x,y,z)) at tensor stride `ts`, and the
-    voxel hash (keys/vals) mapping a coordinate to its row."""
-    __slots__ = ("coords_buf", "n_dev", "n", "keys", "vals", "capacity", "ts", "first_idx_buf")
+    voxel hash (`table`: 16-byte {key, row} slots, struct imf_slot) mapping a coordinate to its row."""
+    __slots__ = ("coords_buf", "n_dev", "n", "table", "capacity", "ts", "first_idx_buf")
 
-    def __init__(self, coords_buf, n_dev, keys, vals, capacity, ts, first_idx_buf=None):
+    def __init__(self, coords_buf, n_dev, table, capacity, ts, first_idx_buf=None):
         self.coords_buf, self.n_dev, self.n = coords_buf, n_dev, None
-        self.keys, self.vals, self.capacity, self.ts = keys, vals, capacity, ts
+        self.table, self.capacity, self.ts = table, capacity, ts
         self.first_idx_buf = first_idx_buf
 
     @property
@@ -94,7 +94,7 @@ class ArenaLevel(Level):
     __slots__ = ("arena", "_desc", "_coords_view", "_first_view", "bbox", "items")
 
     def __init__(self, arena, desc, n_dev):
-        Level.__init__(self, _Addr(desc.coords), n_dev, _Addr(desc.keys), _Addr(desc.vals), desc.capacity,
+        Level.__init__(self, _Addr(desc.coords), n_dev, _Addr(desc.table), desc.capacity,
                        desc.tensor_stride, _Addr(desc.first_idx) if desc.first_idx else None)
         self.arena, self._desc, self._coords_view, self._first_view = arena, desc, None, None
         self.bbox = None              # level 0: [min b,x,y,z, max b,x,y,z] (host ints)
@@ -236,10 +236,9 @@ class Rulebook:
 def _new_table(n, device):
     L = _lib.lib()
     cap = L.imf_hash_capacity(n)
-    keys = torch.empty(cap, dtype=torch.int64, device=device)
-    vals = torch.empty(cap, dtype=torch.int32, device=device)
+    table = torch.empty((cap, 2), dtype=torch.int64, device=device)      # struct imf_slot {u64 key; i32 val; i32 pad}
     ws = torch.empty(L.imf_unique_workspace_bytes(n), dtype=torch.uint8, device=device)
-    return cap, keys, vals, ws
+    return cap, table, ws
 
 
 def new_meta(n_levels, device):
@@ -257,16 +256,16 @@ def voxelize(xyz, voxel_size, batch_index=0, meta=None):
     n, dev = xyz.shape[0], xyz.device
     if n == 0 or xyz.shape[1] != 3:
         raise ImfError(f"xyz must be [N>0, 3], got {tuple(xyz.shape)}")
-    cap, keys, vals, ws = _new_table(n, dev)
+    cap, table, ws = _new_table(n, dev)
     coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
     first = torch.empty(n, dtype=torch.int32, device=dev)
     if meta is None:
         meta = torch.zeros(2, dtype=torch.int32, device=dev)       # [m, err]
     check(_lib.lib().imf_voxelize(xyz.data_ptr(), int(xyz.dtype == torch.float64), n, float(voxel_size),
                                   int(batch_index), coords.data_ptr(), first.data_ptr(),
-                                  meta[0:1].data_ptr(), keys.data_ptr(), vals.data_ptr(), cap,
+                                  meta[0:1].data_ptr(), table.data_ptr(), cap,
                                   ws.data_ptr(), meta[1:2].data_ptr(), _stream()), "imf_voxelize")
-    lv = Level(coords, meta, keys, vals, cap, 1, first)
+    lv = Level(coords, meta, table, cap, 1, first)
     return lv
 
 
@@ -274,13 +273,13 @@ def downsample(level, out_stride, n_in_max=None, meta=None):
     """coordinate_manager.stride(): level at tensor stride `out_stride` (asynchronous)."""
     n_max = int(n_in_max if n_in_max is not None else level.n)
     dev = level.device
-    cap, keys, vals, ws = _new_table(n_max, dev)
+    cap, table, ws = _new_table(n_max, dev)
     coords = torch.empty((n_max, 4), dtype=torch.int32, device=dev)
     m = meta if meta is not None else torch.zeros(2, dtype=torch.int32, device=dev)   # [m, unused]
     check(_lib.lib().imf_downsample(level.coords_buf.data_ptr(), level.n_dev.data_ptr(), n_max,
-                                    int(out_stride), coords.data_ptr(), m.data_ptr(), keys.data_ptr(),
-                                    vals.data_ptr(), cap, ws.data_ptr(), _stream()), "imf_downsample")
-    return Level(coords, m, keys, vals, cap, out_stride)
+                                    int(out_stride), coords.data_ptr(), m.data_ptr(), table.data_ptr(),
+                                    cap, ws.data_ptr(), _stream()), "imf_downsample")
+    return Level(coords, m, table, cap, out_stride)
 
 
 def level_from_coords(coords):
@@ -289,7 +288,7 @@ def level_from_coords(coords):
     _req(coords, torch.int32, "coordinates", 2)
     n = coords.shape[0]
     n_dev = torch.tensor([n, 0], dtype=torch.int32, device=coords.device)
-    src = Level(coords, n_dev, None, None, 0, 1)
+    src = Level(coords, n_dev, None, 0, 1)
     src.n = n
     lv = downsample(src, 1)
     lv.ts = 1
@@ -318,7 +317,7 @@ def rulebook_conv(in_level, out_level, ksize):
     tile_rows = torch.empty(n_slots, dtype=torch.int32, device=dev)
     nbr = torch.empty(kvol * n_slots, dtype=torch.int32, device=dev)
     mask = torch.empty(n_slots // TILE_ROWS * MASK_WORDS, dtype=torch.int32, device=dev)
-    check(L.imf_rulebook_conv(in_level.keys.data_ptr(), in_level.vals.data_ptr(), in_level.capacity,
+    check(L.imf_rulebook_conv(in_level.table.data_ptr(), in_level.capacity,
                               out_level.coords_buf.data_ptr(), n_out, in_level.ts, ksize,
                               tile_rows.data_ptr(), nbr.data_ptr(), mask.data_ptr(), _stream()),
           "imf_rulebook_conv")
@@ -335,7 +334,7 @@ def rulebook_transpose(coarse_level, fine_level, ksize=3):
     nbr = torch.empty(kvol * n_slots, dtype=torch.int32, device=dev)
     mask = torch.empty(n_slots // TILE_ROWS * MASK_WORDS, dtype=torch.int32, device=dev)
     counters = torch.empty(16, dtype=torch.int32, device=dev)
-    check(L.imf_rulebook_transpose(coarse_level.keys.data_ptr(), coarse_level.vals.data_ptr(),
+    check(L.imf_rulebook_transpose(coarse_level.table.data_ptr(),
                                    coarse_level.capacity, fine_level.coords_buf.data_ptr(), n_fine,
                                    fine_level.ts, ksize, tile_rows.data_ptr(), nbr.data_ptr(),
                                    mask.data_ptr(), n_slots, counters.data_ptr(), _stream()),
@@ -383,6 +382,8 @@ H3_DMA = int(os.environ.get("IMF_H3_GLDS", "1")) != 0
 
 
 def conv_kernel_name(variant, cin, cout, staging=None, kernel_tag=0):
+    if kernel_tag & 16:
+        return "k_pointwise_head"
     if variant == 6 and (kernel_tag & 12 or staging in ("wave8", "wave4")):
         return f"k_spconv_w<{8 if (kernel_tag & 4 or staging == 'wave8') else 4}>"
     if variant == 6:
@@ -447,6 +448,34 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     return out
 
 
+def pointwise_head(in_a, in_b, w1_packed, w2_packed, scale1=None, shift1=None, relu1=True, scale2=None, shift2=None,
+                   l2norm=True, out=None, flags=None, n_dev=None):
+    """imf_pointwise_head: conv1_tr + norm1_tr + ReLU + final + L2 normalisation (model/resunet.py:219-233) in one
+    launch.  in_a [n, c_a], in_b [n, c_b] or None; weight images from pack_weights_split16 (kvol 1); hidden width 64,
+    output [n, 32].  Bit-identical to two `spconv(..., variant=6)` calls."""
+    _req(in_a, torch.float32, "in_a", 2)
+    if in_b is not None:
+        _req(in_b, torch.float32, "in_b", 2)
+        if in_b.shape[0] != in_a.shape[0]:
+            raise ImfError("pointwise_head: in_a / in_b row mismatch")
+    n = in_a.shape[0]
+    if out is None:
+        out = torch.empty((n, 32), dtype=torch.float32, device=in_a.device)
+    a = HeadArgs()
+    a.in_a, a.in_b = in_a.data_ptr(), _ptr(in_b)
+    a.c_a, a.c_b = in_a.shape[1], (0 if in_b is None else in_b.shape[1])
+    L = _lib.lib()
+    if w1_packed.numel() != L.imf_packed_weight_floats_split16(1, a.c_a + a.c_b, 64) or \
+            w2_packed.numel() != L.imf_packed_weight_floats_split16(1, 64, 32):
+        raise ImfError("pointwise_head: packed weight images do not match [c_a + c_b, 64] / [64, 32] (split16)")
+    a.w1_packed, a.scale1, a.shift1, a.relu1, a.c_mid = w1_packed.data_ptr(), _ptr(scale1), _ptr(shift1), int(bool(relu1)), 64
+    a.w2_packed, a.scale2, a.shift2, a.l2norm, a.c_out = w2_packed.data_ptr(), _ptr(scale2), _ptr(shift2), int(bool(l2norm)), 32
+    a.n, a.n_dev, a.out = n, _ptr(n_dev), out.data_ptr()
+    a.flags = None if flags is None else flags.data_ptr()
+    check(L.imf_pointwise_head(C.byref(a), _stream()), "imf_pointwise_head")
+    return out
+
+
 def spconv_small_cin(feat, kernel, rb, scale=None, shift=None, relu=False):
     """First-layer conv for cin <= 4 (unpacked ME kernel [kvol,cin,cout])."""
     _req(feat, torch.float32, "feat", 2)
@@ -471,7 +500,7 @@ def conv_first_fused(level, feat, kernel, ksize, scale=None, shift=None, relu=Fa
     if feat is not None:
         _req(feat, torch.float32, "feat", 2)
     out = torch.empty((level.n, cout), dtype=torch.float32, device=k.device)
-    check(_lib.lib().imf_conv_first_fused(level.keys.data_ptr(), level.vals.data_ptr(), level.capacity,
+    check(_lib.lib().imf_conv_first_fused(level.table.data_ptr(), level.capacity,
                                           level.coords_buf.data_ptr(), level.n, level.ts, ksize, _ptr(feat),
                                           cin, k.data_ptr(), cout, _ptr(scale), _ptr(shift), int(bool(relu)),
                                           out.data_ptr(), _stream()), "imf_conv_first_fused")

@@ -42,11 +42,18 @@ int imf_version(void);
 const char *imf_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
- * Voxel hash.  Open-addressing table of `capacity` slots (power of two):
- *   keys  uint64[capacity]   packed (b,x,y,z), 0xFFFF... = empty
- *   vals  int32 [capacity]   row index of that voxel in its level
+ * Voxel hash.  Open-addressing table of `capacity` 16-byte slots (power of two), linear probing:
+ *   key   uint64   packed (b,x,y,z), 0xFFFF... = empty
+ *   val   int32    row index of that voxel in its level
+ * Key and value share a slot so that a probe that hits is ONE 16-byte load (the rulebook builds are bound by
+ * the number of random loads they issue: with separate key / value arrays a hit cost a second random line).
  * Capacity to use for n keys: imf_hash_capacity(n).
  * ---------------------------------------------------------------------------------------------- */
+typedef struct imf_slot {
+  uint64_t key;
+  int32_t val;
+  int32_t pad;
+} imf_slot;
 int64_t imf_hash_capacity(int64_t n);
 
 /* Bytes of scratch imf_voxelize / imf_downsample need for n input rows. */
@@ -62,12 +69,12 @@ size_t imf_unique_workspace_bytes(int64_t n);
  *   coords     int32[n,4]  (only the first *m_out rows are written)
  *   first_idx  int32[n]    index of the first point falling in each voxel (`inds`)
  *   m_out      int32[1]    number of voxels M
- *   keys/vals  hash of the M voxels (capacity = imf_hash_capacity(n)), vals = row
+ *   table      hash of the M voxels (capacity = imf_hash_capacity(n) slots), val = row
  *   err_out    int32[1]    set non-zero if a coordinate was out of range (caller zeroes it)
  */
 int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
                  int32_t *coords, int32_t *first_idx, int32_t *m_out,
-                 uint64_t *keys, int32_t *vals, int64_t capacity,
+                 imf_slot *table, int64_t capacity,
                  void *workspace, int32_t *err_out, void *stream);
 
 /* Replaces: the implicit coordinate_manager.stride() inside every stride-2
@@ -78,8 +85,15 @@ int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, 
 int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_in_max,
                    int out_stride,
                    int32_t *coords_out, int32_t *m_out,
-                   uint64_t *keys, int32_t *vals, int64_t capacity,
+                   imf_slot *table, int64_t capacity,
                    void *workspace, void *stream);
+
+/* Replaces: `return_coords = xyz[inds]` (util/misc.py:92, returned at :104): the representative point of every voxel,
+ * gathered on the device so that only M rows travel back to the host.  xyz as given to imf_voxelize / imf_pyramid_build
+ * (float32 is widened, as Open3D's float64 point array is); first_idx from the same call; m_dev: optional device row
+ * count (capacity mode: rows beyond it are not written), m_cap: rows (upper bound).  out: float64 [m_cap, 3]. */
+int imf_gather_points(const void *xyz, int xyz_is_f64, const int32_t *first_idx, const int32_t *m_dev, int64_t m_cap,
+                      double *out, void *stream);
 
 /* One-call geometry: imf_voxelize followed by (n_levels - 1) imf_downsample (tensor strides 2, 4,
  * ...), all tables and scratch carved out of ONE caller-provided arena, row counts written to
@@ -90,8 +104,7 @@ int imf_downsample(const int32_t *coords_in, const int32_t *n_in_dev, int64_t n_
  * Replaces: util/misc.py:82-95 and the implicit cm.stride() chain of model/resunet.py:54-85. */
 typedef struct imf_level {
   int32_t *coords;       /* [cap_rows, 4] rows (b,x,y,z), first-occurrence order                 */
-  uint64_t *keys;        /* hash table [capacity]                                                 */
-  int32_t *vals;         /*            [capacity]  row of the voxel                               */
+  imf_slot *table;       /* hash table [capacity]: voxel key -> row                               */
   int64_t capacity;
   int32_t *first_idx;    /* level 0: index of each voxel's first point; NULL on coarser levels    */
   int64_t cap_rows;      /* rows allocated (upper bound = n points)                               */
@@ -139,14 +152,14 @@ int64_t imf_rulebook_slots(int64_t n_out);
 /* Replaces: the kernel-map generation implicit in ME.MinkowskiConvolution(kernel_size=ksize,
  *           stride in {1,2}) -- model/resunet.py:42-88,140-158, model/residual_block.py:23-33.
  *   in  = out + off_k * ts_in    (ts_in = tensor stride of the INPUT level)
- * in_keys/in_vals/in_capacity: hash of the input level.  out_coords: the n_out output rows. */
-int imf_rulebook_conv(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+ * in_table/in_capacity: hash of the input level.  out_coords: the n_out output rows. */
+int imf_rulebook_conv(const imf_slot *in_table, int64_t in_capacity,
                       const int32_t *out_coords, int64_t n_out, int ts_in, int ksize,
                       int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream);
 
 /* Capacity mode: tables sized for n_out_cap rows, the actual count read from *n_out_dev; tiles without rows keep
  * mask 0 and their neighbour slices are left unwritten (imf_spconv_fwd never looks at them). */
-int imf_rulebook_conv_dyn(const uint64_t *in_keys, const int32_t *in_vals, int64_t in_capacity,
+int imf_rulebook_conv_dyn(const imf_slot *in_table, int64_t in_capacity,
                           const int32_t *out_coords, int64_t n_out_cap, const int32_t *n_out_dev, int ts_in,
                           int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream);
 
@@ -159,13 +172,12 @@ int64_t imf_rulebook_transpose_slots(int64_t n_fine);
  *           out[f] += in[c] @ W[k]  for  f = c + off_k * ts_fine.
  * Output rows (fine voxels) are grouped by the parity of (coord / ts_fine) so that a tile shares
  * its (at most 8) active offsets.  counters: int32[16] scratch. */
-int imf_rulebook_transpose(const uint64_t *coarse_keys, const int32_t *coarse_vals,
-                           int64_t coarse_capacity,
+int imf_rulebook_transpose(const imf_slot *coarse_table, int64_t coarse_capacity,
                            const int32_t *fine_coords, int64_t n_fine, int ts_fine, int ksize,
                            int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask,
                            int64_t n_slots, int32_t *counters, void *stream);
 
-int imf_rulebook_transpose_dyn(const uint64_t *coarse_keys, const int32_t *coarse_vals, int64_t coarse_capacity,
+int imf_rulebook_transpose_dyn(const imf_slot *coarse_table, int64_t coarse_capacity,
                                const int32_t *fine_coords, int64_t n_fine_cap, const int32_t *n_fine_dev, int ts_fine,
                                int ksize, int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, int64_t n_slots,
                                int32_t *counters, void *stream);   /* n_slots = imf_rulebook_transpose_slots(n_fine_cap) */
@@ -286,6 +298,33 @@ size_t imf_spconv_workspace_bytes(int64_t n_slots, int cout, int split);
  * ascending, then input channel) => deterministic. */
 int imf_spconv_fwd(const imf_conv_args *args /* [host] */, void *stream);
 
+/* Pointwise head: two chained 1x1x1 convolutions with their epilogues as ONE launch, the [n, 64] intermediate never
+ * leaving the registers / LDS of the workgroup that produced it.
+ * Replaces: conv1_tr (ME.MinkowskiConvolutionTranspose kernel_size=1 over ME.cat(out_s1_tr, out_s1)) + norm1_tr +
+ *           MEF.relu + final (ME.MinkowskiConvolution kernel_size=1, has_bias) + the L2 normalisation
+ *           (model/resunet.py:136-158 ctor, 219-233 forward).
+ *   hid = relu?((cat(in_a, in_b) @ W1) * scale1 + shift1)      [n, 64]
+ *   out = l2norm?((hid @ W2) * scale2 + shift2)                  [n, 32]
+ * Same arithmetic and summation order as two imf_spconv_fwd calls with variant 6 (bit-identical result).  Weight
+ * images from imf_pack_weights_split16(kvol = 1).  c_a + c_b in {64, 96, 128}; c_mid == 64, c_out == 32. */
+typedef struct imf_head_args {
+  const float *in_a;       /* [n, c_a] */
+  const float *in_b;       /* [n, c_b] or NULL */
+  int32_t c_a, c_b;
+  const float *w1_packed;  /* split16 image of W1 [1][c_a + c_b][c_mid] */
+  const float *scale1, *shift1;   /* [c_mid] or NULL (folded BatchNorm) */
+  int32_t relu1, c_mid;
+  const float *w2_packed;  /* split16 image of W2 [1][c_mid][c_out] */
+  const float *scale2, *shift2;   /* [c_out] or NULL (shift2 = bias) */
+  int32_t l2norm, c_out;
+  int64_t n;               /* rows (capacity when n_dev is given) */
+  const int32_t *n_dev;    /* optional: actual row count on the device (capacity mode) */
+  float *out;              /* [n, c_out] */
+  int32_t *flags;          /* optional device word: IMF_FLAG_RANGE when a hidden value cannot be a split-f16 operand */
+  void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded around the kernel */
+} imf_head_args;
+int imf_pointwise_head(const imf_head_args *args /* [host] */, void *stream);
+
 /* First-layer convolution for a small number of input channels (cin <= 4, e.g. the all-ones
  * occupancy feature of util/misc.py:76-79 through conv1 k=5, model/resunet.py:42-49).
  * w is the UNPACKED ME kernel [kvol][cin][cout], cout in {32, 64}.  Identity slot order. */
@@ -298,7 +337,7 @@ int imf_spconv_small_cin(const float *in, int cin, const float *w, int kvol, int
  * directly (one wavefront per output voxel) instead of materialising the 125-column neighbour
  * table.  in == NULL means the all-ones occupancy feature of util/misc.py:76-79.
  * Replaces: conv1 + norm1 of model/resunet.py:42-49,168-169 (kernel map included). */
-int imf_conv_first_fused(const uint64_t *keys, const int32_t *vals, int64_t capacity,
+int imf_conv_first_fused(const imf_slot *table, int64_t capacity,
                          const int32_t *coords, int64_t n, int ts, int ksize, const float *in, int cin,
                          const float *w /* [kvol][cin][cout], unpacked */, int cout,
                          const float *scale, const float *shift, int relu, float *out, void *stream);

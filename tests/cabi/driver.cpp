@@ -1,6 +1,7 @@
 // A C-level client of libimfnet_hip.so: no Python, no torch -- only include/imfnet_hip.h and the HIP runtime for
-// device memory.  It voxelises a synthetic cloud, builds the k=3 rulebook and runs one fused sparse convolution with
-// all-ones features and weights, whose exact result is known: out[row][c] = 32 * (number of occupied neighbours).
+// device memory.  It voxelises a synthetic cloud, builds the k=3 rulebook and runs fused sparse convolutions (fp32 MFMA
+// variant 0, the default split-f16 variant 6 on k_spconv_g and on the wave-split k_spconv_w, the fused pointwise head)
+// with all-ones features and weights, whose exact result is known: out[row][c] = 32 * (number of occupied neighbours).
 // Exit code 0 = every check passed.  Built by __graft_entry__.build(), run by tests/test_gpu_cabi_driver.py.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,12 +32,12 @@ int main() {
   const int64_t n = (int64_t)xyz.size() / 3;
   const int64_t cap = imf_hash_capacity(n);
   double *d_xyz = dev<double>(3 * n);
-  int32_t *coords = dev<int32_t>(4 * n), *first = dev<int32_t>(n), *meta = dev<int32_t>(2), *vals = dev<int32_t>(cap);
-  uint64_t *keys = dev<uint64_t>(cap);
+  int32_t *coords = dev<int32_t>(4 * n), *first = dev<int32_t>(n), *meta = dev<int32_t>(2);
+  imf_slot *table = dev<imf_slot>(cap);
   void *ws = dev<char>(imf_unique_workspace_bytes(n));
   HIP(hipMemcpy(d_xyz, xyz.data(), xyz.size() * 8, hipMemcpyHostToDevice));
   HIP(hipMemset(meta, 0, 8));
-  IMF(imf_voxelize(d_xyz, 1, n, voxel, 0, coords, first, meta, keys, vals, cap, ws, meta + 1, nullptr));
+  IMF(imf_voxelize(d_xyz, 1, n, voxel, 0, coords, first, meta, table, cap, ws, meta + 1, nullptr));
   int32_t h_meta[2];
   HIP(hipMemcpy(h_meta, meta, 8, hipMemcpyDeviceToHost));
   const int64_t m = h_meta[0];
@@ -50,7 +51,7 @@ int main() {
   const int64_t slots = imf_rulebook_slots(m);
   int32_t *tile_rows = dev<int32_t>(slots), *nbr = dev<int32_t>(27 * slots);
   uint32_t *mask = dev<uint32_t>(slots / IMF_TILE_ROWS * IMF_MASK_WORDS);
-  IMF(imf_rulebook_conv(keys, vals, cap, coords, m, 1, 3, tile_rows, nbr, mask, nullptr));
+  IMF(imf_rulebook_conv(table, cap, coords, m, 1, 3, tile_rows, nbr, mask, nullptr));
   const int cin = 32, cout = 32;
   std::vector<float> ones((size_t)27 * cin * cout, 1.f), feat((size_t)m * cin, 1.f);
   float *d_w = dev<float>(ones.size()), *d_wp = dev<float>(imf_packed_weight_floats(27, cin, cout)), *d_f = dev<float>(feat.size()),
@@ -76,9 +77,71 @@ int main() {
     for (int c = 0; c < cout; ++c)
       if (out[i * cout + c] != (float)(cnt * cin)) { printf("row %lld col %d: %g != %d\n", (long long)i, c, out[i * cout + c], cnt * cin); return 6; }
   }
+  // the default arithmetic of the model layers: variant 6 (split-f16 operands on the f16 matrix pipe, csrc/spconv_g.hip:
+  // both operands global -> LDS by DMA).  Ones are exact in f16 and the weight image's power-of-two pre-scale is undone
+  // exactly, so the same integers must come out.  Then the wave-split kernel of the coarse levels (csrc/spconv_w.hip,
+  // kernel_tag 4 / 8) on a 64-column layer, and the fused pointwise head.
+  {
+    float *d_wp6 = dev<float>(imf_packed_weight_floats_split16(27, cin, cout));
+    int32_t *d_flag = dev<int32_t>(1);
+    HIP(hipMemset(d_flag, 0, 4));
+    IMF(imf_pack_weights_split16(d_w, 27, cin, cout, d_wp6, nullptr));
+    imf_conv_args b = a;
+    b.w_packed = d_wp6; b.variant = 6; b.dyn_err = d_flag;
+    HIP(hipMemset(d_out, 0, out.size() * 4));
+    IMF(imf_spconv_fwd(&b, nullptr));
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < m; ++i) {
+      int cnt = 0;
+      for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx)
+        cnt += (int)occ.count({h_coords[4 * i + 1] + dx, h_coords[4 * i + 2] + dy, h_coords[4 * i + 3] + dz});
+      for (int c = 0; c < cout; ++c)
+        if (out[i * cout + c] != (float)(cnt * cin)) { printf("variant 6: row %lld col %d: %g != %d\n", (long long)i, c, out[i * cout + c], cnt * cin); return 8; }
+    }
+    const int c64 = 64;
+    std::vector<float> ones64((size_t)27 * cin * c64, 1.f);
+    float *d_w64 = dev<float>(ones64.size()), *d_wp64 = dev<float>(imf_packed_weight_floats_split16(27, cin, c64)),
+          *d_out64 = dev<float>((size_t)m * c64);
+    HIP(hipMemcpy(d_w64, ones64.data(), ones64.size() * 4, hipMemcpyHostToDevice));
+    IMF(imf_pack_weights_split16(d_w64, 27, cin, c64, d_wp64, nullptr));
+    std::vector<float> o64((size_t)m * c64);
+    for (int tag : {4, 8}) {
+      imf_conv_args w = b;
+      w.w_packed = d_wp64; w.cout = c64; w.out = d_out64; w.kernel_tag = tag;
+      HIP(hipMemset(d_out64, 0, o64.size() * 4));
+      IMF(imf_spconv_fwd(&w, nullptr));
+      HIP(hipDeviceSynchronize());
+      HIP(hipMemcpy(o64.data(), d_out64, o64.size() * 4, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < m; ++i)
+        for (int c = 0; c < c64; ++c)
+          if (o64[i * c64 + c] != out[i * cout]) { printf("wave-split kernel (tag %d): row %lld col %d: %g != %g\n", tag, (long long)i, c, o64[i * c64 + c], out[i * cout]); return 9; }
+    }
+    // pointwise head: cat([m,64] ones, [m,32] ones) @ ones[96,64] -> relu -> @ ones[64,32] = 96 * 64, exactly
+    std::vector<float> w1((size_t)96 * 64, 1.f), w2((size_t)64 * 32, 1.f), fa((size_t)m * 64, 1.f);
+    float *d_w1 = dev<float>(w1.size()), *d_w2 = dev<float>(w2.size()), *d_fa = dev<float>(fa.size()),
+          *d_w1p = dev<float>(imf_packed_weight_floats_split16(1, 96, 64)), *d_w2p = dev<float>(imf_packed_weight_floats_split16(1, 64, 32));
+    HIP(hipMemcpy(d_w1, w1.data(), w1.size() * 4, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(d_w2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(d_fa, fa.data(), fa.size() * 4, hipMemcpyHostToDevice));
+    IMF(imf_pack_weights_split16(d_w1, 1, 96, 64, d_w1p, nullptr));
+    IMF(imf_pack_weights_split16(d_w2, 1, 64, 32, d_w2p, nullptr));
+    imf_head_args h;
+    memset(&h, 0, sizeof(h));
+    h.in_a = d_fa; h.c_a = 64; h.in_b = d_f; h.c_b = 32; h.w1_packed = d_w1p; h.relu1 = 1; h.c_mid = 64;
+    h.w2_packed = d_w2p; h.c_out = 32; h.l2norm = 0; h.n = m; h.out = d_out; h.flags = d_flag;
+    IMF(imf_pointwise_head(&h, nullptr));
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < out.size(); ++i)
+      if (out[i] != 6144.f) { printf("pointwise head: element %zu = %g != 6144\n", i, out[i]); return 10; }
+    int32_t h_flag = -1;
+    HIP(hipMemcpy(&h_flag, d_flag, 4, hipMemcpyDeviceToHost));
+    if (h_flag != 0) { printf("range flag raised on in-range data: %d\n", h_flag); return 11; }
+  }
   // a bad argument is reported, not executed
   a.cout = 33;
   if (imf_spconv_fwd(&a, nullptr) != IMF_EINVAL || !strstr(imf_last_error(), "cout")) { printf("argument check missing\n"); return 7; }
-  printf("C ABI driver OK: %lld points -> %lld voxels, conv exact on %lld rows\n", (long long)n, (long long)m, (long long)m);
+  printf("C ABI driver OK: %lld points -> %lld voxels, fp32-MFMA / split-f16 (LDS-DMA, wave-split) convolutions and the pointwise head exact on %lld rows\n", (long long)n, (long long)m, (long long)m);
   return 0;
 }

@@ -332,3 +332,64 @@ def test_native_npz_writer(tmp_path, level):
     dataio.save_descriptors(str(tmp_path / "frag.npz"), arrays["points"], arrays["xyz"], arrays["feature"])
     z = np.load(tmp_path / "frag.npz")
     assert sorted(z.files) == ["feature", "points", "xyz"] and z["points"].dtype == np.float64
+
+
+def test_native_codecs_reject_corrupt_files(tmp_path, clouds):
+    """Untrusted input: size fields taken from a file are checked against the file before anything is
+    allocated, short chunks are refused, no C++ exception crosses the C ABI, unsupported PNG flavours (tRNS, 16-bit
+    colour) are handed to the generic decoder, string arrays go to numpy's NPZ writer, a failing close is reported."""
+    import ctypes as C
+    import struct
+    import zlib
+    from PIL import Image
+    from imfnet_amd import _lib, dataio
+    L = _lib.lib()
+    # PLY whose header promises 2^40 vertices over a 36-byte body
+    p = tmp_path / "huge.ply"
+    p.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 1099511627776\nproperty float x\nproperty float y\n"
+                  b"property float z\nend_header\n" + bytes(36))
+    buf = np.empty((4, 3))
+    assert L.imf_ply_read_points(os.fsencode(str(p)), buf.ctypes.data_as(C.c_void_p), 1 << 41) < 0
+    assert b"declares" in L.imf_last_error()
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    sig = b"\x89PNG\r\n\x1a\n"
+    out = np.empty(64, np.float32)
+    h, w, c = C.c_int(), C.c_int(), C.c_int()
+
+    def read(path):
+        return L.imf_png_read_f32(os.fsencode(str(path)), out.ctypes.data_as(C.c_void_p), out.size, C.byref(h), C.byref(w),
+                                  C.byref(c))
+    # IHDR chunk shorter than 13 bytes
+    p = tmp_path / "short_ihdr.png"
+    p.write_bytes(sig + chunk(b"IHDR", bytes(8)) + chunk(b"IDAT", zlib.compress(bytes(40))) + chunk(b"IEND", b""))
+    assert read(p) == -1 and b"IHDR" in L.imf_last_error()
+    # header promising 2^30 x 2^30 pixels over a few bytes of image data: refused before any allocation
+    p = tmp_path / "bomb.png"
+    p.write_bytes(sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 1 << 30, 1 << 30, 8, 2, 0, 0, 0))
+                  + chunk(b"IDAT", zlib.compress(bytes(40))) + chunk(b"IEND", b""))
+    assert read(p) == -1
+    # tRNS and 16-bit RGB: IMF_EUNSUPPORTED, read_image falls back to the generic decoder
+    rgb = np.random.default_rng(0).integers(0, 256, (4, 4, 3), dtype=np.uint8)
+    pal = Image.fromarray(rgb).convert("P")
+    pal.save(tmp_path / "trns.png", transparency=0)
+    assert read(tmp_path / "trns.png") == -3
+    raw = b"".join(b"\x00" + bytes(4 * 6) for _ in range(4))
+    (tmp_path / "rgb16.png").write_bytes(sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 16, 2, 0, 0, 0))
+                                         + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    assert read(tmp_path / "rgb16.png") == -3
+    assert dataio.read_image(str(tmp_path / "trns.png")).shape[:2] == (4, 4)
+    # a unicode array is written by numpy, not as a corrupt member
+    dataio.save_npz(str(tmp_path / "s.npz"), names=np.array(["a", "bcd"]), x=np.arange(3.0))
+    z = np.load(tmp_path / "s.npz")
+    assert list(z["names"]) == ["a", "bcd"] and (z["x"] == np.arange(3.0)).all()
+    names, dt = (C.c_char_p * 1)(b"names"), (C.c_char_p * 1)(b"<U3")
+    nd, sh, data = (C.c_int32 * 1)(1), (C.c_int64 * 1)(2), (C.c_void_p * 1)(np.array(["a", "bcd"]).ctypes.data)
+    assert L.imf_npz_write(os.fsencode(str(tmp_path / "u.npz")), 1, names, dt, nd, sh, data, 0) == -1
+    # a device that cannot take the data: the error surfaces instead of a truncated archive reported as success
+    if os.path.exists("/dev/full"):
+        dt = (C.c_char_p * 1)(b"<f8")
+        big = np.zeros(1 << 16)
+        sh, data = (C.c_int64 * 1)(big.size), (C.c_void_p * 1)(big.ctypes.data)
+        assert L.imf_npz_write(b"/dev/full", 1, names, dt, nd, sh, data, 0) == -1

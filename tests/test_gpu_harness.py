@@ -95,6 +95,63 @@ def test_large_fragment_200k_voxels(clouds, images, seeded_sd):
     assert (F.cpu() - Fr).abs().max() < 1e-4
 
 
+def test_bench_workload_pair_capacity_mode_vs_oracle(seeded_sd):
+    """THE bench.py workload itself (BASELINE.json configs[1] at the size the metric is quoted on): the S50k fragment
+    pair (cloud_bin_0 + cloud_bin_1 scaled x1.7 @ 2.5 cm, 103 k voxels) as ONE batched forward in capacity mode --
+    built by bench.py's own Workload class, so exactly the launches the headline times -- against the oracle
+    (C geometry + torch-CPU convolutions, each fragment with its own image): voxel sets / order exact, descriptors to
+    the north_star's 1e-4, capacity mode == exact mode bit for bit."""
+    import bench
+    import imf_oracle_cbind as OC
+    dev = torch.device("cuda:0")
+    model, sd = bench.build_model(O, dev)
+    pts, imgs = bench.load_pair(1.7)
+    wl = bench.Workload(model, dev, pts, imgs, 0.025)
+    with torch.no_grad():
+        F_exact = wl.prepare_graph().clone()
+        wl.runner.use_graph = False
+        res = wl.graph_step()
+        torch.cuda.synchronize()
+        assert res.flags == 0
+        F = res.F.clone()
+    assert torch.equal(F, F_exact)
+    row0 = 0
+    for k in (0, 1):
+        coords, inds = OC.voxelize(pts[k], 0.025)
+        m = len(coords)
+        Fr = O.resunet_forward(sd, coords, imgs[k:k + 1], geometry=OC.Geometry(coords))
+        assert (F[row0:row0 + m].cpu() - Fr).abs().max() < 1e-4
+        row0 += m
+    assert row0 == F.shape[0] == res.counts[0] and row0 > 100_000
+
+
+def test_extract_features_stream_equals_extract_features(clouds, images, seeded_sd):
+    """extract_features_stream (pinned staging, copy streams, several fragments in flight through one capacity bucket)
+    returns, in order, exactly what extract_features returns fragment by fragment -- for fragments of different sizes
+    (different buckets), float32 and float64 points, and from a cold runner (first fragment on the exact path)."""
+    from imfnet_amd.extract import extract_features, extract_features_stream
+    from imfnet_amd.model import load_model
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.eval().cuda()
+    dev = torch.device("cuda:0")
+    frs = []
+    for i, (k, sc, dt) in enumerate([(0, 1.0, np.float64), (1, 1.0, np.float64), (0, 1.3, np.float64), (1, 1.0, np.float32),
+                                     (0, 1.0, np.float64), (1, 1.3, np.float64), (0, 1.3, np.float64)]):
+        frs.append(((clouds[k].astype(np.float64) * sc).astype(dt), images[k]))
+    got = list(extract_features_stream(m, iter(frs), 0.05, dev, depth=3))
+    assert len(got) == len(frs)
+    with torch.no_grad():
+        for (xyz, img), (xd, F) in zip(frs, got):
+            xr, Fr = extract_features(m, xyz, voxel_size=0.05, device=dev, skip_check=True, image=img)
+            assert xd.dtype == np.float64 and F.dtype == np.float32
+            assert xd.shape == xr.shape and (xd == xr).all()
+            assert (F == Fr.cpu().numpy()).all()
+    again = list(extract_features_stream(m, iter(frs[:3]), 0.05, dev, depth=2))       # warm runner: all through the buckets
+    for a, b in zip(again, got[:3]):
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
 def kitti_like_cloud(n_points=2_000_000, seed=0):
     """seeded union of 64 random planar patches in a 120 m cube, 2 cm jitter (LiDAR-like surfaces
     at KITTI extents), tuned to ~200 k voxels at 0.3 m."""

@@ -316,6 +316,51 @@ def test_spconv_wave_kernel_epilogues(ops, geom_s5, staging):
                    32, rb, variant=6, staging=staging)
 
 
+@pytest.mark.parametrize("ca,cb,n", [(64, 32, 5182), (64, 32, 64 * 700 + 17), (64, 0, 1000), (64, 64, 333), (96, 0, 63)])
+def test_pointwise_head(ops, ca, cb, n):
+    """imf_pointwise_head (conv1_tr + norm1_tr + ReLU + final + bias + L2 norm, model/resunet.py:219-233, one launch)
+    against an fp64 evaluation of the same formulas (<= 2e-6 on unit rows), bit-identical to the two variant-6
+    convolution launches it replaces (same MFMA order, same epilogue expressions, the intermediate rounded to fp32 at
+    the same place), with the device-side row count of the capacity mode, and the range flag of the hidden block."""
+    from imfnet_amd.ops import Rulebook
+    fa, fb = _rand((n, ca), 80), (_rand((n, cb), 81) if cb else None)
+    w1, w2 = _rand((1, ca + cb, 64), 82, 1.0 / np.sqrt(ca + cb)), _rand((1, 64, 32), 83, 0.125)
+    sc, sh, bias = _rand((64,), 84).abs() + 0.5, _rand((64,), 85), _rand((32,), 86)
+    w1p, w2p = ops.pack_weights(w1.to(DEV), split16=True), ops.pack_weights(w2.to(DEV), split16=True)
+    a, b = fa.to(DEV), (None if fb is None else fb.to(DEV))
+    got = ops.pointwise_head(a, b, w1p, w2p, scale1=sc.to(DEV), shift1=sh.to(DEV), relu1=True, shift2=bias.to(DEV),
+                             l2norm=True)
+    fin = (fa if fb is None else torch.cat([fa, fb], 1)).double()
+    hid = torch.relu(fin @ w1[0].double() * sc.double() + sh.double())
+    ref = hid @ w2[0].double() + bias.double()
+    ref = ref / ref.norm(dim=1, keepdim=True)
+    assert got.shape == (n, 32)
+    assert (got.cpu().double() - ref).abs().max() < 2e-6
+    # the two launches it replaces
+    slots = (n + 63) // 64 * 64
+    rb = Rulebook(None, None, None, slots, n, 1)
+    h = ops.spconv(a, w1p, 64, rb, in_b=b, scale=sc.to(DEV), shift=sh.to(DEV), relu=True, variant=6)
+    two = ops.spconv(h, w2p, 32, rb, shift=bias.to(DEV), l2norm=True, variant=6)
+    assert torch.equal(got, two)
+    # capacity mode: rows beyond the device-side count are neither read into a result nor written
+    m = max(1, n - 37)
+    n_dev = torch.tensor([m], dtype=torch.int32, device=DEV)
+    out = torch.full((n, 32), 7.0, device=DEV)
+    ops.pointwise_head(a, b, w1p, w2p, scale1=sc.to(DEV), shift1=sh.to(DEV), relu1=True, shift2=bias.to(DEV), l2norm=True,
+                       out=out, n_dev=n_dev)
+    assert torch.equal(out[:m], got[:m]) and bool((out[m:] == 7.0).all())
+    # range guard on the hidden block; without ReLU / L2 norm
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.pointwise_head(a * 1e3, b, w1p, w2p, scale1=torch.full((64,), 1e3, device=DEV), flags=flags)   # hidden ~ 1e6
+    assert int(flags.item()) & 32
+    flags.zero_()
+    plain = ops.pointwise_head(a, b, w1p, w2p, relu1=False, l2norm=False, flags=flags).cpu().double()
+    assert int(flags.item()) == 0
+    assert (plain - (fin @ w1[0].double()) @ w2[0].double()).abs().max() < 2e-5
+    with pytest.raises(Exception):
+        ops.pointwise_head(a[:, :32].contiguous(), None, w1p, w2p)
+
+
 def test_spconv_split16_variant(ops, geom_s5):
     """Variant 6 (split-f16 MFMA): the packed image decodes to hi + lo == w within 2^-21, epilogues and
     determinism as the fp32 kernels, and fp32-class error on inputs spanning seven decades."""
@@ -545,7 +590,7 @@ def test_native_executor_equals_python_plan(model, clouds, images, monkeypatch):
             trace, O_.TRACE = O_.TRACE, None
         assert model._native_plan is not None
         assert torch.equal(a, b) and torch.equal(a, c)
-        assert len(trace) == 22 and all(r["ev"].elapsed_ms() > 0 for r in trace)
+        assert len(trace) == 21 and all(r["ev"].elapsed_ms() > 0 for r in trace)
         assert sorted(r["name"] for r in trace)[0] == "block1.conv1"
 
 

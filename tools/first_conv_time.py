@@ -15,7 +15,7 @@ for relu in (0, 2):
     for r in range(8):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.lib().imf_conv_first_fused(levels[0].keys.data_ptr(), levels[0].vals.data_ptr(), levels[0].capacity,
+        _lib.lib().imf_conv_first_fused(levels[0].table.data_ptr(), levels[0].capacity,
                                         levels[0].coords_buf.data_ptr(), levels[0].n, 1, 5, None, 1, w.data_ptr(), 32,
                                         None, None, relu, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
         e1.record(); torch.cuda.synchronize()
