@@ -39,7 +39,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
-PMC_FILE = "r02_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"
 
 
 def load_pair(scale):
@@ -74,9 +74,9 @@ def algorithmic_bytes(rec):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r02_pmc_traffic.json, produced by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
+    (profiles/r03_pmc_traffic.json, produced by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
     separate runs; read side doubled per the gfx950 FETCH_SIZE correction).  None if absent."""
-    for name in (PMC_FILE, "r01_pmc_traffic.json"):
+    for name in (PMC_FILE, "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -86,7 +86,10 @@ def pmc_traffic(kernel):
     # `kernel` names a template FAMILY (k_spconv_g<4, 0> = every (CAT, NB, RB) instance of the 64-column sparse
     # launches, which is what the live timing above groups too): launch-weighted average over its symbols
     key = "imf::" + kernel
-    fam = [v for k, v in ks.items() if k == key or k.startswith(key[:-1] + ",")]
+    if kernel.startswith("k_spconv_w<"):              # k_spconv_w<W> = the symbols k_spconv_w<CAT, W>
+        fam = [v for k, v in ks.items() if k.startswith("imf::k_spconv_w<") and k.endswith(", " + kernel[len("k_spconv_w<"):])]
+    else:
+        fam = [v for k, v in ks.items() if k == key or k.startswith(key[:-1] + ",") or k.startswith(key + "<")]
     if not fam:
         return None, f"{key} not in {os.path.basename(path)}"
     n = sum(v["launches"] for v in fam)
@@ -96,6 +99,30 @@ def pmc_traffic(kernel):
                                             f"WRITE {int(avg('write_bytes'))} B, L2 hit {hit:.4f}; {n} launches of {len(fam)} "
                                             f"symbol(s) of the family) from profiles/{os.path.basename(path)}; below the algorithmic "
                                             f"bytes because feature rows are re-gathered from L2 / Infinity Cache, not HBM")
+
+
+def rocprof_avg_us(kernel, name="r03_kernel_stats.txt"):
+    """Launch-weighted average duration of `kernel`'s symbols in the committed `rocprofv3 --kernel-trace --stats` summary of
+    this same command (profiles/r03_kernel_stats.txt, tools/profile_round.sh) -- printed beside the live HIP-event timing so
+    that roofline.frac can be recomputed from profiles/ alone.  (n, avg_us) or None."""
+    import re
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    n = tot = 0
+    for line in open(path):
+        m = re.match(r"(?:void )?imf::(.*?)\(.*\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s+[\d.]+\s*$", line)
+        if not m:
+            continue
+        sym = m.group(1)
+        if kernel.startswith("k_spconv_w<"):
+            ok = sym.startswith("k_spconv_w<") and sym.endswith(", " + kernel[len("k_spconv_w<"):])
+        else:
+            ok = sym == kernel or sym.startswith(kernel[:-1] + ",") or sym.startswith(kernel + "<")
+        if ok:
+            n += int(m.group(2))
+            tot += float(m.group(3))
+    return (n, tot / n) if n else None
 
 
 def cpu_baseline(xyz, img, voxel, sd, seconds_budget=12.0):
@@ -225,6 +252,8 @@ class Workload:
         r.observe(int(self.xyz.shape[0]), [l.n for l in lv], lv[0].bbox)
         key = r.caps_for(int(self.xyz.shape[0]), len(self.starts), int(self.img.shape[2]), int(self.img.shape[3]),
                          self.voxel, self.xyz.dtype == torch.float64)
+        self.stream.synchronize()
+        self.stream = r.main_stream(self.dev)            # capacity-mode forwards run on the runner's own main stream
         b = self.bucket = r.bucket(key, self.dev, self.stream)
         self.n_points = r.stage(b, self.xyz, self.starts, self.img, self.stream)
         return F
@@ -439,6 +468,12 @@ def main():
                                    for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
                     "timing": "HIP events around each launch on its launch stream, in situ (other streams' kernels of the same "
                               "step overlap), %d steps after the timed regions" % traced_steps}
+        rp = rocprof_avg_us(dom)
+        if rp:
+            roofline["rocprof_avg_launch_us"] = round(rp[1], 2)
+            roofline["rocprof_frac"] = round(roofline["algorithmic_bytes_per_launch"] / (rp[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["rocprof_note"] = ("%d launches of the family in profiles/r03_kernel_stats.txt (rocprofv3 --kernel-trace --stats of "
+                                        "this command; kernel tracing serialises the streams and carries no event records)" % rp[0])
         extras = {}
         with torch.no_grad():
             if dyn and world == 1:
@@ -549,12 +584,24 @@ def extra_legs(O, model, dev, args, sync):
     for _ in extract_features_stream(model, frags(6), voxel, dev):
         pass
     sync()
-    t0 = time.perf_counter()
     n_it = 40
     m_tot = 0
+    prof = None
+    if os.environ.get("IMF_BENCH_PROFILE_STREAM"):
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
+    t0 = time.perf_counter()
     for xd, Fh in extract_features_stream(model, frags(n_it), voxel, dev, copy=False):
         m_tot += Fh.shape[0]
     dt = (time.perf_counter() - t0) / n_it
+    st = model.fragment_runner().stats
+    print("stream leg: %.3f ms wall per fragment, %.3f ms H2D + forward + D2H on the stream per fragment (%d)" %
+          (dt * 1e3, st.get("stream_gpu_ms", 0.0) / max(1, st.get("stream_n", 0)), st.get("stream_n", 0)), file=sys.stderr)
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
     out["e2e_extract_features_stream"] = {"descriptors_per_s": round(m_tot / n_it / dt, 1), "ms_per_fragment": round(dt * 1e3, 3),
                                           "span": "the same span over a stream of %d host fragments through extract_features_stream: "
                                                   "pinned staging, H2D / D2H on copy streams under the neighbouring fragments' "

@@ -746,6 +746,13 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   static const int xcd = getenv("IMF_H3_XCD") ? 1 : 0;
   p.no_xcd_swizzle = !xcd;
   IMF_REQUIRE(!p.dyn_split_kvol || (!p.tickets && a->split_k >= 1), "imf_spconv_fwd: dyn_split_kvol needs an explicit split_k cover and no tickets");
+#ifndef IMF_WITH_H3
+  if (a->variant == 6 && ((a->kernel_tag & 2) || a->tickets)) {
+    set_error("imf_spconv_fwd: the register-staged variant-6 kernel (kernel_tag bit 1, tickets) is compiled into diagnostic "
+              "builds only (make -C imfnet_amd/csrc h3)");
+    return IMF_EUNSUPPORTED;
+  }
+#endif
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
@@ -757,7 +764,11 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
     // offsets so every CU receives the same work.  Needs a little workspace; skipped without it.
     // Measured (S50k): the two 64->64 layers drop 61 -> 56 us, but the extra reduce launch takes the
     // step-level gain back (0.886 vs 0.884 ms), so it is opt-in: IMF_CONV_TAIL=1.
+#ifdef IMF_WITH_H3
     static const int tail_env = getenv("IMF_CONV_TAIL") ? atoi(getenv("IMF_CONV_TAIL")) : 0;
+#else
+    const int tail_env = 0;                                    // the balanced tail lives in k_spconv_h3 (diagnostic builds)
+#endif
     const long long n_tiles = grid.x;
     const int tail_tiles = (int)(n_tiles % 256);
     const int ts = a->kvol >= 16 ? 8 : 4;
@@ -770,7 +781,11 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
       p.tail_split = ts;
       grid.x = (unsigned)(p.tail_begin + tail_tiles * ts);
     }
-    launch_spconv_h3(p, grid, CB, st, a->kernel_tag);
+#ifdef IMF_WITH_H3
+    launch_spconv_h3(p, grid, CB, st, a->kernel_tag);          // diagnostic build: register-staged twin / stamps / tickets
+#else
+    launch_spconv_g(p, grid, CB, st, a->kernel_tag & 1);
+#endif
   } else if (simple) {
     if (CB == 4 && J == 4)      k_spconv_mfma_simple<4, 4><<<grid, 256, 0, st>>>(p);
     else if (CB == 4 && J == 2) k_spconv_mfma_simple<4, 2><<<grid, 256, 0, st>>>(p);

@@ -14,6 +14,12 @@
 // slab x a partition of the tile's active offsets; 16 KiB weight stages double-buffered in LDS with
 // register prefetch; A gathered straight from the input rows (lane l: 8 consecutive channels
 // 32cc + 4(l>>4).. and 32cc + 16 + 4(l>>4).. of row nbr[k][l&15], split to hi/lo in registers).
+//
+// DIAGNOSTIC BUILDS ONLY since round 3 (`make h3`, `make stamps`: -DIMF_WITH_H3): the product library runs variant 6 on
+// k_spconv_g (LDS-DMA staging, spconv_g.hip) and k_spconv_w (spconv_w.hip).  This register-staged kernel -- round 1's
+// default, bit-identical to k_spconv_g -- carries the in-kernel s_memtime stamps, the in-launch split-K combine
+// (tickets) and the balanced tail, all measured and recorded in DESIGN.md 4 / 4c.
+#ifdef IMF_WITH_H3
 #include "spconv_shared.h"
 
 #ifndef IMF_H3_ABL
@@ -23,69 +29,6 @@
 namespace imf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-// Packed image (same size as the fp32 one: two halves per weight):
-//   [y][k][cc][q = 2 cb + h][lane][t],  ci = 32 cc + 16 (t>>2) + 4 (lane>>4) + (t&3),  co = y CW + 16 cb + (lane&15),
-//   (the contraction index of the MFMA is free to permute: lane group q holds channels 4q..4q+3 and 16+4q..16+4q+3 so that
-//   each of the two 16-byte gathers of a row is one contiguous 64-byte segment across the four lanes of that row)
-//   h = 0: hi halves, h = 1: lo halves; one (q, lane) entry = 8 halves = one float4.
-// max |w| of the kernel as float bits (non-negative floats order like unsigned integers)
-__global__ void __launch_bounds__(256)
-k_absmax_bits(const float *__restrict__ w, long long total, unsigned *__restrict__ out) {
-  __shared__ unsigned part[4];
-  unsigned m = 0u;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const unsigned b = __float_as_uint(fabsf(w[i]));
-    if (b < 0x7F800000u) m = b > m ? b : m;          // ignore inf / NaN
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned v = __shfl_xor(m, o, 64);
-    m = v > m ? v : m;
-  }
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int q = 1; q < 4; ++q) m = part[q] > m ? part[q] : m;
-    atomicMax(out, m);
-  }
-}
-
-// Power-of-two pre-scaling of the weight image: with s = 13 - floor(log2 max|w|) the scaled kernel peaks in
-// [2^13, 2^14), so lo = f16(w' - hi) is a NORMAL f16 number for every |w| >= 2^-17 max|w| (unscaled, a typical
-// trained kernel of magnitude 1e-2 has subnormal lo halves: absolute error 3e-8 per weight = 18 bits).  The scaling
-// is exact; the kernels multiply the fp32 accumulators by 2^-s (trailer[1]), also exact.
-__device__ __forceinline__ int weight_shift(unsigned absmax_bits) {
-  if (absmax_bits == 0u) return 0;
-  const int e = (int)(absmax_bits >> 23) - 127;          // floor(log2 max|w|) (subnormal maxima: e = -127)
-  int s = 13 - e;
-  return s < -40 ? -40 : (s > 100 ? 100 : s);
-}
-
-__global__ void __launch_bounds__(256)
-k_pack_weights_h3(const float *__restrict__ w, int kvol, int cin, int cout, _Float16 *__restrict__ packed,
-                  float *__restrict__ trailer) {
-  const long long total = (long long)kvol * cin * cout;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int shift = weight_shift(__float_as_uint(trailer[0]));
-  if (idx == 0) trailer[1] = ldexpf(1.f, -shift);
-  const int CB = co_blk_of(cout), CW = 16 * CB, ncc = cin / 32;
-  long long r = idx;
-  const int t = r & 7; r >>= 3;
-  const int lane = r & 63; r >>= 6;
-  const int cb = r % CB; r /= CB;
-  const int cc = r % ncc; r /= ncc;
-  const int k = r % kvol; r /= kvol;
-  const int y = (int)r;
-  const int ci = cc * 32 + 16 * (t >> 2) + 4 * (lane >> 4) + (t & 3);
-  const int co = y * CW + 16 * cb + (lane & 15);
-  const float v = ldexpf(w[((long long)k * cin + ci) * cout + co], shift);
-  const _Float16 hi = (_Float16)v;
-  const _Float16 lo = (_Float16)(v - (float)hi);
-  const long long q0 = ((((long long)y * kvol + k) * ncc + cc) * (2 * CB) + 2 * cb) * 64 + lane;
-  packed[q0 * 8 + t] = hi;
-  packed[(q0 + 64) * 8 + t] = lo;
-}
 
 __device__ __forceinline__ void split8(const float4 &x0, const float4 &x1, f16x8 &hi, f16x8 &lo) {
   const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -458,22 +401,4 @@ void launch_spconv_h3(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st
 
 }  // namespace imf
 
-using namespace imf;
-
-extern "C" int imf_pack_weights_split16(const float *w, int kvol, int cin, int cout, float *packed,
-                                        void *stream) {
-  IMF_REQUIRE(w && packed, "imf_pack_weights_split16: null pointer");
-  IMF_REQUIRE(kvol >= 1 && kvol <= IMF_MAX_KVOL, "imf_pack_weights_split16: kvol=%d", kvol);
-  IMF_REQUIRE(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0,
-              "imf_pack_weights_split16: cin=%d cout=%d must be multiples of 32", cin, cout);
-  const long long total = (long long)kvol * cin * cout;
-  hipStream_t st = (hipStream_t)stream;
-  float *trailer = packed + total;                       // [0] max |w| (bits), [1] 2^-shift; 64 floats reserved
-  IMF_CHECK_HIP(hipMemsetAsync(trailer, 0, 64 * sizeof(float), st));
-  const long long nb = div_up(total, 256 * 8);
-  k_absmax_bits<<<(unsigned)(nb > 1024 ? 1024 : nb), 256, 0, st>>>(w, total, reinterpret_cast<unsigned *>(trailer));
-  k_pack_weights_h3<<<(unsigned)div_up(total, 256), 256, 0, st>>>(w, kvol, cin, cout,
-                                                                  reinterpret_cast<_Float16 *>(packed), trailer);
-  IMF_CHECK_LAUNCH("k_pack_weights_h3");
-  return IMF_OK;
-}
+#endif  // IMF_WITH_H3

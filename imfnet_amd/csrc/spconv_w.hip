@@ -193,6 +193,18 @@ k_spconv_w(const ConvParams p) {
     e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t0 + 1 < kSubTab ? t0 + 1 : kSubTab - 1]));
     IMF_W_ROWS(rows_nxt, e_nxt)
   }
+  // A sub-stage of a wavefront is two segments, LOAD (wait for its DMAs, 16 fragment reads, issue the 16 DMA pieces of the
+  // next sub-stage: ~1.0 k cycles of the SIMD's address path at ~64 cycles per 1 KiB piece) and COMPUTE (hi / lo split,
+  // 48 MFMAs: ~0.8 k cycles of matrix pipe + ~0.4 k of VALU).  A wavefront issues in order, so the two never overlap
+  // inside it; what overlaps is whatever the SIMD's other wavefront happens to be doing (counters of round 3,
+  // profiles/r03_pmc_counters.txt: 38 % of the wavefront cycles are issue stalls, matrix pipe 27 % busy).  Two schedules
+  // that tried to force the overlap were built on this loop, gave identical sums and were NOT faster (tools/conv_iso.py):
+  //   * the 16 pieces issued one after every third MFMA instead of back to back: 128 -> 128 at 7.7 k rows 25.7 -> 26.5 us,
+  //     64 -> 64 at 103 k rows (4 wavefronts) 89.7 -> 99.2 us -- a piece holds the wavefront wherever it stands;
+  //   * ping-pong: the two halves of an 8-wavefront workgroup half a period apart, held by two workgroup barriers per
+  //     sub-stage (SIMD partners w / w + 4 in opposite segments, MI355X_MICROARCH.md "Two waves per SIMD"): the
+  //     stride-4 / 8 launches 35.2 -> 43.4 us on average -- with a single buffer per wavefront the DMAs issued at the end
+  //     of LOAD get one COMPUTE segment to land, and every wavefront then waits for them in lock step.
 #pragma unroll 1
   for (int t = t0; t < t1; ++t) {
     // sub-stage t has landed: the region is private, the wavefront's own counter is the only wait

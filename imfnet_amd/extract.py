@@ -126,6 +126,7 @@ def _submit_host(runner, slot, host_xyz, host_img, voxel_size, device, stream):
     rows = b.caps.rows[0]
     used_in = b.lay["xyz"] + n * 3 * host_xyz.dtype.itemsize
     with torch.cuda.stream(stream):
+        slot.begin.record(stream)
         b.inbuf[:used_in].copy_(slot.inbuf[:used_in], non_blocking=True)
     b.dyn_values = vals
     res = runner.launch(b, n, 1, stream, meta_to=(v["meta"], slot.done))
@@ -216,11 +217,15 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
     runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
     n_slots = max(1, depth) + 1
     cache = getattr(runner, "stream_state", None) if runner is not None else None
-    if cache is None or cache[0] != device or len(cache[2]) < n_slots:
-        cache = (device, torch.cuda.Stream(device=device), [graph.HostSlot() for _ in range(n_slots)])
+    if cache is None or cache[0] != device or len(cache[1]) < n_slots:
+        cache = (device, [graph.HostSlot(timing=True) for _ in range(n_slots)])
         if runner is not None:
             runner.stream_state = cache               # pinned slots are expensive to create: kept with the runner
-    _, stream, slots = cache
+    _, slots = cache
+    caller = torch.cuda.current_stream(device)
+    stream = runner.main_stream(device) if runner is not None else caller
+    if stream.cuda_stream != caller.cuda_stream:
+        stream.wait_stream(caller)
     free = list(slots[:n_slots])
     inflight = deque()
     lent = []                                         # the slot whose views the consumer currently holds (copy=False)
@@ -234,6 +239,8 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
             slot.done.synchronize()
             if not res.flags:
                 m = res.counts[0]
+                runner.stats["stream_gpu_ms"] = runner.stats.get("stream_gpu_ms", 0.0) + slot.begin.elapsed_time(slot.done)
+                runner.stats["stream_n"] = runner.stats.get("stream_n", 0) + 1
                 if copy:
                     out = v["sel"][:m].copy(), v["F"][:m].copy()
                     free.append(slot)
@@ -267,7 +274,8 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
             inflight.append((host[0], host[1], slot, got))
         while inflight:
             yield finish(inflight.popleft())
-    torch.cuda.current_stream(device).wait_stream(stream)
+    if stream.cuda_stream != caller.cuda_stream:
+        caller.wait_stream(stream)
 
 
 def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=None,

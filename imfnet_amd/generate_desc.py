@@ -55,105 +55,67 @@ def load_fragment(ply_path, config):
     return xyz, image_to_nchw(img)
 
 
-class _HostSlot:
-    """Pinned host buffers of one in-flight fragment (points, image and scalars in; descriptors + first-point indices out)."""
-
-    def __init__(self):
-        self.xyz = self.F = self.inds = self.image = None
-        self.dyn = torch.zeros(16, dtype=torch.int32).pin_memory()
-
-    def fit(self, n_points, rows, width):
-        if self.xyz is None or self.xyz.shape[0] < n_points:
-            self.xyz = torch.empty((int(n_points * 1.25) + 1024, 3), dtype=torch.float64).pin_memory()
-        if self.F is None or self.F.shape[0] < rows or self.F.shape[1] != width:
-            self.F = torch.empty((rows, width), dtype=torch.float32).pin_memory()
-            self.inds = torch.empty(rows, dtype=torch.int32).pin_memory()
-
-    def set_image(self, img):
-        if self.image is None or tuple(self.image.shape) != tuple(img.shape):
-            self.image = torch.empty(tuple(img.shape), dtype=torch.float32).pin_memory()
-        self.image.numpy()[...] = img
-
-
 def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, device, workers, depth=None):
     """The batch loop without the host in the GPU's way (SURVEY 8 f-4 / 8e "bound by host-side decode"): loader threads
-    decode PLY + PNG straight into pinned buffers; the main thread only stages (async H2D), launches the capacity-mode
-    forward and queues the async D2H of descriptors and first-point indices; writer threads wait on each fragment's
-    event, gather xyz_down and write the NPZ.  Nothing on the main thread waits for the GPU.  A fragment the runner
-    flags (capacity / f16 range) is redone by the caller on the exact path.  Returns (seconds per fragment, redo list)."""
+    decode PLY + PNG; the main thread only stages each fragment through a pinned HostSlot (one H2D block), launches the
+    capacity-mode forward and queues the one D2H block (counts | xyz_down | descriptors; xyz_down = xyz[inds] is gathered
+    on the device) -- extract._submit_host; writer threads wait on each fragment's event and write the NPZ straight from
+    the slot's pinned views.  Nothing on the main thread waits for the GPU.  A fragment the runner flags (capacity / f16
+    range) is redone by the caller on the exact path.  Returns (seconds per fragment, redo list)."""
     import queue
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
+    from .extract import _submit_host
+    from .model.graph import HostSlot
     depth = depth or max(4, 2 * workers)
     slots = queue.Queue()
     for _ in range(depth):
-        slots.put(_HostSlot())
-    stream = torch.cuda.Stream(device=device)
+        slots.put(HostSlot(timing=True))
+    stream = runner.main_stream(device)              # the runner's own: never shares a hardware queue with its side / image streams
+    stream.wait_stream(torch.cuda.current_stream(device))
     loader, writer = ThreadPoolExecutor(max_workers=workers), ThreadPoolExecutor(max_workers=workers)
     times, redo, writes = {}, [], []
 
-    def load(job, slot):
+    def load(job):
         scene, fi = job
-        slot.fit(int(_ply_count(fi)), 1, 32)
-        xyz = read_ply_points(fi, out=slot.xyz.numpy())
-        slot.set_image(load_image(fi, config))
-        return slot, xyz
+        return read_ply_points(fi), np.ascontiguousarray(load_image(fi, config), dtype=np.float32)
 
-    def finish(job, slot, xyz, res, ev0, ev1):
+    def finish(job, slot, xyz, got):
         scene, fi = job
         try:
-            ev1.synchronize()
+            res, v = got
+            slot.done.synchronize()
             if res.flags:
                 return job
             n0 = res.counts[0]
-            inds = slot.inds[:n0].numpy().astype(np.int64)
             out_dir = os.path.join(target_path, os.path.basename(scene), "seq-01")
             ensure_dir(out_dir)
-            save_descriptors(os.path.join(out_dir, os.path.basename(fi).replace(".ply", ".npz")), xyz, xyz[inds],
-                             slot.F[:n0].numpy())
-            times[fi] = ev0.elapsed_time(ev1) * 1e-3
+            save_descriptors(os.path.join(out_dir, os.path.basename(fi).replace(".ply", ".npz")), xyz, v["sel"][:n0],
+                             v["F"][:n0])
+            times[fi] = slot.begin.elapsed_time(slot.done) * 1e-3
             return None
         finally:
             slots.put(slot)
 
     todo, inflight = deque(jobs), deque()
 
-    def top_up(block):
+    def top_up():
         while todo and len(inflight) < depth:
-            try:
-                slot = slots.get(block=block and not inflight)     # slots are handed out in job order (no inversion)
-            except queue.Empty:
-                return
             job = todo.popleft()
-            inflight.append((job, loader.submit(load, job, slot)))
+            inflight.append((job, loader.submit(load, job)))
 
-    top_up(True)
+    top_up()
     while inflight:
         job, fut = inflight.popleft()
-        slot, xyz = fut.result()
-        top_up(False)
-        n = xyz.shape[0]
-        key = runner.caps_for(n, 1, int(slot.image.shape[2]), int(slot.image.shape[3]), voxel_size, True)
-        if key is None:                                     # no capacities known (e.g. the bit grid never fitted): exact path
+        xyz, image = fut.result()
+        top_up()
+        slot = slots.get()                                      # blocks only when `depth` fragments are on the GPU / being written
+        got = _submit_host(runner, slot, xyz, image, voxel_size, device, stream)
+        if got is None:                                         # no capacities known (e.g. the bit grid never fitted): exact path
             redo.append(job)
             slots.put(slot)
-            if not inflight:
-                top_up(True)
             continue
-        b = runner.bucket(key, device, stream)
-        slot.fit(n, b.caps.rows[0], b.out.shape[1])
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(stream):
-            ev0.record(stream)
-            runner.stage(b, slot.xyz[:n], [0], slot.image, stream, dyn_host=slot.dyn)
-            res = runner.launch(b, n, 1, stream)
-            rows = b.caps.rows[0]
-            slot.F[:rows].copy_(b.out, non_blocking=True)
-            slot.inds[:rows].copy_(b.first_idx_view(), non_blocking=True)
-            ev1.record(stream)
-        writes.append(writer.submit(finish, job, slot, xyz, res, ev0, ev1))
-        if not inflight:
-            top_up(True)
+        writes.append(writer.submit(finish, job, slot, xyz, got))
     for w in writes:
         j = w.result()
         if j is not None:

@@ -98,9 +98,9 @@ class HostSlot:
     copied in with a plain single-threaded memcpy (np.copyto: 0.13 ms for 6 MB) -- torch's CPU copy_ fans a copy of that
     size out over its whole thread pool, and waking 128 idle OpenMP threads was measured at 10-30 ms per call."""
 
-    def __init__(self):
+    def __init__(self, timing=False):
         self.inbuf = self.outbuf = None
-        self.done = torch.cuda.Event()
+        self.begin, self.done = torch.cuda.Event(enable_timing=timing), torch.cuda.Event(enable_timing=timing)
         self._views = None
 
     def bind(self, b):
@@ -242,7 +242,7 @@ class FragmentRunner:
         self.ratios = None            # max rows_l / n_points seen (4 levels)
         self.grid_words = 0           # largest conv1 bit grid seen
         self.buckets = {}
-        self._own = {}
+        self._main = {}
         self._raw = {}
         # hipGraph replay is opt-in: ROCm 7.2 runs a graph's independent branches back to back (measured 1.77 vs
         # 1.37 ms per fragment pair), the eager capacity-mode call keeps the three streams concurrent
@@ -272,15 +272,28 @@ class FragmentRunner:
         return (npc, tuple(rows), n_items, H, W, gw, float(voxel), bool(is_f64))
 
     def raw_streams(self, dev):
-        """(side, image) hipStream_t of this device, created through the library: torch's stream pool wraps around
-        after 32 streams and would eventually hand out the main stream again."""
+        """(side, image) hipStream_t of this device -- and, with them, the runner's MAIN stream (`main_stream`).  The three
+        are created through the library, one right after the other.  Two reasons: torch's stream pool wraps around after
+        32 streams and would eventually hand out the main stream again; and HIP multiplexes streams onto a few hardware
+        queues (GPU_MAX_HW_QUEUES, 4 by default; a new stream goes to the least-used queue), so a main stream created at
+        some other time by somebody else can land on the queue of this runner's side or image stream -- the three
+        branches of a fragment then run one after the other.  Measured (round 3, tools/e2e_probe.py): the same forward
+        0.76 or 2.0 ms, the host-array stream 1.05 or 2.6-3.1 ms per fragment, depending only on which torch streams the
+        process had created before.  Streams born together sit on different queues."""
         s = self._raw.get(dev)
         if s is None:
             with torch.cuda.device(dev):
-                s = self._raw[dev] = (self.L.imf_stream_create(), self.L.imf_stream_create())
-            if not (s[0] and s[1]):
-                raise ImfError("could not create the side / image streams")
+                raw = (self.L.imf_stream_create(), self.L.imf_stream_create(), self.L.imf_stream_create())
+            if not all(raw):
+                raise ImfError("could not create the main / side / image streams")
+            self._main[dev] = torch.cuda.ExternalStream(raw[0], device=dev)
+            s = self._raw[dev] = (raw[1], raw[2])
         return s
+
+    def main_stream(self, dev):
+        """The stream every capacity-mode forward of this runner is issued on (a torch view of the library-made stream)."""
+        self.raw_streams(dev)
+        return self._main[dev]
 
     def bucket(self, key, dev, stream=None):
         b = self.buckets.get(key)
@@ -294,15 +307,14 @@ class FragmentRunner:
         return b
 
     def _stream_for(self, dev, stream):
-        """Graph capture needs a real stream: work submitted on the legacy default stream goes through an own one."""
-        stream = stream or torch.cuda.current_stream(dev)
-        if stream.cuda_stream != 0:
-            return stream, None
-        own = self._own.get(dev)
-        if own is None:
-            own = self._own[dev] = torch.cuda.Stream(device=dev)
-        own.wait_stream(stream)
-        return own, stream
+        """(the runner's main stream, the caller's stream or None): work submitted on any other stream is ordered
+        behind it on the main stream; the caller's stream waits for the main stream afterwards (`outer.wait_stream`)."""
+        main = self.main_stream(dev)
+        cur = stream or torch.cuda.current_stream(dev)
+        if cur.cuda_stream == main.cuda_stream:
+            return main, None
+        main.wait_stream(cur)
+        return main, cur
 
     # -- execution ------------------------------------------------------------------------------------
     def stage(self, b, xyz, item_starts, image, stream, dyn_host=None):

@@ -396,8 +396,9 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
            relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False, flags=None, staging=None):
     """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd.  `flags`: optional int32[1] device word that
     receives IMF_FLAG_RANGE (32) when an output is NaN or >= 65504 in magnitude.  `staging` (variant 6): None = the
-    library default (LDS-DMA kernel), "regs" = the register-staged kernel (A/B and bit-identity tests), "wave8" /
-    "wave4" = the wave-split kernel for coarse levels (csrc/spconv_w.hip; kvol > 1, cout % 64 == 0, no split-K)."""
+    library default (LDS-DMA kernel k_spconv_g), "wave8" / "wave4" = the wave-split kernel for coarse levels
+    (csrc/spconv_w.hip; kvol > 1, cout % 64 == 0, no split-K); "regs" = the register-staged k_spconv_h3, which exists in
+    diagnostic builds of the library only (IMF_LIB=.../libimfnet_hip_h3.so; the product answers IMF_EUNSUPPORTED)."""
     _req(in_a, torch.float32, "in_a", 2)
     if in_b is not None:
         _req(in_b, torch.float32, "in_b", 2)

@@ -220,18 +220,17 @@ typedef struct imf_conv_args {
   int32_t split_k;        /* 0 = choose automatically; >= 1 = number of kernel-offset partitions  */
   int32_t variant;        /* 0 = pipelined workgroup kernel on the fp32 MFMA; 1 = the same arithmetic without the
                              pipeline (simple reference kernel; any kvol); 2..5 = retired round-1 experiments
-                             (tools/experiments/spconv_variants.hip), rejected with IMF_ERR_INVALID;
+                             (their measurements: DESIGN.md 4), rejected with IMF_EINVAL;
                              6 = fp32-class arithmetic on the f16 matrix pipe with split operands, both operands staged
                                  global -> LDS by DMA (k_spconv_g; see kernel_tag for the register-staged twin)
                                  (w_packed from imf_pack_weights_split16; kvol <= 27; |input| < 65504;
                                  in_a / in_b smaller than 2 GiB each: raw-buffer addressing) */
-  void *workspace;        /* split-K partial sums (NULL allowed iff split_k resolves to 1); with split 1 and
-                             variant 6 an optional scratch that lets launches of >= 512 tiles balance
-                             their last round of workgroups (imf_spconv_workspace_bytes says how much) */
+  void *workspace;        /* split-K partial sums (NULL allowed iff split_k resolves to 1) */
   size_t workspace_bytes; /* >= imf_spconv_workspace_bytes(n_slots, cout, split)                  */
   int32_t *tickets;       /* optional: int32[n_tiles * n_slabs] arrival counters, ZERO on entry (left zero on
                              exit): with split_k > 1 the last partition to finish a tile reduces it inside
-                             the same launch (agent-scope release/acquire) -- no second kernel            */
+                             the same launch (agent-scope release/acquire) -- no second kernel.  Variant 0; with
+                             variant 6 in diagnostic builds only (measured slower than the second launch) */
   void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded on `stream` immediately around the
                               main MFMA kernel (not the split-K reduce): live roofline timing     */
   /* Capacity mode (variant 6), for launch sequences captured once and replayed on fragments of different
@@ -245,10 +244,9 @@ typedef struct imf_conv_args {
   const int32_t *n_out_dev;
   int32_t dyn_split_kvol, slots_extra;
   int32_t kernel_tag;     /* variant 6 only.  bit 0: profiling label -- the identical kernel under a second symbol
-                             (k_spconv_g<.., 1>: the image branch's dense convolutions).  bit 1: run the register-staged
-                             implementation k_spconv_h3 (csrc/spconv_h3.hip) instead of the default k_spconv_g
-                             (csrc/spconv_g.hip: both operands global -> LDS by DMA); same sums bit for bit, kept for A/B
-                             and selected automatically with `tickets`.  Process-wide: env IMF_H3_GLDS=0.
+                             (k_spconv_g<.., 1>: the image branch's dense convolutions).  bit 1: the register-staged twin
+                             k_spconv_h3 (csrc/spconv_h3.hip; same sums bit for bit) -- DIAGNOSTIC builds only (make h3 /
+                             stamps): the product library answers IMF_EUNSUPPORTED, as it does for variant 6 + `tickets`.
                              bit 2 (4) / bit 3 (8): the wave-split kernel k_spconv_w (csrc/spconv_w.hip) with 8 / 4
                              wavefronts per workgroup -- for levels of a few hundred 64-row tiles or fewer: one workgroup
                              owns a (tile, 64-column slab) for all kernel offsets, its wavefronts split the tile's
