@@ -8,6 +8,11 @@
 
 namespace imf {
 
+#ifndef IMF_GEO_ABL
+#define IMF_GEO_ABL 0   // timing experiments only (tools/geo_ablations.sh; wrong results): k_insert_points without 1 the table atomics,
+                        // 2 the fp64 divisions (float instead), 4 the slot_of store, 8 the run-leader election (one insert per point)
+#endif
+
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 4;
 constexpr int kScanTile = kScanThreads * kScanItems;  // 1024 rows per block
@@ -52,9 +57,14 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
   uint64_t key = kEmptyKey;
   if (valid) {
     // util/misc.py:82 -- np.floor(xyz / voxel_size) in float64 (IEEE division, exact floor)
+#if IMF_GEO_ABL & 2
+    const float fv = (float)voxel;
+    double fx = floorf((float)xyz[3 * i + 0] / fv), fy = floorf((float)xyz[3 * i + 1] / fv), fz = floorf((float)xyz[3 * i + 2] / fv);
+#else
     double fx = floor((double)xyz[3 * i + 0] / voxel);
     double fy = floor((double)xyz[3 * i + 1] / voxel);
     double fz = floor((double)xyz[3 * i + 2] / voxel);
+#endif
     bool ok = fx >= -kCoordLim && fx < kCoordLim && fy >= -kCoordLim && fy < kCoordLim &&
               fz >= -kCoordLim && fz < kCoordLim;   // also false for NaN
     if (!ok) {
@@ -69,17 +79,21 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
   // table ends up exactly as with one insert per point.
   const int lane = threadIdx.x & 63;
   const uint64_t prev = __shfl_up(key, 1, 64);
-  const bool leader = valid && (lane == 0 || key != prev);
+  const bool leader = valid && ((IMF_GEO_ABL & 8) || lane == 0 || key != prev);
   uint32_t s = 0;
   if (leader) {
+#if IMF_GEO_ABL & 1
+    s = hash64(key) & capmask;
+#else
     s = hash_insert(tab, capmask, key);
     atomicMin(&tab[s].val, (int32_t)i);
+#endif
   }
   const unsigned long long lead_mask = __ballot(leader);
   const unsigned long long below = lead_mask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
   const int src = below ? 63 - __builtin_clzll(below) : lane;
   s = __shfl((int)s, src, 64);
-  if (valid) slot_of[i] = (int32_t)s;
+  if (valid && !(IMF_GEO_ABL & 4)) slot_of[i] = (int32_t)s;
 }
 
 __global__ void __launch_bounds__(256)

@@ -526,94 +526,145 @@ k_bitgrid_fill(const int32_t *__restrict__ coords, long long n, uint32_t *grid, 
 }
 
 constexpr int kBitsRows = 64;
-constexpr int kBitsLda = 130;    // 2*row + kslot distinct mod 32 => conflict-free A-fragment reads
 
-template <int COUT>
+typedef _Float16 f16x8_b __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2_b __attribute__((ext_vector_type(2)));
+
+// conv1 for the all-ones occupancy feature: out[v] = sum_k occ(v + off_k) * W[k], a [64, kvol] x [kvol, COUT] product per
+// workgroup whose left operand is BINARY.  Round 3: the occupancy window of a voxel is kept as a 128-bit mask (one thread
+// per (voxel, 32-offset word): no LDS atomics, no 33 KiB float matrix, no bank conflicts) and expanded to f16 0 / 1
+// A fragments in registers; 0 and 1 are exact in f16, so only the WEIGHTS are split (hi + lo halves, pre-scaled by a
+// power of two like imf_pack_weights_split16): 2 x v_mfma_f32_16x16x32_f16 per 32 offsets and column block instead of
+// 8 x v_mfma_f32_16x16x4_f32 -- 16 matrix instructions of 16 cycles per wavefront instead of 64 of 32.  The weight split
+// is redone by every workgroup (4 000 values from L2): no packed image, no change to the C ABI.
+template <int COUT, int KS>
 __global__ void __launch_bounds__(256)
 k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_t *__restrict__ grid,
-                  GridDesc g, int ksize, int kvol, const float *__restrict__ w,
+                  GridDesc g, int ksize_rt, int kvol, const float *__restrict__ w,
                   const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                   float *__restrict__ out, const DynGrid dg) {
+  constexpr int CBN = COUT / 16;                         // column blocks; wave w owns row block w
+  constexpr int ksize = KS;
+  constexpr int kMaxWin = KS == 3 ? 11 : 8;              // windows of KS bits that can touch one 32-offset word
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  (void)ksize_rt;
   if (!dyn_grid(dg, ksize, g, n)) return;
   if ((long long)blockIdx.x * kBitsRows >= n) return;
-  float *A_l = lds_f;                                    // [64][kBitsLda]
-  float *W_l = lds_f + kBitsRows * kBitsLda;             // [128][COUT], rows >= kvol are zero
+  float4 *W_l = reinterpret_cast<float4 *>(lds_f);                          // [4 kc][CBN][hi, lo][64 lanes] x 8 halves
+  uint32_t *M_l = reinterpret_cast<uint32_t *>(W_l + 4 * CBN * 2 * 64);     // [64 rows][4 words]: occupancy masks
+  __shared__ unsigned red[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const long long v0 = (long long)blockIdx.x * kBitsRows;
-  // weights as float4 (kvol * COUT is a multiple of 4), zero rows up to 128
-  for (int i = tid; i < 32 * COUT; i += 256)
-    reinterpret_cast<float4 *>(W_l)[i] = 4 * i < kvol * COUT ? reinterpret_cast<const float4 *>(w)[i]
-                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = tid; i < kBitsRows * kBitsLda; i += 256) A_l[i] = 0.f;
-  __syncthreads();
-  // Occupancy windows: one item = (voxel, dy, dz) -> ksize bits along x.  Two phases with every load of a phase in
-  // flight together (coordinates, then grid words): as a per-item loop this was ~12 dependent memory round trips
-  // per workgroup (coordinate -> grid row, six to seven items per thread) and set the kernel's time.
-  const int r = ksize >> 1, nyz = ksize * ksize;
-  constexpr int kItems = (kBitsRows * 25 + 255) / 256;   // 7 (ksize 5); ksize 3 uses 3 of them
-  const int n_items = kBitsRows * nyz;
-  int4 c[kItems];
+  const int nkc = (kvol + 31) >> 5;
+
+  // ---- occupancy masks: thread (v, wd) gathers the windows (dy, dz) whose ksize bits fall into offsets 32 wd .. 32 wd + 31
+  const int v = tid >> 2, wd = tid & 3;
+  const int r = ksize >> 1;
+  const long long row = v0 + v < n ? v0 + v : n - 1;     // clamped: the loads are unconditional
+  const int4 c = reinterpret_cast<const int4 *>(coords)[row];
+  const int k_lo = 32 * wd, k_hi = min(32 * wd + 31, kvol - 1);
+  const int yz_lo = k_lo / ksize;
+  const int n_win = k_hi >= k_lo ? k_hi / ksize - yz_lo + 1 : 0;          // <= kMaxWin
+  const int bx = c.y - r - g.x0;                         // first bit of every window of this voxel, >= 0 by construction
+  const int wi = bx >> 5, sh = bx & 31;
+  const __amdgpu_buffer_rsrc_t rs_grid = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(grid), (short)0, 0x7FFFFFFF, 0x00020000);
+  uint32_t w0[kMaxWin], w1[kMaxWin];
 #pragma unroll
-  for (int j = 0; j < kItems; ++j) {
-    const int it = tid + 256 * j;
-    const int v = (it < n_items ? it : 0) / nyz;
-    const long long row = v0 + v < n ? v0 + v : n - 1;     // clamped: the load is unconditional
-    c[j] = reinterpret_cast<const int4 *>(coords)[row];
-  }
-  uint32_t w0[kItems], w1[kItems];
-#pragma unroll
-  for (int j = 0; j < kItems; ++j) {
-    const int it = tid + 256 * j;
-    const int itc = it < n_items ? it : 0;
-    const int v = itc / nyz, yz = itc - v * nyz;
+  for (int j = 0; j < kMaxWin; ++j) {
+    const int yz = j < n_win ? yz_lo + j : (n_win ? yz_lo : 0);   // unused slots repeat a valid window (the load is unconditional)
     const int dy = yz % ksize - r, dz = yz / ksize - r;
-    const uint32_t *row = grid + grid_row(g, c[j].x, c[j].z + dy, c[j].w + dz);
-    const int bx = c[j].y - r - g.x0;                      // first bit of the window, >= 0 by construction
-    const int wi = bx >> 5, sh = bx & 31;
-    w0[j] = row[wi];
-    w1[j] = row[sh + ksize > 32 ? wi + 1 : wi];            // second word only when the window straddles
+    // both words of the window in ONE 8-byte buffer load (dword-aligned is enough for buffer addressing): a row has
+    // nx / 32 + 2 words and a window starts at most ksize bits before its last occupied bit, so word wi + 1 is in the row
+    const long long off = (grid_row(g, c.x, c.z + dy, c.w + dz) + wi) * 4;
+    const u32x2_b pr = __builtin_amdgcn_raw_buffer_load_b64(rs_grid, (int)off, 0, 0);
+    w0[j] = pr[0];
+    w1[j] = pr[1];
   }
+  // ---- weights: max |w| (block reduce) -> power-of-two scale -> hi / lo f16 B fragments in the MFMA's lane order
+  //      [kc][cb][h][lane][t]: offset k = 32 kc + 16 (t >> 2) + 4 (lane >> 4) + (t & 3), column 16 cb + (lane & 15)
+  unsigned amax = 0u;
+  for (int i = tid; i < kvol * COUT; i += 256) {
+    const unsigned bits = __float_as_uint(fabsf(w[i]));
+    if (bits < 0x7F800000u) amax = bits > amax ? bits : amax;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = __shfl_xor(amax, o, 64);
+    amax = t > amax ? t : amax;
+  }
+  if (lane == 0) red[wave] = amax;
+  __syncthreads();
+  amax = max(max(red[0], red[1]), max(red[2], red[3]));
+  int wshift = 0;
+  if (amax != 0u) {
+    wshift = 13 - ((int)(amax >> 23) - 127);             // the scaled kernel peaks in [2^13, 2^14): lo halves stay normal
+    wshift = wshift < -40 ? -40 : (wshift > 100 ? 100 : wshift);
+  }
+  const float un = ldexpf(1.f, -wshift);
+  for (int i = tid; i < nkc * CBN * 64; i += 256) {
+    const int ln = i & 63, cb = (i >> 6) % CBN, kc = i / (64 * CBN);
+    f16x8_b hi, lo;
 #pragma unroll
-  for (int j = 0; j < kItems; ++j) {
-    const int it = tid + 256 * j;
-    if (it >= n_items) continue;
-    const int v = it / nyz, yz = it - v * nyz;
-    if (v0 + v >= n) continue;
-    const int sh = (c[j].y - r - g.x0) & 31;
-    uint32_t bits = w0[j] >> sh;
-    if (sh + ksize > 32) bits |= w1[j] << (32 - sh);
-    float *dst = A_l + v * kBitsLda + yz * ksize;
-    for (int dx = 0; dx < ksize; ++dx) dst[dx] = (bits >> dx) & 1u ? 1.f : 0.f;
+    for (int t = 0; t < 8; ++t) {
+      const int k = 32 * kc + 16 * (t >> 2) + 4 * (ln >> 4) + (t & 3);
+      const float x = k < kvol ? ldexpf(w[k * COUT + 16 * cb + (ln & 15)], wshift) : 0.f;
+      const _Float16 h = (_Float16)x;
+      hi[t] = h;
+      lo[t] = (_Float16)(x - (float)h);
+    }
+    W_l[((kc * CBN + cb) * 2 + 0) * 64 + ln] = __builtin_bit_cast(float4, hi);
+    W_l[((kc * CBN + cb) * 2 + 1) * 64 + ln] = __builtin_bit_cast(float4, lo);
+  }
+  // ---- combine the windows into this thread's mask word
+  {
+    const uint32_t wmask = (1u << ksize) - 1u;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int j = 0; j < kMaxWin; ++j) {
+      if (j >= n_win) continue;
+      uint32_t bits = w0[j] >> sh;
+      if (sh + ksize > 32) bits |= w1[j] << (32 - sh);
+      bits &= wmask;
+      const int rel = (yz_lo + j) * ksize - k_lo;        // where the window's offset 0 sits in this word (may be < 0)
+      m |= rel >= 0 ? bits << rel : bits >> (-rel);
+    }
+    if (k_hi - k_lo < 31) m &= (1u << (k_hi - k_lo + 1)) - 1u;            // offsets >= kvol do not exist
+    M_l[v * 4 + wd] = v0 + v < n ? m : 0u;
   }
   __syncthreads();
 
-  constexpr int CBN = COUT / 16;                         // column blocks; wave w owns row block w
   const int r16 = lane & 15, q4 = lane >> 4;
   f32x4 acc[CBN];
 #pragma unroll
   for (int cb = 0; cb < CBN; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float *arow = A_l + (wave * 16 + r16) * kBitsLda + q4;
-  const float *wcol = W_l + q4 * COUT + r16;
-#pragma unroll 4
-  for (int s = 0; s < 32; ++s) {
-    const float a = arow[4 * s];
+  for (int kc = 0; kc < nkc; ++kc) {
+    // A fragment of lane (r16, q4): offsets 32 kc + {4 q4 .. 4 q4 + 3, 16 + 4 q4 .. 16 + 4 q4 + 3} of row 16 wave + r16
+    const uint32_t word = M_l[(wave * 16 + r16) * 4 + kc];
+    const uint32_t b8 = ((word >> (4 * q4)) & 0xFu) | (((word >> (16 + 4 * q4)) & 0xFu) << 4);
+    uint32_t aw[4];
 #pragma unroll
-    for (int cb = 0; cb < CBN; ++cb)
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wcol[4 * s * COUT + cb * 16], acc[cb], 0, 0, 0);
+    for (int j = 0; j < 4; ++j)
+      aw[j] = ((b8 >> (2 * j)) & 1u ? 0x3C00u : 0u) | ((b8 >> (2 * j + 1)) & 1u ? 0x3C000000u : 0u);   // f16 1.0 = 0x3C00
+    const f16x8_b a = __builtin_bit_cast(f16x8_b, make_uint4(aw[0], aw[1], aw[2], aw[3]));
+#pragma unroll
+    for (int cb = 0; cb < CBN; ++cb) {
+      const f16x8_b bh = __builtin_bit_cast(f16x8_b, W_l[((kc * CBN + cb) * 2 + 0) * 64 + lane]);
+      const f16x8_b bl = __builtin_bit_cast(f16x8_b, W_l[((kc * CBN + cb) * 2 + 1) * 64 + lane]);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, acc[cb], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int cb = 0; cb < CBN; ++cb) {
     const int col = cb * 16 + r16;
-    const float sc = scale ? scale[col] : 1.f, sh = shift ? shift[col] : 0.f;
+    const float sc = scale ? scale[col] : 1.f, shf = shift ? shift[col] : 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long long row = v0 + wave * 16 + q4 * 4 + e;
-      if (row < n) {
-        float v = acc[cb][e] * sc + sh;
-        if (relu) v = fmaxf(v, 0.f);
-        if (dg.err && out_of_f16_range(v)) atomicOr(dg.err, 32);
-        out[row * COUT + col] = v;
+      const long long orow = v0 + wave * 16 + q4 * 4 + e;
+      if (orow < n) {
+        float y = (acc[cb][e] * un) * sc + shf;
+        if (relu) y = fmaxf(y, 0.f);
+        if (dg.err && out_of_f16_range(y)) atomicOr(dg.err, 32);
+        out[orow * COUT + col] = y;
       }
     }
   }
@@ -883,15 +934,12 @@ static int conv_first_bitgrid_impl(const int32_t *coords, int64_t n, const int32
   if (!grid_is_clear) IMF_CHECK_HIP(hipMemsetAsync(grid, 0, words * sizeof(uint32_t), st));
   k_bitgrid_fill<<<(unsigned)div_up(n, 256), 256, 0, st>>>(coords, n, grid, g, ksize, dg);
   const int kvol = ksize * ksize * ksize;
-  const size_t lds = ((size_t)kBitsRows * kBitsLda + 128 * (size_t)cout) * sizeof(float);
+  const size_t lds = (size_t)4 * (cout / 16) * 2 * 64 * 16 + (size_t)kBitsRows * 4 * sizeof(uint32_t);   // B fragments + masks
   const unsigned nb = (unsigned)div_up(n, kBitsRows);
-  if (cout == 32) {
-    k_conv_first_bits<32><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
-  } else {
-    IMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_first_bits<64>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_conv_first_bits<64><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
-  }
+  if (cout == 32 && ksize == 5)      k_conv_first_bits<32, 5><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
+  else if (cout == 32)               k_conv_first_bits<32, 3><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
+  else if (ksize == 5)               k_conv_first_bits<64, 5><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
+  else                               k_conv_first_bits<64, 3><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
   IMF_CHECK_LAUNCH("k_conv_first_bits");
   return IMF_OK;
 }
