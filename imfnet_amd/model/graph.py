@@ -104,22 +104,27 @@ class HostSlot:
         self._views = None
 
     def bind(self, b):
-        """Views of the pinned blocks in bucket b's layout (blocks grow on demand)."""
-        if self._views is not None and self._views[0] is b:
-            return self._views[1]
+        """Views of the pinned blocks in bucket b's layout (blocks grow on demand; views cached per bucket)."""
+        grown = False
         if self.inbuf is None or self.inbuf.numel() < b.inbuf.numel():
-            self.inbuf = torch.empty(b.inbuf.numel(), dtype=torch.uint8).pin_memory()
+            self.inbuf, grown = torch.empty(b.inbuf.numel(), dtype=torch.uint8).pin_memory(), True
         if self.outbuf is None or self.outbuf.numel() < b.outbuf.numel():
-            self.outbuf = torch.empty(b.outbuf.numel(), dtype=torch.uint8).pin_memory()
-        L, hi, ho = b.lay, self.inbuf.numpy(), self.outbuf.numpy()
-        v = dict(dyn=hi[:4 * DYN_WORDS].view(np.int32),
+            self.outbuf, grown = torch.empty(b.outbuf.numel(), dtype=torch.uint8).pin_memory(), True
+        if grown or self._views is None:
+            self._views = {}
+            self._np = (self.inbuf.numpy(), self.outbuf.numpy())
+        v = self._views.get(id(b))
+        if v is not None and v["bucket"] is b:
+            return v
+        L, (hi, ho) = b.lay, self._np
+        v = dict(bucket=b, dyn=hi[:4 * DYN_WORDS].view(np.int32),
                  image=hi[L["img"]:L["img"] + b.image.numel() * 4].view(np.float32).reshape(tuple(b.image.shape)),
                  xyz=hi[L["xyz"]:L["xyz"] + b.xyz.numel() * b.xyz.element_size()]
                      .view(np.float64 if b.xyz.dtype == torch.float64 else np.float32).reshape(-1, 3),
                  meta=self.outbuf[:4 * META_WORDS].view(torch.int32),
                  sel=ho[L["sel"]:L["sel"] + b.sel.numel() * 8].view(np.float64).reshape(-1, 3),
                  F=ho[L["F"]:L["F"] + b.out.numel() * 4].view(np.float32).reshape(tuple(b.out.shape)))
-        self._views = (b, v)
+        self._views[id(b)] = v
         return v
 
 
@@ -250,6 +255,7 @@ class FragmentRunner:
         self.stats = dict(graph=0, eager=0, redone=0, captured=0)
         self.host_slots = []          # pinned staging of the synchronous host-array path (extract.py)
         self.stream_state = None      # streams + pinned slots of extract_features_stream
+        self.cli_slots = None         # pinned slots of generate_desc's pipelined loop
 
     # -- capacity policy ----------------------------------------------------------------------------
     def observe(self, n_points, counts, bbox):
