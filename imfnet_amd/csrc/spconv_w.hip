@@ -205,6 +205,9 @@ k_spconv_w(const ConvParams p) {
   //     sub-stage (SIMD partners w / w + 4 in opposite segments, MI355X_MICROARCH.md "Two waves per SIMD"): the
   //     stride-4 / 8 launches 35.2 -> 43.4 us on average -- with a single buffer per wavefront the DMAs issued at the end
   //     of LOAD get one COMPUTE segment to land, and every wavefront then waits for them in lock step.
+  //   * one extra load per sub-stage that touches a line per lane of the weight block two sub-stages ahead (a software
+  //     prefetch towards L2 / L1): the stride-4 / 8 launches 35.8 -> 38.3 us, the stride-2 ones 29.3 -> 34.6 us -- every
+  //     additional vector-memory instruction costs the wavefront more than the shorter DMA latency returns.
 #pragma unroll 1
   for (int t = t0; t < t1; ++t) {
     // sub-stage t has landed: the region is private, the wavefront's own counter is the only wait
