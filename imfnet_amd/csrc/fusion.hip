@@ -166,20 +166,28 @@ k_fusion_attn(const FusionParams p) {
   {
     f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
     const int cb[1] = {wave};
-    gemm16<1, 8>(acc, N, kLdX, kFD, p.wq, cb, lane);
+    gemm16<1, 16>(acc, N, kLdX, kFD, p.wq, cb, lane);    // all 16 steps of K = 256 in flight: one L2 round trip, not two
 #pragma unroll
     for (int r = 0; r < 4; ++r) Q[(4 * q4 + r) * kLdQ + wave * 16 + r16] = acc[0][r];
   }
   __syncthreads();
 
   // ---- scores = q K^T * scale : N = tokp (<= 320 -> <= 20 column blocks, round-robin over waves) --
+  // The block is a chain of dependent L2 round trips (~2.5 us each: 16-row workgroups, B fragments straight from L2), so
+  // a wavefront's column blocks c, c + 8, c + 16 go through ONE gemm call with every B fragment in flight together
+  // instead of three calls (round 3: the attention half 28 -> see DESIGN 4d); a missing block repeats the last valid one.
   const int ncb_s = p.tokp / 16;
-  for (int c = wave; c < ncb_s; c += 8) {
-    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-    const int cb[1] = {c};
-    gemm16<1, 8>(acc, Q, kLdQ, kFQ, ktp, cb, lane);
+  if (wave < ncb_s) {
+    f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int c1 = wave + 8 < ncb_s ? wave + 8 : wave, c2 = wave + 16 < ncb_s ? wave + 16 : c1;
+    const int cb[3] = {wave, c1, c2};
+    gemm16<3, 8>(acc, Q, kLdQ, kFQ, ktp, cb, lane);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[(4 * q4 + r) * kLdS + c * 16 + r16] = acc[0][r] * p.scale;
+    for (int i = 0; i < 3; ++i) {
+      if (i > 0 && cb[i] == cb[i - 1]) continue;       // a repeated (missing) block
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(4 * q4 + r) * kLdS + cb[i] * 16 + r16] = acc[i][r] * p.scale;
+    }
   }
   __syncthreads();
 
@@ -215,7 +223,13 @@ k_fusion_attn(const FusionParams p) {
   {
     f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
     const int cb[1] = {wave};
-    gemm16<1, 4>(acc, S, kLdS, p.tokp, vp, cb, lane);   // q was last read before the previous barrier
+    // q was last read before the previous barrier.  K = tokp: as many 16-token steps in flight as divide it
+    const int U = p.tokp / 16;
+    if (U % 20 == 0)      gemm16<1, 20>(acc, S, kLdS, p.tokp, vp, cb, lane);
+    else if (U % 16 == 0) gemm16<1, 16>(acc, S, kLdS, p.tokp, vp, cb, lane);
+    else if (U % 12 == 0) gemm16<1, 12>(acc, S, kLdS, p.tokp, vp, cb, lane);
+    else if (U % 8 == 0)  gemm16<1, 8>(acc, S, kLdS, p.tokp, vp, cb, lane);
+    else                  gemm16<1, 4>(acc, S, kLdS, p.tokp, vp, cb, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) Q[(4 * q4 + r) * kLdQ + wave * 16 + r16] = acc[0][r];
   }
