@@ -523,6 +523,7 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
 
   // conv1's occupancy bit grid (the int arena's tail, as imf_resunet_forward lays it out) is zeroed here, ahead of the
   // pyramid, instead of between the pyramid and conv1
+  IMF_REQUIRE(net->first_ksize == 3 || net->first_ksize == 5, "imf_fragment_forward: first_ksize=%d", net->first_ksize);
   {
     IMF_REQUIRE(net->small_first && caps->bitgrid_words > 0 && fio->int_arena, "imf_fragment_forward: needs the occupancy-feature first convolution and a bit-grid capacity");
     IMF_REQUIRE(fio->int_arena_bytes >= imf_resunet_int_arena_bytes_cap(net, caps->rows, caps->bitgrid_words),
@@ -531,6 +532,9 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
     int32_t *ibase = (int32_t *)(((uintptr_t)fio->int_arena + 255) & ~(uintptr_t)255);
     uint32_t *bitgrid = (uint32_t *)(ibase + int_words(sizes_of(net, caps->rows)));
     IMF_CHECK_HIP(hipMemsetAsync(bitgrid, 0, caps->bitgrid_words * sizeof(uint32_t), main));
+    // ... and FILLED by the level-0 compaction kernel itself (the bounding box comes out of k_insert_points): no
+    // k_bitgrid_fill launch between the pyramid and conv1
+    pb.grid = bitgrid; pb.grid_words = caps->bitgrid_words; pb.grid_ksize = net->first_ksize;
   }
   // level 0 of the pyramid on the main stream (conv1 needs it first); the coarse levels go to the side stream
   if ((rc = pyramid_level0(pb, main, false))) return rc;

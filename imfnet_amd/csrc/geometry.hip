@@ -38,13 +38,39 @@ k_item_starts(const int32_t *__restrict__ coords, const int32_t *__restrict__ n_
   if ((i == 0 || coords[4 * (i - 1)] != b) && b >= 0 && b < IMF_MAX_BATCH) starts[b] = i;
 }
 
+// Bounding box (b,x,y,z min / max) of a workgroup's voxels -> wg_bbox[blockIdx.x][0..7] (plain stores, no atomics:
+// 2 385 workgroups improving 8 shared words with atomics made k_insert_points 32 -> 108 us; same-address atomics
+// serialise in L2).  Block 0 of k_flag_first folds the per-workgroup boxes into the level's box.  lo / hi of lanes
+// without a voxel must be +INT_MAX / INT_MIN.
+__device__ __forceinline__ void block_bbox_store(int4 lo, int4 hi, int32_t *wg_bbox) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    lo.x = min(lo.x, __shfl_down(lo.x, o, 64)); lo.y = min(lo.y, __shfl_down(lo.y, o, 64));
+    lo.z = min(lo.z, __shfl_down(lo.z, o, 64)); lo.w = min(lo.w, __shfl_down(lo.w, o, 64));
+    hi.x = max(hi.x, __shfl_down(hi.x, o, 64)); hi.y = max(hi.y, __shfl_down(hi.y, o, 64));
+    hi.z = max(hi.z, __shfl_down(hi.z, o, 64)); hi.w = max(hi.w, __shfl_down(hi.w, o, 64));
+  }
+  __shared__ int bb[4][8];
+  if (lane == 0) {
+    bb[w][0] = lo.x; bb[w][1] = lo.y; bb[w][2] = lo.z; bb[w][3] = lo.w;
+    bb[w][4] = hi.x; bb[w][5] = hi.y; bb[w][6] = hi.z; bb[w][7] = hi.w;
+  }
+  __syncthreads();
+  if (t < 8) {
+    const bool is_min = t < 4;
+    int v = bb[0][t];
+    for (int q = 1; q < 4; ++q) v = is_min ? min(v, bb[q][t]) : max(v, bb[q][t]);
+    wg_bbox[(long long)blockIdx.x * 8 + t] = v;
+  }
+}
+
 // dyn (optional, device): [0] = number of points, [1] = number of items, [2 + b] = first point of item b --
 // the per-fragment scalars of a captured launch sequence (IMF_DYN_WORDS ints).
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, const BatchStarts bs,
                 const int32_t *__restrict__ dyn,
-                imf_slot *tab, uint32_t capmask, int32_t *slot_of, int32_t *err) {
+                imf_slot *tab, uint32_t capmask, int32_t *slot_of, int32_t *err, int32_t *wg_bbox) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (dyn) {
     n = min((int64_t)dyn[0], n);
@@ -55,6 +81,7 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
   }
   const bool valid = i < n;
   uint64_t key = kEmptyKey;
+  int4 vc = make_int4(0, 0, 0, 0);
   if (valid) {
     // util/misc.py:82 -- np.floor(xyz / voxel_size) in float64 (IEEE division, exact floor)
 #if IMF_GEO_ABL & 2
@@ -72,6 +99,7 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
       fx = fy = fz = 0.0;
     }
     key = pack_key(batch, (int)fx, (int)fy, (int)fz);
+    vc = make_int4(batch, (int)fx, (int)fy, (int)fz);
   }
   // Scan-ordered clouds put consecutive points into the same voxel (~5 points per 2.5 cm voxel): only the first lane
   // of every run of equal keys inside the wavefront touches the table (one atomicCAS + one atomicMin per run instead
@@ -94,6 +122,14 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
   const int src = below ? 63 - __builtin_clzll(below) : lane;
   s = __shfl((int)s, src, 64);
   if (valid && !(IMF_GEO_ABL & 4)) slot_of[i] = (int32_t)s;
+  // the level's bounding box (every voxel has a point here): known BEFORE the compaction, which can then fill conv1's
+  // occupancy bit grid itself (its origin is the box's minimum)
+  if (wg_bbox) {
+    const int big = 0x7FFFFFFF;
+    const int4 lo = valid ? vc : make_int4(big, big, big, big);
+    const int4 hi = valid ? vc : make_int4(-big - 1, -big - 1, -big - 1, -big - 1);
+    block_bbox_store(lo, hi, wg_bbox);
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -121,8 +157,37 @@ __device__ __forceinline__ int block_sum_256(int v, int *lds4) {
 
 __global__ void __launch_bounds__(kScanThreads)
 k_flag_first(int32_t *slot_of, const imf_slot *__restrict__ tab, int64_t n_static,
-             const int32_t *__restrict__ n_dev, int32_t *block_sums) {
+             const int32_t *__restrict__ n_dev, int32_t *block_sums,
+             const int32_t *__restrict__ wg_bbox = nullptr, int n_wg = 0, int32_t *bbox_out = nullptr) {
   __shared__ int lds4[4];
+  if (wg_bbox && blockIdx.x == 0) {   // level 0: fold k_insert_points' per-workgroup boxes into the level's box
+    __shared__ int part[4][8];
+    const int big = 0x7FFFFFFF;
+    int4 lo = make_int4(big, big, big, big), hi = make_int4(-big - 1, -big - 1, -big - 1, -big - 1);
+    for (int g = threadIdx.x; g < n_wg; g += kScanThreads) {       // two 16-byte loads per workgroup box, all in flight
+      const int4 a = reinterpret_cast<const int4 *>(wg_bbox)[2 * g], c = reinterpret_cast<const int4 *>(wg_bbox)[2 * g + 1];
+      lo.x = min(lo.x, a.x); lo.y = min(lo.y, a.y); lo.z = min(lo.z, a.z); lo.w = min(lo.w, a.w);
+      hi.x = max(hi.x, c.x); hi.y = max(hi.y, c.y); hi.z = max(hi.z, c.z); hi.w = max(hi.w, c.w);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      lo.x = min(lo.x, __shfl_down(lo.x, o, 64)); lo.y = min(lo.y, __shfl_down(lo.y, o, 64));
+      lo.z = min(lo.z, __shfl_down(lo.z, o, 64)); lo.w = min(lo.w, __shfl_down(lo.w, o, 64));
+      hi.x = max(hi.x, __shfl_down(hi.x, o, 64)); hi.y = max(hi.y, __shfl_down(hi.y, o, 64));
+      hi.z = max(hi.z, __shfl_down(hi.z, o, 64)); hi.w = max(hi.w, __shfl_down(hi.w, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      int *pw = part[threadIdx.x >> 6];
+      pw[0] = lo.x; pw[1] = lo.y; pw[2] = lo.z; pw[3] = lo.w; pw[4] = hi.x; pw[5] = hi.y; pw[6] = hi.z; pw[7] = hi.w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      const bool is_min = threadIdx.x < 4;
+      int r = part[0][threadIdx.x];
+      for (int j = 1; j < 4; ++j) r = is_min ? min(r, part[j][threadIdx.x]) : max(r, part[j][threadIdx.x]);
+      bbox_out[threadIdx.x] = r;
+    }
+    __syncthreads();
+  }
   const int64_t n = n_dev ? min((int64_t)*n_dev, n_static) : n_static;
   int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   int cnt = 0;
@@ -140,6 +205,14 @@ k_flag_first(int32_t *slot_of, const imf_slot *__restrict__ tab, int64_t n_stati
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
+struct GridFill {            // optional extra of the level-0 compaction: set conv1's occupancy bits (grid zeroed by the caller)
+  uint32_t *grid;
+  unsigned long long words_cap;
+  const int32_t *bbox;       // device: min b,x,y,z, max b,x,y,z (complete: written by k_insert_points)
+  int ksize;
+  int32_t *err;
+};
+
 // ---- K3: order-preserving compaction: row r = rank of the first-occurrence point ---------------
 // The exclusive scan of the per-block counts is done here, by every workgroup for itself (it sums the counts of the
 // blocks before it: <= a few thousand ints from L2) -- a single-workgroup scan kernel between K2 and K3 cost a launch
@@ -149,7 +222,7 @@ __global__ void __launch_bounds__(kScanThreads)
 k_emit_unique(const int32_t *__restrict__ slot_of, imf_slot *tab,
               int64_t n_static, const int32_t *__restrict__ n_dev,
               const int32_t *__restrict__ block_sums, int32_t *m_out, int32_t *coords_out, int32_t *first_idx,
-              int32_t *bbox, int64_t row_cap = 0) {
+              const GridFill gf, int64_t row_cap = 0) {
   __shared__ int wsum[4], psum[4];
   const int64_t n = n_dev ? min((int64_t)*n_dev, n_static) : n_static;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -190,8 +263,20 @@ k_emit_unique(const int32_t *__restrict__ slot_of, imf_slot *tab,
   int woff = 0;
   for (int q = 0; q < w; ++q) woff += wsum[q];
   int r = block_off + woff + inc - cnt;
-  int4 lo = make_int4(0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF);
-  int4 hi = make_int4(-0x7FFFFFFF - 1, -0x7FFFFFFF - 1, -0x7FFFFFFF - 1, -0x7FFFFFFF - 1);
+  // conv1's occupancy bit grid (level 0 of imf_fragment_forward): one bit per voxel, origin = the box computed by
+  // k_insert_points; a box larger than the grid raises IMF_FLAG_BITGRID and leaves the grid alone (conv1 does the same)
+  GridDesc gd;
+  bool fill = gf.grid != nullptr;
+  if (fill) {
+    int32_t bbv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bbv[q] = gf.bbox[q];
+    size_t words = 0;
+    if (!grid_desc_from_bbox(bbv, gf.ksize, gd, words) || words > gf.words_cap) {
+      if (blockIdx.x == 0 && t == 0) atomicOr(gf.err, 4);
+      fill = false;
+    }
+  }
 #pragma unroll
   for (int e = 0; e < kScanItems; ++e) {
     if (s[e] >= 0 && row_cap > 0 && r >= row_cap) {
@@ -208,34 +293,9 @@ k_emit_unique(const int32_t *__restrict__ slot_of, imf_slot *tab,
       if (first_idx) first_idx[r] = (int32_t)(base + e);
       tab[s[e]].val = r;   // the table now maps voxel -> row
       ++r;
-      lo.x = min(lo.x, c.x); lo.y = min(lo.y, c.y); lo.z = min(lo.z, c.z); lo.w = min(lo.w, c.w);
-      hi.x = max(hi.x, c.x); hi.y = max(hi.y, c.y); hi.z = max(hi.z, c.z); hi.w = max(hi.w, c.w);
-    }
-  }
-  if (bbox) {   // bounding box of the level (b,x,y,z): wave + workgroup reduction, then at most 8
-                // atomics per WORKGROUP and only where the box actually grows (same-address atomics
-                // serialise in L2: 8 per wave cost 90 us at 258 k points)
-    for (int o = 32; o > 0; o >>= 1) {
-      lo.x = min(lo.x, __shfl_down(lo.x, o, 64)); lo.y = min(lo.y, __shfl_down(lo.y, o, 64));
-      lo.z = min(lo.z, __shfl_down(lo.z, o, 64)); lo.w = min(lo.w, __shfl_down(lo.w, o, 64));
-      hi.x = max(hi.x, __shfl_down(hi.x, o, 64)); hi.y = max(hi.y, __shfl_down(hi.y, o, 64));
-      hi.z = max(hi.z, __shfl_down(hi.z, o, 64)); hi.w = max(hi.w, __shfl_down(hi.w, o, 64));
-    }
-    __shared__ int bb[4][8];
-    if (lane == 0) {
-      bb[w][0] = lo.x; bb[w][1] = lo.y; bb[w][2] = lo.z; bb[w][3] = lo.w;
-      bb[w][4] = hi.x; bb[w][5] = hi.y; bb[w][6] = hi.z; bb[w][7] = hi.w;
-    }
-    __syncthreads();
-    if (t < 8) {
-      const bool is_min = t < 4;
-      int v = bb[0][t];
-      for (int q = 1; q < 4; ++q) v = is_min ? min(v, bb[q][t]) : max(v, bb[q][t]);
-      const int cur = __hip_atomic_load(bbox + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // monotone: a stale value only costs an atomic
-      if (is_min) {
-        if (v < cur) atomicMin(bbox + t, v);
-      } else {
-        if (v > cur) atomicMax(bbox + t, v);
+      if (fill) {
+        const int bit = c.y - gd.x0;
+        atomicOr(gf.grid + grid_row(gd, c.x, c.z, c.w) + (bit >> 5), 1u << (bit & 31));
       }
     }
   }
@@ -243,12 +303,15 @@ k_emit_unique(const int32_t *__restrict__ slot_of, imf_slot *tab,
 
 static int run_unique_tail(int32_t *slot_of, int32_t *block_sums, imf_slot *tab,
                            int64_t n_max, const int32_t *n_dev, int32_t *coords_out,
-                           int32_t *first_idx, int32_t *m_out, hipStream_t st, int32_t *bbox = nullptr,
-                           int64_t row_cap = 0) {
+                           int32_t *first_idx, int32_t *m_out, hipStream_t st, const GridFill *grid_fill = nullptr,
+                           int64_t row_cap = 0, const int32_t *wg_bbox = nullptr, int n_wg = 0, int32_t *bbox_out = nullptr) {
   const int nb = (int)div_up(n_max, kScanTile);
-  k_flag_first<<<nb, kScanThreads, 0, st>>>(slot_of, tab, n_max, n_dev, block_sums);
+  k_flag_first<<<nb, kScanThreads, 0, st>>>(slot_of, tab, n_max, n_dev, block_sums, wg_bbox, n_wg, bbox_out);
+  GridFill gf;
+  memset(&gf, 0, sizeof(gf));
+  if (grid_fill) gf = *grid_fill;
   k_emit_unique<<<nb, kScanThreads, 0, st>>>(slot_of, tab, n_max, n_dev, block_sums, m_out,
-                                             coords_out, first_idx, bbox, row_cap);
+                                             coords_out, first_idx, gf, row_cap);
   IMF_CHECK_LAUNCH("unique pipeline");
   return IMF_OK;
 }
@@ -427,8 +490,9 @@ int64_t imf_hash_capacity(int64_t n) {
   return cap;
 }
 
+// slot_of[n] | block_sums[div_up(n, 1024) + 16] | per-workgroup bounding boxes of k_insert_points [div_up(n, 256)][8]
 size_t imf_unique_workspace_bytes(int64_t n) {
-  return (size_t)(n + div_up(n, kScanTile) + 16) * sizeof(int32_t);
+  return (size_t)(n + div_up(n, kScanTile) + 16 + 4 + 8 * div_up(n, 256)) * sizeof(int32_t);   // + 4: the boxes start 16-byte aligned
 }
 
 int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, int batch_index,
@@ -453,11 +517,11 @@ int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, 
   if (xyz_is_f64)
     k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index, one, nullptr,
                                                   table, (uint32_t)(capacity - 1), slot_of,
-                                                  err_out);
+                                                  err_out, nullptr);
   else
     k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index, one, nullptr,
                                                  table, (uint32_t)(capacity - 1), slot_of,
-                                                 err_out);
+                                                 err_out, nullptr);
   IMF_CHECK_LAUNCH("k_insert_points");
   return run_unique_tail(slot_of, block_sums, table, n, nullptr, coords, first_idx, m_out, st);
 }
@@ -595,17 +659,22 @@ int pyramid_level0(const PyramidBuild &b, hipStream_t st, bool init) {
     if (rc) return rc;
   }
   const int nblk = (int)div_up(b.n, 256);
+  // [nblk][8] inside the unique workspace, 16-byte aligned (slot_of starts 256-byte aligned; k_flag_first reads int4)
+  int32_t *const wg_bbox = b.slot_of + (b.n + div_up(b.n, kScanTile) + 16 + 3) / 4 * 4;
   if (b.xyz_is_f64)
     k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
                                                   lv[0].table, (uint32_t)(lv[0].capacity - 1), b.slot_of,
-                                                  b.meta + 1);
+                                                  b.meta + 1, wg_bbox);
   else
     k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
                                                  lv[0].table, (uint32_t)(lv[0].capacity - 1), b.slot_of,
-                                                 b.meta + 1);
+                                                 b.meta + 1, wg_bbox);
   IMF_CHECK_LAUNCH("k_insert_points");
+  GridFill gf;
+  memset(&gf, 0, sizeof(gf));
+  gf.grid = b.grid; gf.words_cap = b.grid_words; gf.bbox = b.meta + 2 * b.n_levels; gf.ksize = b.grid_ksize; gf.err = b.meta + 1;
   return run_unique_tail(b.slot_of, b.block_sums, lv[0].table, b.n, b.dyn, lv[0].coords, lv[0].first_idx,
-                         b.meta, st, b.meta + 2 * b.n_levels, b.row_cap[0]);
+                         b.meta, st, b.grid ? &gf : nullptr, b.row_cap[0], wg_bbox, nblk, b.meta + 2 * b.n_levels);
 }
 
 int pyramid_coarse_level(const PyramidBuild &b, int l, hipStream_t st) {

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "spconv_shared.h"
+#include "geometry_internal.h"
 
 namespace imf {
 
@@ -465,54 +466,9 @@ k_conv_first_fused(const imf_slot *__restrict__ tab, uint32_t capmask,
 // occupied offsets".  Occupancy of a 5x5x5 neighbourhood is 25 five-bit windows of a dense bit grid
 // over the fragment's bounding box (0.7 MB for a 3DMatch fragment, L2-resident) instead of 125
 // dependent probes into a multi-MB hash table.  Per workgroup (64 voxels): the windows are expanded
-// into a 0/1 matrix A[64 x 128] in LDS and out = A . W runs on fp32 MFMA (exact: the products are
-// 1*w or 0*w, summed in ascending k) with the folded BatchNorm epilogue.
-struct GridDesc {
-  int b0, x0, y0, z0;      // origin (bounding-box min minus the kernel radius)
-  int nb, nx, ny, nz;      // extent in voxels (margins included)
-  int row_words;           // 32-bit words per x-row (>= nx/32 + 2: an unaligned window never leaves the row)
-};
-
-__host__ __device__ inline bool grid_desc_from_bbox(const int32_t *bbox, int ksize, GridDesc &g, size_t &words) {
-  const int r = ksize >> 1;
-  g.b0 = bbox[0]; g.x0 = bbox[1] - r; g.y0 = bbox[2] - r; g.z0 = bbox[3] - r;
-  g.nb = bbox[4] - bbox[0] + 1;
-  g.nx = bbox[5] - bbox[1] + 1 + 2 * r; g.ny = bbox[6] - bbox[2] + 1 + 2 * r; g.nz = bbox[7] - bbox[3] + 1 + 2 * r;
-  if (g.nb <= 0 || g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
-  g.row_words = g.nx / 32 + 2;
-  const double w = (double)g.nb * g.nz * g.ny * g.row_words;
-  if (w > (double)(1ull << 28)) return false;            // > 1 GiB of grid: use the hash path
-  words = (size_t)w;
-  return true;
-}
-
-// capacity mode: the grid descriptor is derived on the device from the level's bounding box (meta block of
-// imf_pyramid_build); a box that does not fit the provided grid raises bit 2 of *err and the launch does nothing
-struct DynGrid {
-  const int32_t *n_dev, *bbox_dev;
-  int32_t *err;
-  unsigned long long words_cap;
-};
-
-__device__ __forceinline__ bool dyn_grid(const DynGrid &d, int ksize, GridDesc &g, long long &n) {
-  if (!d.bbox_dev) return true;
-  const long long nd = *d.n_dev;
-  n = nd < n ? nd : n;
-  int32_t bb[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) bb[i] = d.bbox_dev[i];
-  size_t words = 0;
-  if (n <= 0) return false;
-  if (!grid_desc_from_bbox(bb, ksize, g, words) || words > d.words_cap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(d.err, 4);
-    return false;
-  }
-  return true;
-}
-
-__device__ __forceinline__ long long grid_row(const GridDesc &g, int b, int y, int z) {
-  return ((((long long)(b - g.b0) * g.nz + (z - g.z0)) * g.ny + (y - g.y0)) * g.row_words);
-}
+// into 128-bit masks and out = A . W runs on the f16 matrix pipe (the 0 / 1 operand is exact in f16, the weights
+// are split hi + lo) with the folded BatchNorm epilogue.
+// GridDesc, grid_desc_from_bbox, DynGrid, dyn_grid, grid_row: geometry_internal.h (the level-0 compaction kernel fills the grid too)
 
 __global__ void __launch_bounds__(256)
 k_bitgrid_fill(const int32_t *__restrict__ coords, long long n, uint32_t *grid, GridDesc g, int ksize,
@@ -931,8 +887,10 @@ static int conv_first_bitgrid_impl(const int32_t *coords, int64_t n, const int32
     IMF_REQUIRE(bbox && grid_desc_from_bbox(bbox, ksize, g, words) && words <= grid_words,
                 "imf_conv_first_bitgrid: bounding box too large for the provided grid");
   hipStream_t st = (hipStream_t)stream;
-  if (!grid_is_clear) IMF_CHECK_HIP(hipMemsetAsync(grid, 0, words * sizeof(uint32_t), st));
-  k_bitgrid_fill<<<(unsigned)div_up(n, 256), 256, 0, st>>>(coords, n, grid, g, ksize, dg);
+  if (!grid_is_clear) {   // grid_is_clear: imf_fragment_forward zeroed it and the level-0 compaction kernel set the bits
+    IMF_CHECK_HIP(hipMemsetAsync(grid, 0, words * sizeof(uint32_t), st));
+    k_bitgrid_fill<<<(unsigned)div_up(n, 256), 256, 0, st>>>(coords, n, grid, g, ksize, dg);
+  }
   const int kvol = ksize * ksize * ksize;
   const size_t lds = (size_t)4 * (cout / 16) * 2 * 64 * 16 + (size_t)kBitsRows * 4 * sizeof(uint32_t);   // B fragments + masks
   const unsigned nb = (unsigned)div_up(n, kBitsRows);
@@ -975,8 +933,8 @@ int imf_conv_first_bitgrid_dyn(const int32_t *coords, int64_t n_cap, const int32
 }  // extern "C"
 
 namespace imf {
-// imf_conv_first_bitgrid_dyn for a grid the caller has already zeroed (imf_fragment_forward clears it before the
-// level-0 pyramid: one launch and one kernel boundary fewer between the pyramid and conv1)
+// imf_conv_first_bitgrid_dyn for a grid the caller has already zeroed AND filled (imf_fragment_forward clears it before
+// the level-0 pyramid, whose compaction kernel sets the bits: two launches fewer between the pyramid and conv1)
 int conv_first_bitgrid_dyn_cleared(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
                                    int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
                                    const float *scale, const float *shift, int relu, float *out, hipStream_t stream) {

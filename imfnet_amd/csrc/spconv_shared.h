@@ -220,7 +220,7 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
 // over its `waves` (8 or 4) wavefronts, partial tiles combined through LDS, epilogue in the same launch
 void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t st);
 
-// spconv.hip: imf_conv_first_bitgrid_dyn on a grid the caller already zeroed
+// spconv.hip: imf_conv_first_bitgrid_dyn on a grid the caller already zeroed and filled (geometry.hip: k_emit_unique)
 int conv_first_bitgrid_dyn_cleared(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
                                    int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
                                    const float *scale, const float *shift, int relu, float *out, hipStream_t stream);
