@@ -142,12 +142,9 @@ int fork_image_branch(const FragmentCtx &c, hipStream_t main) {
   imf_fragment_io *fio = c.fio;
   IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[9], main));
   IMF_CHECK_HIP(hipStreamWaitEvent(c.imgs, (hipEvent_t)fio->events[9], 0));
-  // IMF_IMAGE_SKIP=1 (timing experiments only: the fusion then reads the previous fragment's tokens) leaves the branch out
-  static const bool skip = getenv("IMF_IMAGE_SKIP") && atoi(getenv("IMF_IMAGE_SKIP")) != 0;
-  const int rc = skip ? IMF_OK
-                      : imf_image_branch(c.img, fio->image, c.caps->n_items, c.caps->img_h, c.caps->img_w, fio->image_ws,
-                                         fio->image_ws_bytes, nullptr, fio->kt_packed, fio->v_packed, fio->tokens_padded,
-                                         fio->meta + 1, c.imgs);
+  const int rc = imf_image_branch(c.img, fio->image, c.caps->n_items, c.caps->img_h, c.caps->img_w, fio->image_ws,
+                                  fio->image_ws_bytes, nullptr, fio->kt_packed, fio->v_packed, fio->tokens_padded,
+                                  fio->meta + 1, c.imgs);
   if (rc) return rc;
   IMF_CHECK_HIP(hipEventRecord((hipEvent_t)fio->events[10], c.imgs));
   return IMF_OK;
@@ -511,6 +508,21 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   int rc = pyramid_prepare(pb, fio->xyz, fio->xyz_is_f64, caps->n_points, fio->voxel_size, 0, nullptr, 1, 4, fio->pyramid_arena,
                            fio->pyramid_arena_bytes, fio->meta, fio->levels, fio->dyn, caps->rows);
   if (rc) return rc;
+  // conv1's occupancy bit grid (the int arena's tail, as imf_resunet_forward lays it out) is zeroed ahead of the
+  // pyramid, by the launch that resets the hash tables (pyramid_init), instead of between the pyramid and conv1
+  IMF_REQUIRE(net->first_ksize == 3 || net->first_ksize == 5, "imf_fragment_forward: first_ksize=%d", net->first_ksize);
+  {
+    IMF_REQUIRE(net->small_first && caps->bitgrid_words > 0 && fio->int_arena, "imf_fragment_forward: needs the occupancy-feature first convolution and a bit-grid capacity");
+    IMF_REQUIRE(fio->int_arena_bytes >= imf_resunet_int_arena_bytes_cap(net, caps->rows, caps->bitgrid_words),
+                "imf_fragment_forward: int arena %zu < %zu bytes", fio->int_arena_bytes,
+                imf_resunet_int_arena_bytes_cap(net, caps->rows, caps->bitgrid_words));
+    int32_t *ibase = (int32_t *)(((uintptr_t)fio->int_arena + 255) & ~(uintptr_t)255);
+    uint32_t *bitgrid = (uint32_t *)(ibase + int_words(sizes_of(net, caps->rows)));
+    IMF_REQUIRE(((uintptr_t)bitgrid & 15) == 0 && caps->bitgrid_words % 4 == 0, "imf_fragment_forward: bit grid must be 16-byte aligned, a multiple of 4 words");
+    // ... and FILLED by the level-0 compaction kernel itself (the bounding box comes out of k_insert_points): no
+    // k_bitgrid_fill launch between the pyramid and conv1
+    pb.grid = bitgrid; pb.grid_words = caps->bitgrid_words; pb.grid_ksize = net->first_ksize;
+  }
   if ((rc = pyramid_init(pb, main))) return rc;
 
   // image branch on its own stream, forked from and later joined to the main one (events 9 / 10).  Where it forks
@@ -521,21 +533,6 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   FragmentCtx fctx{&pb, fio->serialize ? -1 : fork_env, img, caps, fio, imgs};
   if (fctx.fork_after < 0 && (rc = fork_image_branch(fctx, main))) return rc;
 
-  // conv1's occupancy bit grid (the int arena's tail, as imf_resunet_forward lays it out) is zeroed here, ahead of the
-  // pyramid, instead of between the pyramid and conv1
-  IMF_REQUIRE(net->first_ksize == 3 || net->first_ksize == 5, "imf_fragment_forward: first_ksize=%d", net->first_ksize);
-  {
-    IMF_REQUIRE(net->small_first && caps->bitgrid_words > 0 && fio->int_arena, "imf_fragment_forward: needs the occupancy-feature first convolution and a bit-grid capacity");
-    IMF_REQUIRE(fio->int_arena_bytes >= imf_resunet_int_arena_bytes_cap(net, caps->rows, caps->bitgrid_words),
-                "imf_fragment_forward: int arena %zu < %zu bytes", fio->int_arena_bytes,
-                imf_resunet_int_arena_bytes_cap(net, caps->rows, caps->bitgrid_words));
-    int32_t *ibase = (int32_t *)(((uintptr_t)fio->int_arena + 255) & ~(uintptr_t)255);
-    uint32_t *bitgrid = (uint32_t *)(ibase + int_words(sizes_of(net, caps->rows)));
-    IMF_CHECK_HIP(hipMemsetAsync(bitgrid, 0, caps->bitgrid_words * sizeof(uint32_t), main));
-    // ... and FILLED by the level-0 compaction kernel itself (the bounding box comes out of k_insert_points): no
-    // k_bitgrid_fill launch between the pyramid and conv1
-    pb.grid = bitgrid; pb.grid_words = caps->bitgrid_words; pb.grid_ksize = net->first_ksize;
-  }
   // level 0 of the pyramid on the main stream (conv1 needs it first); the coarse levels go to the side stream
   if ((rc = pyramid_level0(pb, main, false))) return rc;
 

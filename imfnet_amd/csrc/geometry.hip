@@ -587,13 +587,14 @@ size_t imf_pyramid_arena_bytes_caps(int64_t n_points_cap, int n_levels, const in
 
 // the tables of all levels are one contiguous region: one grid-stride launch empties them and resets the meta block
 __global__ void __launch_bounds__(256)
-k_init_tables2(imf_slot *tab, int64_t n_slots, int n_levels, int32_t *meta, int n_meta) {
+k_init_tables2(imf_slot *tab, int64_t n_slots, int n_levels, int32_t *meta, int n_meta, uint4 *zero, int64_t n_zero16) {
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
   if (i0 < n_meta) meta[i0] = (i0 >= 2 * n_levels && i0 < 2 * n_levels + 8)
                                   ? (i0 < 2 * n_levels + 4 ? 0x7FFFFFFF : -0x7FFFFFFF - 1)    // level-0 bounding box
                                   : (i0 >= 2 * n_levels + 8 ? -1 : 0);                       // item starts / counts
   for (int64_t i = i0; i < n_slots; i += step)
     reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu, 0u);
+  for (int64_t i = i0; i < n_zero16; i += step) zero[i] = make_uint4(0u, 0u, 0u, 0u);   // conv1's occupancy bit grid
 }
 
 }  // extern "C"
@@ -646,7 +647,9 @@ int pyramid_init(const PyramidBuild &b, hipStream_t st) {
   imf_level *lv = b.levels;
   int64_t nb = div_up(b.n_table_slots, 256 * 4);
   nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
-  k_init_tables2<<<(unsigned)nb, 256, 0, st>>>(lv[0].table, b.n_table_slots, b.n_levels, b.meta, b.n_meta);
+  // (+ conv1's bit grid, when the caller handed one over: 16-byte aligned, a whole number of 16-byte words)
+  k_init_tables2<<<(unsigned)nb, 256, 0, st>>>(lv[0].table, b.n_table_slots, b.n_levels, b.meta, b.n_meta,
+                                               reinterpret_cast<uint4 *>(b.grid), b.grid ? (int64_t)(b.grid_words / 4) : 0);
   IMF_CHECK_LAUNCH("k_init_tables2");
   return IMF_OK;
 }
