@@ -275,6 +275,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   };
   int rc;
   int items_event = -1;
+  bool image_joined_side = false;
   if (pyr) {   // level 0 was built on the main stream: the side stream (coarse levels, rulebooks) starts after it
     IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[7], main));
     IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->events[7], 0));
@@ -294,8 +295,6 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   }
   if (pyr) {   // first row of every item at every level (the fusion reads the stride-8 ones)
     if ((rc = pyramid_item_starts(*pyr, side, 0, 4))) return rc;
-    IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[8], side));
-    items_event = 8;
   }
   for (int i = 2; i >= 0; --i) {
     const imf_level &co = io->level[i + 1], &fi = io->level[i];
@@ -307,7 +306,19 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
       rc = imf_rulebook_transpose(co.table, co.capacity, fi.coords, s.n[i], 1 << i, 3, rb_up[i].tile_rows,
                                   rb_up[i].nbr, rb_up[i].tile_mask, rb_up[i].n_slots, counters + 16 * i, side);
     if (rc) return rc;
-    if ((rc = mark(rb_up[i]))) return rc;
+    if (!pyr && (rc = mark(rb_up[i]))) return rc;
+  }
+  if (pyr) {
+    // Fragment forward: ONE join with the side stream for everything the second half of the step needs (item starts for
+    // the fusion, the three transposed rulebooks for the decoder), waited for right before the fusion.  A stream-wait
+    // costs the main stream ~5 us even when its event completed long ago (tools/conv_gaps.py: 10.6 us instead of 5.3 in
+    // front of every convolution that carried one); the side stream's chain ends ~150 us before the main stream gets there.
+    // The image branch joins the SIDE stream here (it was forked before this call, its end event is recorded), so the
+    // main stream waits once, not twice, in front of the fusion.
+    image_joined_side = io->image_ready && fctx->fork_after < 0 && side != main;
+    if (image_joined_side) IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->image_ready, 0));
+    IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[8], side));
+    items_event = 8;
   }
 
   // ---- feature buffers in the float arena ------------------------------------------------------
@@ -431,7 +442,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   }
 
   // ---- bottleneck fusion (model/resunet.py:237-273) ----------------------------------------------------
-  if (io->image_ready) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
+  if (io->image_ready && !image_joined_side) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
   if (items_event >= 0) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->events[items_event], 0));
   if (dyn)
     rc = imf_fusion_attention_dyn(buf[ebuf(3, 2)], s.n[3], meta + 6, meta + kMetaStarts + IMF_MAX_BATCH * 3, io->n_items,
