@@ -565,12 +565,15 @@ def extra_legs(O, model, dev, args, sync):
         return xd, (Fh if Fh is not None else F.cpu().numpy())
     for _ in range(3):
         xd, Fh = e2e()
-    t0 = time.perf_counter()
-    n_it = 10
-    for _ in range(n_it):
+    per_call = []
+    for _ in range(25):                               # synchronous calls, each timed on its own: the MEDIAN is reported (a
+        t0 = time.perf_counter()                      # single allocator / GC hiccup of tens of ms otherwise decides a 10-call mean)
         xd, Fh = e2e()
-    dt = (time.perf_counter() - t0) / n_it
+        per_call.append(time.perf_counter() - t0)
+    per_call.sort()
+    dt = per_call[len(per_call) // 2]
     out["e2e_extract_features"] = {"descriptors_per_s": round(Fh.shape[0] / dt, 1), "ms_per_fragment": round(dt * 1e3, 3),
+                                   "ms_per_fragment_min_max": [round(per_call[0] * 1e3, 3), round(per_call[-1] * 1e3, 3)],
                                    "span": "extract_features(host float64 points [%d,3] + host image) -> xyz_down on the host, "
                                            "and F on the host (PCIe both ways: one pinned H2D block scalars | image | points, one "
                                            "pinned D2H block counts | xyz_down | F -- F.host of the returned tensor), one "
