@@ -29,8 +29,8 @@ cases = [  # name, rulebook, cin, cout, rows_in
 variants = [("v0 auto", dict(variant=0)),
             ("v6 auto", dict(variant=6)), ("v6 s1", dict(variant=6, split_k=1)), ("v6 s2", dict(variant=6, split_k=2)),
             ("v6 s3", dict(variant=6, split_k=3)), ("v6 s4", dict(variant=6, split_k=4)), ("v6 s6", dict(variant=6, split_k=6)),
-            ("v6 s8", dict(variant=6, split_k=8)), ("v6 auto fused", dict(variant=6, fused_reduce=True)),
-            ("v6 s4 fused", dict(variant=6, split_k=4, fused_reduce=True)), ("v6 s8 fused", dict(variant=6, split_k=8, fused_reduce=True))]
+            ("v6 s8", dict(variant=6, split_k=8)), ("v6 wave8", dict(variant=6, staging="wave8")),
+            ("v6 wave4", dict(variant=6, staging="wave4"))]      # (variant 6 + in-launch combine: diagnostic builds only)
 g = torch.Generator().manual_seed(0)
 for name, rb, cin, cout, rows in cases:
     f = torch.randn(rows, cin, generator=g).to(dev)
