@@ -442,6 +442,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   }
 
   // ---- bottleneck fusion (model/resunet.py:237-273) ----------------------------------------------------
+  // diagnostic marks (IMF_DIAG_EVENTS=1, tools/branch_times.py): the main stream's arrival at the join, the fusion's end
+  static const bool diag_events = getenv("IMF_DIAG_EVENTS") && atoi(getenv("IMF_DIAG_EVENTS")) != 0;
+  const bool diag_marks = diag_events && pyr && io->events[11] && io->events[12];
+  if (diag_marks) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[11], main));
   if (io->image_ready && !image_joined_side) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
   if (items_event >= 0) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->events[items_event], 0));
   if (dyn)
@@ -455,6 +459,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
                                             net->conv[12].variant == 6 ? err : nullptr, main);
   if (rc) return rc;
   if (io->fusion_done) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->fusion_done, main));
+  if (diag_marks) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[12], main));
 
   // The head (conv1_tr + norm + ReLU + final + L2 norm, model/resunet.py:219-233) as one launch when its shapes are the
   // ones imf_pointwise_head serves; bit-identical to the two convolution launches (A/B: IMF_HEAD_FUSED=0).
@@ -566,6 +571,7 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   io.float_arena = fio->float_arena; io.float_arena_bytes = fio->float_arena_bytes;
   io.out = fio->out;
   for (int i = 0; i < 9; ++i) io.events[i] = fio->events[i];
+  io.events[11] = fio->events[11]; io.events[12] = fio->events[12];   // optional diagnostic marks
   io.side_stream = side; io.main_stream = main;
   io.trace = fio->trace;
   io.dyn = 1; io.meta = fio->meta; io.bitgrid_words = caps->bitgrid_words; io.pyramid = &fctx;

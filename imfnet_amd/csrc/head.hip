@@ -27,6 +27,10 @@ typedef __attribute__((address_space(3))) void lds_void;
 namespace {
 
 __device__ __forceinline__ void hd_split8(const float4 &x0, const float4 &x1, f16x8 &hi, f16x8 &lo) {
+#ifdef IMF_NOSPLIT_ABL   // timing experiment only (wrong results): what the conversion costs
+  hi = __builtin_bit_cast(f16x8, x0); lo = __builtin_bit_cast(f16x8, x1);
+  return;
+#endif
   const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
   for (int t = 0; t < 8; ++t) {

@@ -162,7 +162,7 @@ class _Bucket:
         self.iarena = u8(L.imf_resunet_int_arena_bytes_cap(C.byref(net), rows_c, grid_words))
         self.farena = u8(L.imf_resunet_float_arena_bytes_cap(C.byref(net), rows_c))
         self.out = self.outbuf[lay["F"]:lay["F"] + rows[0] * net.out_channels * 4].view(torch.float32).view(rows[0], net.out_channels)
-        self.events = [L.imf_event_create() for _ in range(11)]
+        self.events = [L.imf_event_create() for _ in range(13)]   # [11], [12]: IMF_DIAG_EVENTS marks around the fusion
         io = self.io = FragmentIO()
         io.xyz, io.xyz_is_f64, io.voxel_size = self.xyz.data_ptr(), int(is_f64), float(voxel)
         io.dyn, io.image, io.meta = self.dyn.data_ptr(), self.image.data_ptr(), self.meta.data_ptr()
