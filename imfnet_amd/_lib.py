@@ -37,7 +37,7 @@ class ConvArgs(C.Structure):
         ("tickets", C.c_void_p),
         ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p),
         ("n_out_dev", C.c_void_p), ("dyn_split_kvol", C.c_int32), ("slots_extra", C.c_int32),
-        ("kernel_tag", C.c_int32), ("dyn_err", C.c_void_p), ("geglu", C.c_int32),
+        ("kernel_tag", C.c_int32), ("dyn_err", C.c_void_p), ("geglu", C.c_int32), ("operand_format", C.c_int32),
     ]
 
 
@@ -50,7 +50,7 @@ class HeadArgs(C.Structure):
         ("w2_packed", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
         ("l2norm", C.c_int32), ("c_out", C.c_int32),
         ("n", C.c_int64), ("n_dev", C.c_void_p), ("out", C.c_void_p), ("flags", C.c_void_p),
-        ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p),
+        ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p), ("a_split", C.c_int32),
     ]
 
 
@@ -108,7 +108,8 @@ class ResunetIO(C.Structure):
                 ("float_arena", C.c_void_p), ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p),
                 ("events", C.c_void_p * 16), ("side_stream", C.c_void_p), ("main_stream", C.c_void_p),
                 ("trace", C.POINTER(NetTrace)), ("dyn", C.c_int32), ("meta", C.c_void_p),
-                ("bitgrid_words", C.c_size_t), ("pyramid", C.c_void_p), ("flags", C.c_void_p)]
+                ("bitgrid_words", C.c_size_t), ("pyramid", C.c_void_p), ("flags", C.c_void_p),
+                ("fp32_buffers", C.c_int32)]
 
 
 DYN_WORDS = 16
@@ -130,7 +131,8 @@ class FragmentIO(C.Structure):
                 ("int_arena", C.c_void_p), ("int_arena_bytes", C.c_size_t), ("float_arena", C.c_void_p),
                 ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p), ("events", C.c_void_p * 16),
                 ("main_stream", C.c_void_p), ("side_stream", C.c_void_p), ("image_stream", C.c_void_p),
-                ("trace", C.POINTER(NetTrace)), ("levels", LevelDesc * 4), ("serialize", C.c_int32)]
+                ("trace", C.POINTER(NetTrace)), ("levels", LevelDesc * 4), ("serialize", C.c_int32),
+                ("fp32_buffers", C.c_int32)]
 
 
 _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t

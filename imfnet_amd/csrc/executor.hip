@@ -369,31 +369,48 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     return buf[id];
   };
 
+  // ---- operand formats --------------------------------------------------------------------------------------------
+  // With every convolution on the split-f16 pipe, a layer's output is written as the operand image its consumers' main
+  // loops would otherwise derive from the fp32 rows again (imf_conv_args.operand_format; IMF_PRESPLIT=0: fp32 buffers as
+  // before).  fp32 stays where something other than a variant-6 convolution reads the buffer: the fusion's input
+  // (stride-8 block output), the fusion's own outputs, the descriptors.
+  static const bool presplit_env = !(getenv("IMF_PRESPLIT") && atoi(getenv("IMF_PRESPLIT")) == 0);
+  bool presplit = presplit_env && !io->fp32_buffers;
+  for (int i = 0; i < n_steps; ++i) presplit &= net->conv[sched[i].conv].variant == 6;
+  bool is_split[NBUF];
+  for (int i = 0; i < NBUF; ++i) is_split[i] = false;
+  auto fmt_of = [&](int id) { return id >= 0 && is_split[id]; };
+  auto wants_split = [&](int id) { return presplit && id >= 0 && id != ebuf(3, 2) && id != FUSED && id != HEAD; };
+
   // ---- first convolution (Cin <= 4): occupancy bit grid for the all-ones feature, else hash probing --
   if (s.small_first) {
+    const int first_split = wants_split(ebuf(0, 0)) ? 1 : 0;
+    bool wrote_split = first_split != 0;
     if (dyn && pyr) {   // imf_fragment_forward zeroed the grid before the level-0 pyramid
       rc = conv_first_bitgrid_dyn_cleared(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
                                           io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale,
-                                          net->first_shift, 0, buf[ebuf(0, 0)], main);
+                                          net->first_shift, 0, buf[ebuf(0, 0)], main, first_split);
     } else if (dyn) {
-      rc = imf_conv_first_bitgrid_dyn(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
+      rc = conv_first_bitgrid_dyn_fmt(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
                                       io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale,
-                                      net->first_shift, 0, buf[ebuf(0, 0)], main);
+                                      net->first_shift, 0, buf[ebuf(0, 0)], main, first_split);
     } else {
       size_t words = 0;
       if (io->x_all_ones && io->bbox && net->in_channels == 1) words = imf_bitgrid_words(io->bbox, net->first_ksize);
       if (words) {
-        rc = imf_conv_first_bitgrid_flags(io->level[0].coords, s.n[0], io->bbox, net->first_ksize, bitgrid, words,
+        rc = conv_first_bitgrid_flags_fmt(io->level[0].coords, s.n[0], io->bbox, net->first_ksize, bitgrid, words,
                                           net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
-                                          buf[ebuf(0, 0)], err, main);
+                                          buf[ebuf(0, 0)], err, main, first_split);
       } else {
         rc = imf_conv_first_fused(io->level[0].table, io->level[0].capacity, io->level[0].coords,
                                   s.n[0], 1, net->first_ksize, io->x_all_ones ? nullptr : io->x, net->in_channels,
                                   net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
                                   buf[ebuf(0, 0)], main);
+        wrote_split = false;   // (the hash-probing first layer writes fp32)
       }
     }
     if (rc) return rc;
+    is_split[ebuf(0, 0)] = wrote_split;
   }
 
   auto launch = [&](const Step &st) -> int {
@@ -426,6 +443,12 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     a.kernel_tag = imf_resunet_conv_kernel_tag(rb.level, c.kvol, c.cout, c.variant);
     a.variant = c.variant;
     a.workspace = ws; a.workspace_bytes = ws_bytes;   // split-K partials or the balanced tail's
+    IMF_REQUIRE(st.in_b < 0 || fmt_of(st.in_a) == fmt_of(st.in_b), "imf_resunet_forward: conv %d concatenates an operand "
+                "image with an fp32 buffer", st.conv);
+    const bool out_split = wants_split(st.out) && !c.l2norm;
+    a.operand_format = (fmt_of(st.in_a) ? IMF_FMT_A_SPLIT : 0) | (fmt_of(st.residual) ? IMF_FMT_RES_SPLIT : 0) |
+                       (out_split ? IMF_FMT_OUT_SPLIT : 0);
+    if (st.out >= 0) is_split[st.out] = out_split;
     if (io->trace) {
       imf_net_trace &t = io->trace[st.conv];
       a.ev_begin = t.ev_begin; a.ev_end = t.ev_end;
@@ -478,6 +501,8 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     memset(&a, 0, sizeof(a));
     a.in_a = buf[dbuf(0, 2)]; a.c_a = s.tr[2];
     a.in_b = buf[ebuf(0, 2)]; a.c_b = s.ch[1];
+    IMF_REQUIRE(is_split[dbuf(0, 2)] == is_split[ebuf(0, 2)], "imf_resunet_forward: the head's two sources differ in format");
+    a.a_split = is_split[dbuf(0, 2)] ? 1 : 0;
     a.w1_packed = h1.w_packed; a.scale1 = h1.scale; a.shift1 = h1.shift; a.relu1 = h1.relu; a.c_mid = 64;
     a.w2_packed = h2.w_packed; a.scale2 = h2.scale; a.shift2 = h2.shift; a.l2norm = h2.l2norm; a.c_out = 32;
     a.n = s.n[0];
@@ -574,6 +599,7 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   io.events[11] = fio->events[11]; io.events[12] = fio->events[12];   // optional diagnostic marks
   io.side_stream = side; io.main_stream = main;
   io.trace = fio->trace;
+  io.fp32_buffers = fio->fp32_buffers;
   io.dyn = 1; io.meta = fio->meta; io.bitgrid_words = caps->bitgrid_words; io.pyramid = &fctx;
   return imf_resunet_forward(net, &io);
 }

@@ -62,7 +62,8 @@ struct HeadParams {
 }  // namespace
 
 // NCC = (c_a + c_b) / 32 input chunks; hidden width 64, output width 32.
-template <int NCC>
+// PRE: the two sources are split-f16 operand images written by their producers (imf_head_args.a_split).
+template <int NCC, bool PRE = false>
 __global__ void __launch_bounds__(256, NCC <= 3 ? 2 : 1)
 k_pointwise_head(const HeadParams p) {
   constexpr int W1_F4 = NCC * 512;                   // conv1_tr image: NCC sub-stages of 8 KiB
@@ -158,7 +159,12 @@ k_pointwise_head(const HeadParams p) {
 #pragma unroll
     for (int cc = 0; cc < NCC; ++cc) {
       f16x8 ah, al;
-      hd_split8(hd_lds16(&abuf[128 * cc + rd_slot]), hd_lds16(&abuf[128 * cc + 64 + rd_slot]), ah, al);
+      if (PRE) {
+        ah = __builtin_bit_cast(f16x8, hd_lds16(&abuf[128 * cc + rd_slot]));
+        al = __builtin_bit_cast(f16x8, hd_lds16(&abuf[128 * cc + 64 + rd_slot]));
+      } else {
+        hd_split8(hd_lds16(&abuf[128 * cc + rd_slot]), hd_lds16(&abuf[128 * cc + 64 + rd_slot]), ah, al);
+      }
       const float4 *const wbuf = smem + cc * 512;
       f16x8 bh[4], bl[4];
 #pragma unroll
@@ -259,9 +265,9 @@ int imf_pointwise_head(const imf_head_args *a, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
   switch (ncc) {
-    case 2: k_pointwise_head<2><<<grid, 256, 0, st>>>(p); break;
-    case 3: k_pointwise_head<3><<<grid, 256, 0, st>>>(p); break;
-    default: k_pointwise_head<4><<<grid, 256, 0, st>>>(p); break;
+    case 2: if (a->a_split) k_pointwise_head<2, true><<<grid, 256, 0, st>>>(p); else k_pointwise_head<2><<<grid, 256, 0, st>>>(p); break;
+    case 3: if (a->a_split) k_pointwise_head<3, true><<<grid, 256, 0, st>>>(p); else k_pointwise_head<3><<<grid, 256, 0, st>>>(p); break;
+    default: if (a->a_split) k_pointwise_head<4, true><<<grid, 256, 0, st>>>(p); else k_pointwise_head<4><<<grid, 256, 0, st>>>(p); break;
   }
   IMF_CHECK_LAUNCH("k_pointwise_head");
   if (a->ev_end) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_end, st));

@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(256)
 k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_t *__restrict__ grid,
                   GridDesc g, int ksize_rt, int kvol, const float *__restrict__ w,
                   const float *__restrict__ scale, const float *__restrict__ shift, int relu,
-                  float *__restrict__ out, const DynGrid dg) {
+                  float *__restrict__ out, const DynGrid dg, int out_split) {
   constexpr int CBN = COUT / 16;                         // column blocks; wave w owns row block w
   constexpr int ksize = KS;
   constexpr int kMaxWin = KS == 3 ? 11 : 8;              // windows of KS bits that can touch one 32-offset word
@@ -620,7 +620,8 @@ k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_
         float y = (acc[cb][e] * un) * sc + shf;
         if (relu) y = fmaxf(y, 0.f);
         if (dg.err && out_of_f16_range(y)) atomicOr(dg.err, 32);
-        out[orow * COUT + col] = y;
+        if (out_split) store_split(out, orow, COUT, col, y);   // operand image for block1 (ConvParams::a_split)
+        else out[orow * COUT + col] = y;
       }
     }
   }
@@ -746,6 +747,13 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   IMF_REQUIRE(!a->n_out_dev || a->variant == 6, "imf_spconv_fwd: n_out_dev (capacity mode) needs variant 6");
   p.err = a->dyn_err;
   p.geglu = a->geglu;
+  p.a_split = (a->operand_format & IMF_FMT_A_SPLIT) ? 1 : 0;
+  p.res_split = (a->operand_format & IMF_FMT_RES_SPLIT) ? 1 : 0;
+  p.out_split = (a->operand_format & IMF_FMT_OUT_SPLIT) ? 1 : 0;
+  IMF_REQUIRE(!a->operand_format || (a->variant == 6 && split == 1 && !a->tickets && !(a->kernel_tag & 2)),
+              "imf_spconv_fwd: operand_format needs variant 6 and an unsplit launch (split_k=%d)", split);
+  IMF_REQUIRE(!p.out_split || (!a->l2norm && !a->geglu), "imf_spconv_fwd: IMF_FMT_OUT_SPLIT not with l2norm / geglu");
+  IMF_REQUIRE(!p.res_split || a->residual, "imf_spconv_fwd: IMF_FMT_RES_SPLIT without a residual");
   IMF_REQUIRE(!a->geglu || (a->variant == 6 && !wsplit && a->kvol == 1 && a->cout % 64 == 0 && split == 1 && !a->scale &&
                             !a->residual && !a->relu && !a->l2norm && !(a->kernel_tag & 2)),
               "imf_spconv_fwd: geglu needs variant 6 (k_spconv_g), kvol 1, cout %% 64 == 0 and no other epilogue");
@@ -875,7 +883,7 @@ size_t imf_bitgrid_words(const int32_t *bbox, int ksize) {
 static int conv_first_bitgrid_impl(const int32_t *coords, int64_t n, const int32_t *bbox, const DynGrid &dg, int ksize,
                                    uint32_t *grid, size_t grid_words, const float *w, int cout,
                                    const float *scale, const float *shift, int relu, float *out, void *stream,
-                                   bool grid_is_clear = false) {
+                                   bool grid_is_clear = false, int out_split = 0) {
   IMF_REQUIRE(coords && grid && w && out, "imf_conv_first_bitgrid: null pointer");
   IMF_REQUIRE(ksize == 3 || ksize == 5, "imf_conv_first_bitgrid: ksize must be 3 or 5");
   IMF_REQUIRE(cout == 32 || cout == 64, "imf_conv_first_bitgrid: cout=%d not in {32,64}", cout);
@@ -894,10 +902,10 @@ static int conv_first_bitgrid_impl(const int32_t *coords, int64_t n, const int32
   const int kvol = ksize * ksize * ksize;
   const size_t lds = (size_t)4 * (cout / 16) * 2 * 64 * 16 + (size_t)kBitsRows * 4 * sizeof(uint32_t);   // B fragments + masks
   const unsigned nb = (unsigned)div_up(n, kBitsRows);
-  if (cout == 32 && ksize == 5)      k_conv_first_bits<32, 5><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
-  else if (cout == 32)               k_conv_first_bits<32, 3><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
-  else if (ksize == 5)               k_conv_first_bits<64, 5><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
-  else                               k_conv_first_bits<64, 3><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg);
+  if (cout == 32 && ksize == 5)      k_conv_first_bits<32, 5><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg, out_split);
+  else if (cout == 32)               k_conv_first_bits<32, 3><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg, out_split);
+  else if (ksize == 5)               k_conv_first_bits<64, 5><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg, out_split);
+  else                               k_conv_first_bits<64, 3><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg, out_split);
   IMF_CHECK_LAUNCH("k_conv_first_bits");
   return IMF_OK;
 }
@@ -933,14 +941,35 @@ int imf_conv_first_bitgrid_dyn(const int32_t *coords, int64_t n_cap, const int32
 }  // extern "C"
 
 namespace imf {
+// the executor's entry points: as the public ones, with the output optionally written as a split-f16 operand image
+int conv_first_bitgrid_flags_fmt(const int32_t *coords, int64_t n, const int32_t *bbox, int ksize, uint32_t *grid,
+                                 size_t grid_words, const float *w, int cout, const float *scale, const float *shift,
+                                 int relu, float *out, int32_t *flags, hipStream_t stream, int out_split) {
+  IMF_REQUIRE(bbox, "imf_conv_first_bitgrid: null pointer");
+  DynGrid dg;
+  memset(&dg, 0, sizeof(dg));
+  dg.err = flags;
+  return conv_first_bitgrid_impl(coords, n, bbox, dg, ksize, grid, grid_words, w, cout, scale, shift, relu, out, stream,
+                                 false, out_split);
+}
+int conv_first_bitgrid_dyn_fmt(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
+                               int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
+                               const float *scale, const float *shift, int relu, float *out, hipStream_t stream,
+                               int out_split) {
+  IMF_REQUIRE(n_dev && bbox_dev && err && grid_words > 0, "imf_conv_first_bitgrid_dyn: null pointer");
+  DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words};
+  return conv_first_bitgrid_impl(coords, n_cap, nullptr, dg, ksize, grid, grid_words, w, cout, scale, shift, relu, out,
+                                 stream, false, out_split);
+}
 // imf_conv_first_bitgrid_dyn for a grid the caller has already zeroed AND filled (imf_fragment_forward clears it before
 // the level-0 pyramid, whose compaction kernel sets the bits: two launches fewer between the pyramid and conv1)
 int conv_first_bitgrid_dyn_cleared(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
                                    int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
-                                   const float *scale, const float *shift, int relu, float *out, hipStream_t stream) {
+                                   const float *scale, const float *shift, int relu, float *out, hipStream_t stream,
+                                   int out_split) {
   IMF_REQUIRE(n_dev && bbox_dev && err && grid_words > 0, "imf_conv_first_bitgrid_dyn: null pointer");
   DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words};
   return conv_first_bitgrid_impl(coords, n_cap, nullptr, dg, ksize, grid, grid_words, w, cout, scale, shift, relu, out,
-                                 stream, true);
+                                 stream, true, out_split);
 }
 }  // namespace imf

@@ -95,7 +95,10 @@ __device__ __forceinline__ f16x8 lds_read_f16x8(const float4 *__restrict__ src) 
 // (93 -> 98 us at 121 VGPRs).  A third one, eight-wavefront workgroups sharing one weight block between two tiles (DMA
 // instructions per row -25 % at the same 16 wavefronts per CU; tools/experiments/spconv_g_tw2.hip), was bit-identical
 // and slower too (91 -> 99 us).  Only RB 1 with four wavefronts is instantiated here.
-template <int CO_BLK, int USE, bool CAT, int NB, int RB>
+//
+// PRE (round 3): the input rows are split-f16 operand images written by their producer (ConvParams::a_split) -- the two
+// 16-byte pieces a lane reads ARE its hi and lo A fragments, no conversion in the loop.  Same DMA, same sums.
+template <int CO_BLK, int USE, bool CAT, int NB, int RB, bool PRE = false>
 __global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? 4 : 2)
 k_spconv_g(const ConvParams p) {
   constexpr int ROWS = IMF_TILE_ROWS * RB;           // output rows per workgroup
@@ -330,7 +333,7 @@ k_spconv_g(const ConvParams p) {
     }
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
-      if (ABL & 2) {
+      if ((ABL & 2) || PRE) {
         ah[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + rd_slot]));
         al[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + 64 + rd_slot]));
       } else {
@@ -388,7 +391,14 @@ k_spconv_g(const ConvParams p) {
     const int tt = RB == 1 ? total[0] : (tb ? total[RB - 1] : total[0]);
     if (!vt) continue;
     if (S == 1) {
-      if (tt > 0) conv_epilogue<CO_BLK>(p, acc[b], tile, y, wv, r16, q4, p.w_unscale ? *p.w_unscale : 1.f);
+      if (RB == 1 && !p.l2norm && !p.geglu) {   // through LDS: whole 8-channel pieces per lane (16-byte accesses)
+        __syncthreads();                         // every wavefront is past its last fragment reads
+        if (tt > 0)
+          conv_epilogue_staged<CO_BLK>(p, acc[b], reinterpret_cast<float *>(smem) + wave * (16 * (16 * CO_BLK + 4)), tile, y,
+                                       wv, lane, p.w_unscale ? *p.w_unscale : 1.f);
+      } else if (tt > 0) {
+        conv_epilogue<CO_BLK>(p, acc[b], tile, y, wv, r16, q4, p.w_unscale ? *p.w_unscale : 1.f);
+      }
     } else {   // raw partial sums, slot-major (k_spconv_reduce finishes)
       const int CW = 16 * CO_BLK;
 #pragma unroll
@@ -423,10 +433,13 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
     wgs = tiles * grid.y * (s_est < (int)grid.z ? s_est : (int)grid.z);
   }
   const bool deep = nb_env ? nb_env >= 4 : wgs <= nb_wgs;
-#define IMF_G_LAUNCH(CB, USE, CAT)                                              \
-  do {                                                                          \
-    if (deep) k_spconv_g<CB, USE, CAT, 4, 1><<<grid, 256, 0, st>>>(p);          \
-    else      k_spconv_g<CB, USE, CAT, 2, 1><<<grid, 256, 0, st>>>(p);          \
+#define IMF_G_LAUNCH(CB, USE, CAT)                                                         \
+  do {                                                                                     \
+    if (p.a_split) {   /* operand images: the ResUNet's own layers (label 0) */            \
+      if (deep) k_spconv_g<CB, 0, CAT, 4, 1, true><<<grid, 256, 0, st>>>(p);               \
+      else      k_spconv_g<CB, 0, CAT, 2, 1, true><<<grid, 256, 0, st>>>(p);               \
+    } else if (deep) k_spconv_g<CB, USE, CAT, 4, 1><<<grid, 256, 0, st>>>(p);              \
+    else             k_spconv_g<CB, USE, CAT, 2, 1><<<grid, 256, 0, st>>>(p);              \
   } while (0)
   if (p.c_b > 0) {        // two-source input (decoder skip connections)
     if (co_blk == 4) IMF_G_LAUNCH(4, 0, true); else IMF_G_LAUNCH(2, 0, true);

@@ -42,6 +42,16 @@ struct ConvParams {
                             // packed columns of slab y are [32 values | 32 gates] of hidden units 32 y .. 32 y + 31; the output
                             // is [n_out, cout / 2]: out = (v + shift_v) * gelu(g + shift_g), exact-erf GELU
                             // (model/attention_fusion.py:20-23 GEGLU)
+  // Split-f16 operand images (round 3).  A variant-6 convolution multiplies hi/lo f16 halves of its input; instead of every
+  // consumer converting the fp32 rows again (27 times per row for a 3x3x3 map: ~40 % of the main loop's VALU work), the
+  // PRODUCER's epilogue can write the operand image itself: per row and 32-channel chunk 128 bytes (the size of the fp32
+  // chunk, so strides, DMA and buffer sizes do not change) = [4 hi pieces | 4 lo pieces], piece j = the 8 halves of
+  // channels {4j..4j+3, 16+4j..16+4j+3} -- exactly what lane (row, j) of a consumer builds from the fp32 chunk with split8,
+  // so the products are bit for bit the same.  The fp32 value is not kept: a residual read takes float(hi) + float(lo),
+  // which drops the last 2 of the 24 significant bits (relative 2^-22; the convolutions never saw them anyway).
+  int a_split;              // in_a (and in_b) are operand images
+  int res_split;            // `residual` is an operand image
+  int out_split;            // write `out` as an operand image (not with l2norm / geglu)
   int32_t *err;             // flag word (optional): 16 = the rule wanted more partitions than the launch covers
                             // (capacity mode); 32 = an output value left the f16 range (|y| >= 65504 or NaN): the
                             // next split-f16 convolution would turn it into inf -- see IMF_FLAG_RANGE
@@ -91,6 +101,42 @@ __device__ __forceinline__ float4 gather_a(const ConvParams &p, int irow, int ci
   return *reinterpret_cast<const float4 *>(src);
 }
 
+// Operand image addressing (ConvParams::a_split): the hi half of (row, channel) in halves; its lo half sits 32 further.
+__device__ __forceinline__ long long split_index(long long row, int channels, int ch) {
+  const int c32 = ch & 31;
+  return row * channels * 2 + (ch >> 5) * 64 + ((c32 & 15) >> 2) * 8 + ((c32 >> 4) << 2) + (c32 & 3);
+}
+__device__ __forceinline__ void store_split(float *img, long long row, int channels, int ch, float x) {
+  const _Float16 h = (_Float16)x;
+  _Float16 *const dst = reinterpret_cast<_Float16 *>(img) + split_index(row, channels, ch);
+  dst[0] = h;
+  dst[32] = (_Float16)(x - (float)h);
+}
+__device__ __forceinline__ float load_split(const float *img, long long row, int channels, int ch) {
+  const _Float16 *const src = reinterpret_cast<const _Float16 *>(img) + split_index(row, channels, ch);
+  return (float)src[0] + (float)src[32];
+}
+// four consecutive channels ch .. ch + 3 (ch % 4 == 0) of one row: two 8-byte accesses
+__device__ __forceinline__ void store_split4(float *img, long long row, int channels, int ch, const float4 &x) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const float v[4] = {x.x, x.y, x.z, x.w};
+  f16x4 h, l;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    h[t] = (_Float16)v[t];
+    l[t] = (_Float16)(v[t] - (float)h[t]);
+  }
+  _Float16 *const dst = reinterpret_cast<_Float16 *>(img) + split_index(row, channels, ch);
+  *reinterpret_cast<f16x4 *>(dst) = h;
+  *reinterpret_cast<f16x4 *>(dst + 32) = l;
+}
+__device__ __forceinline__ float4 load_split4(const float *img, long long row, int channels, int ch) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const _Float16 *const src = reinterpret_cast<const _Float16 *>(img) + split_index(row, channels, ch);
+  const f16x4 h = *reinterpret_cast<const f16x4 *>(src), l = *reinterpret_cast<const f16x4 *>(src + 32);
+  return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+}
+
 // acc[cb][r] = out[row 4*q4 + r of the wavefront's 16][col 16*cb + r16]
 template <int CO_BLK>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (&acc)[CO_BLK], int tile,
@@ -130,7 +176,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float x = (acc[cb][r] * unscale) * sc + sh;
-      if (p.residual && orow[r] >= 0) x += p.residual[(long long)orow[r] * p.cout + col];
+      if (p.residual && orow[r] >= 0)
+        x += p.res_split ? load_split(p.residual, orow[r], p.cout, col) : p.residual[(long long)orow[r] * p.cout + col];
       if (p.relu) x = fmaxf(x, 0.f);
       v[cb][r] = x;
     }
@@ -161,10 +208,90 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (
 #pragma unroll
   for (int cb = 0; cb < CO_BLK; ++cb) {
     const int col = y * CW + cb * 16 + r16;
+    if (p.out_split) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (orow[r] >= 0) p.out[(long long)orow[r] * p.cout + col] = v[cb][r];
+      for (int r = 0; r < 4; ++r)
+        if (orow[r] >= 0) store_split(p.out, orow[r], p.cout, col, v[cb][r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (orow[r] >= 0) p.out[(long long)orow[r] * p.cout + col] = v[cb][r];
+    }
   }
+}
+
+// The same epilogue through LDS (round 3): the wavefront parks its 16 x CW accumulator block in a private LDS region and
+// every lane takes whole 8-channel PIECES of a row -- channels {4j..4j+3, 16+4j..16+4j+3} of a 32-channel chunk, the unit
+// of an operand image -- so a split residual is read and a split output written with 16-byte accesses (the per-value form
+// above needs two 2-byte accesses each), and fp32 outputs go out as float4.  Element for element the arithmetic of
+// conv_epilogue; not for l2norm / geglu launches.  `stage`: 16 x (CW + 4) floats of LDS owned by this wavefront.
+template <int CO_BLK>
+__device__ __forceinline__ void conv_epilogue_staged(const ConvParams &p, const f32x4 (&acc)[CO_BLK], float *stage, int tile,
+                                                     int y, int wave, int lane, float unscale) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  constexpr int CW = 16 * CO_BLK, LD = CW + 4, PPR = CW / 8;   // pieces per row: 8 or 4
+  const int r16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+  for (int cb = 0; cb < CO_BLK; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stage[(q4 * 4 + r) * LD + cb * 16 + r16] = acc[cb][r];
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < CO_BLK / 2; ++i) {
+    const int item = lane + 64 * i;
+    const int row = item / PPR, pp = item % PPR;
+    const int cloc = (pp >> 2) * 32 + (pp & 3) * 4;            // first channel of the piece inside the slab
+    const int col = y * CW + cloc;
+    const float4 a0 = *reinterpret_cast<const float4 *>(stage + row * LD + cloc);
+    const float4 a1 = *reinterpret_cast<const float4 *>(stage + row * LD + cloc + 16);
+    float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const long long orow = row_of_slot(p, (long long)tile * IMF_TILE_ROWS + wave * 16 + row);
+    float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.scale) {
+      const float4 s0 = *reinterpret_cast<const float4 *>(p.scale + col), s1 = *reinterpret_cast<const float4 *>(p.scale + col + 16);
+      sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+    }
+    if (p.shift) {
+      const float4 s0 = *reinterpret_cast<const float4 *>(p.shift + col), s1 = *reinterpret_cast<const float4 *>(p.shift + col + 16);
+      sh[0] = s0.x; sh[1] = s0.y; sh[2] = s0.z; sh[3] = s0.w; sh[4] = s1.x; sh[5] = s1.y; sh[6] = s1.z; sh[7] = s1.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = (x[t] * unscale) * sc[t] + sh[t];   // the expression of conv_epilogue
+    if (orow < 0) continue;
+    if (p.residual) {
+      if (p.res_split) {
+        const _Float16 *const src = reinterpret_cast<const _Float16 *>(p.residual) + split_index(orow, p.cout, col);
+        const h8 rh = *reinterpret_cast<const h8 *>(src), rl = *reinterpret_cast<const h8 *>(src + 32);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] += (float)rh[t] + (float)rl[t];
+      } else {
+        const float4 r0 = *reinterpret_cast<const float4 *>(p.residual + orow * p.cout + col);
+        const float4 r1 = *reinterpret_cast<const float4 *>(p.residual + orow * p.cout + col + 16);
+        x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
+      }
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) x[t] = fmaxf(x[t], 0.f);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bad |= out_of_f16_range(x[t]);
+    if (p.out_split) {
+      h8 oh, ol;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        oh[t] = (_Float16)x[t];
+        ol[t] = (_Float16)(x[t] - (float)oh[t]);
+      }
+      _Float16 *const dst = reinterpret_cast<_Float16 *>(p.out) + split_index(orow, p.cout, col);
+      *reinterpret_cast<h8 *>(dst) = oh;
+      *reinterpret_cast<h8 *>(dst + 32) = ol;
+    } else {
+      *reinterpret_cast<float4 *>(p.out + orow * p.cout + col) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<float4 *>(p.out + orow * p.cout + col + 16) = make_float4(x[4], x[5], x[6], x[7]);
+    }
+  }
+  if (p.err && __ballot(bad) != 0ull && lane == 0) atomicOr(p.err, 32);
 }
 
 // Sum of the S partial slabs of one 64-row tile (ascending partition order) + epilogue, by the 256
@@ -221,8 +348,16 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
 void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t st);
 
 // spconv.hip: imf_conv_first_bitgrid_dyn on a grid the caller already zeroed and filled (geometry.hip: k_emit_unique)
+int conv_first_bitgrid_flags_fmt(const int32_t *coords, int64_t n, const int32_t *bbox, int ksize, uint32_t *grid,
+                                 size_t grid_words, const float *w, int cout, const float *scale, const float *shift,
+                                 int relu, float *out, int32_t *flags, hipStream_t stream, int out_split);
+int conv_first_bitgrid_dyn_fmt(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
+                               int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
+                               const float *scale, const float *shift, int relu, float *out, hipStream_t stream,
+                               int out_split);
 int conv_first_bitgrid_dyn_cleared(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
                                    int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
-                                   const float *scale, const float *shift, int relu, float *out, hipStream_t stream);
+                                   const float *scale, const float *shift, int relu, float *out, hipStream_t stream,
+                                   int out_split = 0);
 
 }  // namespace imf

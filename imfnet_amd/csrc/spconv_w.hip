@@ -63,7 +63,8 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 
 }  // namespace
 
-template <bool CAT, int W>
+// PRE: the input rows are split-f16 operand images (ConvParams::a_split; see spconv_g.hip) -- no conversion in the loop.
+template <bool CAT, int W, bool PRE = false>
 __global__ void __launch_bounds__(64 * W, 2)
 k_spconv_w(const ConvParams p) {
   constexpr int NT = 64 * W;
@@ -237,7 +238,10 @@ k_spconv_w(const ConvParams p) {
     }
     f16x8 ah[4], al[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) w_split8(a0[b], a1[b], ah[b], al[b]);
+    for (int b = 0; b < 4; ++b) {
+      if (PRE) { ah[b] = __builtin_bit_cast(f16x8, a0[b]); al[b] = __builtin_bit_cast(f16x8, a1[b]); }
+      else w_split8(a0[b], a1[b], ah[b], al[b]);
+    }
     // per accumulator: lo*hi, hi*lo, hi*hi (k_spconv_g's order); consecutive MFMAs on different accumulators
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -294,7 +298,8 @@ k_spconv_w(const ConvParams p) {
     s.x = (s.x * un) * sc.x + sh.x; s.y = (s.y * un) * sc.y + sh.y;
     s.z = (s.z * un) * sc.z + sh.z; s.w = (s.w * un) * sc.w + sh.w;
     if (p.residual && orow >= 0) {
-      const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (long long)orow * p.cout + col);
+      const float4 rr = p.res_split ? load_split4(p.residual, orow, p.cout, col)
+                                    : *reinterpret_cast<const float4 *>(p.residual + (long long)orow * p.cout + col);
       s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
     }
     if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
@@ -312,7 +317,10 @@ k_spconv_w(const ConvParams p) {
       const float nrm = sqrtf(ss);
       s.x /= nrm; s.y /= nrm; s.z /= nrm; s.w /= nrm;   // no eps: resunet.py:230
     }
-    if (orow >= 0) *reinterpret_cast<float4 *>(p.out + (long long)orow * p.cout + col) = s;
+    if (orow >= 0) {
+      if (p.out_split) store_split4(p.out, orow, p.cout, col, make_float4(s.x, s.y, s.z, s.w));
+      else *reinterpret_cast<float4 *>(p.out + (long long)orow * p.cout + col) = s;
+    }
   }
 }
 
@@ -323,7 +331,15 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
   p.w_xcd = xcd_env;
   const dim3 grid(tiles, (unsigned)(p.cout / 64), 1);
   const bool cat = p.c_b > 0;
-  if (waves == 8) {
+  if (p.a_split) {
+    if (waves == 8) {
+      if (cat) k_spconv_w<true, 8, true><<<grid, 512, 0, st>>>(p);
+      else     k_spconv_w<false, 8, true><<<grid, 512, 0, st>>>(p);
+    } else {
+      if (cat) k_spconv_w<true, 4, true><<<grid, 256, 0, st>>>(p);
+      else     k_spconv_w<false, 4, true><<<grid, 256, 0, st>>>(p);
+    }
+  } else if (waves == 8) {
     if (cat) k_spconv_w<true, 8><<<grid, 512, 0, st>>>(p);
     else     k_spconv_w<false, 8><<<grid, 512, 0, st>>>(p);
   } else {

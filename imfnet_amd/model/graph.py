@@ -176,6 +176,7 @@ class _Bucket:
             io.events[i] = e
         io.side_stream, io.image_stream = runner.raw_streams(dev)
         io.trace = None
+        io.fp32_buffers = 1 if os.environ.get("IMFNET_FP32_BUFFERS") == "1" else 0   # (see model/plan.py)
         self.graph = C.c_void_p()
         self.n_nodes = 0
         self.launches = 0
@@ -207,6 +208,14 @@ class _Bucket:
         n = C.c_int(0)
         check(L.imf_graph_end_capture(stream.cuda_stream, C.byref(self.graph), C.byref(n)), "imf_graph_end_capture")
         self.n_nodes = n.value
+
+    def drop_graph(self):
+        """Forget the captured graph (a setting baked into it changed); the next graph launch captures again."""
+        if self.graph:
+            torch.cuda.synchronize()
+            self.L.imf_graph_destroy(self.graph)
+            self.graph = C.c_void_p()
+            self.n_nodes = 0
 
     def __del__(self):
         try:
@@ -348,6 +357,10 @@ class FragmentRunner:
         when `trace_list` is given: per-convolution HIP events are appended to it as ops.TRACE records)."""
         from .. import ops
         from .plan import NativePlan, _RB
+        fp32_buffers = 1 if os.environ.get("IMFNET_FP32_BUFFERS") == "1" else 0
+        if b.io.fp32_buffers != fp32_buffers:         # the mode is part of a captured graph: capture again under the new one
+            b.io.fp32_buffers = fp32_buffers
+            b.drop_graph()
         with torch.cuda.stream(stream):
             if trace_list is not None or not self.use_graph:
                 trace = evs = None

@@ -400,6 +400,9 @@ class NativePlan:
         else:
             io.trace = None
         io.flags = self.model.flag_word(dev).data_ptr()
+        # IMFNET_FP32_BUFFERS=1: every feature buffer fp32 (the arithmetic of the op-by-op executor); default: the layers
+        # hand split-f16 operand images on (include/imfnet_hip.h, imf_conv_args.operand_format)
+        io.fp32_buffers = 1 if os.environ.get("IMFNET_FP32_BUFFERS") == "1" else 0
         check(L.imf_resunet_forward(C.byref(d), C.byref(io)), "imf_resunet_forward")
         if tracing:
             for i, e in enumerate(evs):

@@ -392,9 +392,34 @@ def conv_kernel_name(variant, cin, cout, staging=None, kernel_tag=0):
     return f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>"
 
 
+FMT_A_SPLIT, FMT_RES_SPLIT, FMT_OUT_SPLIT = 1, 2, 4      # imf_conv_args.operand_format (include/imfnet_hip.h)
+
+
+def to_operand_image(x):
+    """fp32 [n, c] (c % 32 == 0) -> the split-f16 operand image of the same shape and dtype (bytes reinterpreted): per row
+    and 32-channel chunk [4 hi pieces | 4 lo pieces], piece j = the 8 halves of channels {4j..4j+3, 16+4j..16+4j+3},
+    hi = f16(x), lo = f16(x - hi) (include/imfnet_hip.h, imf_conv_args.operand_format)."""
+    n, c = x.shape
+    v = x.view(n, c // 32, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(n, c // 32, 32)      # [.., j, half, t]
+    hi = v.to(torch.float16)
+    lo = (v - hi.to(torch.float32)).to(torch.float16)
+    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).view(n, c)
+
+
+def from_operand_image(img):
+    """The values an operand image carries: hi + lo in fp32 (22 significant bits of the original)."""
+    n, c = img.shape
+    h = img.contiguous().view(torch.float16).view(n, c // 32, 2, 32).to(torch.float32)
+    v = (h[:, :, 0] + h[:, :, 1]).view(n, c // 32, 4, 2, 4).permute(0, 1, 3, 2, 4)
+    return v.reshape(n, c).contiguous()
+
+
 def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual=None,
-           relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False, flags=None, staging=None):
-    """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd.  `flags`: optional int32[1] device word that
+           relu=False, l2norm=False, out=None, split_k=0, variant=0, fused_reduce=False, flags=None, staging=None,
+           operand_format=0):
+    """out[o] = epilogue(sum_k in[nbr[k][o]] @ W[k]) -- imf_spconv_fwd.  `operand_format` (variant 6, unsplit): FMT_A_SPLIT
+    | FMT_RES_SPLIT | FMT_OUT_SPLIT -- which of in_a / in_b, residual, out are split-f16 operand images
+    (`to_operand_image`) instead of fp32 rows.  `flags`: optional int32[1] device word that
     receives IMF_FLAG_RANGE (32) when an output is NaN or >= 65504 in magnitude.  `staging` (variant 6): None = the
     library default (LDS-DMA kernel k_spconv_g), "wave8" / "wave4" = the wave-split kernel for coarse levels
     (csrc/spconv_w.hip; kvol > 1, cout % 64 == 0, no split-K); "regs" = the register-staged k_spconv_h3, which exists in
@@ -418,6 +443,7 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     if rb.kvol == 1 or staging in ("wave8", "wave4"):
         split = 1
     a.split_k, a.variant = split, int(variant)
+    a.operand_format = int(operand_format)
     a.dyn_err = None if flags is None else flags.data_ptr()
     if staging not in (None, "dma", "regs", "wave8", "wave4"):
         raise ImfError(f"spconv: staging={staging!r}")
@@ -450,9 +476,9 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
 
 
 def pointwise_head(in_a, in_b, w1_packed, w2_packed, scale1=None, shift1=None, relu1=True, scale2=None, shift2=None,
-                   l2norm=True, out=None, flags=None, n_dev=None):
+                   l2norm=True, out=None, flags=None, n_dev=None, a_split=False):
     """imf_pointwise_head: conv1_tr + norm1_tr + ReLU + final + L2 normalisation (model/resunet.py:219-233) in one
-    launch.  in_a [n, c_a], in_b [n, c_b] or None; weight images from pack_weights_split16 (kvol 1); hidden width 64,
+    launch.  a_split: in_a / in_b are split-f16 operand images (`to_operand_image`).  in_a [n, c_a], in_b [n, c_b] or None; weight images from pack_weights_split16 (kvol 1); hidden width 64,
     output [n, 32].  Bit-identical to two `spconv(..., variant=6)` calls."""
     _req(in_a, torch.float32, "in_a", 2)
     if in_b is not None:
@@ -472,6 +498,7 @@ def pointwise_head(in_a, in_b, w1_packed, w2_packed, scale1=None, shift1=None, r
     a.w1_packed, a.scale1, a.shift1, a.relu1, a.c_mid = w1_packed.data_ptr(), _ptr(scale1), _ptr(shift1), int(bool(relu1)), 64
     a.w2_packed, a.scale2, a.shift2, a.l2norm, a.c_out = w2_packed.data_ptr(), _ptr(scale2), _ptr(shift2), int(bool(l2norm)), 32
     a.n, a.n_dev, a.out = n, _ptr(n_dev), out.data_ptr()
+    a.a_split = int(bool(a_split))
     a.flags = None if flags is None else flags.data_ptr()
     check(L.imf_pointwise_head(C.byref(a), _stream()), "imf_pointwise_head")
     return out

@@ -262,7 +262,19 @@ typedef struct imf_conv_args {
                              weight image's columns are arranged per 64-column slab y as [32 values | 32 gates] of hidden
                              units 32 y .. 32 y + 31 (shift likewise); out is [n_out, cout / 2]:
                              out[r][32 y + c] = (acc_v + shift_v) * gelu(acc_g + shift_g), exact-erf GELU */
+  int32_t operand_format; /* variant 6 (k_spconv_g / k_spconv_w, unsplit launches): which of the row-major [rows, channels]
+                             buffers are SPLIT-F16 OPERAND IMAGES instead of fp32 -- IMF_FMT_A_SPLIT: in_a and in_b;
+                             IMF_FMT_RES_SPLIT: residual; IMF_FMT_OUT_SPLIT: out is written as one (not with l2norm / geglu).
+                             An operand image has the size and row stride of the fp32 buffer: per row and 32-channel chunk
+                             128 bytes = [4 hi pieces | 4 lo pieces], piece j = the 8 halves of channels {4j..4j+3,
+                             16+4j..16+4j+3}, hi = f16(x), lo = f16(x - hi) -- what the kernels' main loops derive from an
+                             fp32 row themselves, 27 times per row for a 3x3x3 map; a producer that writes the image spares
+                             its consumers the conversions (same products bit for bit).  A residual read takes hi + lo,
+                             i.e. the value to 22 significant bits (relative 2^-22). */
 } imf_conv_args;
+#define IMF_FMT_A_SPLIT   1
+#define IMF_FMT_RES_SPLIT 2
+#define IMF_FMT_OUT_SPLIT 4
 
 /* Flag bits the kernels OR into a caller-provided device word (imf_conv_args.dyn_err, imf_resunet_io.flags, meta[1]
  * of the capacity mode).  A flagged result must not be used: redo the fragment (larger capacities / exact mode for
@@ -320,6 +332,7 @@ typedef struct imf_head_args {
   float *out;              /* [n, c_out] */
   int32_t *flags;          /* optional device word: IMF_FLAG_RANGE when a hidden value cannot be a split-f16 operand */
   void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded around the kernel */
+  int32_t a_split;         /* in_a / in_b are split-f16 operand images (imf_conv_args.operand_format) */
 } imf_head_args;
 int imf_pointwise_head(const imf_head_args *args /* [host] */, void *stream);
 
@@ -524,6 +537,10 @@ typedef struct imf_resunet_io {        /* per fragment */
   size_t bitgrid_words;                /* capacity (uint32 words) of the conv1 occupancy grid inside the int arena */
   const void *pyramid;                 /* internal (imf_fragment_forward): coarse pyramid levels still to be built */
   int32_t *flags;                      /* exact mode, optional: device word the kernels OR IMF_FLAG_RANGE into (caller zeroes) */
+  int32_t fp32_buffers;                /* 0 (default): with every convolution on variant 6 the layers hand their outputs on as
+                                          split-f16 operand images (imf_conv_args.operand_format) -- residual reads see 22 of
+                                          the 24 significant bits; 1: every feature buffer stays fp32 (the arithmetic of the
+                                          op-by-op path: each imf_spconv_fwd with operand_format 0) */
 } imf_resunet_io;
 
 size_t imf_resunet_int_arena_bytes(const imf_resunet_desc *net, const int64_t *n /* [4] */,
@@ -571,6 +588,7 @@ typedef struct imf_fragment_io {       /* [host]; all buffers device memory owne
   imf_net_trace *trace;                /* [host] 23 records or NULL */
   imf_level levels[4];                 /* out [host]: where the levels live inside pyramid_arena */
   int32_t serialize;                   /* measurement aid: issue everything on main_stream (no overlap between branches) */
+  int32_t fp32_buffers;                /* as imf_resunet_io.fp32_buffers */
 } imf_fragment_io;
 
 size_t imf_fragment_pyramid_bytes(const imf_fragment_caps *caps);

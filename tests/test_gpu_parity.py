@@ -240,6 +240,60 @@ def test_spconv_chip_filling_launches_match_fp32_mfma(ops, clouds):
         assert ((a - b).abs() <= bound * sc + 1e-6).all(), (ca, cb, cout, float((a - b).abs().max()))
 
 
+def test_spconv_operand_images(ops, clouds):
+    """imf_conv_args.operand_format: a convolution fed the split-f16 operand image of its input forms the SAME products as
+    one fed the fp32 rows (bit-identical output) -- on k_spconv_g (chip-filling and small launches, one and two sources)
+    and on the wave-split kernel; an output written as an operand image carries hi + lo = the fp32 output to 2^-22; a
+    residual handed over as an image is read as hi + lo.  Host-side images: ops.to_operand_image (numpy-free torch)."""
+    xyz = clouds[0].astype(np.float64) * 1.7
+    cm = _build_levels(ops, ops.voxelize(torch.as_tensor(xyz).to(DEV), 0.025))
+    n0, n1 = cm.level(1).n, cm.level(2).n
+    A, R, OUT = ops.FMT_A_SPLIT, ops.FMT_RES_SPLIT, ops.FMT_OUT_SPLIT
+    x = _rand((1000, 96), 70).to(DEV)
+    assert torch.equal(ops.from_operand_image(ops.to_operand_image(x)),
+                       (x.half().float() + (x - x.half().float()).half().float()))
+    for ca, cb, cout, rb, n_in, staging in ((32, 0, 32, cm.conv_rulebook(1, 3, 1), n0, None),
+                                            (64, 0, 64, cm.conv_rulebook(1, 3, 1), n0, None),
+                                            (64, 64, 64, cm.transpose_rulebook(2, 3, 2), n1, None),
+                                            (64, 32, 64, cm.conv_rulebook(1, 1, 1), n0, None),
+                                            (64, 0, 128, cm.conv_rulebook(2, 3, 1), n1, None),
+                                            (64, 0, 64, cm.conv_rulebook(2, 3, 1), n1, "wave4"),
+                                            (64, 64, 128, cm.conv_rulebook(2, 3, 1), n1, "wave8"),
+                                            (32, 0, 64, cm.conv_rulebook(1, 3, 2), n0, "wave4")):
+        fa, fb = _rand((n_in, ca), 71).to(DEV), (_rand((n_in, cb), 72).to(DEV) if cb else None)
+        w = _rand((rb.kvol, ca + cb, cout), 73, 0.05).to(DEV)
+        wp = ops.pack_weights(w, split16=True)
+        sc, sh = (_rand((cout,), 74).abs() + 0.5).to(DEV), _rand((cout,), 75).to(DEV)
+        res = _rand((rb.n_out, cout), 76).to(DEV)
+        ia, ib = ops.to_operand_image(fa), (None if fb is None else ops.to_operand_image(fb))
+        kw = dict(variant=6, split_k=1, staging=staging, scale=sc, shift=sh, relu=True)
+        ref = ops.spconv(fa, wp, cout, rb, in_b=fb, **kw)
+        got = ops.spconv(ia, wp, cout, rb, in_b=ib, operand_format=A, **kw)
+        assert torch.equal(ref, got), (ca, cb, cout, staging)
+        # residual: fp32 vs its image (the image's value is what gets added)
+        res_img = ops.to_operand_image(res)
+        ref_r = ops.spconv(fa, wp, cout, rb, in_b=fb, residual=ops.from_operand_image(res_img), **kw)
+        got_r = ops.spconv(ia, wp, cout, rb, in_b=ib, residual=res_img, operand_format=A | R, **kw)
+        assert torch.equal(ref_r, got_r), (ca, cb, cout, staging)
+        full = ops.spconv(fa, wp, cout, rb, in_b=fb, residual=res, **kw)
+        assert ((ref_r - full).abs() <= 1e-6 * (1 + full.abs())).all()
+        # output as an image: decodes to the fp32 output's hi + lo, and is exactly the image of the fp32 output
+        out_img = ops.spconv(ia, wp, cout, rb, in_b=ib, residual=res_img, operand_format=A | R | OUT, **kw)
+        assert torch.equal(out_img.view(torch.int32), ops.to_operand_image(got_r).view(torch.int32)), (ca, cb, cout, staging)
+        dec = ops.from_operand_image(out_img)
+        # (relative 2^-22; below ~0.06 the lo half is an f16 subnormal: absolute 2^-25)
+        assert ((dec - got_r).abs() <= torch.clamp(got_r.abs() * 2.0 ** -22, min=2.0 ** -25)).all()
+    # the fused head on operand images == on fp32 rows
+    a, b = _rand((n0, 64), 77).to(DEV), _rand((n0, 32), 78).to(DEV)
+    w1, w2 = _rand((1, 96, 64), 79, 0.1).to(DEV), _rand((1, 64, 32), 80, 0.1).to(DEV)
+    w1p, w2p = ops.pack_weights(w1, split16=True), ops.pack_weights(w2, split16=True)
+    s1, h1, h2 = (_rand((64,), 81).abs() + 0.5).to(DEV), _rand((64,), 82).to(DEV), _rand((32,), 83).to(DEV)
+    f32 = ops.pointwise_head(a, b, w1p, w2p, scale1=s1, shift1=h1, shift2=h2)
+    img = ops.pointwise_head(ops.to_operand_image(a), ops.to_operand_image(b), w1p, w2p, scale1=s1, shift1=h1, shift2=h2,
+                             a_split=True)
+    assert torch.equal(f32, img)
+
+
 def test_spconv_epilogues(ops, geom_s5):
     cm, g = geom_s5
     rb, nbr_ref = cm.conv_rulebook(1, 3, 1), g.k3[0]
@@ -559,7 +613,9 @@ def test_fused_equals_layerwise(model, clouds, images):
 
 def test_native_executor_equals_python_plan(model, clouds, images, monkeypatch):
     """imf_resunet_forward (one C call per fragment) issues the launches of the Python arena executor:
-    descriptors must be bit-identical, for both fragments and two voxel sizes, also when traced."""
+    with fp32 feature buffers (what the op-by-op executor has) descriptors must be bit-identical, for both fragments
+    and two voxel sizes, also when traced; in its default mode -- layers hand split-f16 operand images on, residual
+    reads see 22 of 24 bits -- within 2e-6."""
     from imfnet_amd import ops as O_
     from imfnet_amd.extract import sparse_tensor_from_points
     for k, voxel in ((0, 0.05), (1, 0.05), (0, 0.025)):
@@ -570,6 +626,9 @@ def test_native_executor_equals_python_plan(model, clouds, images, monkeypatch):
             st, _ = sparse_tensor_from_points(xyz, voxel, torch.device(DEV))
             a = model(st, img).F.clone()
             monkeypatch.delenv("IMFNET_PYTHON_EXECUTOR")
+            st4, _ = sparse_tensor_from_points(xyz, voxel, torch.device(DEV))
+            d = model(st4, img).F.clone()                      # default: operand images
+            monkeypatch.setenv("IMFNET_FP32_BUFFERS", "1")
             st2, _ = sparse_tensor_from_points(xyz, voxel, torch.device(DEV))
             b = model(st2, img).F.clone()
             O_.TRACE = []
@@ -577,8 +636,10 @@ def test_native_executor_equals_python_plan(model, clouds, images, monkeypatch):
             c = model(st3, img).F.clone()
             torch.cuda.synchronize()
             trace, O_.TRACE = O_.TRACE, None
+            monkeypatch.delenv("IMFNET_FP32_BUFFERS")
         assert model._native_plan is not None
         assert torch.equal(a, b) and torch.equal(a, c)
+        assert (a - d).abs().max() < 2e-6 and not torch.equal(a, d)
         assert len(trace) == 21 and all(r["ev"].elapsed_ms() > 0 for r in trace)
         assert sorted(r["name"] for r in trace)[0] == "block1.conv1"
 
@@ -641,6 +702,11 @@ def test_native_batched_pair_matches_single_fragments(model, clouds, images, mon
                                        image=torch.as_tensor(images[k])) for k in (0, 1)]
             single = [(a, b.clone()) for a, b in single]
             batched = extract_features_batch(model, pts, voxel, DEV, imgs)
+            batched = [(a, b.clone()) for a, b in batched]
+            monkeypatch.setenv("IMFNET_FP32_BUFFERS", "1")                     # the op-by-op executor's arithmetic
+            batched_f32 = extract_features_batch(model, pts, voxel, DEV, imgs)
+            batched_f32 = [(a, b.clone()) for a, b in batched_f32]
+            monkeypatch.delenv("IMFNET_FP32_BUFFERS")
             monkeypatch.setenv("IMFNET_PYTHON_EXECUTOR", "1")
             batched_py = extract_features_batch(model, pts, voxel, DEV, imgs)
             monkeypatch.delenv("IMFNET_PYTHON_EXECUTOR")
@@ -649,7 +715,8 @@ def test_native_batched_pair_matches_single_fragments(model, clouds, images, mon
             assert (batched[k][0] == single[k][0]).all()                       # same voxels, same order
             assert batched[k][1].shape == single[k][1].shape
             assert (batched[k][1] - single[k][1]).abs().max() < 2e-6
-            assert (batched_py[k][1] - batched[k][1]).abs().max() == 0.0       # both executors, same launches
+            assert (batched_py[k][1] - batched_f32[k][1]).abs().max() == 0.0   # both executors, same launches
+            assert (batched_py[k][1] - batched[k][1]).abs().max() < 2e-6       # operand images: 22-bit residual reads
     # three items, different sizes, float32 points
     three = [clouds[0][::3], clouds[1][::5], clouds[0][1::7]]
     imgs3 = np.concatenate([images[0], images[1], images[0]], 0)
