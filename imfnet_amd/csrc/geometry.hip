@@ -28,14 +28,22 @@ struct BatchStarts {
   int nb;
 };
 
-// first row of every batch item at one level (rows are grouped by batch index, ascending)
-__global__ void __launch_bounds__(256)
-k_item_starts(const int32_t *__restrict__ coords, const int32_t *__restrict__ n_dev, int32_t *__restrict__ starts) {
-  const int n = *n_dev;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// first row of every batch item at up to four levels in one launch (rows are grouped by batch index, ascending); level j
+// owns the blocks [blk0[j], blk0[j+1])
+struct ItemJobs {
+  const int32_t *coords[4], *n_dev[4];
+  int32_t *starts[4];
+  int blk0[5];
+};
+__global__ void __launch_bounds__(256) k_item_starts(const ItemJobs js) {
+  int l = 0;
+  while (l < 3 && (int)blockIdx.x >= js.blk0[l + 1]) ++l;
+  const int n = *js.n_dev[l];
+  const int i = ((int)blockIdx.x - js.blk0[l]) * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int32_t *coords = js.coords[l];
   const int b = coords[4 * i];
-  if ((i == 0 || coords[4 * (i - 1)] != b) && b >= 0 && b < IMF_MAX_BATCH) starts[b] = i;
+  if ((i == 0 || coords[4 * (i - 1)] != b) && b >= 0 && b < IMF_MAX_BATCH) js.starts[l][b] = i;
 }
 
 // Bounding box (b,x,y,z min / max) of a workgroup's voxels -> wg_bbox[blockIdx.x][0..7] (plain stores, no atomics:
@@ -747,13 +755,23 @@ int pyramid_coarse_level(const PyramidBuild &b, int l, hipStream_t st) {
 
 // where every item's rows begin at every level: meta[2L+8 + IMF_MAX_BATCH*l + b] (-1 = no row)
 int pyramid_item_starts(const PyramidBuild &b, hipStream_t st, int l_begin, int l_end) {
-  if (!b.batched) return IMF_OK;
+  if (!b.batched || l_end <= l_begin) return IMF_OK;
+  IMF_REQUIRE(l_end - l_begin <= 4, "pyramid_item_starts: at most 4 levels per launch");
   int32_t *starts = b.meta + 2 * b.n_levels + 8;
-  for (int l = l_begin; l < l_end; ++l) {
-    k_item_starts<<<(unsigned)div_up(b.levels[l].cap_rows, 256), 256, 0, st>>>(b.levels[l].coords, b.meta + 2 * l,
-                                                                                starts + IMF_MAX_BATCH * l);
-    IMF_CHECK_LAUNCH("k_item_starts");
+  ItemJobs js;
+  memset(&js, 0, sizeof(js));
+  int nblk = 0;
+  for (int j = 0; j < 4; ++j) {
+    const int l = l_begin + j < l_end ? l_begin + j : l_begin;      // (unused entries repeat the first: valid pointers)
+    js.coords[j] = b.levels[l].coords;
+    js.n_dev[j] = b.meta + 2 * l;
+    js.starts[j] = starts + IMF_MAX_BATCH * l;
+    js.blk0[j] = nblk;
+    if (l_begin + j < l_end) nblk += (int)div_up(b.levels[l].cap_rows, 256);
   }
+  js.blk0[4] = nblk;
+  k_item_starts<<<(unsigned)nblk, 256, 0, st>>>(js);
+  IMF_CHECK_LAUNCH("k_item_starts");
   return IMF_OK;
 }
 

@@ -94,7 +94,8 @@ __device__ __forceinline__ f16x8 lds_read_f16x8(const float4 *__restrict__ src) 
 // maps up to 1.6x slower: only two workgroups fit a CU) and register double-buffering of the LDS -> VGPR fragment reads
 // (93 -> 98 us at 121 VGPRs).  A third one, eight-wavefront workgroups sharing one weight block between two tiles (DMA
 // instructions per row -25 % at the same 16 wavefronts per CU; tools/experiments/spconv_g_tw2.hip), was bit-identical
-// and slower too (91 -> 99 us).  Only RB 1 with four wavefronts is instantiated here.
+// and slower too (91 -> 99 us).  RB 2 was tried once more on operand images (PRE, no conversions left in the loop; round 3):
+// bit-identical, pair step 0.989 -> 1.001 ms.  Only RB 1 with four wavefronts is instantiated here.
 //
 // PRE (round 3): the input rows are split-f16 operand images written by their producer (ConvParams::a_split) -- the two
 // 16-byte pieces a lane reads ARE its hi and lo A fragments, no conversion in the loop.  Same DMA, same sums.
@@ -381,6 +382,8 @@ k_spconv_g(const ConvParams p) {
 
   IMF_GSTAMP(2);
   if ((IMF_G_ABL & 256) && acc[0][0][0] != 12345.f) return;
+  const bool staged = S == 1 && !p.l2norm && !p.geglu;
+  if (staged) __syncthreads();                       // every wavefront is past its last fragment reads: LDS is free
   // block b of wavefront w holds rows 16 (RB w + b) .. + 15 of the workgroup's ROWS: tile and 16-row block inside it
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
@@ -391,10 +394,9 @@ k_spconv_g(const ConvParams p) {
     const int tt = RB == 1 ? total[0] : (tb ? total[RB - 1] : total[0]);
     if (!vt) continue;
     if (S == 1) {
-      if (RB == 1 && !p.l2norm && !p.geglu) {   // through LDS: whole 8-channel pieces per lane (16-byte accesses)
-        __syncthreads();                         // every wavefront is past its last fragment reads
+      if (staged) {   // through LDS: whole 8-channel pieces per lane (16-byte accesses)
         if (tt > 0)
-          conv_epilogue_staged<CO_BLK>(p, acc[b], reinterpret_cast<float *>(smem) + wave * (16 * (16 * CO_BLK + 4)), tile, y,
+          conv_epilogue_staged<CO_BLK>(p, acc[b], reinterpret_cast<float *>(smem) + blk * (16 * (16 * CO_BLK + 4)), tile, y,
                                        wv, lane, p.w_unscale ? *p.w_unscale : 1.f);
       } else if (tt > 0) {
         conv_epilogue<CO_BLK>(p, acc[b], tile, y, wv, r16, q4, p.w_unscale ? *p.w_unscale : 1.f);
