@@ -25,6 +25,7 @@ With --gpus N > 1 and no torchrun environment the script launches its own N rank
 import argparse
 import json
 import os
+import re
 import statistics
 import subprocess
 import sys
@@ -87,7 +88,11 @@ def pmc_traffic(kernel):
     # launches, which is what the live timing above groups too): launch-weighted average over its symbols
     key = "imf::" + kernel
     if kernel.startswith("k_spconv_w<"):              # k_spconv_w<W> = the symbols k_spconv_w<CAT, W>
-        fam = [v for k, v in ks.items() if k.startswith("imf::k_spconv_w<") and k.endswith(", " + kernel[len("k_spconv_w<"):])]
+        # the ResUNet's launches read operand images (third argument true); the two-argument symbols of the same kernel
+        # are the image trunk's small dense convolutions, which the live timing above does not group either
+        w = kernel[len("k_spconv_w<"):-1]
+        fam = [v for k, v in ks.items() if re.match(r"imf::k_spconv_w<(true|false), %s, true>" % w, k)] or \
+              [v for k, v in ks.items() if re.match(r"imf::k_spconv_w<(true|false), %s>" % w, k)]
     else:
         fam = [v for k, v in ks.items() if k == key or k.startswith(key[:-1] + ",") or k.startswith(key + "<")]
     if not fam:
@@ -105,23 +110,21 @@ def rocprof_avg_us(kernel, name="r03_kernel_stats.txt"):
     """Launch-weighted average duration of `kernel`'s symbols in the committed `rocprofv3 --kernel-trace --stats` summary of
     this same command (profiles/r03_kernel_stats.txt, tools/profile_round.sh) -- printed beside the live HIP-event timing so
     that roofline.frac can be recomputed from profiles/ alone.  (n, avg_us) or None."""
-    import re
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None
-    n = tot = 0
+    rows = []
     for line in open(path):
         m = re.match(r"(?:void )?imf::(.*?)\(.*\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s+[\d.]+\s*$", line)
-        if not m:
-            continue
-        sym = m.group(1)
-        if kernel.startswith("k_spconv_w<"):
-            ok = sym.startswith("k_spconv_w<") and sym.endswith(", " + kernel[len("k_spconv_w<"):])
-        else:
-            ok = sym == kernel or sym.startswith(kernel[:-1] + ",") or sym.startswith(kernel + "<")
-        if ok:
-            n += int(m.group(2))
-            tot += float(m.group(3))
+        if m:
+            rows.append((m.group(1), int(m.group(2)), float(m.group(3))))
+    if kernel.startswith("k_spconv_w<"):   # (operand-image symbols if the profile has them: see pmc_traffic)
+        w = kernel[len("k_spconv_w<"):-1]
+        fam = [r for r in rows if re.match(r"k_spconv_w<(true|false), %s, true>$" % w, r[0])] or \
+              [r for r in rows if re.match(r"k_spconv_w<(true|false), %s>$" % w, r[0])]
+    else:
+        fam = [r for r in rows if r[0] == kernel or r[0].startswith(kernel[:-1] + ",") or r[0].startswith(kernel + "<")]
+    n, tot = sum(r[1] for r in fam), sum(r[2] for r in fam)
     return (n, tot / n) if n else None
 
 

@@ -373,14 +373,14 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   // With every convolution on the split-f16 pipe, a layer's output is written as the operand image its consumers' main
   // loops would otherwise derive from the fp32 rows again (imf_conv_args.operand_format; IMF_PRESPLIT=0: fp32 buffers as
   // before).  fp32 stays where something other than a variant-6 convolution reads the buffer: the fusion's input
-  // (stride-8 block output), the fusion's own outputs, the descriptors.
+  // (stride-8 block output, read by the fp32-MFMA attention kernel), the descriptors.
   static const bool presplit_env = !(getenv("IMF_PRESPLIT") && atoi(getenv("IMF_PRESPLIT")) == 0);
   bool presplit = presplit_env && !io->fp32_buffers;
   for (int i = 0; i < n_steps; ++i) presplit &= net->conv[sched[i].conv].variant == 6;
   bool is_split[NBUF];
   for (int i = 0; i < NBUF; ++i) is_split[i] = false;
   auto fmt_of = [&](int id) { return id >= 0 && is_split[id]; };
-  auto wants_split = [&](int id) { return presplit && id >= 0 && id != ebuf(3, 2) && id != FUSED && id != HEAD; };
+  auto wants_split = [&](int id) { return presplit && id >= 0 && id != ebuf(3, 2) && id != HEAD; };
 
   // ---- first convolution (Cin <= 4): occupancy bit grid for the all-ones feature, else hash probing --
   if (s.small_first) {
@@ -471,15 +471,17 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   if (diag_marks) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[11], main));
   if (io->image_ready && !image_joined_side) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
   if (items_event >= 0) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->events[items_event], 0));
+  const int fused_split = wants_split(FUSED) ? 1 : 0;   // the block's output: conv4_tr's operand image
+  is_split[FUSED] = fused_split != 0;
   if (dyn)
-    rc = imf_fusion_attention_dyn(buf[ebuf(3, 2)], s.n[3], meta + 6, meta + kMetaStarts + IMF_MAX_BATCH * 3, io->n_items,
+    rc = fusion_attention_dyn_fmt(buf[ebuf(3, 2)], s.n[3], meta + 6, meta + kMetaStarts + IMF_MAX_BATCH * 3, io->n_items,
                                   err, io->kt_packed, io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
-                                  net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4, main);
+                                  net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4, main, fused_split);
   else
-    rc = imf_fusion_attention_batched_flags(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
-                                            io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
-                                            net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4,
-                                            net->conv[12].variant == 6 ? err : nullptr, main);
+    rc = fusion_attention_batched_fmt(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
+                                      io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
+                                      net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4,
+                                      net->conv[12].variant == 6 ? err : nullptr, main, fused_split);
   if (rc) return rc;
   if (io->fusion_done) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->fusion_done, main));
   if (diag_marks) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[12], main));

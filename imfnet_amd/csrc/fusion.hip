@@ -18,7 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "common.h"
+#include "spconv_shared.h"   // (common.h + the internal *_fmt declarations)
 
 namespace imf {
 
@@ -286,8 +286,10 @@ constexpr size_t kWsFloatsPerRow = 2 * kFD + kFH;
 //   g = GEGLU(n2 W1^T + b1)   k_spconv_g, 64-column slabs [32 values | 32 gates], GEGLU epilogue      (84 % of the
 //   z = g W2^T + b2 + y       k_spconv_w, 8 wavefronts split K = 1024, bias + residual epilogue        block's FLOPs)
 // both on the split-f16 matrix pipe (fp32-class arithmetic, spconv_g.hip) with weights staged through LDS by DMA.
+// The GEGLU output travels as a split-f16 operand image (the only reader is the second GEMM: same products, no
+// conversions in its loop); out_split: the block's output too (its reader is conv4_tr, imf_resunet_forward decides).
 static int run_feed_forward(const imf_fusion_weights *w, long long n, const int32_t *n_dev, float *ws, float *out,
-                            int32_t *err, hipStream_t st) {
+                            int32_t *err, hipStream_t st, int out_split) {
   float *y = ws, *n2 = ws + (size_t)n * kFD, *g = ws + (size_t)n * 2 * kFD;
   const long long slots = (n + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
   imf_conv_args a;
@@ -295,6 +297,7 @@ static int run_feed_forward(const imf_fusion_weights *w, long long n, const int3
   a.in_a = n2; a.c_a = kFD; a.w_packed = w->w1_p; a.kvol = 1; a.cout = 2 * kFH;
   a.n_slots = slots; a.n_out = n; a.shift = w->b1; a.out = g; a.split_k = 1; a.variant = 6; a.geglu = 1;
   a.n_out_dev = n_dev; a.dyn_err = err;
+  a.operand_format = IMF_FMT_OUT_SPLIT;
   int rc = imf_spconv_fwd(&a, st);
   if (rc) return rc;
   memset(&a, 0, sizeof(a));
@@ -302,6 +305,7 @@ static int run_feed_forward(const imf_fusion_weights *w, long long n, const int3
   a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = 6;
   a.kernel_tag = 4;                                  // wave-split, 8 wavefronts: K = 1024 is 32 sub-stages per tile
   a.n_out_dev = n_dev; a.dyn_err = err;              // z feeds conv4_tr (split-f16): range guard
+  a.operand_format = IMF_FMT_A_SPLIT | (out_split ? IMF_FMT_OUT_SPLIT : 0);
   return imf_spconv_fwd(&a, st);
 }
 
@@ -325,6 +329,17 @@ int imf_fusion_attention_dyn(const float *x, int64_t n_cap, const int32_t *n_dev
                              int n_items, int32_t *err, const float *const *kt_packed, const float *const *v_packed,
                              int n_tokens, int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
                              void *workspace, size_t workspace_bytes, void *stream) {
+  return imf::fusion_attention_dyn_fmt(x, n_cap, n_dev, item_starts_dev, n_items, err, kt_packed, v_packed, n_tokens,
+                                       tokens_padded, w, scale, out, workspace, workspace_bytes, stream, 0);
+}
+
+}  // extern "C"
+
+namespace imf {
+int fusion_attention_dyn_fmt(const float *x, int64_t n_cap, const int32_t *n_dev, const int32_t *item_starts_dev,
+                             int n_items, int32_t *err, const float *const *kt_packed, const float *const *v_packed,
+                             int n_tokens, int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
+                             void *workspace, size_t workspace_bytes, void *stream, int out_split) {
   IMF_REQUIRE(x && n_dev && item_starts_dev && err && kt_packed && v_packed && w && out && workspace,
               "imf_fusion_attention_dyn: null pointer");
   IMF_REQUIRE(n_items >= 1 && n_items <= IMF_MAX_BATCH && n_cap > 0, "imf_fusion_attention_dyn: n_items=%d", n_items);
@@ -345,8 +360,11 @@ int imf_fusion_attention_dyn(const float *x, int64_t n_cap, const int32_t *n_dev
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_attn(p, st);
   if (rc) return rc;
-  return run_feed_forward(w, n_cap, n_dev, (float *)workspace, out, err, st);
+  return run_feed_forward(w, n_cap, n_dev, (float *)workspace, out, err, st, out_split);
 }
+}  // namespace imf
+
+extern "C" {
 
 int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
                                  const float *const *kt_packed, const float *const *v_packed, int n_tokens,
@@ -360,6 +378,17 @@ int imf_fusion_attention_batched_flags(const float *x, int n_items, const int64_
                                        const float *const *kt_packed, const float *const *v_packed, int n_tokens,
                                        int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
                                        void *workspace, size_t workspace_bytes, int32_t *flags, void *stream) {
+  return imf::fusion_attention_batched_fmt(x, n_items, item_row0, item_rows, kt_packed, v_packed, n_tokens, tokens_padded, w,
+                                           scale, out, workspace, workspace_bytes, flags, stream, 0);
+}
+
+}  // extern "C"
+
+namespace imf {
+int fusion_attention_batched_fmt(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
+                                 const float *const *kt_packed, const float *const *v_packed, int n_tokens,
+                                 int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
+                                 void *workspace, size_t workspace_bytes, int32_t *flags, void *stream, int out_split) {
   IMF_REQUIRE(x && item_row0 && item_rows && kt_packed && v_packed && w && out, "imf_fusion_attention: null pointer");
   IMF_REQUIRE(n_items >= 1 && n_items <= IMF_MAX_BATCH, "imf_fusion_attention: n_items=%d", n_items);
   IMF_REQUIRE(w->ln1_g && w->ln1_b && w->wq_p && w->wo_p && w->bo && w->ln2_g && w->ln2_b && w->w1_p && w->b1 &&
@@ -385,8 +414,11 @@ int imf_fusion_attention_batched_flags(const float *x, int n_items, const int64_
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_attn(p, st);
   if (rc) return rc;
-  return run_feed_forward(w, n, nullptr, (float *)workspace, out, flags, st);
+  return run_feed_forward(w, n, nullptr, (float *)workspace, out, flags, st, out_split);
 }
+}  // namespace imf
+
+extern "C" {
 
 int imf_fusion_attention(const float *x, int64_t n, const float *kt_packed, const float *v_packed, int n_tokens,
                          int tokens_padded, const imf_fusion_weights *w, float scale, float *out, void *workspace,

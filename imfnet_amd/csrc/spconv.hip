@@ -752,7 +752,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   p.out_split = (a->operand_format & IMF_FMT_OUT_SPLIT) ? 1 : 0;
   IMF_REQUIRE(!a->operand_format || (a->variant == 6 && split == 1 && !a->tickets && !(a->kernel_tag & 2)),
               "imf_spconv_fwd: operand_format needs variant 6 and an unsplit launch (split_k=%d)", split);
-  IMF_REQUIRE(!p.out_split || (!a->l2norm && !a->geglu), "imf_spconv_fwd: IMF_FMT_OUT_SPLIT not with l2norm / geglu");
+  IMF_REQUIRE(!p.out_split || !a->l2norm, "imf_spconv_fwd: IMF_FMT_OUT_SPLIT not with l2norm");
   IMF_REQUIRE(!p.res_split || a->residual, "imf_spconv_fwd: IMF_FMT_RES_SPLIT without a residual");
   IMF_REQUIRE(!a->geglu || (a->variant == 6 && !wsplit && a->kvol == 1 && a->cout % 64 == 0 && split == 1 && !a->scale &&
                             !a->residual && !a->relu && !a->l2norm && !(a->kernel_tag & 2)),

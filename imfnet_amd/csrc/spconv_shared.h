@@ -160,7 +160,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (
         const float val = acc[cb][r] * unscale + bv, gate = acc[(cb + 2) % CO_BLK][r] * unscale + bg;
         const float g = val * (0.5f * gate * (1.f + erff(gate * 0.70710678118654752f)));
         bad |= orow[r] >= 0 && out_of_f16_range(g);
-        if (orow[r] >= 0) p.out[(long long)orow[r] * half + oc] = g;
+        if (orow[r] >= 0) {
+          if (p.out_split) store_split(p.out, orow[r], half, oc, g);
+          else p.out[(long long)orow[r] * half + oc] = g;
+        }
       }
     }
     if (p.err && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(p.err, 32);
@@ -348,6 +351,15 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
 void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t st);
 
 // spconv.hip: imf_conv_first_bitgrid_dyn on a grid the caller already zeroed and filled (geometry.hip: k_emit_unique)
+// the fusion block with its output optionally written as a split-f16 operand image (fusion.hip; for imf_resunet_forward)
+int fusion_attention_dyn_fmt(const float *x, int64_t n_cap, const int32_t *n_dev, const int32_t *item_starts_dev,
+                             int n_items, int32_t *err, const float *const *kt_packed, const float *const *v_packed,
+                             int n_tokens, int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
+                             void *workspace, size_t workspace_bytes, void *stream, int out_split);
+int fusion_attention_batched_fmt(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
+                                 const float *const *kt_packed, const float *const *v_packed, int n_tokens,
+                                 int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
+                                 void *workspace, size_t workspace_bytes, int32_t *flags, void *stream, int out_split);
 int conv_first_bitgrid_flags_fmt(const int32_t *coords, int64_t n, const int32_t *bbox, int ksize, uint32_t *grid,
                                  size_t grid_words, const float *w, int cout, const float *scale, const float *shift,
                                  int relu, float *out, int32_t *flags, hipStream_t stream, int out_split);

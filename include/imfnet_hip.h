@@ -264,7 +264,7 @@ typedef struct imf_conv_args {
                              out[r][32 y + c] = (acc_v + shift_v) * gelu(acc_g + shift_g), exact-erf GELU */
   int32_t operand_format; /* variant 6 (k_spconv_g / k_spconv_w, unsplit launches): which of the row-major [rows, channels]
                              buffers are SPLIT-F16 OPERAND IMAGES instead of fp32 -- IMF_FMT_A_SPLIT: in_a and in_b;
-                             IMF_FMT_RES_SPLIT: residual; IMF_FMT_OUT_SPLIT: out is written as one (not with l2norm / geglu).
+                             IMF_FMT_RES_SPLIT: residual; IMF_FMT_OUT_SPLIT: out is written as one (not with l2norm).
                              An operand image has the size and row stride of the fp32 buffer: per row and 32-channel chunk
                              128 bytes = [4 hi pieces | 4 lo pieces], piece j = the 8 halves of channels {4j..4j+3,
                              16+4j..16+4j+3}, hi = f16(x), lo = f16(x - hi) -- what the kernels' main loops derive from an
