@@ -757,9 +757,16 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   IMF_REQUIRE(!a->geglu || (a->variant == 6 && !wsplit && a->kvol == 1 && a->cout % 64 == 0 && split == 1 && !a->scale &&
                             !a->residual && !a->relu && !a->l2norm && !(a->kernel_tag & 2)),
               "imf_spconv_fwd: geglu needs variant 6 (k_spconv_g), kvol 1, cout %% 64 == 0 and no other epilogue");
-  // XCD-contiguous tile order: measured SLOWER (pair step 1.53 vs 1.38 ms; round 2) -- opt-in for experiments only
-  static const int xcd = getenv("IMF_H3_XCD") ? 1 : 0;
-  p.no_xcd_swizzle = !xcd;
+  // XCD-contiguous tile order of k_spconv_g (IMF_G_XCD: bit 0 = the 64-column launches, bit 1 = the 32-column ones; default
+  // both): workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2.  In launch order each XCD gathers from ALL input
+  // rows (26 MB for 64 channels at 103 k rows); when XCD x instead walks ONE range of consecutive tiles -- rows are in scan
+  // order, a tile's neighbours sit in nearby tiles -- its L2 serves ~1/8 of the rows.  The ranges are cut from the ACTUAL
+  // tiles on the device (capacity mode; cut from the capacity they left the last XCDs idle: round 2 measured that form
+  // slower), the grid's x extent is padded to a multiple of 8 so that a workgroup's XCD is blockIdx.x & 7.  Same sums.
+  // Measured (round 3, pair step, same box): 0.979 -> 0.955 ms together with the same order in k_spconv_w.
+  static const int xcd = getenv("IMF_G_XCD") ? atoi(getenv("IMF_G_XCD")) : 3;
+  const bool g_xcd = a->variant == 6 && !wsplit && ((CB == 4 && (xcd & 1)) || (CB == 2 && (xcd & 2)));
+  p.no_xcd_swizzle = !g_xcd;
   IMF_REQUIRE(!p.dyn_split_kvol || (!p.tickets && a->split_k >= 1), "imf_spconv_fwd: dyn_split_kvol needs an explicit split_k cover and no tickets");
 #ifndef IMF_WITH_H3
   if (a->variant == 6 && ((a->kernel_tag & 2) || a->tickets)) {
@@ -769,6 +776,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   }
 #endif
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
+  if (g_xcd) grid.x = (grid.x + 7u) / 8u * 8u;
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
   if (wsplit) {

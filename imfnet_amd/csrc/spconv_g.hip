@@ -120,23 +120,21 @@ k_spconv_g(const ConvParams p) {
   int *const klist = reinterpret_cast<int *>(smem + NB * BUF_F4 + NBR_F4 + TAB_F4);       // [kKCache]
 
   int super = blockIdx.x, z = blockIdx.z, S = gridDim.z;
-  if (!p.no_xcd_swizzle) {   // opt-in XCD-contiguous tile order, as in k_spconv_h3
-    const int nx = gridDim.x;
-    const int off = (int)(((long long)nx * (blockIdx.y + (long long)gridDim.y * blockIdx.z)) & 7);
-    const int x = (super + off) & 7;
-    int start = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int first = (q - off) & 7;
-      const int cnt = first < nx ? (nx - first + 7) >> 3 : 0;
-      if (q < x) start += cnt;
-    }
-    super = start + ((super - ((x - off) & 7)) >> 3);
+  long long slots_act = p.n_slots;
+  if (p.n_out_dev) slots_act = conv_slots(p, conv_rows(p));   // capacity mode: the actual rows
+  if (!p.no_xcd_swizzle && (gridDim.x & 7u) == 0) {
+    // XCD-contiguous tile order (launch_spconv_g pads gridDim.x to a multiple of 8, so the XCD of a workgroup is
+    // blockIdx.x & 7 whatever y / z): XCD x walks ONE range of consecutive tiles, cut from the ACTUAL tiles -- the rows
+    // neighbouring tiles gather are neighbours in space, its L2 then serves ~1/8 of the input rows instead of all of them.
+    const unsigned t_act = (unsigned)((slots_act / IMF_TILE_ROWS + RB - 1) / RB);
+    const unsigned chunk = (t_act + 7u) >> 3;
+    const unsigned j = blockIdx.x >> 3;
+    if (j >= chunk) return;
+    super = (int)((blockIdx.x & 7u) * chunk + j);
+    if ((unsigned)super >= t_act) return;
   }
   const int tile0 = super * RB;
-  long long slots_act = p.n_slots;
   if (p.n_out_dev) {   // capacity mode: padding tiles leave; the split is the rule applied to the actual rows
-    slots_act = conv_slots(p, conv_rows(p));
     if ((long long)tile0 * IMF_TILE_ROWS >= slots_act) return;
     if (p.dyn_split_kvol) {
       S = auto_split_rule(slots_act, p.cout, p.dyn_split_kvol, p.split_min_blocks, p.split_target);

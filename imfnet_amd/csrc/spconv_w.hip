@@ -81,17 +81,27 @@ k_spconv_w(const ConvParams p) {
   // (x = tile, y = slab) order every XCD's 4 MiB L2 sees every slab of the weight image (7 MB for 256 -> 256).  Here the
   // slab is a function of the XCD (launch index mod 8), each L2 then holds 1 / n_slabs of the weights.
   int tile = blockIdx.x, y = blockIdx.y;
-  if (p.w_xcd && gridDim.y > 1 && gridDim.y <= 8 && (gridDim.y & (gridDim.y - 1)) == 0) {
-    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, ns = gridDim.y;
+  long long slots_act = p.n_slots;
+  if (p.n_out_dev) slots_act = conv_slots(p, conv_rows(p));   // capacity mode: tiles beyond the actual rows leave
+  const unsigned ns = gridDim.y;
+  if (p.w_xcd == 2 && ns <= 8 && (ns & (ns - 1)) == 0) {
+    // contiguous: the XCD's workgroups walk ONE range of consecutive tiles -- rows of neighbouring tiles are
+    // neighbours in space, the XCD's L2 then serves a fraction of the input rows instead of all of them.  Ranges are cut
+    // from the ACTUAL tiles; the launcher pads gridDim.x to a multiple of 8 so that every XCD has enough workgroups.
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned xcd = lin & 7u, j = lin >> 3;
+    const unsigned groups = 8u / ns, t_act = (unsigned)(slots_act / IMF_TILE_ROWS);
+    const unsigned chunk = (t_act + groups - 1) / groups;
+    y = (int)(xcd % ns);
+    if (j >= chunk) return;
+    tile = (int)((xcd / ns) * chunk + j);
+  } else if (p.w_xcd && ns > 1 && ns <= 8 && (ns & (ns - 1)) == 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
     const unsigned xcd = lin & 7u, j = lin >> 3;
     y = (int)(xcd % ns);
     tile = (int)(j * (8u / ns) + xcd / ns);
   }
-  long long slots_act = p.n_slots;
-  if (p.n_out_dev) {                                 // capacity mode: tiles beyond the actual rows leave
-    slots_act = conv_slots(p, conv_rows(p));
-    if ((long long)tile * IMF_TILE_ROWS >= slots_act) return;
-  }
+  if ((long long)tile * IMF_TILE_ROWS >= slots_act) return;
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cin = p.c_a + (CAT ? p.c_b : 0);
@@ -326,10 +336,13 @@ k_spconv_w(const ConvParams p) {
 
 // grid = (tiles, cout / 64); `waves` = 8 (512 threads, one workgroup per CU) or 4 (256 threads, two per CU)
 void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st) {
-  static const int xcd_env = getenv("IMF_W_XCD") ? atoi(getenv("IMF_W_XCD")) : 1;   // measured: pair step 1.092 -> 1.074 ms
+  // IMF_W_XCD: 1 = slab by XCD, tiles interleaved (pair step 1.092 -> 1.074 ms); 2 (default) = slab by XCD AND one range of
+  // consecutive tiles per XCD (0.953 -> 0.940 ms on top: the XCD's L2 serves a fraction of the input rows)
+  static const int xcd_env = getenv("IMF_W_XCD") ? atoi(getenv("IMF_W_XCD")) : 2;
   ConvParams p = p_in;
   p.w_xcd = xcd_env;
-  const dim3 grid(tiles, (unsigned)(p.cout / 64), 1);
+  const unsigned slabs = (unsigned)(p.cout / 64);
+  const dim3 grid(xcd_env == 2 && slabs <= 8 && (slabs & (slabs - 1)) == 0 ? (tiles + 7u) / 8u * 8u : tiles, slabs, 1);
   const bool cat = p.c_b > 0;
   if (p.a_split) {
     if (waves == 8) {
