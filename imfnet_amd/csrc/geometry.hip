@@ -119,9 +119,9 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
   uint32_t s = 0;
   if (leader) {
 #if IMF_GEO_ABL & 1
-    s = hash64(key) & capmask;
+    s = hash_slot(key, 0, capmask);
 #else
-    s = hash_insert(tab, capmask, key);
+    s = hash_insert(tab, capmask, key, 0);
     atomicMin(&tab[s].val, (int32_t)i);
 #endif
   }
@@ -149,7 +149,7 @@ k_insert_coords(const int32_t *__restrict__ cin, const int32_t *__restrict__ n_d
   int x = floor_div(c.y, stride) * stride;
   int y = floor_div(c.z, stride) * stride;
   int z = floor_div(c.w, stride) * stride;
-  uint32_t s = hash_insert(tab, capmask, pack_key(c.x, x, y, z));
+  uint32_t s = hash_insert(tab, capmask, pack_key(c.x, x, y, z), __builtin_ctz((unsigned)stride));
   atomicMin(&tab[s].val, (int32_t)i);
   slot_of[i] = (int32_t)s;
 }
@@ -358,6 +358,8 @@ k_rulebook(const imf_slot *__restrict__ tab, uint32_t capmask,
   }
   // a tile without rows (capacity padding) gets mask 0: the convolution never looks at its neighbour slice
   const bool empty_tile = __ballot(row >= 0) == 0ull;
+  // the probed table's level: the input's (conv; its coordinates are multiples of ts) or the coarse one's (transposed: 2 ts)
+  const int tshift = __builtin_ctz((unsigned)ts) + (SIGN < 0 ? 1 : 0);
   uint32_t m[IMF_MASK_WORDS] = {0u, 0u, 0u, 0u};
   if (!(empty_tile && n_out_dev)) {   // (exact-size tables: padding tiles are written as 'no input' too)
     int4 c = make_int4(0, 0, 0, 0);
@@ -380,7 +382,7 @@ k_rulebook(const imf_slot *__restrict__ tab, uint32_t capmask,
           const int x = c.y + SIGN * dx * ts, y = c.z + SIGN * dy * ts, z = c.w + SIGN * dz * ts;
           if (coord_in_range(x, y, z)) {
             want[j] = pack_key(c.x, x, y, z);
-            hs[j] = hash64(want[j]) & capmask;
+            hs[j] = hash_slot(want[j], tshift, capmask);
           }
         }
       }
@@ -394,7 +396,7 @@ k_rulebook(const imf_slot *__restrict__ tab, uint32_t capmask,
         if (want[j] != kEmptyKey) {
           const uint64_t k0 = ((uint64_t)got[j].y << 32) | got[j].x;
           if (k0 == want[j]) found = (int)got[j].z;
-          else if (k0 != kEmptyKey) found = hash_find(tab, capmask, want[j]);   // collision: walk on
+          else if (k0 != kEmptyKey) found = hash_find(tab, capmask, want[j], tshift);   // collision: walk on
         }
         nbr[(int64_t)k * n_slots + slot] = found;
         if (__ballot(found >= 0) != 0ull) m[k >> 5] |= 1u << (k & 31);
@@ -406,7 +408,7 @@ k_rulebook(const imf_slot *__restrict__ tab, uint32_t capmask,
           int dx, dy, dz;
           kernel_offset(k, ksize, dx, dy, dz);
           const int x = c.y + SIGN * dx * ts, y = c.z + SIGN * dy * ts, z = c.w + SIGN * dz * ts;
-          if (coord_in_range(x, y, z)) found = hash_find(tab, capmask, pack_key(c.x, x, y, z));
+          if (coord_in_range(x, y, z)) found = hash_find(tab, capmask, pack_key(c.x, x, y, z), tshift);
         }
         nbr[(int64_t)k * n_slots + slot] = found;
         if (__ballot(found >= 0) != 0ull) m[k >> 5] |= 1u << (k & 31);

@@ -409,7 +409,7 @@ k_conv_first_fused(const imf_slot *__restrict__ tab, uint32_t capmask,
       const int x = c.y + dx * ts, y = c.z + dy * ts, z = c.w + dz * ts;
       if (coord_in_range(x, y, z)) {
         want[j] = pack_key(c.x, x, y, z);
-        hs[j] = hash64(want[j]) & capmask;
+        hs[j] = hash_slot(want[j], __builtin_ctz((unsigned)ts), capmask);
       }
     }
   }
@@ -421,7 +421,7 @@ k_conv_first_fused(const imf_slot *__restrict__ tab, uint32_t capmask,
     if (want[j] != kEmptyKey) {
       const uint64_t k0 = ((uint64_t)got[j].y << 32) | got[j].x;
       if (k0 == want[j]) found = (int)got[j].z;
-      else if (k0 != kEmptyKey) found = hash_find(tab, capmask, want[j]);   // collision: slow path
+      else if (k0 != kEmptyKey) found = hash_find(tab, capmask, want[j], __builtin_ctz((unsigned)ts));   // collision: slow path
     }
     nbr_l[j * 256 + tid] = found;
   }
