@@ -765,7 +765,10 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   // slower), the grid's x extent is padded to a multiple of 8 so that a workgroup's XCD is blockIdx.x & 7.  Same sums.
   // Measured (round 3, pair step, same box): 0.979 -> 0.955 ms together with the same order in k_spconv_w.
   static const int xcd = getenv("IMF_G_XCD") ? atoi(getenv("IMF_G_XCD")) : 3;
-  const bool g_xcd = a->variant == 6 && !wsplit && ((CB == 4 && (xcd & 1)) || (CB == 2 && (xcd & 2)));
+  // (not for parity-grouped transposed maps: a range of consecutive tiles there is one parity class spread over the whole
+  // level -- no locality to win, measured 43 -> 54 us for conv2_tr)
+  const bool g_xcd = a->variant == 6 && !wsplit && ((CB == 4 && (xcd & 1)) || (CB == 2 && (xcd & 2))) &&
+                     a->n_slots == imf_rulebook_slots(a->n_out);
   p.no_xcd_swizzle = !g_xcd;
   IMF_REQUIRE(!p.dyn_split_kvol || (!p.tickets && a->split_k >= 1), "imf_spconv_fwd: dyn_split_kvol needs an explicit split_k cover and no tickets");
 #ifndef IMF_WITH_H3

@@ -340,9 +340,11 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
   // consecutive tiles per XCD (0.953 -> 0.940 ms on top: the XCD's L2 serves a fraction of the input rows)
   static const int xcd_env = getenv("IMF_W_XCD") ? atoi(getenv("IMF_W_XCD")) : 2;
   ConvParams p = p_in;
-  p.w_xcd = xcd_env;
+  // (a transposed map's tiles are grouped by parity class: consecutive tiles there are not neighbours in space -- mode 1)
+  const bool transposed = p.n_slots != (p.n_out + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
+  p.w_xcd = xcd_env == 2 && transposed ? 1 : xcd_env;
   const unsigned slabs = (unsigned)(p.cout / 64);
-  const dim3 grid(xcd_env == 2 && slabs <= 8 && (slabs & (slabs - 1)) == 0 ? (tiles + 7u) / 8u * 8u : tiles, slabs, 1);
+  const dim3 grid(p.w_xcd == 2 && slabs <= 8 && (slabs & (slabs - 1)) == 0 ? (tiles + 7u) / 8u * 8u : tiles, slabs, 1);
   const bool cat = p.c_b > 0;
   if (p.a_split) {
     if (waves == 8) {
