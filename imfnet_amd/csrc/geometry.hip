@@ -122,7 +122,10 @@ k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, c
     s = hash_slot(key, 0, capmask);
 #else
     s = hash_insert(tab, capmask, key, 0);
-    atomicMin(&tab[s].val, (int32_t)i);
+    // the slot's row index only ever decreases: a run whose first point comes after the one already recorded has nothing
+    // to add (a stale read is larger than the truth, i.e. errs towards doing the atomic)
+    if (__hip_atomic_load(&tab[s].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)i)
+      atomicMin(&tab[s].val, (int32_t)i);
 #endif
   }
   const unsigned long long lead_mask = __ballot(leader);
@@ -150,7 +153,8 @@ k_insert_coords(const int32_t *__restrict__ cin, const int32_t *__restrict__ n_d
   int y = floor_div(c.z, stride) * stride;
   int z = floor_div(c.w, stride) * stride;
   uint32_t s = hash_insert(tab, capmask, pack_key(c.x, x, y, z), __builtin_ctz((unsigned)stride));
-  atomicMin(&tab[s].val, (int32_t)i);
+  if (__hip_atomic_load(&tab[s].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)i)   // (see k_insert_points)
+    atomicMin(&tab[s].val, (int32_t)i);
   slot_of[i] = (int32_t)s;
 }
 
