@@ -610,8 +610,9 @@ def extra_legs(O, model, dev, args, sync):
         pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
     out["e2e_extract_features_stream"] = {"descriptors_per_s": round(m_tot / n_it / dt, 1), "ms_per_fragment": round(dt * 1e3, 3),
                                           "span": "the same span over a stream of %d host fragments through extract_features_stream: "
-                                                  "pinned staging, H2D / D2H on copy streams under the neighbouring fragments' "
-                                                  "kernels, xyz_down and F delivered as host arrays (views of the pinned slots, copy=False), in order" % n_it}
+                                                  "two fragments per forward (the model's batched call), one pinned H2D block and one pinned D2H block "
+                                                  "per forward queued under the neighbouring forwards' kernels, xyz_down and F delivered "
+                                                  "as host arrays (views of the pinned slots, copy=False), in order" % n_it}
 
     pts2, imgs2 = load_pair(args.scale)
     wl2 = Workload(model, dev, pts2, imgs2, voxel)

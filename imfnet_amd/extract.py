@@ -13,7 +13,7 @@ import torch
 from . import ops
 from . import sparse as ME
 from .model import graph
-from ._lib import FLAG_RANGE, ImfError, check
+from ._lib import MAX_BATCH, FLAG_RANGE, ImfError, check
 
 
 def _cuda_device(device):
@@ -109,27 +109,41 @@ def _host_inputs(xyz, image):
 
 
 def _submit_host(runner, slot, host_xyz, host_img, voxel_size, device, stream):
-    """Stage one host fragment through `slot` (pinned), launch it in capacity mode and queue the copy back -- ONE
-    host-to-device copy (scalars | image | points) and ONE device-to-host copy (counts | xyz_down | descriptors) per
-    fragment; xyz_down = xyz[inds] is gathered on the device (imf_gather_points).  Asynchronous; `slot.done` marks
-    completion.  Returns (result, views of the slot's pinned blocks) or None when no capacities are known."""
-    n = host_xyz.shape[0]
-    key = runner.caps_for(n, 1, int(host_img.shape[2]), int(host_img.shape[3]), voxel_size, host_xyz.dtype == np.float64)
+    """One fragment through `_submit_host_items`."""
+    return _submit_host_items(runner, slot, [(host_xyz, host_img)], voxel_size, device, stream)
+
+
+def _submit_host_items(runner, slot, items, voxel_size, device, stream):
+    """Stage host fragments -- ONE, or several as one batched forward (rows grouped by fragment, one image each: the batched
+    call of model/resunet.py:241-250) -- through `slot` (pinned), launch them in capacity mode and queue the copy back: ONE
+    host-to-device copy (scalars | images | points) and ONE device-to-host copy (counts | xyz_down | descriptors) per
+    call; xyz_down = xyz[inds] is gathered on the device (imf_gather_points).  Asynchronous; `slot.done` marks completion.
+    items: [(xyz [N,3] host array, image [1,3,H,W] host array)], same point dtype and image size.  Returns (result, views
+    of the slot's pinned blocks) -- `result.items()` gives every fragment's (first row, rows) -- or None when no capacities
+    are known."""
+    k = len(items)
+    n_each = [int(x.shape[0]) for x, _ in items]
+    n = sum(n_each)
+    x0, i0 = items[0]
+    key = runner.caps_for(n, k, int(i0.shape[2]), int(i0.shape[3]), voxel_size, x0.dtype == np.float64)
     if key is None:
         return None
     b = runner.bucket(key, device, stream)
     v = slot.bind(b)
-    np.copyto(v["xyz"][:n], host_xyz)
-    np.copyto(v["image"], host_img)
-    vals = [n, 1, 0]
+    vals, at = [n, k], 0
+    for j, (xyz, img) in enumerate(items):
+        np.copyto(v["xyz"][at:at + n_each[j]], xyz)
+        np.copyto(v["image"][j:j + 1], img)
+        vals.append(at)
+        at += n_each[j]
     v["dyn"][:len(vals)] = vals
     rows = b.caps.rows[0]
-    used_in = b.lay["xyz"] + n * 3 * host_xyz.dtype.itemsize
+    used_in = b.lay["xyz"] + n * 3 * x0.dtype.itemsize
     with torch.cuda.stream(stream):
         slot.begin.record(stream)
         b.inbuf[:used_in].copy_(slot.inbuf[:used_in], non_blocking=True)
     b.dyn_values = vals
-    res = runner.launch(b, n, 1, stream, meta_to=(v["meta"], slot.done))
+    res = runner.launch(b, n, k, stream, meta_to=(v["meta"], slot.done))
     check(runner.L.imf_gather_points(b.xyz.data_ptr(), int(b.xyz.dtype == torch.float64), b.first_idx_view().data_ptr(),
                                      b.meta.data_ptr(), rows, b.sel.data_ptr(), stream.cuda_stream), "imf_gather_points")
     with torch.cuda.stream(stream):
@@ -200,13 +214,16 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image):
     return sel, F
 
 
-def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, copy=True):
+def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, copy=True, batch=2):
     """`extract_features` over a STREAM of host fragments (SURVEY 8d's span -- host arrays in, descriptors back on the
     host -- pipelined): yields (xyz_down float64 [M,3], F float32 [M,32] numpy) per fragment, in order.  `fragments`:
-    iterable of (xyz [N,3] host array, image [1,3,H,W] host array).  Up to `depth` fragments are queued on the GPU, so
-    the host's share of fragment i + 1 (pinned staging, ~150 launches) runs under fragment i's kernels; per fragment the
-    stream carries one H2D copy, the forward and one D2H copy.  (Copies on streams of their own -- device mirrors per
+    iterable of (xyz [N,3] host array, image [1,3,H,W] host array).  Up to `depth` forwards are queued on the GPU, so
+    the host's share of the next one (pinned staging, ~150 launches) runs under the current one's kernels; per forward the
+    stream carries one H2D copy, the launches and one D2H copy.  (Copies on streams of their own -- device mirrors per
     slot, events both ways -- were measured SLOWER on this stack: 2.0-2.7 vs 1.3 ms per fragment, tools/e2e_probe.py.)
+    batch: consecutive fragments per forward (the model's batched call, model/resunet.py:241-250: rows grouped by
+    fragment, one image each) -- the stride-4/8 levels of ONE fragment leave half the chip idle, two fill it: 0.47 vs 0.68 ms
+    of GPU time per S50k fragment; fragments of a batch share point dtype and image size (others go alone).
     copy=True: the arrays of a yield are fresh host copies; copy=False: views of the pinned slot, valid until the NEXT
     item is requested (a 6.5 MB copy into newly faulted pages costs ~0.3 ms per fragment).  Fragments the capacity mode
     cannot take (no capacities yet, a flag) go through `extract_features`, in order."""
@@ -229,51 +246,79 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
     free = list(slots[:n_slots])
     inflight = deque()
     lent = []                                         # the slot whose views the consumer currently holds (copy=False)
+    batch = max(1, min(int(batch), MAX_BATCH))
 
     def finish(entry):
-        xyz, image, slot, got = entry
+        """The results of one forward (generator: one (xyz_down, F) per fragment of the entry, in order)."""
+        items, slot, got = entry
         while lent:
             free.append(lent.pop())
         if got is not None:
             res, v = got
             slot.done.synchronize()
             if not res.flags:
-                m = res.counts[0]
                 runner.stats["stream_gpu_ms"] = runner.stats.get("stream_gpu_ms", 0.0) + slot.begin.elapsed_time(slot.done)
-                runner.stats["stream_n"] = runner.stats.get("stream_n", 0) + 1
-                if copy:
-                    out = v["sel"][:m].copy(), v["F"][:m].copy()
-                    free.append(slot)
-                else:
-                    out = v["sel"][:m], v["F"][:m]
+                runner.stats["stream_n"] = runner.stats.get("stream_n", 0) + len(items)
+                spans = res.items() if len(items) > 1 else [(0, res.counts[0])]
+                if not copy:
                     lent.append(slot)
-                return out
-            runner.stats["redone"] += 1
+                outs = [(v["sel"][r0:r0 + m].copy(), v["F"][r0:r0 + m].copy()) if copy else (v["sel"][r0:r0 + m], v["F"][r0:r0 + m])
+                        for r0, m in spans]
+                if copy:
+                    free.append(slot)
+                yield from outs
+                return
+            runner.stats["redone"] += len(items)
+            if len(items) > 1 and (res.flags & 4):    # the batch's bounding box outgrew the grid: size the next one by it
+                runner.observe_batch(len(items), res.bbox)
         free.append(slot)
-        with torch.no_grad():
-            xd, F = extract_features(model, xyz, voxel_size=voxel_size, device=device, skip_check=True, image=image)
-        return xd, F.cpu().numpy()
+        for xyz, image in items:
+            with torch.no_grad():
+                xd, F = extract_features(model, xyz, voxel_size=voxel_size, device=device, skip_check=True, image=image)
+            yield xd, F.cpu().numpy()
+
+    def submit(group):
+        """Queue `group` (host fragments) as ONE forward; False when the runner cannot take it yet."""
+        slot = free.pop()
+        got = None
+        if runner is not None and runner.ratios is not None:
+            got = _submit_host_items(runner, slot, group, voxel_size, device, stream)
+        if got is None:
+            free.append(slot)
+            return False
+        inflight.append((group, slot, got))
+        return True
 
     with torch.no_grad():
+        group = []
+
+        def flush():
+            nonlocal runner
+            if not group:
+                return
+            g = list(group)
+            del group[:]
+            while len(free) < 2 and inflight:         # one slot stays spare: a lent one comes back at the next finish
+                yield from finish(inflight.popleft())
+            if not submit(g):                         # teach the runner on the exact path first, in order
+                while inflight:
+                    yield from finish(inflight.popleft())
+                slot = free.pop()
+                yield from finish((g, slot, None))
+                runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
+
         for xyz, image in fragments:
             host = _host_inputs(xyz, image)
             if host is None:
                 raise ImfError("extract_features_stream takes host arrays")
-            while len(free) < 2 and inflight:         # one slot stays spare: a lent one comes back at the next finish
-                yield finish(inflight.popleft())
-            slot = free.pop()
-            got = None
-            if runner is not None and runner.ratios is not None:
-                got = _submit_host(runner, slot, host[0], host[1], voxel_size, device, stream)
-            if got is None:                           # teach the runner on the exact path first, in order
-                while inflight:
-                    yield finish(inflight.popleft())
-                yield finish((host[0], host[1], slot, None))
-                runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
-                continue
-            inflight.append((host[0], host[1], slot, got))
+            if group and (host[0].dtype != group[0][0].dtype or host[1].shape != group[0][1].shape):
+                yield from flush()
+            group.append(host)
+            if len(group) >= batch:
+                yield from flush()
+        yield from flush()
         while inflight:
-            yield finish(inflight.popleft())
+            yield from finish(inflight.popleft())
     if stream.cuda_stream != caller.cuda_stream:
         caller.wait_stream(stream)
 

@@ -255,6 +255,7 @@ class FragmentRunner:
         self.image_branch_mode = "native-hip (csrc/image.hip, inside imf_fragment_forward)" if self.supported else None
         self.ratios = None            # max rows_l / n_points seen (4 levels)
         self.grid_words = 0           # largest conv1 bit grid seen
+        self.grid_words_items = {}    # the same for batches of several fragments (n_items -> words), `observe_batch`
         self.buckets = {}
         self._main = {}
         self._raw = {}
@@ -283,8 +284,17 @@ class FragmentRunner:
             c = min(_grid_up(want, 1.125, (4096, 1024, 256, 128)[l]), prev)
             rows.append(c)
             prev = c
-        gw = _grid_up(self.grid_words * 1.5, 2.0, 1 << 18)
+        # conv1's bit grid spans the batch's common bounding box once per item: for several fragments in one forward it is
+        # learned from the boxes such batches produced (`observe_batch`), starting from a guess
+        words = self.grid_words if n_items == 1 else self.grid_words_items.get(n_items, self.grid_words * n_items * 2)
+        gw = _grid_up(words * 1.5, 2.0, 1 << 18)
         return (npc, tuple(rows), n_items, H, W, gw, float(voxel), bool(is_f64))
+
+    def observe_batch(self, n_items, bbox):
+        """The bounding box a batch of `n_items` fragments produced (FragmentResult.bbox): sizes the next such bucket's grid."""
+        box = (C.c_int32 * 8)(*bbox)
+        w = int(self.L.imf_bitgrid_words(box, self.model.conv1.kernel_size))
+        self.grid_words_items[n_items] = max(self.grid_words_items.get(n_items, 0), w)
 
     def raw_streams(self, dev):
         """(side, image) hipStream_t of this device -- and, with them, the runner's MAIN stream (`main_stream`).  The three

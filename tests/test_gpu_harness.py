@@ -126,9 +126,11 @@ def test_bench_workload_pair_capacity_mode_vs_oracle(seeded_sd):
 
 
 def test_extract_features_stream_equals_extract_features(clouds, images, seeded_sd):
-    """extract_features_stream (pinned staging, copy streams, several fragments in flight through one capacity bucket)
-    returns, in order, exactly what extract_features returns fragment by fragment -- for fragments of different sizes
-    (different buckets), float32 and float64 points, and from a cold runner (first fragment on the exact path)."""
+    """extract_features_stream (pinned staging, several forwards in flight through the capacity buckets) returns, in order,
+    what extract_features returns fragment by fragment -- for fragments of different sizes (different buckets), float32 and
+    float64 points, and from a cold runner (first fragment on the exact path): exactly with one fragment per forward
+    (batch=1); with two per forward (the default) the voxels exactly and the descriptors to rounding (2e-6: a row's partial
+    sums are grouped by its tile's active offsets, and its tile-mates differ in a batch)."""
     from imfnet_amd.extract import extract_features, extract_features_stream
     from imfnet_amd.model import load_model
     m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
@@ -139,7 +141,7 @@ def test_extract_features_stream_equals_extract_features(clouds, images, seeded_
     for i, (k, sc, dt) in enumerate([(0, 1.0, np.float64), (1, 1.0, np.float64), (0, 1.3, np.float64), (1, 1.0, np.float32),
                                      (0, 1.0, np.float64), (1, 1.3, np.float64), (0, 1.3, np.float64)]):
         frs.append(((clouds[k].astype(np.float64) * sc).astype(dt), images[k]))
-    got = list(extract_features_stream(m, iter(frs), 0.05, dev, depth=3))
+    got = list(extract_features_stream(m, iter(frs), 0.05, dev, depth=3, batch=1))
     assert len(got) == len(frs)
     with torch.no_grad():
         for (xyz, img), (xd, F) in zip(frs, got):
@@ -147,9 +149,20 @@ def test_extract_features_stream_equals_extract_features(clouds, images, seeded_
             assert xd.dtype == np.float64 and F.dtype == np.float32
             assert xd.shape == xr.shape and (xd == xr).all()
             assert (F == Fr.cpu().numpy()).all()
-    again = list(extract_features_stream(m, iter(frs[:3]), 0.05, dev, depth=2))       # warm runner: all through the buckets
+    again = list(extract_features_stream(m, iter(frs[:3]), 0.05, dev, depth=2, batch=1))   # warm runner: all through the buckets
     for a, b in zip(again, got[:3]):
         assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    runner = m.fragment_runner()
+    before = dict(runner.stats)
+    for rep in range(2):                               # the first pass may size the pair buckets' grids (observe_batch)
+        pairs = list(extract_features_stream(m, iter(frs), 0.05, dev, depth=3))            # two fragments per forward
+    assert len(pairs) == len(frs)
+    for a, b in zip(pairs, got):
+        assert a[0].shape == b[0].shape and (a[0] == b[0]).all()
+        assert np.abs(a[1] - b[1]).max() < 2e-6
+    assert runner.stats["eager"] + runner.stats["graph"] > before["eager"] + before["graph"]   # (went through the buckets)
+    views = list(extract_features_stream(m, iter(frs[:4]), 0.05, dev, depth=2, copy=False))
+    assert len(views) == 4
 
 
 def kitti_like_cloud(n_points=2_000_000, seed=0):
