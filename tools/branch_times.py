@@ -35,7 +35,9 @@ with torch.no_grad():
         torch.cuda.synchronize()
         ev = wl.bucket.events
         ms = lambda a, b: L.imf_event_elapsed_ms(a, b) * 1e3
-        rows.append((ms(e0, ev[7]), ms(e0, ev[10]), ms(e0, ev[8]), ms(e0, ev[11]), ms(e0, ev[12]), ms(e0, e1)))
+        rows.append((ms(e0, ev[7]), ms(e0, ev[10]), ms(e0, ev[8]), ms(e0, ev[11]), ms(e0, ev[12]), ms(e0, e1),
+                     ms(e0, ev[0]), ms(e0, ev[1]), ms(e0, ev[2]), ms(e0, ev[3])))
 r = np.median(np.array(rows), axis=0)
 print("medians, us from the step's start: level-0 pyramid done %.0f | image branch done %.0f | side stream done (incl. its join "
-      "with the image branch) %.0f | main stream reaches the join %.0f | fusion done %.0f | step done %.0f" % tuple(r))
+      "with the image branch) %.0f | main stream reaches the join %.0f | fusion done %.0f | step done %.0f" % tuple(r[:6]))
+print("side stream's marks: level-0 3x3x3 map ready %.0f | stride-2 level + its maps %.0f | stride-4 %.0f | stride-8 %.0f" % tuple(r[6:]))
