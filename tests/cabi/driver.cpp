@@ -11,6 +11,8 @@
 
 #include <set>
 #include <tuple>
+#include <array>
+#include <map>
 #include <vector>
 
 #include "imfnet_hip.h"
@@ -99,6 +101,37 @@ int main() {
       for (int c = 0; c < cout; ++c)
         if (out[i * cout + c] != (float)(cnt * cin)) { printf("variant 6: row %lld col %d: %g != %d\n", (long long)i, c, out[i * cout + c], cnt * cin); return 8; }
     }
+    if (cin == cout) {
+      // operand images (imf_conv_args.operand_format): the layer above written as a split-f16 image, then a second layer fed
+      // that image and fed the fp32 rows -- same output, and the exact integers: out2[i] = cin * sum over i's neighbours of out1
+      float *d_img = dev<float>(out.size()), *d_o2a = dev<float>(out.size()), *d_o2b = dev<float>(out.size());
+      imf_conv_args p1 = b, p2 = b, p3 = b;
+      p1.out = d_img; p1.operand_format = IMF_FMT_OUT_SPLIT;
+      p2.in_a = d_img; p2.out = d_o2a; p2.operand_format = IMF_FMT_A_SPLIT;
+      p3.in_a = d_out; p3.out = d_o2b;
+      p2.dyn_err = p3.dyn_err = nullptr;   // (their sums leave the f16 range: nothing reads them as operands)
+      IMF(imf_spconv_fwd(&p1, nullptr));
+      IMF(imf_spconv_fwd(&p2, nullptr));
+      IMF(imf_spconv_fwd(&p3, nullptr));
+      HIP(hipDeviceSynchronize());
+      std::vector<float> o2a(out.size()), o2b(out.size());
+      HIP(hipMemcpy(o2a.data(), d_o2a, out.size() * 4, hipMemcpyDeviceToHost));
+      HIP(hipMemcpy(o2b.data(), d_o2b, out.size() * 4, hipMemcpyDeviceToHost));
+      std::map<std::array<int, 3>, int64_t> row_of;
+      for (int64_t i = 0; i < m; ++i) row_of[{h_coords[4 * i + 1], h_coords[4 * i + 2], h_coords[4 * i + 3]}] = i;
+      for (int64_t i = 0; i < m; ++i) {
+        double want = 0;
+        for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+          auto it = row_of.find({h_coords[4 * i + 1] + dx, h_coords[4 * i + 2] + dy, h_coords[4 * i + 3] + dz});
+          if (it != row_of.end()) want += (double)out[it->second * cout] * cin;
+        }
+        for (int c = 0; c < cout; ++c)
+          if (o2a[i * cout + c] != o2b[i * cout + c] || o2a[i * cout + c] != (float)want) {
+            printf("operand image: row %lld col %d: image-fed %g, fp32-fed %g, expected %g\n", (long long)i, c, o2a[i * cout + c], o2b[i * cout + c], want);
+            return 12;
+          }
+      }
+    }
     const int c64 = 64;
     std::vector<float> ones64((size_t)27 * cin * c64, 1.f);
     float *d_w64 = dev<float>(ones64.size()), *d_wp64 = dev<float>(imf_packed_weight_floats_split16(27, cin, c64)),
@@ -142,6 +175,6 @@ int main() {
   // a bad argument is reported, not executed
   a.cout = 33;
   if (imf_spconv_fwd(&a, nullptr) != IMF_EINVAL || !strstr(imf_last_error(), "cout")) { printf("argument check missing\n"); return 7; }
-  printf("C ABI driver OK: %lld points -> %lld voxels, fp32-MFMA / split-f16 (LDS-DMA, wave-split) convolutions and the pointwise head exact on %lld rows\n", (long long)n, (long long)m, (long long)m);
+  printf("C ABI driver OK: %lld points -> %lld voxels, fp32-MFMA / split-f16 (LDS-DMA, wave-split, operand images) convolutions and the pointwise head exact on %lld rows\n", (long long)n, (long long)m, (long long)m);
   return 0;
 }
