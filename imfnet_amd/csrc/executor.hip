@@ -274,6 +274,9 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     return IMF_OK;
   };
   int rc;
+  // conv1 + the level-0 map in one launch (IMF_FIRST_AND_MAP=0: two launches on two streams, as before)
+  static const bool fam_env = !(getenv("IMF_FIRST_AND_MAP") && atoi(getenv("IMF_FIRST_AND_MAP")) == 0);
+  const bool first_and_map = fam_env && dyn && pyr && s.small_first && side != main;
   int items_event = -1;
   bool image_joined_side = false;
   if (pyr) {   // level 0 was built on the main stream: the side stream (coarse levels, rulebooks) starts after it
@@ -283,6 +286,8 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   if (!s.small_first) {
     if ((rc = build_conv(rb_first, 0, 0, net->first_ksize, main))) return rc;
     if ((rc = build_conv(rb_k3[0], 0, 0, 3, main))) return rc;
+  } else if (first_and_map) {
+    // (fragment forward: conv1 and the level-0 3x3x3 map are ONE launch on the main stream, below)
   } else {   // conv1 needs no rulebook: k3@1 is built under it
     if ((rc = build_conv(rb_k3[0], 0, 0, 3, side))) return rc;
     if ((rc = mark(rb_k3[0]))) return rc;
@@ -386,7 +391,12 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   if (s.small_first) {
     const int first_split = wants_split(ebuf(0, 0)) ? 1 : 0;
     bool wrote_split = first_split != 0;
-    if (dyn && pyr) {   // imf_fragment_forward zeroed the grid before the level-0 pyramid
+    if (first_and_map) {
+      rc = conv_first_and_map_dyn(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
+                                  io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
+                                  buf[ebuf(0, 0)], first_split, io->level[0].table, io->level[0].capacity, rb_k3[0].tile_rows,
+                                  rb_k3[0].nbr, rb_k3[0].tile_mask, main);
+    } else if (dyn && pyr) {   // imf_fragment_forward zeroed the grid before the level-0 pyramid
       rc = conv_first_bitgrid_dyn_cleared(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
                                           io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale,
                                           net->first_shift, 0, buf[ebuf(0, 0)], main, first_split);

@@ -22,6 +22,7 @@
 
 #include "spconv_shared.h"
 #include "geometry_internal.h"
+#include "rulebook_tile.h"
 
 namespace imf {
 
@@ -494,23 +495,23 @@ typedef unsigned int u32x2_b __attribute__((ext_vector_type(2)));
 // 8 x v_mfma_f32_16x16x4_f32 -- 16 matrix instructions of 16 cycles per wavefront instead of 64 of 32.  The weight split
 // is redone by every workgroup (4 000 values from L2): no packed image, no change to the C ABI.
 template <int COUT, int KS>
-__global__ void __launch_bounds__(256)
-k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_t *__restrict__ grid,
-                  GridDesc g, int ksize_rt, int kvol, const float *__restrict__ w,
-                  const float *__restrict__ scale, const float *__restrict__ shift, int relu,
-                  float *__restrict__ out, const DynGrid dg, int out_split) {
+__device__ __forceinline__ void conv_first_bits_body(const int32_t *__restrict__ coords, long long n,
+                                                     const uint32_t *__restrict__ grid, GridDesc g, int ksize_rt, int kvol,
+                                                     const float *__restrict__ w, const float *__restrict__ scale,
+                                                     const float *__restrict__ shift, int relu, float *__restrict__ out,
+                                                     const DynGrid dg, int out_split, const long long blk) {
   constexpr int CBN = COUT / 16;                         // column blocks; wave w owns row block w
   constexpr int ksize = KS;
   constexpr int kMaxWin = KS == 3 ? 11 : 8;              // windows of KS bits that can touch one 32-offset word
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   (void)ksize_rt;
   if (!dyn_grid(dg, ksize, g, n)) return;
-  if ((long long)blockIdx.x * kBitsRows >= n) return;
+  if (blk * kBitsRows >= n) return;
   float4 *W_l = reinterpret_cast<float4 *>(lds_f);                          // [4 kc][CBN][hi, lo][64 lanes] x 8 halves
   uint32_t *M_l = reinterpret_cast<uint32_t *>(W_l + 4 * CBN * 2 * 64);     // [64 rows][4 words]: occupancy masks
   __shared__ unsigned red[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const long long v0 = (long long)blockIdx.x * kBitsRows;
+  const long long v0 = blk * kBitsRows;
   const int nkc = (kvol + 31) >> 5;
 
   // ---- occupancy masks: thread (v, wd) gathers the windows (dy, dz) whose ksize bits fall into offsets 32 wd .. 32 wd + 31
@@ -624,6 +625,41 @@ k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_
         else out[orow * COUT + col] = y;
       }
     }
+  }
+}
+
+template <int COUT, int KS>
+__global__ void __launch_bounds__(256)
+k_conv_first_bits(const int32_t *__restrict__ coords, long long n, const uint32_t *__restrict__ grid,
+                  GridDesc g, int ksize_rt, int kvol, const float *__restrict__ w,
+                  const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                  float *__restrict__ out, const DynGrid dg, int out_split) {
+  conv_first_bits_body<COUT, KS>(coords, n, grid, g, ksize_rt, kvol, w, scale, shift, relu, out, dg, out_split, blockIdx.x);
+}
+
+// conv1 AND the level-0 3x3x3 neighbour map in one launch (imf_fragment_forward): both need only the level-0 rows (and
+// grid / table), block1 needs both, and as two launches one of them has to cross streams -- the hand-over (event record,
+// stream wait) costs ~15 us on the critical path.  Even workgroups run conv1's 64-row blocks, odd ones the map's tiles.
+struct MapArgs {
+  const imf_slot *tab;
+  uint32_t capmask;
+  const int32_t *n_out_dev;
+  int32_t *tile_rows, *nbr;
+  uint32_t *tile_mask;
+  long long n_slots;
+};
+template <int COUT, int KS>
+__global__ void __launch_bounds__(256)
+k_conv_first_and_map(const int32_t *__restrict__ coords, long long n, const uint32_t *__restrict__ grid,
+                     GridDesc g, int kvol, const float *__restrict__ w, const float *__restrict__ scale,
+                     const float *__restrict__ shift, int relu, float *__restrict__ out, const DynGrid dg, int out_split,
+                     const MapArgs m) {
+  const long long idx = blockIdx.x >> 1;
+  if (blockIdx.x & 1) {
+    if (idx < m.n_slots / IMF_TILE_ROWS)
+      rulebook_tile<+1, false>(m.tab, m.capmask, coords, n, m.n_out_dev, 1, 3, 27, m.tile_rows, m.nbr, m.tile_mask, m.n_slots, idx);
+  } else {
+    conv_first_bits_body<COUT, KS>(coords, n, grid, g, KS, kvol, w, scale, shift, relu, out, dg, out_split, idx);
   }
 }
 
@@ -971,6 +1007,31 @@ int conv_first_bitgrid_dyn_fmt(const int32_t *coords, int64_t n_cap, const int32
   DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words};
   return conv_first_bitgrid_impl(coords, n_cap, nullptr, dg, ksize, grid, grid_words, w, cout, scale, shift, relu, out,
                                  stream, false, out_split);
+}
+// conv1 on a grid the caller has zeroed and filled (as conv_first_bitgrid_dyn_cleared) TOGETHER with the level-0 3x3x3
+// neighbour map (as imf_rulebook_conv_dyn, tensor stride 1) in one launch: k_conv_first_and_map
+int conv_first_and_map_dyn(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev, int32_t *err,
+                           int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout, const float *scale,
+                           const float *shift, int relu, float *out, int out_split, const imf_slot *table, int64_t capacity,
+                           int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, hipStream_t st) {
+  IMF_REQUIRE(coords && n_dev && bbox_dev && err && grid && grid_words > 0 && w && out && table && tile_rows && nbr && tile_mask,
+              "conv_first_and_map_dyn: null pointer");
+  IMF_REQUIRE((ksize == 3 || ksize == 5) && (cout == 32 || cout == 64) && n_cap > 0, "conv_first_and_map_dyn: ksize / cout / n");
+  IMF_REQUIRE((capacity & (capacity - 1)) == 0, "conv_first_and_map_dyn: capacity not a power of 2");
+  DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words};
+  GridDesc g;
+  memset(&g, 0, sizeof(g));
+  const int kvol = ksize * ksize * ksize;
+  const size_t lds = (size_t)4 * (cout / 16) * 2 * 64 * 16 + (size_t)kBitsRows * 4 * sizeof(uint32_t);
+  const int64_t n_slots = imf_rulebook_slots(n_cap);
+  MapArgs m{table, (uint32_t)(capacity - 1), n_dev, tile_rows, nbr, tile_mask, (long long)n_slots};
+  const unsigned nb = 2u * (unsigned)(n_slots / IMF_TILE_ROWS);      // conv1's 64-row blocks == the map's tiles
+  if (cout == 32 && ksize == 5)      k_conv_first_and_map<32, 5><<<nb, 256, lds, st>>>(coords, n_cap, grid, g, kvol, w, scale, shift, relu, out, dg, out_split, m);
+  else if (cout == 32)               k_conv_first_and_map<32, 3><<<nb, 256, lds, st>>>(coords, n_cap, grid, g, kvol, w, scale, shift, relu, out, dg, out_split, m);
+  else if (ksize == 5)               k_conv_first_and_map<64, 5><<<nb, 256, lds, st>>>(coords, n_cap, grid, g, kvol, w, scale, shift, relu, out, dg, out_split, m);
+  else                               k_conv_first_and_map<64, 3><<<nb, 256, lds, st>>>(coords, n_cap, grid, g, kvol, w, scale, shift, relu, out, dg, out_split, m);
+  IMF_CHECK_LAUNCH("k_conv_first_and_map");
+  return IMF_OK;
 }
 // imf_conv_first_bitgrid_dyn for a grid the caller has already zeroed AND filled (imf_fragment_forward clears it before
 // the level-0 pyramid, whose compaction kernel sets the bits: two launches fewer between the pyramid and conv1)

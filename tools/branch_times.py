@@ -35,9 +35,12 @@ with torch.no_grad():
         torch.cuda.synchronize()
         ev = wl.bucket.events
         ms = lambda a, b: L.imf_event_elapsed_ms(a, b) * 1e3
-        rows.append((ms(e0, ev[7]), ms(e0, ev[10]), ms(e0, ev[8]), ms(e0, ev[11]), ms(e0, ev[12]), ms(e0, e1),
-                     ms(e0, ev[0]), ms(e0, ev[1]), ms(e0, ev[2]), ms(e0, ev[3])))
-r = np.median(np.array(rows), axis=0)
+        # the side stream's marks: with conv1 + the level-0 map as one launch on the main stream (the default) there are
+        # three (stride 2 / 4 / 8), with IMF_FIRST_AND_MAP=0 a fourth in front (the level-0 map)
+        fam = os.environ.get("IMF_FIRST_AND_MAP", "1") != "0"
+        marks = (float("nan"), ms(e0, ev[0]), ms(e0, ev[1]), ms(e0, ev[2])) if fam else tuple(ms(e0, ev[i]) for i in range(4))
+        rows.append((ms(e0, ev[7]), ms(e0, ev[10]), ms(e0, ev[8]), ms(e0, ev[11]), ms(e0, ev[12]), ms(e0, e1)) + marks)
+r = np.nanmedian(np.array(rows), axis=0) if not np.isnan(np.array(rows)[:, 6]).all() else np.concatenate([np.median(np.array(rows)[:, :6], axis=0), [float('nan')], np.median(np.array(rows)[:, 7:], axis=0)])
 print("medians, us from the step's start: level-0 pyramid done %.0f | image branch done %.0f | side stream done (incl. its join "
       "with the image branch) %.0f | main stream reaches the join %.0f | fusion done %.0f | step done %.0f" % tuple(r[:6]))
 print("side stream's marks: level-0 3x3x3 map ready %.0f | stride-2 level + its maps %.0f | stride-4 %.0f | stride-8 %.0f" % tuple(r[6:]))
