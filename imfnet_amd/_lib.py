@@ -135,6 +135,17 @@ class FragmentIO(C.Structure):
                 ("fp32_buffers", C.c_int32)]
 
 
+class Job(C.Structure):
+    """struct imf_job (one forward of the streaming pipeline)."""
+    _fields_ = [("net", C.POINTER(ResunetDesc)), ("img", C.POINTER(ImageDesc)), ("caps", C.POINTER(FragmentCaps)),
+                ("io", C.POINTER(FragmentIO)), ("host_in", C.c_void_p), ("dev_in", C.c_void_p), ("in_bytes", C.c_size_t),
+                ("dev_out", C.c_void_p), ("host_out", C.c_void_p), ("out_bytes", C.c_size_t), ("sel", C.c_void_p),
+                ("sel_offset", C.c_size_t), ("out_offset", C.c_size_t), ("out_row_bytes", C.c_int32),
+                ("defer_download", C.c_int32)]
+
+
+PIPELINE_SDMA_COPIES = 1
+
 _P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/imfnet_hip.h declares
@@ -169,6 +180,11 @@ SIGNATURES = {
     "imf_fragment_pyramid_bytes": (_Z, [C.POINTER(FragmentCaps)]),
     "imf_fragment_forward": (_I, [C.POINTER(ResunetDesc), C.POINTER(ImageDesc), C.POINTER(FragmentCaps),
                                   C.POINTER(FragmentIO)]),
+    "imf_pipeline_create": (_P, [_P, _I, _I]),
+    "imf_pipeline_destroy": (None, [_P]),
+    "imf_pipeline_submit": (_I, [_P, C.POINTER(Job)]),
+    "imf_pipeline_wait": (_I, [_P, _I, C.POINTER(C.c_float)]),
+    "imf_host_narrow_points": (_I, [_P, _L, _P]),
     "imf_graph_begin_capture": (_I, [_P]),
     "imf_graph_end_capture": (_I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "imf_graph_abort_capture": (_I, [_P]),

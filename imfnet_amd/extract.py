@@ -108,51 +108,6 @@ def _host_inputs(xyz, image):
     return np.ascontiguousarray(a), np.ascontiguousarray(img, dtype=np.float32)
 
 
-def _submit_host(runner, slot, host_xyz, host_img, voxel_size, device, stream):
-    """One fragment through `_submit_host_items`."""
-    return _submit_host_items(runner, slot, [(host_xyz, host_img)], voxel_size, device, stream)
-
-
-def _submit_host_items(runner, slot, items, voxel_size, device, stream):
-    """Stage host fragments -- ONE, or several as one batched forward (rows grouped by fragment, one image each: the batched
-    call of model/resunet.py:241-250) -- through `slot` (pinned), launch them in capacity mode and queue the copy back: ONE
-    host-to-device copy (scalars | images | points) and ONE device-to-host copy (counts | xyz_down | descriptors) per
-    call; xyz_down = xyz[inds] is gathered on the device (imf_gather_points).  Asynchronous; `slot.done` marks completion.
-    items: [(xyz [N,3] host array, image [1,3,H,W] host array)], same point dtype and image size.  Returns (result, views
-    of the slot's pinned blocks) -- `result.items()` gives every fragment's (first row, rows) -- or None when no capacities
-    are known."""
-    k = len(items)
-    n_each = [int(x.shape[0]) for x, _ in items]
-    n = sum(n_each)
-    x0, i0 = items[0]
-    key = runner.caps_for(n, k, int(i0.shape[2]), int(i0.shape[3]), voxel_size, x0.dtype == np.float64)
-    if key is None:
-        return None
-    b = runner.bucket(key, device, stream)
-    v = slot.bind(b)
-    vals, at = [n, k], 0
-    for j, (xyz, img) in enumerate(items):
-        np.copyto(v["xyz"][at:at + n_each[j]], xyz)
-        np.copyto(v["image"][j:j + 1], img)
-        vals.append(at)
-        at += n_each[j]
-    v["dyn"][:len(vals)] = vals
-    rows = b.caps.rows[0]
-    used_in = b.lay["xyz"] + n * 3 * x0.dtype.itemsize
-    with torch.cuda.stream(stream):
-        slot.begin.record(stream)
-        b.inbuf[:used_in].copy_(slot.inbuf[:used_in], non_blocking=True)
-    b.dyn_values = vals
-    res = runner.launch(b, n, k, stream, meta_to=(v["meta"], slot.done))
-    check(runner.L.imf_gather_points(b.xyz.data_ptr(), int(b.xyz.dtype == torch.float64), b.first_idx_view().data_ptr(),
-                                     b.meta.data_ptr(), rows, b.sel.data_ptr(), stream.cuda_stream), "imf_gather_points")
-    with torch.cuda.stream(stream):
-        nb = b.outbuf.numel()
-        slot.outbuf[:nb].copy_(b.outbuf, non_blocking=True)
-        slot.done.record(stream)
-    return res, v
-
-
 def _extract_with_runner(runner, xyz, voxel_size, device, image):
     """extract_features through the capacity-mode graph; None = not applicable / flagged (caller runs the exact path)."""
     n = int(xyz.shape[0])
@@ -163,37 +118,41 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image):
     stream, outer = runner._stream_for(device, None)
     host = _host_inputs(xyz, image)
     if host is not None:
-        # host arrays (the reference's call, scripts/generate_desc.py:100): pinned staging both ways -- a parallel CPU
-        # copy + asynchronous DMA instead of the runtime's blocking pageable copies; xyz_down = xyz[inds] is gathered on
-        # the device (imf_gather_points) and comes back with the counts
+        # host arrays (the reference's call, scripts/generate_desc.py:100): one job of the streaming pipeline (stream.py) --
+        # pinned staging both ways, float32 upload when the float64 values are float32 values, xyz_down = xyz[inds]
+        # gathered on the device, only the rows that exist copied back
         slots = runner.host_slots
         slot = slots[0] if slots else graph.HostSlot()
         if not slots:
             slots.append(slot)
-        got = _submit_host(runner, slot, host[0], host[1], voxel_size, device, stream)
-        if got is None:
+        job = runner.streamer(device).submit([host], voxel_size, slot)
+        if job is None:
             return None
-        res, v = got
-        with torch.cuda.stream(stream):
-            F = res.bucket.out.clone()                # the caller owns its descriptors (the bucket is reused)
-        slot.done.synchronize()
+        res = job.wait()
         if res.flags:                                 # does not fit this bucket: exact path (which re-observes)
             runner.stats["redone"] += 1
             if outer is not None:
                 outer.wait_stream(stream)
             return None
         m = res.counts[0]
+        v = job.views
+        with torch.cuda.stream(stream):
+            F = res.bucket.out[:m].clone()            # the caller owns its descriptors (the bucket is reused)
         sel = v["sel"][:m].copy()
         if outer is not None:
             outer.wait_stream(stream)
-        F = F[:m]
+            F.record_stream(outer)
         F.host = v["F"][:m]                           # the same descriptors, already on the host (pinned; valid until the
         return sel, F                                 # next extract_features call): saves the caller's F.cpu()
     key = runner.caps_for(n, 1, int(img.shape[2]), int(img.shape[3]), voxel_size, is_f64)
     if key is None:
         return None
     b = runner.bucket(key, device, stream)
-    runner.stage(b, xyz, [0], img, stream)
+    # a host point array next to a device image (util/misc.py:97 takes the mix through torch.as_tensor)
+    src = xyz if torch.is_tensor(xyz) else torch.from_numpy(np.ascontiguousarray(np.asarray(xyz)))
+    if src.dtype not in (torch.float32, torch.float64):
+        src = src.double()
+    runner.stage(b, src, [0], img, stream)
     res = runner.launch(b, n, 1, stream)
     if res.flags:                                     # does not fit this bucket: exact path (which re-observes)
         runner.stats["redone"] += 1
@@ -211,16 +170,17 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image):
             sel = host_xyz[inds_host].astype(np.float64, copy=False)
     if outer is not None:
         outer.wait_stream(stream)
+        F.record_stream(outer)                        # allocated on the runner's stream, used on the caller's
     return sel, F
 
 
 def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, copy=True, batch=2):
     """`extract_features` over a STREAM of host fragments (SURVEY 8d's span -- host arrays in, descriptors back on the
     host -- pipelined): yields (xyz_down float64 [M,3], F float32 [M,32] numpy) per fragment, in order.  `fragments`:
-    iterable of (xyz [N,3] host array, image [1,3,H,W] host array).  Up to `depth` forwards are queued on the GPU, so
-    the host's share of the next one (pinned staging, ~150 launches) runs under the current one's kernels; per forward the
-    stream carries one H2D copy, the launches and one D2H copy.  (Copies on streams of their own -- device mirrors per
-    slot, events both ways -- were measured SLOWER on this stack: 2.0-2.7 vs 1.3 ms per fragment, tools/e2e_probe.py.)
+    iterable of (xyz [N,3] host array, image [1,3,H,W] host array).  Every forward is a job of the library's pipeline
+    (stream.py / csrc/pipeline.hip): this thread only stages the next fragments into a pinned block while the pipeline's
+    worker issues launches; the upload of job k+1 and the download of job k-1 are copy kernels on their own streams under
+    job k's kernels.  Up to `depth` jobs are in flight.
     batch: consecutive fragments per forward (the model's batched call, model/resunet.py:241-250: rows grouped by
     fragment, one image each) -- the stride-4/8 levels of ONE fragment leave half the chip idle, two fill it: 0.47 vs 0.68 ms
     of GPU time per S50k fragment; fragments of a batch share point dtype and image size (others go alone).
@@ -232,80 +192,96 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
     if model.training:
         model.eval()
     runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
-    n_slots = max(1, depth) + 1
-    cache = getattr(runner, "stream_state", None) if runner is not None else None
-    if cache is None or cache[0] != device or len(cache[1]) < n_slots:
-        cache = (device, [graph.HostSlot(timing=True) for _ in range(n_slots)])
-        if runner is not None:
-            runner.stream_state = cache               # pinned slots are expensive to create: kept with the runner
-    _, slots = cache
-    caller = torch.cuda.current_stream(device)
-    stream = runner.main_stream(device) if runner is not None else caller
-    if stream.cuda_stream != caller.cuda_stream:
-        stream.wait_stream(caller)
-    free = list(slots[:n_slots])
-    inflight = deque()
-    lent = []                                         # the slot whose views the consumer currently holds (copy=False)
+    depth = max(1, int(depth))
+    n_slots = depth + 2                               # in flight + the one the consumer holds (copy=False) + one being staged
     batch = max(1, min(int(batch), MAX_BATCH))
 
-    def finish(entry):
-        """The results of one forward (generator: one (xyz_down, F) per fragment of the entry, in order)."""
-        items, slot, got = entry
-        while lent:
-            free.append(lent.pop())
-        if got is not None:
-            res, v = got
-            slot.done.synchronize()
-            if not res.flags:
-                runner.stats["stream_gpu_ms"] = runner.stats.get("stream_gpu_ms", 0.0) + slot.begin.elapsed_time(slot.done)
-                runner.stats["stream_n"] = runner.stats.get("stream_n", 0) + len(items)
-                spans = res.items() if len(items) > 1 else [(0, res.counts[0])]
-                if not copy:
-                    lent.append(slot)
-                outs = [(v["sel"][r0:r0 + m].copy(), v["F"][r0:r0 + m].copy()) if copy else (v["sel"][r0:r0 + m], v["F"][r0:r0 + m])
-                        for r0, m in spans]
-                if copy:
-                    free.append(slot)
-                yield from outs
-                return
-            runner.stats["redone"] += len(items)
-            if len(items) > 1 and (res.flags & 4):    # the batch's bounding box outgrew the grid: size the next one by it
-                runner.observe_batch(len(items), res.bbox)
-        free.append(slot)
+    def state(runner):
+        """(streamer, pinned slots) of this runner and device; pinned blocks are expensive to create: kept with the runner."""
+        if runner is None:
+            return None, []
+        cache = runner.stream_state
+        if cache is None or cache[0] != device or len(cache[1]) < n_slots:
+            cache = runner.stream_state = (device, [graph.HostSlot() for _ in range(n_slots)])
+        return runner.streamer(device), list(cache[1][:n_slots])
+
+    streamer, free = state(runner)
+    caller = torch.cuda.current_stream(device)
+    if runner is not None:
+        runner.main_stream(device).wait_stream(caller)
+    inflight = deque()                                # (items, StreamJob or None)
+    lent = []                                         # the slot whose views the consumer currently holds (copy=False)
+
+    def exact(items):
         for xyz, image in items:
             with torch.no_grad():
                 xd, F = extract_features(model, xyz, voxel_size=voxel_size, device=device, skip_check=True, image=image)
-            yield xd, F.cpu().numpy()
+            Fh = getattr(F, "host", None)
+            yield xd, (Fh.copy() if Fh is not None else F.cpu().numpy())
 
-    def submit(group):
-        """Queue `group` (host fragments) as ONE forward; False when the runner cannot take it yet."""
-        slot = free.pop()
-        got = None
-        if runner is not None and runner.ratios is not None:
-            got = _submit_host_items(runner, slot, group, voxel_size, device, stream)
-        if got is None:
-            free.append(slot)
-            return False
-        inflight.append((group, slot, got))
-        return True
+    def finish(entry):
+        """The results of one forward (generator: one (xyz_down, F) per fragment of the entry, in order)."""
+        items, job = entry
+        while lent:
+            free.append(lent.pop())
+        res = job.wait()
+        if not res.flags:
+            st = runner.stats
+            st["stream_gpu_ms"] = st.get("stream_gpu_ms", 0.0) + sum(job.ms)
+            st["stream_n"] = st.get("stream_n", 0) + len(items)
+            st["stream_jobs"] = st.get("stream_jobs", 0) + 1
+            if "stream_trace" in st:
+                st["stream_trace"].append(job.stamps)
+            for i, k in enumerate(("queue_ms", "issue_ms", "to_download_ms", "to_done_ms", "wait_ms")):
+                st["stream_" + k] = st.get("stream_" + k, 0.0) + job.host_ms[i]
+            v = job.views
+            spans = res.items() if len(items) > 1 else [(0, res.counts[0])]
+            if copy:
+                outs = [(v["sel"][r0:r0 + m].copy(), v["F"][r0:r0 + m].copy()) for r0, m in spans]
+                free.append(job.slot)
+            else:
+                outs = [(v["sel"][r0:r0 + m], v["F"][r0:r0 + m]) for r0, m in spans]
+                lent.append(job.slot)
+            yield from outs
+            return
+        runner.stats["redone"] += len(items)
+        if len(items) > 1 and (res.flags & 4):        # the batch's bounding box outgrew the grid: size the next one by it
+            runner.observe_batch(len(items), res.bbox)
+        free.append(job.slot)
+        yield from exact(items)
 
     with torch.no_grad():
         group = []
 
         def flush():
-            nonlocal runner
+            nonlocal runner, streamer, free
             if not group:
                 return
             g = list(group)
             del group[:]
-            while len(free) < 2 and inflight:         # one slot stays spare: a lent one comes back at the next finish
+            while inflight and (len(inflight) >= depth or not free):
                 yield from finish(inflight.popleft())
-            if not submit(g):                         # teach the runner on the exact path first, in order
-                while inflight:
-                    yield from finish(inflight.popleft())
+            job = None
+            if streamer is not None and runner.ratios is not None:
                 slot = free.pop()
-                yield from finish((g, slot, None))
-                runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
+                job = streamer.submit(g, voxel_size, slot, more_follow=True)
+                if job is None:
+                    free.append(slot)
+            if job is not None:
+                inflight.append((g, job))
+                if slot.grown:                        # a new size: grow every FREE slot now, not one by one beside the worker
+                    for other in free:
+                        other.reserve_like(slot, device)
+                return
+            while inflight:                           # teach the runner on the exact path first, in order
+                yield from finish(inflight.popleft())
+            yield from exact(g)
+            new = model.fragment_runner() if hasattr(model, "fragment_runner") else None
+            if new is not runner:                     # (a refresh rebuilt the plans: the new runner has its own streamer / slots)
+                while lent:
+                    free.append(lent.pop())
+                runner = new
+                streamer, free = state(runner)
 
         for xyz, image in fragments:
             host = _host_inputs(xyz, image)
@@ -319,8 +295,8 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
         yield from flush()
         while inflight:
             yield from finish(inflight.popleft())
-    if stream.cuda_stream != caller.cuda_stream:
-        caller.wait_stream(stream)
+    if runner is not None:
+        caller.wait_stream(runner.main_stream(device))
 
 
 def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=None,

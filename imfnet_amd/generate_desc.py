@@ -57,68 +57,80 @@ def load_fragment(ply_path, config):
 
 def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, device, workers, depth=None):
     """The batch loop without the host in the GPU's way (SURVEY 8 f-4 / 8e "bound by host-side decode"): loader threads
-    decode PLY + PNG; the main thread only stages each fragment through a pinned HostSlot (one H2D block), launches the
-    capacity-mode forward and queues the one D2H block (counts | xyz_down | descriptors; xyz_down = xyz[inds] is gathered
-    on the device) -- extract._submit_host; writer threads wait on each fragment's event and write the NPZ straight from
-    the slot's pinned views.  Nothing on the main thread waits for the GPU.  A fragment the runner flags (capacity / f16
-    range) is redone by the caller on the exact path.  Returns (seconds per fragment, redo list)."""
+    decode PLY + PNG; the main thread only stages each fragment into a pinned HostSlot and hands it to the library's
+    streaming pipeline (stream.py: upload kernel, capacity-mode forward, xyz_down = xyz[inds] gathered on the device,
+    download kernel -- issued by the pipeline's worker thread, transfers under the neighbouring forwards); ONE thread waits
+    for the jobs in order and fans the NPZ writes (straight from the slot's pinned views) out to the writer pool.  A
+    fragment the runner flags (capacity / f16 range) is redone by the caller on the exact path.
+    Returns (seconds per fragment, redo list)."""
     import queue
+    import threading
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
-    from .extract import _submit_host
     from .model.graph import HostSlot
     depth = depth or max(4, 2 * workers)
     pool = getattr(runner, "cli_slots", None)           # pinned blocks are expensive to create (~7 ms each): kept with the runner
     if pool is None:
         pool = runner.cli_slots = []
     while len(pool) < depth:
-        pool.append(HostSlot(timing=True))
+        pool.append(HostSlot())
     slots = queue.Queue()
     for sl in pool[:depth]:
         slots.put(sl)
-    stream = runner.main_stream(device)              # the runner's own: never shares a hardware queue with its side / image streams
-    stream.wait_stream(torch.cuda.current_stream(device))
+    streamer = runner.streamer(device)
+    runner.main_stream(device).wait_stream(torch.cuda.current_stream(device))
     loader, writer = ThreadPoolExecutor(max_workers=workers), ThreadPoolExecutor(max_workers=workers)
-    times, redo, writes = {}, [], []
+    times, redo, writes, failure = {}, [], [], []
+    done_q = queue.Queue()
 
     def load(job):
         scene, fi = job
         return read_ply_points(fi), np.ascontiguousarray(load_image(fi, config), dtype=np.float32)
 
-    def write(job, slot, xyz, res, v):
+    def write(job, slot, xyz, n0, v):
         scene, fi = job
         try:
-            n0 = res.counts[0]
             out_dir = os.path.join(target_path, os.path.basename(scene), "seq-01")
             ensure_dir(out_dir)
             save_descriptors(os.path.join(out_dir, os.path.basename(fi).replace(".ply", ".npz")), xyz, v["sel"][:n0],
                              v["F"][:n0])
-            return None
         finally:
             slots.put(slot)
 
-    done_q = queue.Queue()
-
     def waiter():
-        # ONE thread waits for the fragments' events, in submission order (many threads blocked in hipEventSynchronize
-        # slowed the main thread's launches ~5x: measured 2.7 vs 0.5 ms per enqueue); the NPZ writes fan out to the pool
+        # ONE thread waits for the jobs, in submission order (many threads blocked in hipEventSynchronize slowed the
+        # launches ~5x: measured 2.7 vs 0.5 ms per enqueue); the NPZ writes fan out to the pool.  It stays ONE JOB BEHIND
+        # the submissions: waiting for job k ends the deferral of its download (csrc/pipeline.hip), which belongs behind
+        # job k+1's launches.  Whatever goes wrong here is recorded, every slot still comes back, and the queue is
+        # drained so that the main thread never blocks on it.
+        held = None
         while True:
             item = done_q.get()
+            item, held = held, item
             if item is None:
-                return
-            job, slot, xyz, (res, v) = item
-            slot.done.synchronize()
-            if res.flags:
-                redo.append(job)
-                slots.put(slot)
+                if held is None:
+                    return
                 continue
-            times[job[1]] = slot.begin.elapsed_time(slot.done) * 1e-3
-            writes.append(writer.submit(write, job, slot, xyz, res, v))
+            job, sj, xyz = item
+            try:
+                if failure:
+                    raise failure[0]
+                res = sj.wait()
+                if res.flags:
+                    redo.append(job)
+                    slots.put(sj.slot)
+                else:
+                    times[job[1]] = sum(sj.ms) * 1e-3
+                    writes.append(writer.submit(write, job, sj.slot, xyz, res.counts[0], sj.views))
+            except BaseException as e:                  # noqa: BLE001 -- re-raised by the main thread after the join
+                if not failure:
+                    failure.append(e)
+                slots.put(sj.slot)
+            if held is None:                            # the sentinel: that was the last job
+                return
 
-    import threading
     wt = threading.Thread(target=waiter, daemon=True)
     wt.start()
-
     todo, inflight = deque(jobs), deque()
 
     def top_up():
@@ -126,25 +138,51 @@ def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, devic
             job = todo.popleft()
             inflight.append((job, loader.submit(load, job)))
 
-    top_up()
-    while inflight:
-        job, fut = inflight.popleft()
-        xyz, image = fut.result()
+    try:
         top_up()
-        slot = slots.get()                                      # blocks only when `depth` fragments are on the GPU / being written
-        got = _submit_host(runner, slot, xyz, image, voxel_size, device, stream)
-        if got is None:                                         # no capacities known (e.g. the bit grid never fitted): exact path
-            redo.append(job)
-            slots.put(slot)
-            continue
-        done_q.put((job, slot, xyz, got))
-    done_q.put(None)
-    wt.join()
-    for w in writes:
-        w.result()
-    loader.shutdown()
-    writer.shutdown()
-    torch.cuda.current_stream(device).wait_stream(stream)
+        while inflight and not failure:
+            job, fut = inflight.popleft()
+            xyz, image = fut.result()
+            top_up()
+            while True:                                         # blocks only when `depth` fragments are on the GPU / being written
+                try:
+                    slot = slots.get(timeout=5.0)
+                    break
+                except queue.Empty:
+                    if failure or not wt.is_alive():
+                        raise failure[0] if failure else RuntimeError("generate_desc: the waiter thread died")
+            sj = streamer.submit([(xyz, image)], voxel_size, slot, more_follow=True)
+            if sj is None:                                      # no capacities known (e.g. the bit grid never fitted): exact path
+                redo.append(job)
+                slots.put(slot)
+                continue
+            done_q.put((job, sj, xyz))
+            if slot.grown:                                      # a new size: grow every FREE slot now (HostSlot.reserve)
+                idle = []
+                while True:
+                    try:
+                        idle.append(slots.get_nowait())
+                    except queue.Empty:
+                        break
+                for other in idle:
+                    other.reserve_like(slot, device)
+                    slots.put(other)
+    finally:
+        done_q.put(None)
+        wt.join()
+        for _, fut in inflight:
+            fut.cancel()
+        loader.shutdown()
+        errs = []
+        for w in writes:
+            try:
+                w.result()
+            except BaseException as e:                          # noqa: BLE001
+                errs.append(e)
+        writer.shutdown()
+        torch.cuda.current_stream(device).wait_stream(runner.main_stream(device))
+    if failure or errs:
+        raise (failure or errs)[0]
     return [times[fi] for _, fi in jobs if fi in times], redo
 
 

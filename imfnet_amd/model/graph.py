@@ -102,14 +102,28 @@ class HostSlot:
         self.inbuf = self.outbuf = None
         self.begin, self.done = torch.cuda.Event(enable_timing=timing), torch.cuda.Event(enable_timing=timing)
         self._views = None
+        self.grown = False
+
+    def reserve(self, in_bytes, out_bytes, device):
+        """Grow the pinned blocks to at least these sizes.  hipHostMalloc holds the runtime's lock for ~7 ms per 16 MB and
+        every other thread's HIP call waits behind it (measured: the pipeline's worker stalled 7-70 ms mid-stream when a
+        slot grew beside it) -- callers grow ALL their slots at the first job of a new size (`reserve_like`)."""
+        grown = False
+        if self.inbuf is None or self.inbuf.numel() < in_bytes:
+            self.inbuf, grown = torch.empty(int(in_bytes), dtype=torch.uint8, pin_memory=True), True
+        if self.outbuf is None or self.outbuf.numel() < out_bytes:
+            self.outbuf, grown = torch.empty(int(out_bytes), dtype=torch.uint8, pin_memory=True), True
+        if grown:
+            self._views = None
+        return grown
+
+    def reserve_like(self, other, device):
+        return self.reserve(other.inbuf.numel(), other.outbuf.numel(), device)
 
     def bind(self, b):
         """Views of the pinned blocks in bucket b's layout (blocks grow on demand; views cached per bucket)."""
-        grown = False
-        if self.inbuf is None or self.inbuf.numel() < b.inbuf.numel():
-            self.inbuf, grown = torch.empty(b.inbuf.numel(), dtype=torch.uint8).pin_memory(), True
-        if self.outbuf is None or self.outbuf.numel() < b.outbuf.numel():
-            self.outbuf, grown = torch.empty(b.outbuf.numel(), dtype=torch.uint8).pin_memory(), True
+        grown = self.reserve(b.inbuf.numel(), b.outbuf.numel(), b.inbuf.device)
+        self.grown = grown
         if grown or self._views is None:
             self._views = {}
             self._np = (self.inbuf.numpy(), self.outbuf.numpy())
@@ -231,7 +245,7 @@ class FragmentRunner:
     """Capacity-mode / hipGraph front end of one model (eval mode, IMFNet's configuration)."""
 
     MARGIN = 1.2          # head room over the largest voxel-per-point ratio seen
-    MAX_BUCKETS = 12
+    MAX_BUCKETS = 24      # (the streaming pipeline keeps up to three of one capacity key in flight: `lane`)
 
     def __init__(self, model):
         from .plan import FusedPlan, NativePlan
@@ -259,6 +273,7 @@ class FragmentRunner:
         self.buckets = {}
         self._main = {}
         self._raw = {}
+        self._streamers = {}
         # hipGraph replay is opt-in: ROCm 7.2 runs a graph's independent branches back to back (measured 1.77 vs
         # 1.37 ms per fragment pair), the eager capacity-mode call keeps the three streams concurrent
         self.use_graph = bool(os.environ.get("IMFNET_FRAGMENT_GRAPH"))
@@ -315,20 +330,31 @@ class FragmentRunner:
             s = self._raw[dev] = (raw[1], raw[2])
         return s
 
+    def streamer(self, dev, **kw):
+        """The device's FragmentStreamer (stream.py): pinned host blocks in, pinned host blocks out, transfers overlapped."""
+        st = self._streamers.get(dev)
+        if st is None:
+            from ..stream import FragmentStreamer
+            st = self._streamers[dev] = FragmentStreamer(self, dev, **kw)
+        return st
+
     def main_stream(self, dev):
         """The stream every capacity-mode forward of this runner is issued on (a torch view of the library-made stream)."""
         self.raw_streams(dev)
         return self._main[dev]
 
-    def bucket(self, key, dev, stream=None):
-        b = self.buckets.get(key)
+    def bucket(self, key, dev, stream=None, lane=0):
+        """The capacity bucket of `key`; lane > 0: further buckets of the same capacities (forwards in flight side by side
+        in the streaming pipeline need their own buffers)."""
+        bk = key if lane == 0 else (key, lane)
+        b = self.buckets.get(bk)
         if b is None:
             if len(self.buckets) >= self.MAX_BUCKETS:           # drop the least used
                 victim = min(self.buckets, key=lambda k: self.buckets[k].launches)
                 torch.cuda.synchronize(dev)
                 del self.buckets[victim]
             with torch.cuda.stream(stream or torch.cuda.current_stream(dev)):   # static tables are built on it
-                b = self.buckets[key] = _Bucket(self, key, dev)
+                b = self.buckets[bk] = _Bucket(self, key, dev)
         return b
 
     def _stream_for(self, dev, stream):

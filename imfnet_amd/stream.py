@@ -1,0 +1,188 @@
+"""Host arrays in -> descriptors on the host, as a stream: the Python face of the library's pipeline
+(csrc/pipeline.hip, `imf_pipeline_*`).
+
+The reference's loop body (scripts/generate_desc.py:99-123) is `extract_features(model, xyz, ..., image)` on host
+arrays followed by `feature.detach().cpu().numpy()`.  Here that span is a JOB: the caller's thread stages the
+fragment(s) into a pinned block (`FragmentStreamer.submit`: one C pass over the points, narrowing float64 values that
+are float32 values -- what a PLY holds -- so half the bytes cross PCIe), the pipeline's worker thread issues the upload
+kernel, the ~150 launches of `imf_fragment_forward` and the download kernel on three streams, and `StreamJob.wait()`
+returns once xyz_down and the descriptors sit in the job's pinned output block.  Uploads and downloads of neighbouring
+jobs run under the current forward's kernels; the interpreter is not on the issue path.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import META_WORDS, ImfError, Job, check
+from .model import graph
+
+
+class StreamJob:
+    """One submitted forward: `wait()` -> FragmentResult (counts, flags, item spans); `views` are the numpy views of the
+    pinned blocks (`sel` = xyz_down rows, `F` = descriptors) -- valid until the slot is handed to another submit."""
+
+    def __init__(self, streamer, items, slot, bucket, views, ticket, narrowed):
+        self.streamer, self.items, self.slot, self.bucket, self.views = streamer, items, slot, bucket, views
+        self.ticket, self.narrowed = ticket, narrowed
+        self.res = None
+        self.ms = None               # (upload, forward incl. queueing behind the previous one, download) in ms
+        self.host_ms = None
+        self._lock = threading.Lock()
+
+    def wait(self):
+        return self.streamer._complete(self)
+
+
+class FragmentStreamer:
+    """Capacity buckets (device) + the library pipeline of one FragmentRunner on one device.  `n_buckets` forwards of one
+    capacity key can be in flight (upload of k+1, forward of k, download of k-1); pinned HostSlots belong to the caller."""
+
+    def __init__(self, runner, device, n_buckets=3, sdma_copies=None, copy_blocks=0):
+        self.runner, self.device, self.n_buckets = runner, device, max(1, int(n_buckets))
+        self.L = runner.L
+        main = runner.main_stream(device)
+        if sdma_copies is None:                       # copy engines when hipMemcpyAsync cannot block the worker (see __init__.py)
+            from . import SDMA_ASYNC
+            sdma_copies = SDMA_ASYNC
+        self.sdma_copies = bool(sdma_copies)
+        flags = (_lib.PIPELINE_SDMA_COPIES if sdma_copies else 0) | ((int(copy_blocks) & 0xFFF) << 8)
+        with torch.cuda.device(device):
+            self.handle = self.L.imf_pipeline_create(main.cuda_stream, 32, flags)
+        if not self.handle:
+            raise ImfError("imf_pipeline_create failed: " + self.L.imf_last_error().decode())
+        self.main = main
+        self._free = {}              # capacity key -> lanes not in flight
+        self._made = {}              # capacity key -> lanes created so far
+        self._inflight = []          # StreamJobs not yet completed, in submit order
+        self._lock = threading.RLock()
+        self._scratch32 = None
+
+    def close(self):
+        if self.handle:
+            for job in list(self._inflight):
+                try:
+                    self._complete(job)
+                except ImfError:
+                    pass
+            self.L.imf_pipeline_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                             # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    # -- buckets ------------------------------------------------------------------------------------------------------
+    def _acquire(self, key):
+        """A bucket of capacity `key` that no job is using; completes the oldest job of that key when all are busy."""
+        while True:
+            with self._lock:
+                free = self._free.setdefault(key, [])
+                if free:
+                    return free.pop()
+                if self._made.get(key, 0) < self.n_buckets:
+                    lane = self._made.get(key, 0)
+                    self._made[key] = lane + 1
+                    return self.runner.bucket(key, self.device, self.main, lane=lane)
+                old = next((j for j in self._inflight if j.bucket.key == key), None)
+            if old is None:
+                raise ImfError("streamer: no bucket of this capacity is free and none is in flight")
+            self._complete(old)                       # (outside the lock: it blocks on the GPU)
+
+    # -- submit / wait ------------------------------------------------------------------------------------------------
+    def submit(self, items, voxel_size, slot, more_follow=False):
+        """Queue `items` = [(xyz [N,3] host float32/float64 array, image [1,3,H,W] host float32 array)] as ONE forward
+        (several items: the model's batched call, model/resunet.py:241-250) with `slot` (graph.HostSlot) as its pinned
+        staging.  more_follow: another submit is coming -- this job's download is then issued behind the next job's
+        launches (the side stream's idle half) instead of in front of them; `wait()` ends the deferral.  Returns a
+        StreamJob, or None when the runner has no capacities for it yet (the caller runs the exact path, which teaches the
+        runner)."""
+        runner = self.runner
+        k = len(items)
+        n_each = [int(x.shape[0]) for x, _ in items]
+        n = sum(n_each)
+        x0, i0 = items[0]
+        H, W = int(i0.shape[2]), int(i0.shape[3])
+        narrowed = False
+        v = b = None
+        if x0.dtype == np.float64:
+            # float64 values that are float32 values (a PLY's points widened by the reader): stage and upload as float32
+            key = runner.caps_for(n, k, H, W, voxel_size, False)
+            if key is None:
+                return None
+            b = self._acquire(key)
+            v = slot.bind(b)
+            narrowed, at = True, 0
+            for j, (xyz, _) in enumerate(items):
+                src = np.ascontiguousarray(xyz)
+                dst = v["xyz"][at:at + n_each[j]]
+                rc = self.L.imf_host_narrow_points(src.ctypes.data, src.size, dst.ctypes.data)
+                if rc != 1:
+                    narrowed = False
+                    break
+                at += n_each[j]
+            if not narrowed:
+                with self._lock:
+                    self._free[key].append(b)
+                b = None
+        if b is None:
+            key = runner.caps_for(n, k, H, W, voxel_size, x0.dtype == np.float64)
+            if key is None:
+                return None
+            b = self._acquire(key)
+            v = slot.bind(b)
+            at = 0
+            for j, (xyz, _) in enumerate(items):
+                np.copyto(v["xyz"][at:at + n_each[j]], xyz)
+                at += n_each[j]
+        vals, at = [n, k], 0
+        for j, (_, img) in enumerate(items):
+            np.copyto(v["image"][j:j + 1], img)
+            vals.append(at)
+            at += n_each[j]
+        v["dyn"][:len(vals)] = vals
+        b.dyn_values = vals
+        job = Job()
+        job.net, job.img = C.pointer(runner.net_desc), C.pointer(runner.img_plan.desc)
+        job.caps, job.io = C.pointer(b.caps), C.pointer(b.io)
+        job.host_in, job.dev_in = slot.inbuf.data_ptr(), b.inbuf.data_ptr()
+        job.in_bytes = b.lay["xyz"] + n * 3 * b.xyz.element_size()
+        job.dev_out, job.host_out, job.out_bytes = b.outbuf.data_ptr(), slot.outbuf.data_ptr(), b.outbuf.numel()
+        job.sel, job.sel_offset = b.sel.data_ptr(), b.lay["sel"]
+        job.out_offset, job.out_row_bytes = b.lay["F"], int(b.out.shape[1]) * 4
+        job.defer_download = 1 if more_follow else 0
+        b.io.trace = None
+        ticket = self.L.imf_pipeline_submit(self.handle, C.byref(job))
+        if ticket < 0:
+            with self._lock:
+                self._free[key].append(b)
+            check(ticket, "imf_pipeline_submit")
+        b.launches += 1
+        runner.stats["eager"] += 1
+        sj = StreamJob(self, items, slot, b, v, ticket, narrowed)
+        with self._lock:
+            self._inflight.append(sj)
+        return sj
+
+    def _complete(self, sj):
+        with sj._lock:                                # one waiter per job; the streamer's lock only guards the bookkeeping
+            if sj.res is not None:
+                return sj.res
+            ms = (C.c_float * 24)()
+            rc = self.L.imf_pipeline_wait(self.handle, sj.ticket, ms)
+            with self._lock:
+                self._inflight.remove(sj)
+                self._free[sj.bucket.key].append(sj.bucket)
+            check(rc, "imf_pipeline_wait")
+            sj.ms = (float(ms[0]), float(ms[1]), float(ms[2]))
+            sj.stamps = tuple(float(ms[i]) for i in range(8, 21))   # device x5, host x3 (ms since the pipeline's creation)
+            sj.host_ms = tuple(float(ms[i]) for i in range(3, 8))   # queue wait, issue, to download issue, to completion, in wait()
+            res = graph.FragmentResult(sj.bucket, sum(int(x.shape[0]) for x, _ in sj.items), len(sj.items), None, None,
+                                       pooled=False)
+            res._meta = sj.views["meta"].numpy().copy()
+            sj.res = res
+            return res

@@ -595,6 +595,55 @@ size_t imf_fragment_pyramid_bytes(const imf_fragment_caps *caps);
 int imf_fragment_forward(const imf_resunet_desc *net /* [host] */, const imf_image_desc *img /* [host] */,
                          const imf_fragment_caps *caps, imf_fragment_io *io);
 
+/* ---- Streaming pipeline: host arrays in -> descriptors on the host, transfers under the neighbouring forwards ----
+ * Replaces: the per-fragment body of scripts/generate_desc.py:99-123 (extract_features(...) on host arrays, then
+ * feature.detach().cpu().numpy()) = util/misc.py:82-104 end to end, for a stream of fragments.  A job = one
+ * imf_fragment_forward (one fragment or a batch) whose inputs sit in a PINNED host block laid out like the bucket's
+ * device input block [dyn | images | points] and whose results land in a pinned block laid out like the device output
+ * block [meta | xyz_down | descriptors]:
+ *     image stream: host_in -> dev_in            (in_bytes; issued behind the PREVIOUS job's image branch)
+ *     main stream : imf_fragment_forward(job->io), then xyz_down = xyz[first_idx] into `sel` (imf_gather_points)
+ *     side stream : dev_out -> host_out          (meta, and the meta[0] rows of xyz_down and of the descriptors; with
+ *                   defer_download issued behind the NEXT job's launches, i.e. behind its coarse levels and rulebooks)
+ * ordered by events, so job k+1's upload and job k-1's download run under job k's kernels, in the idle halves of the two
+ * streams a forward has besides its main stream (HIP has four hardware queues: further streams would share one of these
+ * queues in an order nobody chose).  The transfers are copy KERNELS that address the pinned blocks directly (no copy
+ * command ever sits in front of a launch: a hipMemcpyAsync issued behind queued kernels blocks the calling thread on
+ * this stack); IMF_PIPELINE_SDMA_COPIES selects hipMemcpyAsync of the whole blocks instead (A/B).  Every HIP call of a
+ * job is made by the pipeline's own worker thread: imf_pipeline_submit only queues a copy of the descriptor and returns
+ * a ticket (>= 0) at once, imf_pipeline_wait blocks until that job's results are in host_out (it ends a deferral) and
+ * frees the ticket.  The caller owns all memory and must not reuse a bucket (job->io and its blocks) or its pinned blocks
+ * before the job's wait has returned; jobs run in submit order.  main_stream: a non-blocking stream distinct from every
+ * job's io->side_stream / io->image_stream (all jobs of a pipeline should share those two). */
+typedef struct imf_job {               /* [host] */
+  const imf_resunet_desc *net;
+  const imf_image_desc *img;
+  const imf_fragment_caps *caps;
+  imf_fragment_io *io;                 /* the bucket; main_stream is set by the pipeline */
+  const void *host_in; void *dev_in; size_t in_bytes;       /* pinned -> device, 16-byte aligned */
+  const void *dev_out; void *host_out; size_t out_bytes;    /* device -> pinned (whole block; SDMA mode copies all of it) */
+  double *sel;                         /* device [caps->rows[0], 3] inside dev_out at sel_offset: xyz[first_idx]; NULL: none */
+  size_t sel_offset;                   /* byte offset of `sel` in the output block */
+  size_t out_offset; int32_t out_row_bytes;                 /* the descriptors' offset in the output block and bytes per row */
+  int32_t defer_download;              /* another job follows: issue this one's download behind that job's launches */
+} imf_job;
+#define IMF_PIPELINE_SDMA_COPIES 1     /* flags bit 0; bits 8..19: workgroups per copy kernel (0 = 64) */
+void *imf_pipeline_create(void *main_stream, int depth /* tickets */, int flags);
+void imf_pipeline_destroy(void *pipeline);
+int imf_pipeline_submit(void *pipeline, const imf_job *job);          /* ticket >= 0, or IMF_E* */
+/* ms [host], 24 floats or NULL.  Device (HIP events): [0] upload, [1] upload done -> forward done (includes queueing behind
+ * the previous forward), [2] forward done -> download done (includes a deferral).  Host clock: [3] submit -> taken by the
+ * worker, [4] -> forward issued, [5] -> download issued, [6] -> seen complete, [7] time spent inside this call.  Time stamps
+ * in ms since imf_pipeline_create -- device clock: [8] upload begins, [9] upload ends, [10] forward begins, [11] forward
+ * ends, [12] download ends; host clock: [13] submit, [14] forward issued, [15] this call returns, [16] taken by the worker,
+ * [17] / [18] upload issue begins / ends, [19] / [20] download issue begins / ends. */
+int imf_pipeline_wait(void *pipeline, int ticket, float *ms);
+/* [host pointers] float64 -> float32 when every value is a float32 (PLY points widened by the reader,
+ * scripts/generate_desc.py:83-84): returns 1 and dst holds the narrowed values, 0 when some value does not survive
+ * (the caller stages the float64 rows instead).  Voxels from the narrowed points are bit-identical (the voxeliser
+ * widens before its fp64 divide, util/misc.py:82). */
+int imf_host_narrow_points(const double *src, int64_t n_values, float *dst);
+
 /* hipGraph plumbing for the above (thread-local capture mode: other host threads may keep using HIP).
  * imf_graph_end_capture instantiates; the handle is replayed with imf_graph_launch on any stream. */
 int imf_graph_begin_capture(void *stream);
