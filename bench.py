@@ -16,8 +16,13 @@ counts, no host readback, ~150 launches issued natively on three streams; bit-id
 (asserted below).  --mode graph replays the same call as ONE captured hipGraph: also bit-identical, but ROCm 7.2
 executes a graph's independent branches one after the other (profiles/r02_graph_replay_kernel_stats.txt), which
 puts the image branch, the coarse pyramid levels and the rulebook builds on the critical path -- measured slower,
-reported in config.graph_replay.  --mode exact is round 1's path (count readback + native executor).  Every
---trace-every'th timed step records HIP events around each convolution for the live roofline block.
+reported in config.graph_replay.  --mode exact is round 1's path (count readback + native executor).
+
+`value` / `ms_per_step` follow the bench contract (inputs resident in HBM when the timed region starts; the points of
+every step come from a different one of 26 replicas, 330 MB in all, so that no step finds its input in the 256 MiB
+Infinity Cache).  The SAME JSON line carries `host_span`: SURVEY 8(d)'s span -- host float64 arrays in, xyz_down and the
+descriptors back on the host, PCIe both ways -- timed the same way (exactly --steps pair-steps between barrier +
+synchronize, median of the repeats) through the library's streaming pipeline (imf_pipeline_*: csrc/pipeline.hip).
 
   python bench.py [--gpus N --steps K --warmup W]        one JSON line on rank 0
 With --gpus N > 1 and no torchrun environment the script launches its own N ranks.
@@ -33,14 +38,17 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import imfnet_amd  # noqa: E402,F401  (before torch touches the HIP runtime: sets ROC_CPU_WAIT_FOR_SIGNAL=0, see its __init__)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
-PMC_FILE = "r03_pmc_traffic.json"
+L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md: aggregate L2 bandwidth
+PMC_FILE = "r04_pmc_traffic.json"
+STATS_FILE = "r04_kernel_stats.txt"
+COUNTERS_FILE = "r04_pmc_counters.txt"
 
 
 def load_pair(scale):
@@ -77,7 +85,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/r03_pmc_traffic.json, produced by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
     separate runs; read side doubled per the gfx950 FETCH_SIZE correction).  None if absent."""
-    for name in (PMC_FILE, "r02_pmc_traffic.json"):
+    for name in (PMC_FILE, "r03_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -106,12 +114,15 @@ def pmc_traffic(kernel):
                                             f"bytes because feature rows are re-gathered from L2 / Infinity Cache, not HBM")
 
 
-def rocprof_avg_us(kernel, name="r03_kernel_stats.txt"):
+def rocprof_avg_us(kernel, name=None):
     """Launch-weighted average duration of `kernel`'s symbols in the committed `rocprofv3 --kernel-trace --stats` summary of
     this same command (profiles/r03_kernel_stats.txt, tools/profile_round.sh) -- printed beside the live HIP-event timing so
     that roofline.frac can be recomputed from profiles/ alone.  (n, avg_us) or None."""
-    path = os.path.join(ROOT, "profiles", name)
-    if not os.path.exists(path):
+    for cand in ([name] if name else [STATS_FILE, "r03_kernel_stats.txt"]):
+        path = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(path):
+            break
+    else:
         return None
     rows = []
     for line in open(path):
@@ -125,7 +136,33 @@ def rocprof_avg_us(kernel, name="r03_kernel_stats.txt"):
     else:
         fam = [r for r in rows if r[0] == kernel or r[0].startswith(kernel[:-1] + ",") or r[0].startswith(kernel + "<")]
     n, tot = sum(r[1] for r in fam), sum(r[2] for r in fam)
-    return (n, tot / n) if n else None
+    return (n, tot / n, os.path.basename(path)) if n else None
+
+
+def pmc_counters(kernel):
+    """(matrix-pipe busy %, MFMA instructions per launch, file) of `kernel`'s family from the committed counter table
+    (profiles/r04_pmc_counters.txt, tools/pmc_table.py), launch-weighted; None if absent."""
+    for cand in (COUNTERS_FILE, "r03_pmc_counters.txt"):
+        path = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(path):
+            break
+    else:
+        return None
+    rows = []
+    for line in open(path):
+        m = re.match(r"(k_\S.*?)\s+(\d+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+\d+\s+(\d+) /", line)
+        if m:
+            rows.append((m.group(1).strip(), int(m.group(2)), float(m.group(5)), int(m.group(7))))
+    if kernel.startswith("k_spconv_w<"):
+        w = kernel[len("k_spconv_w<"):-1]
+        fam = [r for r in rows if re.match(r"k_spconv_w<(true|false), %s, true>$" % w, r[0])]
+    else:
+        fam = [r for r in rows if r[0] == kernel or r[0].startswith(kernel[:-1] + ",") or r[0].startswith(kernel + "<")]
+        fam = [r for r in fam if r[0].endswith("true>")] or fam      # the ResUNet's launches read operand images
+    n = sum(r[1] for r in fam)
+    if not n:
+        return None
+    return (sum(r[2] * r[1] for r in fam) / n, sum(r[3] * r[1] for r in fam) / n, os.path.basename(path))
 
 
 def cpu_baseline(xyz, img, voxel, sd, seconds_budget=12.0):
@@ -137,6 +174,7 @@ def cpu_baseline(xyz, img, voxel, sd, seconds_budget=12.0):
     probe (torch's intra-op pool does not scale to all cores of a large host: 256 threads are 6x SLOWER than 16 on the
     EPYC GPU box) and reported as `cores`; the single-thread rate of the faster implementation is reported too
     ("1 thread and all cores")."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))       # the checker: only this leg ever imports it
     import imf_oracle as O
     import imf_oracle_cbind as OC
     ncpu = os.cpu_count() or 1
@@ -198,14 +236,16 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def build_model(O, dev, variant=None):
+def build_model(dev, variant=None):
+    """ResUNetBN2C with the seeded weights of imfnet_amd/seeded.py (no checkpoint is reachable)."""
     from imfnet_amd import ops
     from imfnet_amd.model import load_model
+    from imfnet_amd.seeded import seeded_state_dict
     prev = ops.CONV_VARIANT
     if variant is not None:
         ops.CONV_VARIANT = variant
     try:
-        sd = O.seeded_state_dict(seed=0, with_unused_image_layers=True)
+        sd = seeded_state_dict(seed=0, with_unused_image_layers=True)
         model = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True,
                                           conv1_kernel_size=5, D=3, config=None)
         model.load_state_dict(sd, strict=True)
@@ -222,6 +262,8 @@ def build_model(O, dev, variant=None):
 class Workload:
     """Inputs resident in HBM + the two ways of running one step on them."""
 
+    MALL_BYTES = 320 << 20        # replicas of the points beyond the 256 MiB Infinity Cache
+
     def __init__(self, model, dev, pts_list, imgs, voxel):
         from imfnet_amd.extract import sparse_tensor_from_points, start_geometry
         self.model, self.dev, self.voxel = model, dev, voxel
@@ -235,6 +277,7 @@ class Workload:
         self._sp, self._geo = sparse_tensor_from_points, start_geometry
         self.runner = self.bucket = None
         self.stream = torch.cuda.Stream(device=dev)
+        self.replicas, self._turn = [], 0
 
     def exact_step(self):
         """Round 1's path: geometry stream + one count readback + native executor."""
@@ -244,8 +287,9 @@ class Workload:
             self.last_st = st
             return self.model(st, self.img).F
 
-    def prepare_graph(self):
-        """Capacity bucket from one exact step's counts; inputs staged in the bucket's static buffers."""
+    def prepare_graph(self, replicate=False):
+        """Capacity bucket from one exact step's counts; inputs staged in the bucket's static buffers.  replicate: the
+        points additionally as enough device copies to exceed the Infinity Cache; every step reads the next one."""
         F = self.exact_step()
         torch.cuda.synchronize()
         cm = self.last_st.coordinate_manager
@@ -253,15 +297,26 @@ class Workload:
         r = self.runner = self.model.fragment_runner()
         assert r is not None, "this model configuration is not covered by the fragment graph"
         r.observe(int(self.xyz.shape[0]), [l.n for l in lv], lv[0].bbox)
+        if len(self.starts) > 1:
+            r.observe_batch(len(self.starts), lv[0].bbox)
         key = r.caps_for(int(self.xyz.shape[0]), len(self.starts), int(self.img.shape[2]), int(self.img.shape[3]),
                          self.voxel, self.xyz.dtype == torch.float64)
         self.stream.synchronize()
         self.stream = r.main_stream(self.dev)            # capacity-mode forwards run on the runner's own main stream
         b = self.bucket = r.bucket(key, self.dev, self.stream)
         self.n_points = r.stage(b, self.xyz, self.starts, self.img, self.stream)
+        if replicate:
+            nbytes = self.xyz.numel() * self.xyz.element_size()
+            self.replicas = [self.xyz.clone() for _ in range(max(2, -(-self.MALL_BYTES // nbytes)))]
+            self._home = b.io.xyz
         return F
 
     def graph_step(self, trace_list=None):
+        if self.replicas and not self.runner.use_graph:  # (a captured graph has the bucket's own buffer baked in)
+            self.bucket.io.xyz = self.replicas[self._turn % len(self.replicas)].data_ptr()
+            self._turn += 1
+        elif self.replicas:
+            self.bucket.io.xyz = self._home
         res = self.runner.launch(self.bucket, self.n_points, len(self.starts), self.stream, trace_list=trace_list)
         self.last_res = res
         return res
@@ -276,6 +331,141 @@ def timed(fn, steps, sync):
     return (time.perf_counter() - t0) / steps
 
 
+def median(vals):
+    v = sorted(vals)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def host_span_leg(model, dev, args, barrier, sync, pts, imgs, voxel, f32_valued=False):
+    """SURVEY 8(d)'s span as a stream: host arrays in -> xyz_down + descriptors on the host, two fragments per forward
+    (one `step` = the pair), through imf_pipeline_* (worker thread, transfers on the copy engines under the neighbouring
+    forwards).  Timed like the headline: exactly --steps steps between barrier + synchronize, median of the repeats."""
+    from imfnet_amd.extract import extract_features_stream
+    if f32_valued:                                       # what a PLY holds (float32 values widened by the reader)
+        pts = [p.astype(np.float32).astype(np.float64) for p in pts]
+    R = 6                                                # host replicas: a step's source pages are not the previous step's
+    frags = [[(p.copy(), np.ascontiguousarray(imgs[k:k + 1])) for k, p in enumerate(pts)] for _ in range(R)]
+
+    def run(n_steps):
+        gen = (frags[s % R][k] for s in range(n_steps) for k in range(len(pts)))
+        m = 0
+        for xd, Fh in extract_features_stream(model, gen, voxel, dev, depth=3, copy=False, batch=len(pts)):
+            m += Fh.shape[0]
+        return m
+
+    run(max(args.warmup, 8))                             # every pinned slot and bucket lane has been through the pipeline
+    sync()
+    st = model.fragment_runner().stats
+    for k in [k for k in st if k.startswith("stream_")]:
+        st.pop(k)
+    st["stream_trace"] = []
+    rep, m = [], 0
+    for _ in range(max(3, min(args.repeats, 5))):
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        m = run(args.steps)
+        sync()
+        barrier()
+        rep.append(time.perf_counter() - t0)
+    trace = st.pop("stream_trace")
+    jobs = max(1, st.get("stream_jobs", 1))
+    t = median(rep)
+    streamer = model.fragment_runner().streamer(dev)
+    out = {"value": round(m / t, 1), "unit": "descriptors/s", "ms_per_step": round(t / args.steps * 1e3, 4),
+           "ms_per_fragment": round(t / args.steps / len(pts) * 1e3, 4),
+           "ms_per_step_all": [round(v / args.steps * 1e3, 4) for v in sorted(rep)],
+           "span": "host float64 point arrays + host images -> (voxelise, pyramid, rulebooks, image branch, 23 convolutions, "
+                   "fusion) -> xyz_down float64 and descriptors float32 as host arrays (views of the pinned block), "
+                   "PCIe both ways; extract_features_stream(batch=%d, depth=3, copy=False)" % len(pts),
+           "points": "float32-valued float64 (a PLY's points: uploaded as float32)" if f32_valued else
+                     "arbitrary float64 (fixture x 1.7: uploaded as float64)",
+           "transfers": "copy engines (hipMemcpyAsync, ROC_CPU_WAIT_FOR_SIGNAL=0)" if streamer.sdma_copies else "copy kernels"}
+    if trace:
+        k = len(trace)
+        out["per_job_ms"] = {
+            "device": {"upload": round(sum(r[1] - r[0] for r in trace) / k, 4),
+                       "forward": round(sum(r[3] - r[2] for r in trace) / k, 4),
+                       "forward_period": round((trace[-1][2] - trace[0][2]) / (k - 1), 4) if k > 1 else None,
+                       "download_done_after_forward": round(sum(r[4] - r[3] for r in trace) / k, 4)},
+            "host": {n[len("stream_"):]: round(st[n] / jobs, 4) for n in sorted(st) if n.endswith("_ms") and n != "stream_gpu_ms"},
+            "note": "HIP events / host clock per job of the LAST repeat's window; forward_period = spacing of consecutive "
+                    "forwards' first kernels (the pipeline's steady state: transfers hidden when it equals `forward`)"}
+    return out, trace
+
+
+def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=12):
+    """SURVEY 8(e) as a measurement: a synthetic test set (slabs of the in-tree pair, seeded scales and sizes, the same on
+    every rank) is LPT-sharded over the ranks (imfnet_amd.dist.shard_fragments), every rank streams ITS fragments through
+    the host-array pipeline, then ONE variable-length gather brings all [M_i, 32] blocks to rank 0 (RCCL send / recv under
+    nccl).  Rank 0 checks counts, order and every block bit for bit against the CRC its producer took."""
+    import zlib
+    from imfnet_amd import dist as idist
+    from imfnet_amd.extract import extract_features, extract_features_stream
+    z = np.load(os.path.join(ROOT, "tests", "golden", "fixture_clouds.npz"))
+    im = np.load(os.path.join(ROOT, "tests", "golden", "fixture_images.npz"))
+    rng = np.random.default_rng(7)
+    n_frag = per_rank * world
+    frags = []
+    for i in range(n_frag):
+        base = z[f"cloud_bin_{i % 2}"]
+        scale = np.float32(rng.uniform(1.0, 1.9))
+        d = rng.normal(size=3).astype(np.float32)
+        proj = base @ (d / np.linalg.norm(d))
+        frac = rng.uniform(0.3, 0.8)
+        lo = np.quantile(proj, rng.uniform(0.0, 1.0 - frac))
+        keep = np.flatnonzero(proj >= lo)[: int(frac * len(base))]
+        pts = (base[np.sort(keep)] * scale).astype(np.float64)           # float32-valued, as a PLY's points
+        frags.append((pts, np.transpose(im[f"image_{i % 2}"], (2, 0, 1))[None].copy()))
+    shards = idist.shard_fragments([len(p) for p, _ in frags], world)
+    mine = shards[rank]
+    with torch.no_grad():
+        if model.fragment_runner().ratios is None:       # (teach the runner: one fragment on the exact path)
+            extract_features(model, frags[0][0], voxel_size=voxel, device=dev, skip_check=True, image=frags[0][1])
+        for _ in extract_features_stream(model, (frags[i] for i in mine), voxel, dev, batch=2):
+            pass                                         # untimed pass: the capacity buckets of these sizes exist afterwards
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        results, crcs = {}, torch.zeros((n_frag, 2), dtype=torch.int64)
+        coll = idist._collective_device()
+        for i, (xd, Fh) in zip(mine, extract_features_stream(model, (frags[i] for i in mine), voxel, dev, batch=2)):
+            crcs[i, 0], crcs[i, 1] = zlib.crc32(Fh.tobytes()), Fh.shape[0]
+            results[i] = torch.from_numpy(Fh).to(coll, non_blocking=False)
+        torch.cuda.synchronize()
+        t_stream = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        gathered = idist.gather_fragment_descriptors(results, n_frag, shards, dst=0, device=coll)
+        if coll.type == "cuda":
+            torch.cuda.synchronize()
+        t_gather = time.perf_counter() - t1
+    tt = torch.tensor([t_stream, t_gather], dtype=torch.float64, device=coll)
+    crcs = crcs.to(coll)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(crcs, op=dist.ReduceOp.MAX)      # every entry is written by exactly one rank, zero elsewhere
+    if rank != 0:
+        return None
+    crcs = crcs.cpu()
+    assert gathered is not None and sorted(gathered) == list(range(n_frag)), "gather: fragments missing / out of order"
+    rows = 0
+    for i in range(n_frag):
+        blk = gathered[i].cpu().numpy()
+        assert blk.shape == (int(crcs[i, 1]), 32), f"gather: fragment {i} has {blk.shape} rows, producer said {int(crcs[i, 1])}"
+        assert zlib.crc32(blk.tobytes()) == int(crcs[i, 0]), f"gather: fragment {i} differs from what its rank computed"
+        rows += blk.shape[0]
+    ts, tg = float(tt[0]), float(tt[1])
+    return {"fragments": n_frag, "ranks": world, "backend": backend, "descriptors": rows,
+            "fragments_per_s": round(n_frag / ts, 1), "descriptors_per_s": round(rows / ts, 1),
+            "stream_s_max_over_ranks": round(ts, 4), "gather_ms": round(tg * 1e3, 3),
+            "gather_bytes": rows * 128, "verified": "every block on rank 0: rows and CRC-32 equal to its producer's",
+            "note": "host-array pipeline per rank (LPT shards by point count) + one variable-length gather of the [M_i,32] blocks "
+                    "to rank 0; fragments of %d-%d k points" % (min(len(p) for p, _ in frags) // 1000, max(len(p) for p, _ in frags) // 1000)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,9 +473,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scale", type=float, default=1.7)
     ap.add_argument("--voxel", type=float, default=0.025)
-    ap.add_argument("--batch", type=int, default=2, choices=(1, 2),
+    ap.add_argument("--batch", type=int, default=2, choices=(1, 2, 4, 8),
                     help="fragments per forward: 2 = the in-tree fragment PAIR (cloud_bin_0 + cloud_bin_1, one image "
-                         "each) as ONE batched sparse tensor, the batched call of model/resunet.py:241-250")
+                         "each) as ONE batched sparse tensor, the batched call of model/resunet.py:241-250; 4 / 8: the pair "
+                         "repeated (IMF_MAX_BATCH = 8)")
     ap.add_argument("--mode", default="auto", choices=("auto", "capacity", "graph", "exact"),
                     help="capacity: imf_fragment_forward per step (device-side counts, no host readback); graph: the same "
                          "as one hipGraph replay; auto (default): both are timed after the clocks have settled and the faster "
@@ -299,7 +490,9 @@ def main():
     ap.add_argument("--trace-steps", type=int, default=3,
                     help="steps AFTER the timed regions that carry HIP events around every convolution (live roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the single-fragment / end-to-end / fp32-MFMA legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-fragment / batch / fp32-MFMA / graph legs")
+    ap.add_argument("--no-host-span", action="store_true", help="skip the host-array stream leg (profiling runs)")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-pipeline + gather leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -307,7 +500,6 @@ def main():
 
     from imfnet_amd import dist as idist
     from imfnet_amd import ops
-    import imf_oracle as O                              # seeded weights + cpu_baseline only
 
     # test hooks (single-GPU box): IMF_DIST_BACKEND=gloo IMF_FORCE_DEVICE=0 run N ranks on one device
     backend = os.environ.get("IMF_DIST_BACKEND", "nccl")
@@ -322,9 +514,10 @@ def main():
     dev = torch.device("cuda", local)
 
     xyz1, img1, voxel = load_workload(args.scale, args.voxel)
-    model, sd = build_model(O, dev)
-    if args.batch == 2:
+    model, sd = build_model(dev)
+    if args.batch >= 2:
         pts, imgs = load_pair(args.scale)
+        pts, imgs = pts * (args.batch // 2), np.concatenate([imgs] * (args.batch // 2), 0)
     else:
         pts, imgs = [xyz1], img1
     wl = Workload(model, dev, pts, imgs, voxel)
@@ -337,7 +530,7 @@ def main():
     graph_info = None
     with torch.no_grad():
         dyn = args.mode != "exact"
-        F_exact = wl.prepare_graph().clone() if dyn else None
+        F_exact = wl.prepare_graph(replicate=True).clone() if dyn else None
         step = (lambda tl=None: wl.graph_step(tl)) if dyn else (lambda tl=None: wl.exact_step())
         if dyn:
             wl.runner.use_graph = args.mode == "graph"
@@ -383,7 +576,7 @@ def main():
             graph_info = {"hipgraph_replay": bool(wl.runner.use_graph), "graph_nodes": wl.bucket.n_nodes,
                           "equals_exact_path_bitwise": same, "host_readbacks_per_step": 0,
                           "capacities": {"points": wl.bucket.caps.n_points, "rows": list(wl.bucket.caps.rows)},
-                          **picked}
+                          "input_replicas": len(wl.replicas), **picked}
         else:
             out = step()
             sync()
@@ -392,7 +585,7 @@ def main():
 
         # ---- the timed regions: EXACTLY --steps steps each, barrier + synchronize on both sides, nothing else inside
         # (no event records, no readbacks).  Fragments are independent units: no data-path collective (each rank
-        # would write its own <frag>.npz; the optional --gather of generate_desc is not the path).
+        # would write its own <frag>.npz; the gather of the sharded leg below is measured on its own).
         rep = []
         for _ in range(max(1, args.repeats)):
             barrier()
@@ -405,7 +598,7 @@ def main():
             rep.append(time.perf_counter() - t0)
         F_last = out.F if dyn else out
 
-        # every step recomputes the same input: the last timed step must reproduce the warm-up step bit for bit
+        # every step recomputes the same points (from another replica): the last timed step must reproduce the warm-up step
         drift = float((F_last - F_ref).abs().max())
         assert drift < 1e-5, f"descriptors of the last timed step differ from the warm-up step by {drift}"
         bit_reproducible = drift == 0.0
@@ -424,16 +617,32 @@ def main():
         sync()
         trace = trace_all
 
+        # ---- SURVEY 8(d)'s span, timed the same way on every rank (host arrays in, descriptors on the host)
+        host_span = host_trace = None
+        if not args.no_host_span and dyn:
+            pts2, imgs2 = load_pair(args.scale)
+            host_span, host_trace = host_span_leg(model, dev, args, barrier, sync, pts2, imgs2, voxel)
+        sharded = None
+        if not args.no_sharded and dyn:
+            sharded = sharded_pipeline_leg(model, dev, voxel, rank, world, backend)
+
     t = torch.tensor(rep, dtype=torch.float64, device=dev)
+    hs = torch.tensor([host_span["ms_per_step"] if host_span else 0.0, float(M)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per repeat: the slowest rank
         m = torch.tensor([M], dtype=torch.int64, device=dev)
         dist.all_reduce(m, op=dist.ReduceOp.SUM)
         total_m = int(m.item())
+        hmax = hs.clone()
+        dist.all_reduce(hmax, op=dist.ReduceOp.MAX)
+        if host_span:                                     # whole job: all ranks' descriptors over the slowest rank's time
+            host_span["ms_per_step"] = round(float(hmax[0]), 4)
+            host_span["value"] = round(total_m * 1e3 / float(hmax[0]), 1)
+            host_span["n_gpus"] = world
     else:
         total_m = M
     rep = sorted(float(v) for v in t.tolist())
-    elapsed = rep[len(rep) // 2] if len(rep) % 2 else 0.5 * (rep[len(rep) // 2 - 1] + rep[len(rep) // 2])
+    elapsed = median(rep)
 
     if rank == 0:
         # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
@@ -457,7 +666,30 @@ def main():
         g = groups[dom]
         achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
         conv_ms = sum(v["ms"] for v in groups.values()) / traced_steps
+        conv_bytes = sum(v["bytes"] for v in groups.values()) / traced_steps
         traffic, traffic_note = pmc_traffic(dom)
+
+        def binding(kernel, avg_us):
+            """What actually binds a variant-6 kernel: the L2 -> LDS DMA stream.  Every 48 MFMAs (one sub-stage of a
+            64 x 64 tile) move 16 KiB (8 KiB of gathered rows + 8 KiB of weights); MFMA count and matrix-pipe busy from the
+            committed counter table."""
+            pc = pmc_counters(kernel)
+            if not pc:
+                return {}
+            busy, mfma, src = pc
+            l2_bytes = mfma / 48.0 * 16384.0
+            return {"mfma_busy": round(busy / 100.0, 4), "mfma_per_launch": int(mfma),
+                    "l2_lds_bytes_per_launch": int(l2_bytes),
+                    "l2_lds_frac": round(l2_bytes / (avg_us * 1e-6) / 1e9 / L2_PEAK_GBS, 4), "counters": "profiles/" + src}
+
+        def per_kernel_entry(v):
+            avg_us = v["ms"] * 1e3 / v["n"]
+            frac = v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            e = {"launches_per_step": v["n"] // traced_steps, "avg_launch_us": round(avg_us, 2), "frac": round(frac, 4)}
+            if frac > 1.0:
+                e["note"] = "served from cache: the gathers' algorithmic bytes come from L2 / LDS reuse, not HBM"
+            return e
+
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_note": traffic_note,
@@ -466,17 +698,22 @@ def main():
                     "algorithmic_bytes_per_launch": g["bytes"] // g["n"],
                     "achieved_tflops_useful": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2),
                     "all_sparse_conv_ms_per_step": round(conv_ms, 3),
-                    "per_kernel": {k: {"launches_per_step": v["n"] // traced_steps, "avg_launch_us": round(v["ms"] * 1e3 / v["n"], 2),
-                                       "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    "step_frac": round(conv_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                    "step_frac_note": "sum of the convolutions' algorithmic bytes per step / ms_per_step / 8 TB/s (the whole "
+                                      "step against the contract's roofline: geometry, image branch and fusion count as time only)",
+                    "per_kernel": {k: {**per_kernel_entry(v), **binding(k, v["ms"] * 1e3 / v["n"])}
                                    for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
                     "timing": "HIP events around each launch on its launch stream, in situ (other streams' kernels of the same "
                               "step overlap), %d steps after the timed regions" % traced_steps}
+        roofline.update({"binding_resource": binding(dom, g["ms"] * 1e3 / g["n"]),
+                         "binding_note": "bound: hbm is the contract's notional roofline; every variant-6 kernel is bound by its "
+                                         "L2 -> LDS DMA stream (l2_lds_frac of 34.5 TB/s) at the matrix-pipe occupancy mfma_busy"})
         rp = rocprof_avg_us(dom)
         if rp:
             roofline["rocprof_avg_launch_us"] = round(rp[1], 2)
             roofline["rocprof_frac"] = round(roofline["algorithmic_bytes_per_launch"] / (rp[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-            roofline["rocprof_note"] = ("%d launches of the family in profiles/r03_kernel_stats.txt (rocprofv3 --kernel-trace --stats of "
-                                        "this command; kernel tracing serialises the streams and carries no event records)" % rp[0])
+            roofline["rocprof_note"] = ("%d launches of the family in profiles/%s (rocprofv3 --kernel-trace --stats of "
+                                        "this command; kernel tracing serialises the streams and carries no event records)" % (rp[0], rp[2]))
         extras = {}
         with torch.no_grad():
             if dyn and world == 1:
@@ -494,11 +731,16 @@ def main():
                     roofline["isolated_avg_launch_us"] = round(gi["ms"] * 1e3 / gi["n"], 2)
                     roofline["isolated_frac"] = round(gi["bytes"] / (gi["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             if world == 1 and not args.no_extras:
-                extras = extra_legs(O, model, dev, args, sync)
+                extras = extra_legs(model, dev, args, sync)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(xyz1, img1, voxel, sd)
         n_pts = int(wl.xyz.shape[0])
+        if host_span:
+            host_span["vs_device_resident"] = round(host_span["ms_per_step"] / (elapsed / args.steps * 1e3), 3)
+            if host_trace:                               # a window of consecutive jobs: ms since the pipeline's creation (device clock)
+                host_span["timeline_ms"] = {"columns": ["upload_begin", "upload_end", "forward_begin", "forward_end", "download_end"],
+                                            "jobs": [[round(v, 3) for v in r[:5]] for r in host_trace[-6:]]}
         out = {
             "metric": "descriptors/sec (32-D) on 3DMatch fragments",
             "value": round(total_m * args.steps / elapsed, 1),
@@ -511,16 +753,22 @@ def main():
                        "ms_per_step_all": [round(v / args.steps * 1e3, 4) for v in rep],
                        "settle_steps": settle_steps, "settle_ms": args.settle_ms,
                        "traced_steps_in_timed_region": 0},
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (3xf16-split operands, 22-bit; fp32 accumulate)" if ops.CONV_VARIANT == 6 else "f32",
             "data": ("synthetic (reference fixture fragment%s scaled x%.2f, seeded random weights)"
-                     % (" PAIR cloud_bin_0 + cloud_bin_1" if args.batch == 2 else " cloud_bin_0", args.scale)),
+                     % (" PAIR cloud_bin_0 + cloud_bin_1" + (" x%d" % (args.batch // 2) if args.batch > 2 else "")
+                        if args.batch >= 2 else " cloud_bin_0", args.scale)),
+            "host_span": host_span,
             "config": {"workload": (f"3DMatch-shaped fragment pair: {n_pts} points -> {M} voxels @ "
-                                    f"{voxel * 100:.1f} cm, one 120x160 image each, ResUNetBN2C 32-D, conv1 k5; the pair is "
+                                    f"{voxel * 100:.1f} cm, one 120x160 image each, ResUNetBN2C 32-D, conv1 k5; the {args.batch} fragments are "
                                     f"ONE batched forward per step per GPU, geometry rebuilt every step"
-                                    if args.batch == 2 else
+                                    if args.batch >= 2 else
                                     f"3DMatch-shaped fragment: {n_pts} points -> {M} voxels @ "
                                     f"{voxel * 100:.1f} cm, image 120x160, ResUNetBN2C 32-D, conv1 k5; "
                                     f"one fragment per step per GPU, geometry rebuilt every step"),
+                       "value_span": "inputs resident in HBM when the timed region starts, as the bench contract defines `value` "
+                                     "(a different replica of the points every step: no step reads its input from the Infinity "
+                                     "Cache); SURVEY 8(d)'s host-to-host span is `host_span` of this line, timed the same way",
                        "voxels_per_step_per_gpu": M, "points_per_step_per_gpu": n_pts,
                        "last_step_equals_warmup_bitwise": bit_reproducible,
                        "fragments_per_step": world * args.batch,
@@ -532,7 +780,9 @@ def main():
                        "image_branch": model.image_branch_mode if not dyn else wl.runner.image_branch_mode,
                        "conv_arithmetic": ("fp32 operands split into f16 hi+lo (weights pre-scaled by a power of two), "
                                            "3x v_mfma_f32_16x16x32_f16 with fp32 accumulation (fp32-class: max |dF| 3e-7 vs "
-                                           "an fp64-accumulated network)" if ops.CONV_VARIANT == 6 else "fp32 MFMA"),
+                                           "an fp64-accumulated network); activations outside the f16 range raise a flag and the "
+                                           "fragment is redone on fp32 MFMA (strict_fp32 below)" if ops.CONV_VARIANT == 6 else "fp32 MFMA"),
+                       "sharded_pipeline": sharded,
                        **extras},
             "roofline": roofline, "cpu_baseline": cpu,
         }
@@ -541,11 +791,13 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_legs(O, model, dev, args, sync):
+def extra_legs(model, dev, args, sync):
     """Numbers the headline does not show (each a few hundred ms of GPU time):
       single_fragment        one S50k fragment per step (the reference harness is one fragment per call)
-      e2e_extract_features   SURVEY §8(d)'s span: host arrays in -> voxelise + forward -> sync -> F copied back to the host
-      fp32_mfma_variant0     the same pair with true-fp32 matrix instructions (v_mfma_f32_16x16x4_f32) everywhere"""
+      batch_4 / batch_8      the pair twice / four times in ONE forward (IMF_MAX_BATCH = 8): the coarse levels fill the chip
+      e2e_extract_features   SURVEY 8(d)'s span, one synchronous call at a time
+      host_span_f32_valued   the stream leg on float32-valued points (what a PLY holds): uploaded as float32
+      strict_fp32            the same pair with true-fp32 matrix instructions (v_mfma_f32_16x16x4_f32) everywhere"""
     from imfnet_amd.extract import extract_features
     xyz1, img1, voxel = load_workload(args.scale, args.voxel)
     out = {}
@@ -553,15 +805,40 @@ def extra_legs(O, model, dev, args, sync):
     wl1.prepare_graph()
     wl1.runner.use_graph = False
     for _ in range(3):
-        r = wl1.graph_step()
+        wl1.graph_step()
     dt = timed(wl1.graph_step, 20, sync)
     m1 = wl1.last_res.counts[0]
     out["single_fragment"] = {"descriptors_per_s": round(m1 / dt, 1), "ms_per_fragment": round(dt * 1e3, 4), "voxels": m1,
                               "execution": "capacity mode, one fragment per forward"}
     dt = timed(wl1.exact_step, 20, sync)
     out["single_fragment"]["exact_mode_ms_per_fragment"] = round(dt * 1e3, 4)
+    del wl1
+
+    pts2, imgs2 = load_pair(args.scale)
+    for nb in (4, 8):
+        if nb == args.batch:
+            continue
+        wlb = Workload(model, dev, pts2 * (nb // 2), np.concatenate([imgs2] * (nb // 2), 0), voxel)
+        wlb.prepare_graph()
+        wlb.runner.use_graph = False
+        for _ in range(3):
+            r = wlb.graph_step()
+        sync()
+        if r.flags:                                       # (the batch's bit grid: sized from this batch's own box, once)
+            wlb.runner.observe_batch(nb, r.bbox)
+            wlb.prepare_graph()
+            for _ in range(3):
+                r = wlb.graph_step()
+            sync()
+        dt = timed(wlb.graph_step, 12, sync)
+        mb = wlb.last_res.counts[0]
+        out["batch_%d" % nb] = {"descriptors_per_s": round(mb / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+                                "ms_per_fragment": round(dt * 1e3 / nb, 4), "voxels": mb, "flags": wlb.last_res.flags,
+                                "execution": "capacity mode, %d fragments (the pair x%d) per forward" % (nb, nb // 2)}
+        del wlb
 
     xyz_host = xyz1.astype(np.float64)
+
     def e2e():
         xd, F = extract_features(model, xyz_host, voxel_size=voxel, device=dev, skip_check=True, image=img1)
         Fh = getattr(F, "host", None)                 # the descriptors as they came back with the counts (pinned block)
@@ -578,67 +855,38 @@ def extra_legs(O, model, dev, args, sync):
     out["e2e_extract_features"] = {"descriptors_per_s": round(Fh.shape[0] / dt, 1), "ms_per_fragment": round(dt * 1e3, 3),
                                    "ms_per_fragment_min_max": [round(per_call[0] * 1e3, 3), round(per_call[-1] * 1e3, 3)],
                                    "span": "extract_features(host float64 points [%d,3] + host image) -> xyz_down on the host, "
-                                           "and F on the host (PCIe both ways: one pinned H2D block scalars | image | points, one "
-                                           "pinned D2H block counts | xyz_down | F -- F.host of the returned tensor), one "
+                                           "and F on the host (one job of the pipeline: stage, upload, forward, download), one "
                                            "fragment at a time, synchronous" % len(xyz_host),
-                                   "runner": dict(model.fragment_runner().stats) if model.fragment_runner() else None}
+                                   "runner": {k: v for k, v in model.fragment_runner().stats.items() if not k.startswith("stream_")}}
 
-    from imfnet_amd.extract import extract_features_stream
-    def frags(k):
-        for _ in range(k):
-            yield xyz_host, img1
-    for _ in extract_features_stream(model, frags(6), voxel, dev):
-        pass
-    sync()
-    n_it = 40
-    m_tot = 0
-    prof = None
-    if os.environ.get("IMF_BENCH_PROFILE_STREAM"):
-        import cProfile
-        prof = cProfile.Profile()
-        prof.enable()
-    t0 = time.perf_counter()
-    for xd, Fh in extract_features_stream(model, frags(n_it), voxel, dev, copy=False):
-        m_tot += Fh.shape[0]
-    dt = (time.perf_counter() - t0) / n_it
-    st = model.fragment_runner().stats
-    print("stream leg: %.3f ms wall per fragment, %.3f ms H2D + forward + D2H on the stream per fragment (%d)" %
-          (dt * 1e3, st.get("stream_gpu_ms", 0.0) / max(1, st.get("stream_n", 0)), st.get("stream_n", 0)), file=sys.stderr)
-    if prof is not None:
-        import pstats
-        prof.disable()
-        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
-    out["e2e_extract_features_stream"] = {"descriptors_per_s": round(m_tot / n_it / dt, 1), "ms_per_fragment": round(dt * 1e3, 3),
-                                          "span": "the same span over a stream of %d host fragments through extract_features_stream: "
-                                                  "two fragments per forward (the model's batched call), one pinned H2D block and one pinned D2H block "
-                                                  "per forward queued under the neighbouring forwards' kernels, xyz_down and F delivered "
-                                                  "as host arrays (views of the pinned slots, copy=False), in order" % n_it}
+    hs32, _ = host_span_leg(model, dev, args, lambda: None, sync, pts2, imgs2, voxel, f32_valued=True)
+    hs32.pop("per_job_ms", None)
+    out["host_span_f32_valued"] = hs32
 
-    pts2, imgs2 = load_pair(args.scale)
     wl2 = Workload(model, dev, pts2, imgs2, voxel)
     wl2.prepare_graph()
     r = wl2.runner
     prev = r.use_graph
     r.use_graph = True
     for _ in range(3):
-        res = wl2.graph_step()
+        wl2.graph_step()
     dt = timed(wl2.graph_step, 20, sync)
     out["graph_replay"] = {"descriptors_per_s": round(wl2.last_res.counts[0] / dt, 1), "ms_per_step": round(dt * 1e3, 4),
                            "graph_nodes": wl2.bucket.n_nodes,
-                           "note": "the pair as ONE hipGraph replay per step (same launches, bit-identical descriptors): ROCm 7.2 "
-                                   "runs the graph's independent branches back to back, so the image branch, coarse pyramid "
-                                   "levels and rulebook builds no longer overlap the convolutions"}
+                           "note": "the pair as ONE hipGraph replay per step (same launches, bit-identical descriptors)"}
     r.use_graph = prev
     del wl2
 
-    m0, _ = build_model(O, dev, variant=0)
-    pts, imgs = load_pair(args.scale)
-    wl0 = Workload(m0, dev, pts, imgs, voxel)
+    m0, _ = build_model(dev, variant=0)
+    wl0 = Workload(m0, dev, pts2, imgs2, voxel)
     for _ in range(3):
         F0 = wl0.exact_step()
     dt = timed(wl0.exact_step, 10, sync)
-    out["fp32_mfma_variant0"] = {"descriptors_per_s": round(F0.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 4),
-                                 "note": "the pair, exact mode, every convolution on v_mfma_f32_16x16x4_f32 (IMF_CONV_VARIANT=0)"}
+    out["strict_fp32"] = {"descriptors_per_s": round(F0.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+                          "dtype": "f32 (v_mfma_f32_16x16x4_f32, fp32 operands and accumulation)",
+                          "note": "the pair, exact mode (one count readback), every convolution, the image trunk and the fusion "
+                                  "feed-forward on true-fp32 matrix instructions (IMF_CONV_VARIANT=0): the arithmetic of the "
+                                  "reference's fp32 path, and what a fragment flagged IMF_FLAG_RANGE is redone with"}
     del m0, wl0
     return out
 

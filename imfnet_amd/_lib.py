@@ -64,7 +64,7 @@ class LevelDesc(C.Structure):
 class FusionWeights(C.Structure):
     """struct imf_fusion_weights (include/imfnet_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "wq_p", "wo_p", "bo", "ln2_g", "ln2_b", "w1_p", "b1",
-                                          "w2_p", "b2")]
+                                          "w2_p", "b2", "w1_f32", "w2_f32")]
 
 
 class NetConv(C.Structure):
@@ -229,6 +229,9 @@ SIGNATURES = {
                                           C.POINTER(C.c_void_p), _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P,
                                           _Z, _P]),
     "imf_fusion_attention": (_I, [_P, _L, _P, _P, _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P, _Z, _P]),
+    "imf_fusion_attention_batched_v": (_I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p), _I, _I, C.POINTER(FusionWeights), C.c_float, _P, _P,
+                                            _Z, _P, _I, _P]),
     "imf_image_workspace_bytes": (_Z, [_I, _I, _I]),
     "imf_image_tokens": (_I, [_I, _I]),
     "imf_image_tables_build": (_I, [_I, _I, _I, _P, _Z, _P]),

@@ -491,7 +491,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     rc = fusion_attention_batched_fmt(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
                                       io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
                                       net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4,
-                                      net->conv[12].variant == 6 ? err : nullptr, main, fused_split);
+                                      err, main, fused_split, net->conv[12].variant == 6 ? 6 : 0);
   if (rc) return rc;
   if (io->fusion_done) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->fusion_done, main));
   if (diag_marks) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[12], main));

@@ -289,10 +289,25 @@ constexpr size_t kWsFloatsPerRow = 2 * kFD + kFH;
 // The GEGLU output travels as a split-f16 operand image (the only reader is the second GEMM: same products, no
 // conversions in its loop); out_split: the block's output too (its reader is conv4_tr, imf_resunet_forward decides).
 static int run_feed_forward(const imf_fusion_weights *w, long long n, const int32_t *n_dev, float *ws, float *out,
-                            int32_t *err, hipStream_t st, int out_split) {
+                            int32_t *err, hipStream_t st, int out_split, int variant = 6) {
   float *y = ws, *n2 = ws + (size_t)n * kFD, *g = ws + (size_t)n * 2 * kFD;
   const long long slots = (n + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
   imf_conv_args a;
+  if (variant != 6) {   // the network runs on fp32 MFMA (the f16-range recompute): so does the feed-forward, on fp32 images
+    IMF_REQUIRE(variant == 0 && w->w1_f32 && w->w2_f32 && !n_dev && !out_split,
+                "imf_fusion_attention: variant %d needs the fp32 feed-forward images (w1_f32 / w2_f32), exact mode", variant);
+    memset(&a, 0, sizeof(a));
+    a.in_a = n2; a.c_a = kFD; a.w_packed = w->w1_f32; a.kvol = 1; a.cout = 2 * kFH;
+    a.n_slots = slots; a.n_out = n; a.shift = w->b1; a.out = g; a.split_k = 1; a.variant = 0; a.geglu = 1;
+    a.dyn_err = err;
+    int rc0 = imf_spconv_fwd(&a, st);
+    if (rc0) return rc0;
+    memset(&a, 0, sizeof(a));
+    a.in_a = g; a.c_a = kFH; a.w_packed = w->w2_f32; a.kvol = 1; a.cout = kFD;
+    a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = 0;
+    a.dyn_err = err;
+    return imf_spconv_fwd(&a, st);
+  }
   memset(&a, 0, sizeof(a));
   a.in_a = n2; a.c_a = kFD; a.w_packed = w->w1_p; a.kvol = 1; a.cout = 2 * kFH;
   a.n_slots = slots; a.n_out = n; a.shift = w->b1; a.out = g; a.split_k = 1; a.variant = 6; a.geglu = 1;
@@ -379,7 +394,15 @@ int imf_fusion_attention_batched_flags(const float *x, int n_items, const int64_
                                        int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
                                        void *workspace, size_t workspace_bytes, int32_t *flags, void *stream) {
   return imf::fusion_attention_batched_fmt(x, n_items, item_row0, item_rows, kt_packed, v_packed, n_tokens, tokens_padded, w,
-                                           scale, out, workspace, workspace_bytes, flags, stream, 0);
+                                           scale, out, workspace, workspace_bytes, flags, stream, 0, 6);
+}
+
+int imf_fusion_attention_batched_v(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
+                                   const float *const *kt_packed, const float *const *v_packed, int n_tokens,
+                                   int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
+                                   void *workspace, size_t workspace_bytes, int32_t *flags, int variant, void *stream) {
+  return imf::fusion_attention_batched_fmt(x, n_items, item_row0, item_rows, kt_packed, v_packed, n_tokens, tokens_padded, w,
+                                           scale, out, workspace, workspace_bytes, flags, stream, 0, variant);
 }
 
 }  // extern "C"
@@ -388,7 +411,8 @@ namespace imf {
 int fusion_attention_batched_fmt(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
                                  const float *const *kt_packed, const float *const *v_packed, int n_tokens,
                                  int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
-                                 void *workspace, size_t workspace_bytes, int32_t *flags, void *stream, int out_split) {
+                                 void *workspace, size_t workspace_bytes, int32_t *flags, void *stream, int out_split,
+                                 int variant) {
   IMF_REQUIRE(x && item_row0 && item_rows && kt_packed && v_packed && w && out, "imf_fusion_attention: null pointer");
   IMF_REQUIRE(n_items >= 1 && n_items <= IMF_MAX_BATCH, "imf_fusion_attention: n_items=%d", n_items);
   IMF_REQUIRE(w->ln1_g && w->ln1_b && w->wq_p && w->wo_p && w->bo && w->ln2_g && w->ln2_b && w->w1_p && w->b1 &&
@@ -414,7 +438,7 @@ int fusion_attention_batched_fmt(const float *x, int n_items, const int64_t *ite
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_attn(p, st);
   if (rc) return rc;
-  return run_feed_forward(w, n, nullptr, (float *)workspace, out, flags, st, out_split);
+  return run_feed_forward(w, n, nullptr, (float *)workspace, out, flags, st, out_split, variant);
 }
 }  // namespace imf
 

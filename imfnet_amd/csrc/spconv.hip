@@ -790,9 +790,9 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
               "imf_spconv_fwd: operand_format needs variant 6 and an unsplit launch (split_k=%d)", split);
   IMF_REQUIRE(!p.out_split || !a->l2norm, "imf_spconv_fwd: IMF_FMT_OUT_SPLIT not with l2norm");
   IMF_REQUIRE(!p.res_split || a->residual, "imf_spconv_fwd: IMF_FMT_RES_SPLIT without a residual");
-  IMF_REQUIRE(!a->geglu || (a->variant == 6 && !wsplit && a->kvol == 1 && a->cout % 64 == 0 && split == 1 && !a->scale &&
-                            !a->residual && !a->relu && !a->l2norm && !(a->kernel_tag & 2)),
-              "imf_spconv_fwd: geglu needs variant 6 (k_spconv_g), kvol 1, cout %% 64 == 0 and no other epilogue");
+  IMF_REQUIRE(!a->geglu || ((a->variant == 6 || (a->variant == 0 && !simple)) && !wsplit && a->kvol == 1 && a->cout % 64 == 0 &&
+                            split == 1 && !a->scale && !a->residual && !a->relu && !a->l2norm && !(a->kernel_tag & 2)),
+              "imf_spconv_fwd: geglu needs variant 6 (k_spconv_g) or 0, kvol 1, cout %% 64 == 0, an unsplit launch and no other epilogue");
   // XCD-contiguous tile order of k_spconv_g (IMF_G_XCD: bit 0 = the 64-column launches, bit 1 = the 32-column ones; default
   // both): workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2.  In launch order each XCD gathers from ALL input
   // rows (26 MB for 64 channels at 103 k rows); when XCD x instead walks ONE range of consecutive tiles -- rows are in scan

@@ -359,7 +359,8 @@ int fusion_attention_dyn_fmt(const float *x, int64_t n_cap, const int32_t *n_dev
 int fusion_attention_batched_fmt(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
                                  const float *const *kt_packed, const float *const *v_packed, int n_tokens,
                                  int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
-                                 void *workspace, size_t workspace_bytes, int32_t *flags, void *stream, int out_split);
+                                 void *workspace, size_t workspace_bytes, int32_t *flags, void *stream, int out_split,
+                                 int variant = 6);
 int conv_first_bitgrid_flags_fmt(const int32_t *coords, int64_t n, const int32_t *bbox, int ksize, uint32_t *grid,
                                  size_t grid_words, const float *w, int cout, const float *scale, const float *shift,
                                  int relu, float *out, int32_t *flags, hipStream_t stream, int out_split);

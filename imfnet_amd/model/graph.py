@@ -322,11 +322,9 @@ class FragmentRunner:
         process had created before.  Streams born together sit on different queues."""
         s = self._raw.get(dev)
         if s is None:
-            with torch.cuda.device(dev):
-                raw = (self.L.imf_stream_create(), self.L.imf_stream_create(), self.L.imf_stream_create())
-            if not all(raw):
-                raise ImfError("could not create the main / side / image streams")
-            self._main[dev] = torch.cuda.ExternalStream(raw[0], device=dev)
+            from .. import ops
+            raw, views = ops.aux_streams(dev)
+            self._main[dev] = views[0]
             s = self._raw[dev] = (raw[1], raw[2])
         return s
 

@@ -162,9 +162,7 @@ class FusedPlan:
         all_rb = ([] if self.small_first else [rb_first]) + rb_k3 + rb_dn + rb_up
         words = sum(r.words() for r in all_rb) + 16 * 3
         main = torch.cuda.current_stream(dev)
-        side = self._side.get(dev)
-        if side is None:
-            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        side = ops.aux_streams(dev)[1][1]        # born with the geometry / image streams: distinct hardware queues
         with torch.cuda.stream(side):           # side-stream pool: no need to wait for the main stream
             iarena = torch.empty(words, dtype=torch.int32, device=dev)
         iarena.record_stream(main)
@@ -351,9 +349,7 @@ class NativePlan:
         lv = [cm.level(ts) for ts in (1, 2, 4, 8)]
         dev = x.F.device
         main = torch.cuda.current_stream(dev)
-        side = self._side.get(dev)
-        if side is None:
-            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        side = ops.aux_streams(dev)[1][1]        # born with the geometry / image streams: distinct hardware queues
         for i, l in enumerate(lv):
             ld = io.level[i]
             ld.coords, ld.table = l.coords_buf.data_ptr(), l.table.data_ptr()

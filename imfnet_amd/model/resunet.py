@@ -187,9 +187,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._refresh()
         on_device = torch.is_tensor(image) and image.is_cuda
         dev = image.device if on_device else torch.device(device if device is not None else "cuda")
-        side = self._side.get(dev)
-        if side is None:
-            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        side = ops.aux_streams(dev)[1][2]        # the package's image-branch stream (ops.aux_streams)
         cur = torch.cuda.current_stream(dev)
         if on_device and not inputs_ready:
             side.wait_stream(cur)
@@ -365,7 +363,7 @@ class ResUNet2(ME.MinkowskiNetwork):
                 for t in packed[0] + packed[1]:
                     t.record_stream(cur)
                 out = ops.fusion_attention_batched(f8, items, packed[0], packed[1], packed[2], packed[3],
-                                                   self._fusion_weights())
+                                                   self._fusion_weights(), flags=self.flag_word(f8.device))
             elif kv is not None and image_feat.shape[0] == 1:
                 kv.record_stream(cur)
                 out = self._fusion_fast(f8, kv[0])

@@ -121,17 +121,37 @@ class ArenaLevel(Level):
         return self.arena.device
 
 
-_GEOM_STREAMS = {}
+_AUX_STREAMS = {}
 _PINNED = {}
 
 
-def geometry_stream(device):
-    """Dedicated high-priority stream for the geometry build: its row-count readback must not queue
-    behind the previous fragment's convolutions on the main stream."""
-    s = _GEOM_STREAMS.get(device)
+def aux_streams(device):
+    """The package's THREE streams of a device: (raw hipStream_t handles, torch views), created through the library one
+    right after the other.  HIP multiplexes streams onto four hardware queues (a new stream goes to the least-used one),
+    and torch's pool hands its streams out in an order the process's history decides: branches that should overlap then
+    share a queue and run one after the other (round 3: the same forward 0.75 or 2.0 ms, the fp32 exact-mode pair 2.3 or
+    3.4 ms).  Streams born together sit on different queues.  Every executor takes its auxiliary streams from here:
+        capacity mode (model/graph.py, stream.py):  main, side (coarse levels + rulebooks), image branch
+        exact mode (extract.py, model/plan.py):      geometry, side (rulebooks), image branch
+    -- the two modes never run at the same time, and the caller's own stream is the fourth."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    s = _AUX_STREAMS.get(device)
     if s is None:
-        s = _GEOM_STREAMS[device] = torch.cuda.Stream(device=device, priority=-1)
+        L = _lib.lib()
+        with torch.cuda.device(device):
+            raw = (L.imf_stream_create(), L.imf_stream_create(), L.imf_stream_create())
+        if not all(raw):
+            raise ImfError("could not create the package's three streams")
+        s = _AUX_STREAMS[device] = (raw, tuple(torch.cuda.ExternalStream(r, device=device) for r in raw))
     return s
+
+
+def geometry_stream(device):
+    """Dedicated stream for the exact-mode geometry build: its row-count readback must not queue behind the previous
+    fragment's convolutions on the caller's stream."""
+    return aux_streams(device)[1][0]
 
 
 class PyramidFuture:
@@ -582,16 +602,22 @@ class FusionKernelWeights:
         self.t = dict(ln1_g=f(blk0.norm.weight), ln1_b=f(blk0.norm.bias), wq_p=pack_weights(f(att.to_q.weight).t()),
                       wo_p=pack_weights(f(att.to_out.weight).t()), bo=f(att.to_out.bias), ln2_g=f(blk1.norm.weight),
                       ln2_b=f(blk1.norm.bias), w1_p=pack_weights(w1t, split16=True), b1=f(ff[0].bias)[perm].contiguous(),
-                      w2_p=pack_weights(f(ff[2].weight).t(), split16=True), b2=f(ff[2].bias))
+                      w2_p=pack_weights(f(ff[2].weight).t(), split16=True), b2=f(ff[2].bias),
+                      # the same two matrices as fp32 images: the feed-forward of the variant-0 (fp32 MFMA) recompute
+                      w1_f32=pack_weights(w1t), w2_f32=pack_weights(f(ff[2].weight).t()))
         self.c = FusionWeights(**{k: v.data_ptr() for k, v in self.t.items()})
 
 
-def fusion_attention_batched(x, items, kt_packed, v_packed, n_tokens, tokens_padded, fw, out=None):
+def fusion_attention_batched(x, items, kt_packed, v_packed, n_tokens, tokens_padded, fw, out=None, flags=None, variant=None):
     """Rows [row0, row0+rows) of x for every (row0, rows) in `items` attend to image b's packed K^T / V
-    (lists, one per item): imf_fusion_attention_batched."""
+    (lists, one per item): imf_fusion_attention_batched_v.  flags: device int32[1] that receives IMF_FLAG_RANGE when a
+    value feeding an f16 operand leaves the f16 range (None: not observed); variant: arithmetic of the feed-forward (6
+    split-f16, 0 fp32 MFMA; default: the process-wide CONV_VARIANT, so that the fp32 recompute is fp32 throughout)."""
     _req(x, torch.float32, "x", 2)
     if out is None:
         out = torch.empty_like(x)
+    if variant is None:
+        variant = 6 if CONV_VARIANT == 6 else 0
     B = len(items)
     L = _lib.lib()
     r0 = (C.c_int64 * B)(*[int(a) for a, _ in items])
@@ -600,21 +626,14 @@ def fusion_attention_batched(x, items, kt_packed, v_packed, n_tokens, tokens_pad
     vp = (C.c_void_p * B)(*[t.data_ptr() for t in v_packed])
     nbytes = L.imf_fusion_workspace_bytes(x.shape[0])
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
-    check(L.imf_fusion_attention_batched(x.data_ptr(), B, r0, rn, kp, vp, int(n_tokens), int(tokens_padded),
-                                         C.byref(fw.c), C.c_float(fw.scale), out.data_ptr(), ws.data_ptr(), nbytes,
-                                         _stream()), "imf_fusion_attention_batched")
+    check(L.imf_fusion_attention_batched_v(x.data_ptr(), B, r0, rn, kp, vp, int(n_tokens), int(tokens_padded),
+                                           C.byref(fw.c), C.c_float(fw.scale), out.data_ptr(), ws.data_ptr(), nbytes,
+                                           _ptr(flags), int(variant), _stream()), "imf_fusion_attention_batched")
     return out
 
 
-def fusion_attention(x, kt_packed, v_packed, n_tokens, tokens_padded, fw, out=None):
-    """x [n,256] -> [n,256]: imf_fusion_attention (attention kernel + the two feed-forward GEMMs on the conv kernels)."""
-    _req(x, torch.float32, "x", 2)
-    if out is None:
-        out = torch.empty_like(x)
-    L = _lib.lib()
-    nbytes = L.imf_fusion_workspace_bytes(x.shape[0])
-    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
-    check(L.imf_fusion_attention(x.data_ptr(), x.shape[0], kt_packed.data_ptr(), v_packed.data_ptr(),
-                                 int(n_tokens), int(tokens_padded), C.byref(fw.c), C.c_float(fw.scale),
-                                 out.data_ptr(), ws.data_ptr(), nbytes, _stream()), "imf_fusion_attention")
-    return out
+def fusion_attention(x, kt_packed, v_packed, n_tokens, tokens_padded, fw, out=None, flags=None, variant=None):
+    """x [n,256] -> [n,256]: the fusion block for one image (attention kernel + the two feed-forward GEMMs on the conv
+    kernels); flags / variant as in `fusion_attention_batched`."""
+    return fusion_attention_batched(x, [(0, x.shape[0])], [kt_packed], [v_packed], n_tokens, tokens_padded, fw, out=out,
+                                    flags=flags, variant=variant)

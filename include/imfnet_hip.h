@@ -391,6 +391,10 @@ int imf_conv_first_bitgrid_dyn(const int32_t *coords, int64_t n_cap, const int32
  * workspace: imf_fusion_workspace_bytes(n) bytes, 16-byte aligned (y, LN2(y) and the GEGLU hidden, 6 KB per row). */
 typedef struct imf_fusion_weights {
   const float *ln1_g, *ln1_b, *wq_p, *wo_p, *bo, *ln2_g, *ln2_b, *w1_p, *b1, *w2_p, *b2;
+  /* the same two feed-forward matrices as fp32 imf_pack_weights images (same column order), or NULL: what the block
+   * multiplies when the network runs on variant 0 -- the fp32 recompute of a fragment whose activations left the f16
+   * range must not pass through f16 operands anywhere (the attention half is fp32 MFMA in either case) */
+  const float *w1_f32, *w2_f32;
 } imf_fusion_weights;
 /* Workspace of the block's three launches (attention half -> GEGLU GEMM -> output GEMM): 6 KB per row. */
 size_t imf_fusion_workspace_bytes(int64_t n);
@@ -404,6 +408,13 @@ int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *ite
                                  const float *const *kt_packed, const float *const *v_packed, int n_tokens,
                                  int tokens_padded, const imf_fusion_weights *w /* [host] */, float scale, float *out,
                                  void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the arithmetic of the feed-forward chosen (variant 6: split-f16 images w1_p / w2_p; variant 0: fp32 MFMA on
+ * w1_f32 / w2_f32) and a flag word (device int32, may be NULL; caller zeroes) that receives IMF_FLAG_RANGE when a value
+ * that feeds an f16 operand -- LN2's output, the GEGLU hidden, the block's output -- is NaN or >= 65504 in magnitude. */
+int imf_fusion_attention_batched_v(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
+                                   const float *const *kt_packed, const float *const *v_packed, int n_tokens,
+                                   int tokens_padded, const imf_fusion_weights *w /* [host] */, float scale, float *out,
+                                   void *workspace, size_t workspace_bytes, int32_t *flags, int variant, void *stream);
 
 typedef struct imf_net_conv {          /* static half of one fused convolution */
   const float *w_packed;               /* imf_pack_weights / imf_pack_weights_split16 image (see variant) */

@@ -104,7 +104,7 @@ def test_bench_workload_pair_capacity_mode_vs_oracle(seeded_sd):
     import bench
     import imf_oracle_cbind as OC
     dev = torch.device("cuda:0")
-    model, sd = bench.build_model(O, dev)
+    model, sd = bench.build_model(dev)
     pts, imgs = bench.load_pair(1.7)
     wl = bench.Workload(model, dev, pts, imgs, 0.025)
     with torch.no_grad():
@@ -202,3 +202,23 @@ def test_kitti_like_fragment_voxel_30cm(seeded_sd):
     assert m.fragment_runner().stats["eager"] + m.fragment_runner().stats["graph"] >= 1
     Fr = O.resunet_forward(seeded_sd, coords, img, geometry=OC.Geometry(coords))
     assert (F.cpu() - Fr).abs().max() < 1e-4
+
+
+def test_extract_features_numpy_points_with_a_device_image(clouds, images, seeded_sd):
+    """util/misc.py:97 takes a host point array next to a device image (torch.as_tensor); on a warm runner this
+    mix goes through the device-staging branch of the capacity path."""
+    from imfnet_amd.extract import extract_features
+    from imfnet_amd.model import load_model
+    model_s = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    model_s.load_state_dict(seeded_sd, strict=True)
+    model_s = model_s.eval().cuda()
+    dev = torch.device("cuda:0")
+    xyz = clouds[0][::3].astype(np.float64)
+    with torch.no_grad():
+        xd0, F0 = extract_features(model_s, xyz, voxel_size=0.05, device=dev, skip_check=True, image=images[0])
+        xd1, F1 = extract_features(model_s, xyz, voxel_size=0.05, device=dev, skip_check=True,
+                                   image=torch.as_tensor(images[0]).to(dev))      # warm runner, CUDA image
+        xd2, F2 = extract_features(model_s, torch.as_tensor(xyz).to(dev), voxel_size=0.05, device=dev, skip_check=True,
+                                   image=images[0])                                # CUDA points, host image
+    assert (xd0 == xd1).all() and (xd0 == xd2).all()
+    assert torch.equal(F0, F1) and torch.equal(F0, F2)

@@ -561,6 +561,40 @@ def test_fused_fusion_kernel_matches_reference_module(ops, model, golden):
     assert (out - ref_torch).abs().max() < 5e-5
     out2 = ops.fusion_attention(x, ops.pack_weights(kt), ops.pack_weights(vp), 300, 320, fw)
     assert torch.equal(out, out2)                                       # deterministic
+    # the fp32-MFMA feed-forward (variant 0: what the f16-range recompute runs) on the fp32 images of the same matrices
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out0 = ops.fusion_attention(x, ops.pack_weights(kt), ops.pack_weights(vp), 300, 320, fw, flags=flags, variant=0)
+    assert np.abs(out0.cpu().numpy() - golden["af_out"]).max() < 5e-5 and int(flags.item()) == 0
+    assert (out0 - out).abs().max() < 5e-6
+
+
+def test_fusion_range_flag_in_both_variants(ops, model, golden):
+    """the feed-forward's f16 range guard is armed whatever the plan's variant.  Rows scaled until the GEGLU
+    hidden passes 65504: variant 6 must raise IMF_FLAG_RANGE (its operands would be inf); variant 0 raises it too (its
+    output would feed conv4_tr's f16 operands) but computes finite fp32 values."""
+    fw = model._fusion_weights()
+    x = torch.as_tensor(golden["af_in"]).to(DEV)
+    ctx = torch.as_tensor(golden["af_ctx"]).to(DEV)
+    blk = model.attention_fusion.cross_attend_blocks[0]
+    ff = model.attention_fusion.cross_attend_blocks[1].fn.net
+    with torch.no_grad():
+        kv = blk.fn.to_kv(blk.norm_context(ctx))
+        kt = torch.zeros(128, 320, device=DEV); kt[:, :300] = kv[:, :128].t()
+        vp = torch.zeros(320, 128, device=DEV); vp[:300] = kv[:, 128:]
+        w0, b0 = ff[0].weight.clone(), ff[0].bias.clone()
+        try:
+            ff[0].weight.mul_(3000.0); ff[0].bias.mul_(3000.0)            # hidden ~ 1e7 * gelu
+            from imfnet_amd.ops import FusionKernelWeights
+            big = FusionKernelWeights(model.attention_fusion)
+            for variant in (6, 0):
+                flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+                out = ops.fusion_attention(x, ops.pack_weights(kt), ops.pack_weights(vp), 300, 320, big, flags=flags,
+                                           variant=variant)
+                assert int(flags.item()) & 32, f"variant {variant}: no range flag"
+                if variant == 0:
+                    assert torch.isfinite(out).all()
+        finally:
+            ff[0].weight.copy_(w0); ff[0].bias.copy_(b0)
 
 
 def test_forward_matches_reference_golden_S5(model, clouds, images, golden):

@@ -212,3 +212,14 @@ def test_cpu_conv_twin_matches_the_torch_restatement(clouds):
     finally:
         O.SPCONV_IMPL = "torch"
     assert float((F_t - F_c).abs().max()) < 2e-6
+
+
+def test_product_side_seeded_weights_equal_the_oracles():
+    """bench.py and the tools take their seeded weights from imfnet_amd/seeded.py (the product side never imports the
+    oracle); the checks take theirs from the oracle: "seed s" must be the same network on both sides."""
+    import torch
+    from imfnet_amd.seeded import seeded_state_dict
+    for kw in (dict(seed=0, with_unused_image_layers=True), dict(seed=3, conv1_kernel_size=3)):
+        a, b = O.seeded_state_dict(**kw), seeded_state_dict(**kw)
+        assert list(a) == list(b)
+        assert all(a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]) for k in a)

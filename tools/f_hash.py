@@ -7,7 +7,7 @@ import numpy as np, torch
 import imf_oracle as O
 import bench
 dev = torch.device("cuda:0")
-model, sd = bench.build_model(O, dev)
+model, sd = bench.build_model(dev)
 pts, imgs = bench.load_pair(1.7)
 wl = bench.Workload(model, dev, pts, imgs, 0.025)
 with torch.no_grad():

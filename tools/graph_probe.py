@@ -6,7 +6,7 @@ import numpy as np, torch
 import imf_oracle as O
 import bench as B
 dev = torch.device("cuda:0")
-model, sd = B.build_model(O, dev)
+model, sd = B.build_model(dev)
 batch = int(os.environ.get("BATCH", "2"))
 pts, imgs = B.load_pair(1.7) if batch == 2 else ([B.load_workload(1.7, 0.025)[0]], B.load_workload(1.7, 0.025)[1])
 sync = torch.cuda.synchronize

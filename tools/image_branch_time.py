@@ -8,7 +8,7 @@ import numpy as np, torch
 import imf_oracle as O
 import bench
 dev = torch.device("cuda:0")
-model, sd = bench.build_model(O, dev)
+model, sd = bench.build_model(dev)
 pts, imgs = bench.load_pair(1.7)
 img = torch.as_tensor(np.asarray(imgs, dtype=np.float32)).to(dev).contiguous()
 with torch.no_grad():

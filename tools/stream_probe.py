@@ -18,7 +18,7 @@ import imf_oracle as O
 from imfnet_amd.extract import extract_features, extract_features_stream
 xyz, img, voxel = load_workload(1.7, 0.025)
 xyz = xyz.astype(np.float32 if args.f32 else np.float64)
-model, sd = build_model(O, dev)
+model, sd = build_model(dev)
 with torch.no_grad():
     model.fragment_runner().streamer(dev, n_buckets=args.buckets, sdma_copies=None if args.sdma < 0 else bool(args.sdma), copy_blocks=args.blocks)
     xd0, F0 = extract_features(model, xyz, voxel_size=voxel, device=dev, skip_check=True, image=img)   # exact path: teaches the runner

@@ -10,7 +10,7 @@ import imf_oracle as O
 import bench
 from imfnet_amd.model.graph import FragmentRunner
 dev = torch.device("cuda:0")
-model, sd = bench.build_model(O, dev)
+model, sd = bench.build_model(dev)
 pts, imgs = bench.load_pair(1.7)
 with torch.no_grad():
     lanes = []
