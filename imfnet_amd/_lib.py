@@ -161,6 +161,8 @@ SIGNATURES = {
     "imf_resize_bilinear_f32": (_I, [_P, _I, _I, _I, _P, _I, _I, _I]),
     "imf_npz_write": (_I, [C.c_char_p, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
                            C.POINTER(C.c_int64), C.POINTER(C.c_void_p), _I]),
+    "imf_npz_write_mt": (_I, [C.c_char_p, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
+                              C.POINTER(C.c_int64), C.POINTER(C.c_void_p), _I, _I]),
     "imf_stream_create": (_P, []),
     "imf_stream_destroy": (None, [_P]),
     "imf_event_create": (_P, []),

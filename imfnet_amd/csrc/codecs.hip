@@ -13,9 +13,11 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -319,18 +321,31 @@ int imf_resize_bilinear_f32(const float *in, int H, int W, int C, float *out, in
  * names[i]: member name without ".npy"; dtype[i]: numpy descr string ("<f8", "<f4", "<i4", ...); shape: ndim[i] dims each,
  * concatenated; data[i]: host pointers; level: 0 = stored (np.savez), 1..9 = raw deflate at that zlib level
  * (np.savez_compressed uses 6; 1 is ~4x faster for a few percent more bytes).  np.load reads either; the arrays are
- * identical.  Members must stay below 4 GiB (no ZIP64). */
-int imf_npz_write(const char *path, int n_arrays, const char *const *names, const char *const *dtype, const int32_t *ndim,
-                  const int64_t *shape, const void *const *data, int level) {
+ * identical.  Members must stay below 4 GiB (no ZIP64).
+ * threads > 1: BLOCK-PARALLEL deflate -- a member's bytes are cut into 256 KiB blocks, every block becomes an independent
+ * raw-deflate segment that ends on a byte boundary (Z_SYNC_FLUSH; the last one Z_FINISH), the segments are concatenated
+ * (a valid deflate stream: what pigz writes) and the CRC-32s of the blocks are combined (crc32_combine).  The file's bytes
+ * are a function of the arrays and `level` only -- the blocks and the per-member strategy never depend on `threads`.  The
+ * reference's np.savez_compressed of ~14 MB per fragment is ~0.5 s of one core -- eight GPUs' worth of fragments need it
+ * spread. */
+int imf_npz_write_mt(const char *path, int n_arrays, const char *const *names, const char *const *dtype, const int32_t *ndim,
+                     const int64_t *shape, const void *const *data, int level, int threads) {
   return guarded<int>("imf_npz_write", [&]() -> int {
   IMF_REQUIRE(path && names && dtype && ndim && shape && data && n_arrays > 0 && level >= 0 && level <= 9,
               "imf_npz_write: bad argument");
-  File fh(path, "wb");
-  IMF_REQUIRE(fh.f, "imf_npz_write: cannot create %s (%s)", path, strerror(errno));
-  std::vector<unsigned char> central;
-  std::vector<unsigned char> comp;
-  uint32_t offset = 0;
+  threads = threads < 1 ? 1 : (threads > 256 ? 256 : threads);
+  constexpr size_t kBlock = 256 << 10;
+  struct Member {
+    std::vector<unsigned char> head;   // the .npy header
+    const unsigned char *src; size_t nbytes; uint32_t usize; int strategy; size_t first_block, n_blocks;
+  };
+  struct Block { int member; size_t lo, len, out_at, out_cap, used; uLong crc; size_t in_len; int rc; };
+  std::vector<Member> mem((size_t)n_arrays);
+  std::vector<Block> blocks;
+  size_t arena_bytes = 0;
   const int64_t *sh = shape;
+
+  // ---- phase 1 (this thread): headers, the per-member strategy, the block list ---------------------------------------
   for (int i = 0; i < n_arrays; ++i) {
     // numeric / bool descrs only ("<f8", "<i4", "|u1", "|b1" ...): the digits are the item size.  Strings ("<U7": 4 bytes
     // per character, "|S3") and anything else are refused -- the caller writes such arrays with numpy
@@ -347,54 +362,139 @@ int imf_npz_write(const char *path, int n_arrays, const char *const *names, cons
     }
     shp += ")";
     sh += ndim[i];
-    const size_t nbytes = count * (size_t)itemsize;
-    IMF_REQUIRE(nbytes < (1ull << 32) - 256, "imf_npz_write: member %s too large", names[i]);
+    Member &m = mem[(size_t)i];
+    m.nbytes = count * (size_t)itemsize;
+    IMF_REQUIRE(m.nbytes < (1ull << 32) - 256, "imf_npz_write: member %s too large", names[i]);
+    IMF_REQUIRE(data[i] || m.nbytes == 0, "imf_npz_write: member %s has no data", names[i]);
     std::string hdr = std::string("{'descr': '") + dtype[i] + "', 'fortran_order': False, 'shape': " + shp + ", }";
     const size_t unpadded = 10 + hdr.size() + 1;
     hdr.append((64 - unpadded % 64) % 64, ' ');
     hdr += '\n';
-    std::vector<unsigned char> npy_head = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
-    put16(npy_head, (uint32_t)hdr.size());
-    npy_head.insert(npy_head.end(), hdr.begin(), hdr.end());
-    const uint32_t usize = (uint32_t)(npy_head.size() + nbytes);
-    uLong crc = crc32(0L, Z_NULL, 0);
-    crc = crc32(crc, npy_head.data(), (uInt)npy_head.size());
-    const unsigned char *src = (const unsigned char *)data[i];
-    for (size_t done = 0; done < nbytes;) {               // crc32 takes 32-bit lengths
-      const size_t chunk = nbytes - done < (1u << 30) ? nbytes - done : (1u << 30);
-      crc = crc32(crc, src + done, (uInt)chunk);
-      done += chunk;
+    m.head = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+    put16(m.head, (uint32_t)hdr.size());
+    m.head.insert(m.head.end(), hdr.begin(), hdr.end());
+    m.usize = (uint32_t)(m.head.size() + m.nbytes);
+    m.src = (const unsigned char *)data[i];
+    // Strategy per member, decided by the data alone (never by `threads`: the file's bytes do not depend on it): a probe
+    // deflates the array's first 64 KiB; when LZ77 finds next to nothing (float32 descriptors: 0.93 of the input at 25 MB/s
+    // per core) the member is Huffman-coded only (the same 0.93 at ~95 MB/s); point arrays (0.2 at ~110 MB/s) keep it.
+    m.strategy = Z_DEFAULT_STRATEGY;
+    if (level > 0 && m.nbytes >= (64 << 10)) {
+      z_stream ps;
+      memset(&ps, 0, sizeof(ps));
+      IMF_REQUIRE(deflateInit2(&ps, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK, "imf_npz_write: deflateInit2");
+      std::vector<unsigned char> tmp(deflateBound(&ps, 64 << 10) + 64);
+      ps.next_in = const_cast<unsigned char *>(m.src); ps.avail_in = 64 << 10;
+      ps.next_out = tmp.data(); ps.avail_out = (uInt)tmp.size();
+      const int prc = deflate(&ps, Z_FINISH);
+      const size_t got = (size_t)ps.total_out;
+      deflateEnd(&ps);
+      if (prc == Z_STREAM_END && got * 100 > (size_t)(64 << 10) * 85) m.strategy = Z_HUFFMAN_ONLY;
     }
-    uint32_t csize = usize;
-    const unsigned char *payload_head = npy_head.data();
-    if (level > 0) {
-      z_stream zs;
-      memset(&zs, 0, sizeof(zs));
-      IMF_REQUIRE(deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK, "imf_npz_write: deflateInit2");
-      comp.resize(deflateBound(&zs, usize) + 64);
-      zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
-      zs.next_in = npy_head.data(); zs.avail_in = (uInt)npy_head.size();
-      int rc = deflate(&zs, Z_NO_FLUSH);
-      zs.next_in = const_cast<unsigned char *>(src); zs.avail_in = (uInt)nbytes;
-      if (rc == Z_OK) rc = deflate(&zs, Z_FINISH);
-      csize = (uint32_t)zs.total_out;
-      deflateEnd(&zs);
-      IMF_REQUIRE(rc == Z_STREAM_END, "imf_npz_write: deflate failed (%d)", rc);
+    // block b covers [b * kBlock, ...) of the array's bytes; block 0 is preceded by the .npy header
+    m.first_block = blocks.size();
+    m.n_blocks = m.nbytes ? (m.nbytes + kBlock - 1) / kBlock : 1;
+    for (size_t bi = 0; bi < m.n_blocks; ++bi) {
+      Block bl;
+      memset(&bl, 0, sizeof(bl));
+      bl.member = i;
+      bl.lo = bi * kBlock;
+      bl.len = m.nbytes - bl.lo < kBlock ? m.nbytes - bl.lo : kBlock;
+      bl.in_len = bl.len + (bi == 0 ? m.head.size() : 0);
+      bl.out_cap = level > 0 ? bl.in_len + bl.in_len / 512 + 256 : 0;   // >= deflateBound for raw deflate + the sync marker
+      bl.out_at = arena_bytes;
+      arena_bytes += bl.out_cap;
+      blocks.push_back(bl);
     }
+  }
+
+  // ---- phase 2 (all threads): CRC-32 and one raw-deflate segment per block, into slices of ONE arena --------------------
+  // The arena belongs to the calling thread and is kept between calls (writer threads call this file after file): a fresh
+  // 14 MB buffer per file, or a 256 KiB one per block, is an mmap + page faults + munmap per allocation, and with a hundred
+  // threads doing it the kernel's address-space lock -- not zlib -- set the rate (measured: 128 writers x 1 thread 8x slower
+  // per file than one writer alone).
+  static thread_local std::vector<unsigned char> arena;
+  if (arena.size() < arena_bytes) arena.resize(arena_bytes + arena_bytes / 4);
+  unsigned char *const out0 = arena.data();
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    z_stream zs;
+    bool live = false;
+    for (size_t b = next.fetch_add(1); b < blocks.size(); b = next.fetch_add(1)) {
+      Block &bl = blocks[b];
+      const Member &m = mem[(size_t)bl.member];
+      const bool first = bl.lo == 0, last = b + 1 == m.first_block + m.n_blocks;
+      uLong crc = crc32(0L, Z_NULL, 0);
+      if (first) crc = crc32(crc, m.head.data(), (uInt)m.head.size());
+      if (bl.len) crc = crc32(crc, m.src + bl.lo, (uInt)bl.len);
+      bl.crc = crc;
+      bl.rc = Z_OK;
+      if (level == 0) continue;
+      if (!live) {
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, m.strategy) != Z_OK) { bl.rc = Z_MEM_ERROR; continue; }
+        live = true;
+      } else if (deflateReset(&zs) != Z_OK) {
+        bl.rc = Z_STREAM_ERROR;
+        continue;
+      }
+      zs.next_out = out0 + bl.out_at; zs.avail_out = (uInt)bl.out_cap;
+      zs.next_in = const_cast<unsigned char *>(m.head.data()); zs.avail_in = 0;
+      int rc = deflateParams(&zs, level, m.strategy);            // (no input consumed yet: only switches the strategy)
+      if (rc == Z_OK && first) {
+        zs.next_in = const_cast<unsigned char *>(m.head.data()); zs.avail_in = (uInt)m.head.size();
+        rc = deflate(&zs, Z_NO_FLUSH);
+      }
+      zs.next_in = const_cast<unsigned char *>(m.src + bl.lo); zs.avail_in = (uInt)bl.len;
+      if (rc == Z_OK) rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+      bl.rc = (last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0 && zs.avail_out > 0)) ? Z_OK : Z_STREAM_ERROR;
+      bl.used = (size_t)zs.total_out;
+    }
+    if (live) deflateEnd(&zs);
+  };
+  {
+    const int extra = (int)(blocks.size() < (size_t)threads ? blocks.size() : (size_t)threads) - 1;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < extra; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+  }
+
+  // ---- phase 3 (this thread): the ZIP file -----------------------------------------------------------------------------
+  File fh(path, "wb");
+  IMF_REQUIRE(fh.f, "imf_npz_write: cannot create %s (%s)", path, strerror(errno));
+  std::vector<unsigned char> central;
+  uint32_t offset = 0;
+  for (int i = 0; i < n_arrays; ++i) {
+    const Member &m = mem[(size_t)i];
+    uLong crc = 0;
+    size_t csize64 = 0;
+    for (size_t b = m.first_block; b < m.first_block + m.n_blocks; ++b) {
+      IMF_REQUIRE(blocks[b].rc == Z_OK, "imf_npz_write: deflate failed in block %zu of %s", b - m.first_block, names[i]);
+      crc = b == m.first_block ? blocks[b].crc : crc32_combine(crc, blocks[b].crc, (z_off_t)blocks[b].in_len);
+      csize64 += blocks[b].used;
+    }
+    IMF_REQUIRE(level == 0 || csize64 < (1ull << 32) - 256, "imf_npz_write: member %s too large", names[i]);
+    const uint32_t csize = level > 0 ? (uint32_t)csize64 : m.usize;
     const std::string fname = std::string(names[i]) + ".npy";
     std::vector<unsigned char> local;
     put32(local, 0x04034b50); put16(local, 20); put16(local, 0); put16(local, level > 0 ? 8 : 0);
     put16(local, 0); put16(local, 0x21);                                  // time / date (1980-01-01)
-    put32(local, (uint32_t)crc); put32(local, csize); put32(local, usize);
+    put32(local, (uint32_t)crc); put32(local, csize); put32(local, m.usize);
     put16(local, (uint32_t)fname.size()); put16(local, 0);
     local.insert(local.end(), fname.begin(), fname.end());
     bool ok = fwrite(local.data(), 1, local.size(), fh.f) == local.size();
-    if (level > 0) ok = ok && fwrite(comp.data(), 1, csize, fh.f) == csize;
-    else ok = ok && fwrite(payload_head, 1, npy_head.size(), fh.f) == npy_head.size() && fwrite(src, 1, nbytes, fh.f) == nbytes;
+    if (level > 0) {
+      for (size_t b = m.first_block; b < m.first_block + m.n_blocks && ok; ++b)
+        ok = fwrite(out0 + blocks[b].out_at, 1, blocks[b].used, fh.f) == blocks[b].used;
+    } else {
+      ok = ok && fwrite(m.head.data(), 1, m.head.size(), fh.f) == m.head.size() &&
+           (m.nbytes == 0 || fwrite(m.src, 1, m.nbytes, fh.f) == m.nbytes);
+    }
     IMF_REQUIRE(ok, "imf_npz_write: short write to %s", path);
     put32(central, 0x02014b50); put16(central, 20); put16(central, 20); put16(central, 0); put16(central, level > 0 ? 8 : 0);
     put16(central, 0); put16(central, 0x21);
-    put32(central, (uint32_t)crc); put32(central, csize); put32(central, usize);
+    put32(central, (uint32_t)crc); put32(central, csize); put32(central, m.usize);
     put16(central, (uint32_t)fname.size()); put16(central, 0); put16(central, 0); put16(central, 0); put16(central, 0);
     put32(central, 0); put32(central, offset);
     central.insert(central.end(), fname.begin(), fname.end());
@@ -408,6 +508,11 @@ int imf_npz_write(const char *path, int n_arrays, const char *const *names, cons
   IMF_REQUIRE(fh.close(), "imf_npz_write: flush / close of %s failed (%s)", path, strerror(errno));
   return IMF_OK;
   });
+}
+
+int imf_npz_write(const char *path, int n_arrays, const char *const *names, const char *const *dtype, const int32_t *ndim,
+                  const int64_t *shape, const void *const *data, int level) {
+  return imf_npz_write_mt(path, n_arrays, names, dtype, ndim, shape, data, level, 1);
 }
 
 }  // extern "C"

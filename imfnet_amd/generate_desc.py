@@ -326,8 +326,12 @@ def main(argv=None):
     p.add_argument("--extract_features", default=True, action="store_true")
     p.add_argument("--with_cuda", default=True, action="store_true")
     p.add_argument("--gather", action="store_true", help="multi-GPU: gather descriptors on rank 0 (RCCL)")
-    p.add_argument("--workers", type=int, default=4,
-                   help="loader / writer threads around the GPU (0 = the reference's sequential order)")
+    p.add_argument("--workers", type=int, default=None,
+                   help="loader / writer threads around the GPU (0 = the reference's sequential order; default: from "
+                        "os.cpu_count() // world_size -- 4..16)")
+    p.add_argument("--npz_threads", type=int, default=None,
+                   help="host threads of ONE descriptor file's block-parallel deflate (imf_npz_write_mt; default: from "
+                        "os.cpu_count() // world_size // workers -- 1..16, or $IMFNET_NPZ_THREADS)")
     p.add_argument("--npz_level", type=int, default=None,
                    help="zlib level of the descriptor files: 0 = stored (np.savez), 1..9 deflate (np.savez_compressed is "
                         "6); default 1 or $IMFNET_NPZ_LEVEL.  np.load returns identical arrays either way")
@@ -335,10 +339,18 @@ def main(argv=None):
                    help="no checkpoint: random weights from this seed (plumbing / benchmarking)")
     args = p.parse_args(argv)
 
+    from . import dataio
     if args.npz_level is not None:
-        from . import dataio
         dataio.NPZ_LEVEL = args.npz_level
     rank, world, local = idist.init_from_env("nccl")
+    # host threads: this rank's share of the box ("bound by host-side decode long before xGMI")
+    share = max(1, (os.cpu_count() or 1) // max(1, world))
+    if args.workers is None:
+        args.workers = max(4, min(16, share // 16))
+    if args.npz_threads is not None:
+        dataio.NPZ_THREADS = max(1, args.npz_threads)
+    elif dataio.NPZ_THREADS <= 0:
+        dataio.NPZ_THREADS = max(1, min(16, share // (2 * max(1, args.workers))))
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     ensure_dir(args.target)

@@ -745,6 +745,11 @@ int imf_resize_bilinear_f32(const float *in, int H, int W, int C, float *out, in
  * file; the arrays are identical to numpy's own writers'. */
 int imf_npz_write(const char *path, int n_arrays, const char *const *names, const char *const *dtype,
                   const int32_t *ndim, const int64_t *shape, const void *const *data, int level);
+/* The same with block-parallel deflate on `threads` host threads (256 KiB blocks as independent raw-deflate segments that
+ * end on a byte boundary, concatenated; CRC-32s combined): the bytes differ from the single-threaded file's, the arrays
+ * np.load returns do not.  threads <= 1 is imf_npz_write.  scripts/generate_desc.py:118-123 at the rate of eight GPUs. */
+int imf_npz_write_mt(const char *path, int n_arrays, const char *const *names, const char *const *dtype,
+                     const int32_t *ndim, const int64_t *shape, const void *const *data, int level, int threads);
 
 /* Measurement helpers (bench.py): HIP events on the caller's stream. */
 void *imf_stream_create(void);     /* non-blocking hipStream_t, distinct from any framework pool stream */

@@ -60,6 +60,61 @@ def test_conv_args_struct_matches_header_layout():
     assert names == [f[0] for f in ConvArgs._fields_]
 
 
+def _struct_fields(name):
+    text = open(os.path.join(ROOT, "include", "imfnet_hip.h")).read()
+    body = text[text.index("typedef struct %s {" % name):text.index("} %s;" % name)]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [n.strip(" *") for n in re.sub(r"^(const\s+)?\w+\s", "", decl).split(",")]
+    return names
+
+
+def test_pipeline_job_and_fusion_weight_structs_match_the_header():
+    """ctypes mirrors of struct imf_job (the streaming pipeline) and imf_fusion_weights (fp32 feed-forward images added in
+    round 4): field order / count tracks the header."""
+    from imfnet_amd._lib import FusionWeights, Job
+    assert _struct_fields("imf_job") == [f[0] for f in Job._fields_]
+    assert _struct_fields("imf_fusion_weights") == [f[0] for f in FusionWeights._fields_]
+
+
+def test_host_narrow_points_is_exact_or_refuses():
+    """imf_host_narrow_points (host code, no GPU): float64 values that are float32 values narrow bit-exactly; one value
+    that is not makes the call refuse (return 0); NaNs travel; odd lengths (the tail loop) too."""
+    from imfnet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 7, 8, 9, 100003):
+        a = rng.normal(size=n).astype(np.float32).astype(np.float64)
+        d = np.full(n, 7.0, np.float32)
+        assert L.imf_host_narrow_points(a.ctypes.data, n, d.ctypes.data) == 1
+        assert (d.astype(np.float64) == a).all()
+        if n:
+            b = a.copy()
+            b[n // 2] += 1e-12 if b[n // 2] != 0 else 1e-300
+            assert L.imf_host_narrow_points(b.ctypes.data, n, d.ctypes.data) == 0
+            c = a.copy()
+            c[n - 1] = np.nan
+            assert L.imf_host_narrow_points(c.ctypes.data, n, d.ctypes.data) == 1 and np.isnan(d[n - 1])
+    big = np.array([1e300, -1e300, 3.5], np.float64)              # beyond float32: inf after narrowing, not equal
+    assert L.imf_host_narrow_points(big.ctypes.data, 3, np.empty(3, np.float32).ctypes.data) == 0
+
+
+def test_package_import_prepares_the_runtime_for_async_copies():
+    """Importing imfnet_amd before the HIP runtime starts sets ROC_CPU_WAIT_FOR_SIGNAL=0 (hipMemcpyAsync behind queued
+    kernels must not block the pipeline's worker); a value the user set is left alone and decides SDMA_ASYNC."""
+    import subprocess
+    import sys
+    code = "import os, imfnet_amd; print(os.environ.get('ROC_CPU_WAIT_FOR_SIGNAL'), imfnet_amd.SDMA_ASYNC)"
+    env = {k: v for k, v in os.environ.items() if k != "ROC_CPU_WAIT_FOR_SIGNAL"}
+    env["PYTHONPATH"] = ROOT
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split() == ["0", "True"]
+    env["ROC_CPU_WAIT_FOR_SIGNAL"] = "1"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split() == ["1", "False"]
+
+
 def test_errors_are_loud_without_gpu():
     from imfnet_amd import ImfError, ops
     with pytest.raises(ImfError):
@@ -393,3 +448,31 @@ def test_native_codecs_reject_corrupt_files(tmp_path, clouds):
         big = np.zeros(1 << 16)
         sh, data = (C.c_int64 * 1)(big.size), (C.c_void_p * 1)(big.ctypes.data)
         assert L.imf_npz_write(b"/dev/full", 1, names, dt, nd, sh, data, 0) == -1
+
+
+def test_npz_block_parallel_deflate_is_thread_count_independent(tmp_path):
+    """imf_npz_write_mt: np.load returns the arrays bit for bit at every level; the FILE's bytes depend on the arrays and
+    the level only, never on the number of deflate threads; a descriptor-like float32 member (incompressible for LZ77) is
+    Huffman-coded, a point-like member keeps LZ77 -- both read back; empty, scalar and sub-block members too."""
+    import zipfile
+    from imfnet_amd.dataio import save_npz
+    rng = np.random.default_rng(0)
+    pts = np.cumsum(rng.normal(size=(120000, 3)).astype(np.float32), 0).astype(np.float64)      # 2.9 MB, compressible
+    F = rng.normal(size=(30000, 32)).astype(np.float32)                                         # 3.8 MB, not
+    arrays = dict(points=pts, xyz=pts[::7].copy(), feature=F, empty=np.zeros((0, 3)), one=np.float32(2.5).reshape(()),
+                  small=np.arange(1000, dtype=np.int32), edge=np.arange(256 << 10, dtype=np.uint8))
+    ref = {}
+    for level in (0, 1, 6):
+        for threads in (1, 3, 8):
+            path = str(tmp_path / f"l{level}_t{threads}.npz")
+            save_npz(path, level=level, threads=threads, **arrays)
+            z = np.load(path)
+            assert set(z.files) == set(arrays)
+            for k, a in arrays.items():
+                assert z[k].dtype == a.dtype and z[k].shape == a.shape and (z[k] == a).all(), (level, threads, k)
+            assert zipfile.ZipFile(path).testzip() is None
+            data = open(path, "rb").read()
+            assert ref.setdefault(level, data) == data, f"level {level}: bytes differ with {threads} threads"
+    info = {i.filename: i for i in zipfile.ZipFile(str(tmp_path / "l1_t8.npz")).infolist()}
+    assert info["points.npy"].compress_size < 0.8 * info["points.npy"].file_size
+    assert info["feature.npy"].compress_size < info["feature.npy"].file_size
