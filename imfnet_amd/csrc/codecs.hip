@@ -13,7 +13,12 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -72,6 +77,86 @@ inline int paeth(int a, int b, int c) {
   const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
   return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
+
+// Helper threads of the block-parallel deflate: ONE pool per process, grown on demand and kept.  A std::thread per call was
+// measured to cap the box at ~300 files/s however the writers x threads were split (every thread start maps and unmaps an
+// 8 MiB stack: the same address-space lock as the per-block buffers before them).
+class DeflatePool {
+ public:
+  ~DeflatePool() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (std::thread &t : threads_) t.join();
+  }
+  // run `fn` on up to `helpers` pool threads beside the caller; returns when every started copy has returned
+  void run(int helpers, const std::function<void()> &fn) {
+    struct Latch { std::mutex m; std::condition_variable c; int left; } latch;
+    latch.left = 0;
+    if (helpers > 0) {
+      std::lock_guard<std::mutex> g(mu_);
+      const unsigned cap = std::max(1u, std::thread::hardware_concurrency());
+      while ((int)threads_.size() < helpers && threads_.size() < cap) threads_.emplace_back([this] { loop(); });
+      helpers = std::min<int>(helpers, (int)threads_.size());
+      latch.left = helpers;
+      for (int i = 0; i < helpers; ++i)
+        queue_.push_back([&fn, &latch] {
+          fn();
+          std::lock_guard<std::mutex> g2(latch.m);
+          if (--latch.left == 0) latch.c.notify_one();
+        });
+    }
+    if (helpers > 0) cv_.notify_all();
+    fn();
+    std::unique_lock<std::mutex> lk(latch.m);
+    latch.c.wait(lk, [&] { return latch.left == 0; });
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    while (true) {
+      cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+      if (queue_.empty()) return;
+      std::function<void()> job = std::move(queue_.front());
+      queue_.pop_front();
+      lk.unlock();
+      job();
+      lk.lock();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> queue_;
+  std::vector<std::thread> threads_;
+  bool stop_ = false;
+};
+DeflatePool &deflate_pool() {
+  static DeflatePool pool;
+  return pool;
+}
+
+// One deflate state per thread, kept between blocks, members and files (deflateInit2 allocates ~270 KiB: mmap territory).
+struct ThreadDeflate {
+  z_stream zs;
+  bool live = false;
+  ~ThreadDeflate() { if (live) deflateEnd(&zs); }
+  int begin(int level, int strategy) {
+    if (!live) {
+      memset(&zs, 0, sizeof(zs));
+      if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) != Z_OK) return Z_MEM_ERROR;
+      live = true;
+      return Z_OK;
+    }
+    if (deflateReset(&zs) != Z_OK) return Z_STREAM_ERROR;
+    zs.next_in = nullptr; zs.avail_in = 0;
+    static unsigned char sink[16];
+    zs.next_out = sink; zs.avail_out = sizeof(sink);
+    return deflateParams(&zs, level, strategy);   // nothing consumed yet: only switches level / strategy
+  }
+};
 
 void put16(std::vector<unsigned char> &v, uint32_t x) { v.push_back(x & 255); v.push_back((x >> 8) & 255); }
 void put32(std::vector<unsigned char> &v, uint32_t x) { put16(v, x & 0xFFFF); put16(v, x >> 16); }
@@ -418,8 +503,8 @@ int imf_npz_write_mt(const char *path, int n_arrays, const char *const *names, c
   unsigned char *const out0 = arena.data();
   std::atomic<size_t> next{0};
   auto work = [&]() {
-    z_stream zs;
-    bool live = false;
+    static thread_local ThreadDeflate td;
+    z_stream &zs = td.zs;
     for (size_t b = next.fetch_add(1); b < blocks.size(); b = next.fetch_add(1)) {
       Block &bl = blocks[b];
       const Member &m = mem[(size_t)bl.member];
@@ -430,35 +515,20 @@ int imf_npz_write_mt(const char *path, int n_arrays, const char *const *names, c
       bl.crc = crc;
       bl.rc = Z_OK;
       if (level == 0) continue;
-      if (!live) {
-        memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, m.strategy) != Z_OK) { bl.rc = Z_MEM_ERROR; continue; }
-        live = true;
-      } else if (deflateReset(&zs) != Z_OK) {
-        bl.rc = Z_STREAM_ERROR;
-        continue;
-      }
+      int rc = td.begin(level, m.strategy);
+      if (rc != Z_OK) { bl.rc = rc; continue; }
       zs.next_out = out0 + bl.out_at; zs.avail_out = (uInt)bl.out_cap;
-      zs.next_in = const_cast<unsigned char *>(m.head.data()); zs.avail_in = 0;
-      int rc = deflateParams(&zs, level, m.strategy);            // (no input consumed yet: only switches the strategy)
-      if (rc == Z_OK && first) {
+      if (first) {
         zs.next_in = const_cast<unsigned char *>(m.head.data()); zs.avail_in = (uInt)m.head.size();
         rc = deflate(&zs, Z_NO_FLUSH);
       }
       zs.next_in = const_cast<unsigned char *>(m.src + bl.lo); zs.avail_in = (uInt)bl.len;
       if (rc == Z_OK) rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
       bl.rc = (last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0 && zs.avail_out > 0)) ? Z_OK : Z_STREAM_ERROR;
-      bl.used = (size_t)zs.total_out;
+      bl.used = (size_t)((out0 + bl.out_at + bl.out_cap - zs.avail_out) - (out0 + bl.out_at));
     }
-    if (live) deflateEnd(&zs);
   };
-  {
-    const int extra = (int)(blocks.size() < (size_t)threads ? blocks.size() : (size_t)threads) - 1;
-    std::vector<std::thread> pool;
-    for (int t = 0; t < extra; ++t) pool.emplace_back(work);
-    work();
-    for (std::thread &t : pool) t.join();
-  }
+  deflate_pool().run((int)std::min<size_t>(blocks.size(), (size_t)threads) - 1, work);
 
   // ---- phase 3 (this thread): the ZIP file -----------------------------------------------------------------------------
   File fh(path, "wb");

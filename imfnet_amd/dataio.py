@@ -178,7 +178,7 @@ def save_npz(path, level=None, threads=None, **arrays):
     if not str(path).endswith(".npz"):
         path = str(path) + ".npz"
     names = list(arrays)
-    arrs = [np.ascontiguousarray(arrays[k]) for k in names]
+    arrs = [np.require(arrays[k], requirements='C') for k in names]      # (ascontiguousarray would make a 0-d array 1-d)
     for a in arrs:
         if a.dtype.byteorder == ">" or a.dtype.hasobject or a.dtype.fields is not None or a.dtype.kind not in "fiub":
             return np.savez_compressed(path, **arrays)        # strings / exotic dtypes: numpy's writer
