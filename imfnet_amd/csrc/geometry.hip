@@ -9,10 +9,6 @@
 
 namespace imf {
 
-#ifndef IMF_GEO_ABL
-#define IMF_GEO_ABL 0   // timing experiments only (tools/geo_ablations.sh; wrong results): k_insert_points without 1 the table atomics,
-                        // 2 the fp64 divisions (float instead), 4 the slot_of store, 8 the run-leader election (one insert per point)
-#endif
 
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 4;
@@ -75,73 +71,102 @@ __device__ __forceinline__ void block_bbox_store(int4 lo, int4 hi, int32_t *wg_b
 
 // dyn (optional, device): [0] = number of points, [1] = number of items, [2 + b] = first point of item b --
 // the per-fragment scalars of a captured launch sequence (IMF_DYN_WORDS ints).
+//
+// Voxel insert of the raw points (util/misc.py:82-87) with the keys of a WORKGROUP's 1 024 points deduplicated in LDS first
+// (round 4).  A 2.5 cm voxel holds ~5 points, but only runs of neighbours in point order share a wavefront: electing one
+// leader per run (rounds 2-3) still sent ~151 k of a 258 k-point fragment's keys to the table for 51 k voxels -- and every
+// device-scope atomic is a 64-byte line written back beyond the XCD's L2 (PMC, round 3: 62 MB per launch for 16 MB of
+// algorithmic bytes).  Here every point goes into a 2 048-slot LDS table (ds_cmpst_b64 on the key, ds_min on the point
+// index), the table's distinct keys (83 k per fragment) are inserted into the level's table once each with the workgroup's
+// smallest point index, and the points pick their global slot up from LDS.  The level's table ends up with the same keys
+// and the same minimum point index per key as one insert per point (which SLOT a key lands in may differ; nothing reads
+// that).  Points per workgroup, measured on the pair (imf_voxelize / step): 512: 49.4 us / 0.931 ms, 1 024: 49.6 / 0.931,
+// 2 048: 56.8 / 0.943, 4 096: 78.2 / 0.953 (fewer, longer workgroups: the global inserts of a workgroup are a dependent
+// chain per thread); the run-leader kernel: 62.3 / 0.943.
+#ifndef IMF_INS_PPT
+#define IMF_INS_PPT 4
+#endif
+constexpr int kInsThreads = 256, kInsPerThread = IMF_INS_PPT, kInsPoints = kInsThreads * kInsPerThread, kInsSlots = 2 * kInsPoints;
+
 template <typename T>
-__global__ void __launch_bounds__(256)
-k_insert_points(const T *__restrict__ xyz, int64_t n, double voxel, int batch, const BatchStarts bs,
-                const int32_t *__restrict__ dyn,
-                imf_slot *tab, uint32_t capmask, int32_t *slot_of, int32_t *err, int32_t *wg_bbox) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(kInsThreads)
+k_insert_points_wg(const T *__restrict__ xyz, int64_t n, double voxel, int batch0, const BatchStarts bs,
+                   const int32_t *__restrict__ dyn, imf_slot *tab, uint32_t capmask, int32_t *slot_of, int32_t *err,
+                   int32_t *wg_bbox) {
+  __shared__ unsigned long long lkey[kInsSlots];
+  __shared__ int32_t lval[kInsSlots];                 // smallest point index of the key, later its global slot
+  const int t = threadIdx.x;
+  for (int s = t; s < kInsSlots; s += kInsThreads) {
+    lkey[s] = kEmptyKey;
+    lval[s] = 0x7FFFFFFF;
+  }
+  int nb = bs.nb;
   if (dyn) {
     n = min((int64_t)dyn[0], n);
-    const int nb = min(max(dyn[1], 1), IMF_MAX_BATCH);
-    for (int b = 1; b < nb; ++b) batch += (i >= dyn[2 + b]) ? 1 : 0;
-  } else {
-    for (int b = 1; b < bs.nb; ++b) batch += (i >= bs.start[b]) ? 1 : 0;   // items are contiguous point ranges
+    nb = min(max(dyn[1], 1), IMF_MAX_BATCH);
   }
-  const bool valid = i < n;
-  uint64_t key = kEmptyKey;
-  int4 vc = make_int4(0, 0, 0, 0);
-  if (valid) {
-    // util/misc.py:82 -- np.floor(xyz / voxel_size) in float64 (IEEE division, exact floor)
-#if IMF_GEO_ABL & 2
-    const float fv = (float)voxel;
-    double fx = floorf((float)xyz[3 * i + 0] / fv), fy = floorf((float)xyz[3 * i + 1] / fv), fz = floorf((float)xyz[3 * i + 2] / fv);
-#else
-    double fx = floor((double)xyz[3 * i + 0] / voxel);
-    double fy = floor((double)xyz[3 * i + 1] / voxel);
-    double fz = floor((double)xyz[3 * i + 2] / voxel);
-#endif
-    bool ok = fx >= -kCoordLim && fx < kCoordLim && fy >= -kCoordLim && fy < kCoordLim &&
-              fz >= -kCoordLim && fz < kCoordLim;   // also false for NaN
-    if (!ok) {
-      atomicOr(err, 1);
-      fx = fy = fz = 0.0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kInsPoints;
+  const int big = 0x7FFFFFFF;
+  int4 lo = make_int4(big, big, big, big), hi = make_int4(-big - 1, -big - 1, -big - 1, -big - 1);
+  uint32_t mine[kInsPerThread / 2];                   // LDS slot of each of this thread's points, 16 bits each
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < kInsPerThread; ++j) {
+    const int64_t i = base + (int64_t)j * kInsThreads + t;
+    uint32_t l = 0;
+    if (i < n) {
+      int batch = batch0;
+      if (dyn) {
+        for (int b = 1; b < nb; ++b) batch += (i >= dyn[2 + b]) ? 1 : 0;
+      } else {
+        for (int b = 1; b < nb; ++b) batch += (i >= bs.start[b]) ? 1 : 0;   // items are contiguous point ranges
+      }
+      // util/misc.py:82 -- np.floor(xyz / voxel_size) in float64 (IEEE division, exact floor)
+      double fx = floor((double)xyz[3 * i + 0] / voxel);
+      double fy = floor((double)xyz[3 * i + 1] / voxel);
+      double fz = floor((double)xyz[3 * i + 2] / voxel);
+      const bool ok = fx >= -kCoordLim && fx < kCoordLim && fy >= -kCoordLim && fy < kCoordLim &&
+                      fz >= -kCoordLim && fz < kCoordLim;   // also false for NaN
+      if (!ok) {
+        bad = true;
+        fx = fy = fz = 0.0;
+      }
+      const int x = (int)fx, y = (int)fy, z = (int)fz;
+      lo.x = min(lo.x, batch); lo.y = min(lo.y, x); lo.z = min(lo.z, y); lo.w = min(lo.w, z);
+      hi.x = max(hi.x, batch); hi.y = max(hi.y, x); hi.z = max(hi.z, y); hi.w = max(hi.w, z);
+      const unsigned long long key = pack_key(batch, x, y, z);
+      l = hash64(key) & (kInsSlots - 1);
+      while (true) {                                  // <= 2 048 keys in 4 096 slots: always terminates
+        const unsigned long long prev = atomicCAS(&lkey[l], (unsigned long long)kEmptyKey, key);
+        if (prev == kEmptyKey || prev == key) break;
+        l = (l + 1) & (kInsSlots - 1);
+      }
+      atomicMin(&lval[l], (int32_t)i);
     }
-    key = pack_key(batch, (int)fx, (int)fy, (int)fz);
-    vc = make_int4(batch, (int)fx, (int)fy, (int)fz);
+    if (j & 1) mine[j >> 1] |= l << 16;
+    else mine[j >> 1] = l;
   }
-  // Scan-ordered clouds put consecutive points into the same voxel (~5 points per 2.5 cm voxel): only the first lane
-  // of every run of equal keys inside the wavefront touches the table (one atomicCAS + one atomicMin per run instead
-  // of per point); its slot is handed to the followers.  The leader carries the run's smallest point index, so the
-  // table ends up exactly as with one insert per point.
-  const int lane = threadIdx.x & 63;
-  const uint64_t prev = __shfl_up(key, 1, 64);
-  const bool leader = valid && ((IMF_GEO_ABL & 8) || lane == 0 || key != prev);
-  uint32_t s = 0;
-  if (leader) {
-#if IMF_GEO_ABL & 1
-    s = hash_slot(key, 0, capmask);
-#else
-    s = hash_insert(tab, capmask, key, 0);
-    // the slot's row index only ever decreases: a run whose first point comes after the one already recorded has nothing
-    // to add (a stale read is larger than the truth, i.e. errs towards doing the atomic)
-    if (__hip_atomic_load(&tab[s].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)i)
-      atomicMin(&tab[s].val, (int32_t)i);
-#endif
+  if (bad) atomicOr(err, 1);
+  __syncthreads();
+  for (int s = t; s < kInsSlots; s += kInsThreads) {
+    const unsigned long long key = lkey[s];
+    if (key == kEmptyKey) continue;
+    const int32_t first = lval[s];
+    const uint32_t g = hash_insert(tab, capmask, key, 0);
+    // the slot's row index only ever decreases: a stale read is larger than the truth, i.e. errs towards doing the atomic
+    if (__hip_atomic_load(&tab[g].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > first) atomicMin(&tab[g].val, first);
+    lval[s] = (int32_t)g;
   }
-  const unsigned long long lead_mask = __ballot(leader);
-  const unsigned long long below = lead_mask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-  const int src = below ? 63 - __builtin_clzll(below) : lane;
-  s = __shfl((int)s, src, 64);
-  if (valid && !(IMF_GEO_ABL & 4)) slot_of[i] = (int32_t)s;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kInsPerThread; ++j) {
+    const int64_t i = base + (int64_t)j * kInsThreads + t;
+    if (i < n) slot_of[i] = lval[(mine[j >> 1] >> ((j & 1) * 16)) & 0xFFFF];
+  }
   // the level's bounding box (every voxel has a point here): known BEFORE the compaction, which can then fill conv1's
   // occupancy bit grid itself (its origin is the box's minimum)
-  if (wg_bbox) {
-    const int big = 0x7FFFFFFF;
-    const int4 lo = valid ? vc : make_int4(big, big, big, big);
-    const int4 hi = valid ? vc : make_int4(-big - 1, -big - 1, -big - 1, -big - 1);
-    block_bbox_store(lo, hi, wg_bbox);
-  }
+  if (wg_bbox) block_bbox_store(lo, hi, wg_bbox);
 }
 
 __global__ void __launch_bounds__(256)
@@ -489,19 +514,17 @@ int imf_voxelize(const void *xyz, int xyz_is_f64, int64_t n, double voxel_size, 
   int32_t *block_sums = slot_of + n;
   int rc = init_table(table, capacity, st);
   if (rc) return rc;
-  const int nblk = (int)div_up(n, 256);
+  const int nblk = (int)div_up(n, kInsPoints);
   BatchStarts one;
   memset(&one, 0, sizeof(one));
   one.nb = 1;
   if (xyz_is_f64)
-    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)xyz, n, voxel_size, batch_index, one, nullptr,
-                                                  table, (uint32_t)(capacity - 1), slot_of,
-                                                  err_out, nullptr);
+    k_insert_points_wg<double><<<nblk, kInsThreads, 0, st>>>((const double *)xyz, n, voxel_size, batch_index, one, nullptr,
+                                                             table, (uint32_t)(capacity - 1), slot_of, err_out, nullptr);
   else
-    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)xyz, n, voxel_size, batch_index, one, nullptr,
-                                                 table, (uint32_t)(capacity - 1), slot_of,
-                                                 err_out, nullptr);
-  IMF_CHECK_LAUNCH("k_insert_points");
+    k_insert_points_wg<float><<<nblk, kInsThreads, 0, st>>>((const float *)xyz, n, voxel_size, batch_index, one, nullptr,
+                                                            table, (uint32_t)(capacity - 1), slot_of, err_out, nullptr);
+  IMF_CHECK_LAUNCH("k_insert_points_wg");
   return run_unique_tail(slot_of, block_sums, table, n, nullptr, coords, first_idx, m_out, st);
 }
 
@@ -640,18 +663,18 @@ int pyramid_level0(const PyramidBuild &b, hipStream_t st, bool init) {
     const int rc = pyramid_init(b, st);
     if (rc) return rc;
   }
-  const int nblk = (int)div_up(b.n, 256);
-  // [nblk][8] inside the unique workspace, 16-byte aligned (slot_of starts 256-byte aligned; k_flag_first reads int4)
+  const int nblk = (int)div_up(b.n, kInsPoints);
+  // [<= div_up(n, 256)][8] inside the unique workspace, 16-byte aligned (slot_of starts 256-byte aligned; k_flag_first reads int4)
   int32_t *const wg_bbox = b.slot_of + (b.n + div_up(b.n, kScanTile) + 16 + 3) / 4 * 4;
   if (b.xyz_is_f64)
-    k_insert_points<double><<<nblk, 256, 0, st>>>((const double *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
-                                                  lv[0].table, (uint32_t)(lv[0].capacity - 1), b.slot_of,
-                                                  b.meta + 1, wg_bbox);
+    k_insert_points_wg<double><<<nblk, kInsThreads, 0, st>>>((const double *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
+                                                             lv[0].table, (uint32_t)(lv[0].capacity - 1), b.slot_of,
+                                                             b.meta + 1, wg_bbox);
   else
-    k_insert_points<float><<<nblk, 256, 0, st>>>((const float *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
-                                                 lv[0].table, (uint32_t)(lv[0].capacity - 1), b.slot_of,
-                                                 b.meta + 1, wg_bbox);
-  IMF_CHECK_LAUNCH("k_insert_points");
+    k_insert_points_wg<float><<<nblk, kInsThreads, 0, st>>>((const float *)b.xyz, b.n, b.voxel, b.batch_index, bs, b.dyn,
+                                                            lv[0].table, (uint32_t)(lv[0].capacity - 1), b.slot_of,
+                                                            b.meta + 1, wg_bbox);
+  IMF_CHECK_LAUNCH("k_insert_points_wg");
   GridFill gf;
   memset(&gf, 0, sizeof(gf));
   gf.grid = b.grid; gf.words_cap = b.grid_words; gf.bbox = b.meta + 2 * b.n_levels; gf.ksize = b.grid_ksize; gf.err = b.meta + 1;
