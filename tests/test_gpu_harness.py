@@ -56,6 +56,37 @@ def test_generate_desc_cli_matches_oracle(tmp_path, clouds, seeded_sd):
         assert np.abs(out["feature"] - F_ref.numpy()).max() < 1e-4
 
 
+def test_generate_desc_cli_resizes_a_640x480_png(tmp_path, clouds, seeded_sd):
+    """The data set's images are 640 x 480 (scripts/generate_desc.py:92-97 -> util/uio.py:33-40 resizes them to the
+    checkpoint's 160 x 120): the CLI's decode -> resize -> forward on such a PNG (content that the 4:1 resize really mixes)
+    against the oracle's resize (O.resize_bilinear) + forward."""
+    from PIL import Image
+    from imfnet_amd.checkpoint import Config
+    from imfnet_amd import generate_desc as gd
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fixture_images.npz"))
+    rng = np.random.default_rng(5)
+    d = src / "scene" / "seq-01"
+    d.mkdir(parents=True)
+    frags = {}
+    for k in (0, 1):
+        big = np.kron(z[f"image_{k}"], np.ones((4, 4, 1), np.float32)) + rng.uniform(-0.08, 0.08, (480, 640, 3)).astype(np.float32)
+        img8 = np.clip(np.rint(big * 255), 0, 255).astype(np.uint8)
+        Image.fromarray(img8).save(d / f"cloud_bin_{k}_0.png")
+        pts = clouds[k][k::6].copy()
+        _write_ply(d / f"cloud_bin_{k}.ply", pts)
+        small = O.resize_bilinear(np.divide(img8, 255, dtype=np.float32), 120, 160)           # util/uio.py:33-40
+        frags[k] = (pts.astype(np.float64), np.transpose(small, (2, 0, 1))[None].copy())
+    ckpt = tmp_path / "ckpt.pth"
+    torch.save({"state_dict": seeded_sd, "config": dict(Config(voxel_size=0.05)), "epoch": 1}, ckpt)
+    gd.main(["--source", str(src), "--target", str(dst), "-m", str(ckpt)])
+    for k, (pts, img) in frags.items():
+        out = np.load(dst / "scene" / "seq-01" / f"cloud_bin_{k}.npz")
+        xyz_ref, F_ref = O.extract_features(seeded_sd, pts, 0.05, img)
+        assert (out["points"] == pts).all() and (out["xyz"] == xyz_ref).all()
+        assert np.abs(out["feature"] - F_ref.numpy()).max() < 1e-4
+
+
 def test_extract_features_with_rgb_and_checks(clouds, images, seeded_sd):
     """util/misc.py:48-79: optional rgb input (3 channels) and the argument checks."""
     from imfnet_amd.extract import extract_features

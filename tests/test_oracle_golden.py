@@ -223,3 +223,26 @@ def test_product_side_seeded_weights_equal_the_oracles():
         a, b = O.seeded_state_dict(**kw), seeded_state_dict(**kw)
         assert list(a) == list(b)
         assert all(a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]) for k in a)
+
+
+def test_native_png_decode_and_resize_on_the_reference_image(images):
+    """The reference's own 480x640 image (files/cloud_bin_0_0.png) through the native PNG decoder and bilinear resize
+    (csrc/codecs.hip) -- the path scripts/generate_desc.py:92-97 + util/uio.py:33-40 take for every fragment: the decoded
+    pixels equal matplotlib's at the committed sample grid (`png0_rows` = imread(...)[::60, ::80], tests/golden/gen_golden.py),
+    and the resized image equals the committed 120x160 fixture (O.resize_bilinear of matplotlib's decode).  The PNG itself
+    lives in the reference tree: where that is absent (the GPU box) only the committed samples' consistency is checked."""
+    z = np.load(os.path.join(GOLDEN, "fixture_images.npz"))
+    rows = z["png0_rows"]
+    assert rows.shape == (8, 8, 3) and rows.dtype == np.float32 and 0.0 <= rows.min() and rows.max() <= 1.0
+    assert (np.rint(rows * 255) / 255 - rows).__abs__().max() < 1e-7          # 8-bit PNG values / 255, as matplotlib returns them
+    path = "/root/reference/files/cloud_bin_0_0.png"
+    if not os.path.exists(path):
+        pytest.skip("the reference's PNG is not on this machine")
+    from imfnet_amd.dataio import process_image, read_image, image_to_nchw
+    img = read_image(path)
+    assert img.dtype == np.float32 and img.shape == (480, 640, 3)
+    assert (img[::60, ::80] == rows).all()
+    small = process_image(image=img, aim_H=120, aim_W=160)
+    assert small.shape == (120, 160, 3)
+    assert np.abs(small - z["image_0"]).max() < 2e-7
+    assert np.abs(image_to_nchw(small) - images[0]).max() < 2e-7
