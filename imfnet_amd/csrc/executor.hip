@@ -274,9 +274,8 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     return IMF_OK;
   };
   int rc;
-  // conv1 + the level-0 map in one launch (IMF_FIRST_AND_MAP=0: two launches on two streams, as before)
-  static const bool fam_env = !(getenv("IMF_FIRST_AND_MAP") && atoi(getenv("IMF_FIRST_AND_MAP")) == 0);
-  const bool first_and_map = fam_env && dyn && pyr && s.small_first && side != main;
+  // conv1 + the level-0 map in one launch (fragment forward; measured against two launches on two streams in round 3)
+  const bool first_and_map = dyn && pyr && s.small_first && side != main;
   int items_event = -1;
   bool image_joined_side = false;
   if (pyr) {   // level 0 was built on the main stream: the side stream (coarse levels, rulebooks) starts after it
@@ -379,8 +378,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   // loops would otherwise derive from the fp32 rows again (imf_conv_args.operand_format; IMF_PRESPLIT=0: fp32 buffers as
   // before).  fp32 stays where something other than a variant-6 convolution reads the buffer: the fusion's input
   // (stride-8 block output, read by the fp32-MFMA attention kernel), the descriptors.
-  static const bool presplit_env = !(getenv("IMF_PRESPLIT") && atoi(getenv("IMF_PRESPLIT")) == 0);
-  bool presplit = presplit_env && !io->fp32_buffers;
+  bool presplit = !io->fp32_buffers;
   for (int i = 0; i < n_steps; ++i) presplit &= net->conv[sched[i].conv].variant == 6;
   bool is_split[NBUF];
   for (int i = 0; i < NBUF; ++i) is_split[i] = false;
@@ -475,9 +473,8 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   }
 
   // ---- bottleneck fusion (model/resunet.py:237-273) ----------------------------------------------------
-  // diagnostic marks (IMF_DIAG_EVENTS=1, tools/branch_times.py): the main stream's arrival at the join, the fusion's end
-  static const bool diag_events = getenv("IMF_DIAG_EVENTS") && atoi(getenv("IMF_DIAG_EVENTS")) != 0;
-  const bool diag_marks = diag_events && pyr && io->events[11] && io->events[12];
+  // diagnostic marks (tools/branch_times.py hands events[11], [12] in): the main stream's arrival at the join, the fusion's end
+  const bool diag_marks = pyr && io->events[11] && io->events[12];
   if (diag_marks) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[11], main));
   if (io->image_ready && !image_joined_side) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
   if (items_event >= 0) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->events[items_event], 0));
@@ -497,11 +494,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   if (diag_marks) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[12], main));
 
   // The head (conv1_tr + norm + ReLU + final + L2 norm, model/resunet.py:219-233) as one launch when its shapes are the
-  // ones imf_pointwise_head serves; bit-identical to the two convolution launches (A/B: IMF_HEAD_FUSED=0).
-  static const bool head_env = !(getenv("IMF_HEAD_FUSED") && atoi(getenv("IMF_HEAD_FUSED")) == 0);
+  // ones imf_pointwise_head serves; bit-identical to the two convolution launches.
   const imf_net_conv &h1 = net->conv[21], &h2 = net->conv[22];
   const int head_cin = s.tr[2] + s.ch[1];
-  const bool fused_head = head_env && h1.w_packed && h2.w_packed && h1.variant == 6 && h2.variant == 6 && h1.kvol == 1 &&
+  const bool fused_head = h1.w_packed && h2.w_packed && h1.variant == 6 && h2.variant == 6 && h1.kvol == 1 &&
                           h2.kvol == 1 && h1.cout == 64 && h2.cin == 64 && h2.cout == 32 && h1.cin == head_cin &&
                           s.tr[2] % 32 == 0 && s.ch[1] % 32 == 0 && head_cin >= 64 && head_cin <= 128 && !h1.l2norm &&
                           (size_t)s.n[0] * (size_t)(s.tr[2] > s.ch[1] ? s.tr[2] : s.ch[1]) * 4 < (1ull << 31);
@@ -578,11 +574,11 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
   }
   if ((rc = pyramid_init(pb, main))) return rc;
 
-  // image branch on its own stream, forked from and later joined to the main one (events 9 / 10).  Where it forks
-  // (IMF_IMAGE_FORK: -1 = here, ahead of the pyramid; i >= 0 = after encoder step i of the schedule: 1 block1, 2 conv2,
-  // 4 block2, 5 conv3, 7 block3) decides what its ~50 small launches (~0.2 ms as a chain) run beside: it must be done by
-  // the fusion block, and the stride-4 / 8 levels leave CUs idle that the level-0 kernels do not.
-  static const int fork_env = getenv("IMF_IMAGE_FORK") ? atoi(getenv("IMF_IMAGE_FORK")) : -1;
+  // image branch on its own stream, forked from and later joined to the main one (events 9 / 10), ahead of the pyramid:
+  // its ~50 small launches (~0.2 ms as a chain) must be done by the fusion block.  Forking it later in the step -- after
+  // block1 / conv2 / block2 / conv3 / block3, beside the levels that leave CUs idle -- was measured slower (1.07 ->
+  // 1.15 ... 1.23 ms, round 3): the chain then ends after the encoder and the fusion waits for it.
+  const int fork_env = -1;
   FragmentCtx fctx{&pb, fio->serialize ? -1 : fork_env, img, caps, fio, imgs};
   if (fctx.fork_after < 0 && (rc = fork_image_branch(fctx, main))) return rc;
 

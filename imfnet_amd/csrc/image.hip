@@ -299,13 +299,6 @@ int imf_image_branch(const imf_image_desc *net, const float *image, int B, int H
   }
   const Plan p = plan_of(s, workspace);
   hipStream_t st = (hipStream_t)stream;
-  static int img_waves[2] = {-2, -2};
-  if (img_waves[0] == -2) {
-    int a = -1, b = -1;
-    const char *e = getenv("IMF_IMG_WAVES");
-    if (e) sscanf(e, "%d,%d", &a, &b);
-    img_waves[1] = b; img_waves[0] = a;
-  }
 
   auto conv = [&](const imf_net_conv &c, const Table *t, int64_t n_rows, const float *in, const float *residual,
                   float *out) -> int {
@@ -326,12 +319,10 @@ int imf_image_branch(const imf_image_desc *net, const float *image, int B, int H
     // 3x3 convolutions of the trunk: the wave-split kernel (one workgroup per tile, the 9 taps x cin/32 sub-stages split
     // over its wavefronts, no split-K partials and no reduce launch).  Measured on the pair's 2 x 120 x 160 images (38 and
     // 10 tiles): branch alone 229 -> 182 us, pair step 1.030 -> 1.018 ms on the same box (14 launches fewer on a chain that
-    // reaches the fusion's join last).  8 wavefronts (one workgroup per CU) while that fills <= 2 rounds of the chip, 4 beyond.
-    // IMF_IMG_WAVES="<layer1>,<layer2>" overrides (0 = k_spconv_g with split-K + reduce, 4, 8).
-    const int64_t wgs = (t ? t->n_slots : imf_rulebook_slots(n_rows)) / IMF_TILE_ROWS * (c.cout / 64);
-    const int by_size = wgs <= 512 ? 8 : 4;
-    const int forced = c.cout == kC1 ? img_waves[0] : img_waves[1];
-    const int waves = c.kvol == 9 && c.variant == 6 && c.cout % 64 == 0 ? (forced >= 0 ? forced : by_size) : 0;
+    // reaches the fusion's join last).  Always the 8-wavefront instance: the wavefront count is part of the arithmetic (it
+    // cuts the sub-stage ranges, csrc/spconv_w.hip), so it is a static choice per layer -- never a function of the batch or
+    // image size, or an image's features would differ in the last bits between batch sizes.
+    const int waves = c.kvol == 9 && c.variant == 6 && c.cout % 64 == 0 ? 8 : 0;
     if (waves == 8) a.kernel_tag = 4;
     else if (waves == 4) a.kernel_tag = 8;
     if (waves) a.split_k = 1;

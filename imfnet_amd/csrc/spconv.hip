@@ -706,11 +706,11 @@ int imf_spconv_occupancy(int variant, int co_blk, int j) {
 }
 
 static int split_min_blocks() {
-  static const int v = getenv("IMF_SPLIT_MIN_BLOCKS") ? atoi(getenv("IMF_SPLIT_MIN_BLOCKS")) : 400;   // measured: 438 unsplit workgroups (a pair's stride-2 level) beat split 2 + reduce by 1.5 % per step
+  const int v = 400;   // measured: 438 unsplit workgroups (a pair's stride-2 level) beat split 2 + reduce by 1.5 % per step
   return v;
 }
 static int split_target() {
-  static const int v = getenv("IMF_SPLIT_TARGET") ? atoi(getenv("IMF_SPLIT_TARGET")) : 768;   // tuning aid
+  const int v = 768;   // (round-1 values; 512 ... 1536 measured in round 2)
   return v;
 }
 
@@ -800,7 +800,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   // tiles on the device (capacity mode; cut from the capacity they left the last XCDs idle: round 2 measured that form
   // slower), the grid's x extent is padded to a multiple of 8 so that a workgroup's XCD is blockIdx.x & 7.  Same sums.
   // Measured (round 3, pair step, same box): 0.979 -> 0.955 ms together with the same order in k_spconv_w.
-  static const int xcd = getenv("IMF_G_XCD") ? atoi(getenv("IMF_G_XCD")) : 3;
+  const int xcd = 3;
   // (not for parity-grouped transposed maps: a range of consecutive tiles there is one parity class spread over the whole
   // level -- no locality to win, measured 43 -> 54 us for conv2_tr)
   const bool g_xcd = a->variant == 6 && !wsplit && ((CB == 4 && (xcd & 1)) || (CB == 2 && (xcd & 2))) &&

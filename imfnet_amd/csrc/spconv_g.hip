@@ -419,8 +419,7 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
   // deep ring (NB 4, two workgroups per CU) when the whole launch is resident at once that way (<= 512 workgroups);
   // measured (tools/layer_times.py): 438 unsplit workgroups of a pair's stride-2 level 43 -> 33 us, but 544 workgroups
   // 28 -> 33 us (a second round of 32), and every launch that fills the chip is faster with four workgroups per CU
-  static const int nb_env = getenv("IMF_G_NB") ? atoi(getenv("IMF_G_NB")) : 0;
-  static const int nb_wgs = getenv("IMF_G_NB_WGS") ? atoi(getenv("IMF_G_NB_WGS")) : 512;
+  const int nb_env = 0, nb_wgs = 512;   // ring depth: by size (the deep ring when the whole launch is resident, <= 512 workgroups)
   long long wgs = (long long)grid.x * grid.y * grid.z;
   if (p.n_out_dev) {
     // capacity mode: the grid covers a capacity and the largest split, the working workgroups are decided on the

@@ -336,9 +336,9 @@ k_spconv_w(const ConvParams p) {
 
 // grid = (tiles, cout / 64); `waves` = 8 (512 threads, one workgroup per CU) or 4 (256 threads, two per CU)
 void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st) {
-  // IMF_W_XCD: 1 = slab by XCD, tiles interleaved (pair step 1.092 -> 1.074 ms); 2 (default) = slab by XCD AND one range of
+  // w_xcd 1 = slab by XCD, tiles interleaved (pair step 1.092 -> 1.074 ms, round 3); 2 = slab by XCD AND one range of
   // consecutive tiles per XCD (0.953 -> 0.940 ms on top: the XCD's L2 serves a fraction of the input rows)
-  static const int xcd_env = getenv("IMF_W_XCD") ? atoi(getenv("IMF_W_XCD")) : 2;
+  const int xcd_env = 2;
   ConvParams p = p_in;
   // (a transposed map's tiles are grouped by parity class: consecutive tiles there are not neighbours in space -- mode 1)
   const bool transposed = p.n_slots != (p.n_out + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;

@@ -176,7 +176,7 @@ class _Bucket:
         self.iarena = u8(L.imf_resunet_int_arena_bytes_cap(C.byref(net), rows_c, grid_words))
         self.farena = u8(L.imf_resunet_float_arena_bytes_cap(C.byref(net), rows_c))
         self.out = self.outbuf[lay["F"]:lay["F"] + rows[0] * net.out_channels * 4].view(torch.float32).view(rows[0], net.out_channels)
-        self.events = [L.imf_event_create() for _ in range(13)]   # [11], [12]: IMF_DIAG_EVENTS marks around the fusion
+        self.events = [L.imf_event_create() for _ in range(13)]   # [11], [12]: diagnostic marks around the fusion (runner.diag_events)
         io = self.io = FragmentIO()
         io.xyz, io.xyz_is_f64, io.voxel_size = self.xyz.data_ptr(), int(is_f64), float(voxel)
         io.dyn, io.image, io.meta = self.dyn.data_ptr(), self.image.data_ptr(), self.meta.data_ptr()
@@ -187,7 +187,7 @@ class _Bucket:
         io.float_arena, io.float_arena_bytes = self.farena.data_ptr(), self.farena.numel()
         io.out = self.out.data_ptr()
         for i, e in enumerate(self.events):
-            io.events[i] = e
+            io.events[i] = e if i < 11 or runner.diag_events else None
         io.side_stream, io.image_stream = runner.raw_streams(dev)
         io.trace = None
         io.fp32_buffers = 1 if os.environ.get("IMFNET_FP32_BUFFERS") == "1" else 0   # (see model/plan.py)
@@ -277,6 +277,7 @@ class FragmentRunner:
         # hipGraph replay is opt-in: ROCm 7.2 runs a graph's independent branches back to back (measured 1.77 vs
         # 1.37 ms per fragment pair), the eager capacity-mode call keeps the three streams concurrent
         self.use_graph = bool(os.environ.get("IMFNET_FRAGMENT_GRAPH"))
+        self.diag_events = bool(os.environ.get("IMFNET_DIAG_EVENTS"))   # tools/branch_times.py: two extra marks per step
         self.stats = dict(graph=0, eager=0, redone=0, captured=0)
         self.host_slots = []          # pinned staging of the synchronous host-array path (extract.py)
         self.stream_state = None      # streams + pinned slots of extract_features_stream

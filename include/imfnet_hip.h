@@ -42,11 +42,19 @@ int imf_version(void);
 const char *imf_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
- * Voxel hash.  Open-addressing table of `capacity` 16-byte slots (power of two), linear probing:
- *   key   uint64   packed (b,x,y,z), 0xFFFF... = empty
+ * Voxel hash.  Open-addressing table of `capacity` 16-byte slots (power of two):
+ *   key   uint64   packed (b,x,y,z) = b:9 | x:18 | y:18 | z:18 (two's complement fields), 0xFFFF... = empty
  *   val   int32    row index of that voxel in its level
  * Key and value share a slot so that a probe that hits is ONE 16-byte load (the rulebook builds are bound by
  * the number of random loads they issue: with separate key / value arrays a hit cost a second random line).
+ * Probe sequence (csrc/common.h hash_slot / hash_step; a client that probes a table itself must walk the same one):
+ * the level's coordinates are multiples of 2^shift (shift = log2 of the level's tensor stride); the 4 x 4 x 4 block of
+ * voxels a key belongs to -- bits shift, shift + 1 of each coordinate field cleared -- is hashed (murmur3 finaliser) to a
+ * 64-slot window, the two cleared bits of x, y, z pick the slot inside it (z fastest); a collision moves on by the
+ * key-dependent ODD stride (hash(key) >> 3) | 1 (double hashing), modulo the capacity.  The library derives `shift` from the
+ * stride arguments of its entry points: imf_rulebook_conv probes `in_table` with shift = log2(ts_in);
+ * imf_rulebook_transpose probes the COARSE table with shift = log2(ts_fine) + 1, i.e. it serves coarse stride = 2 x fine
+ * stride only (the three transposed convolutions of model/resunet.py:101-134) -- tables of other stride ratios miss.
  * Capacity to use for n keys: imf_hash_capacity(n).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct imf_slot {

@@ -2,7 +2,7 @@
 Elapsed times between the executor's own events: [7] level-0 pyramid done (main), [8] end of the side stream's chain,
 [10] end of the image branch, and the end of the step.  usage: python tools/branch_times.py"""
 import os, sys
-os.environ["IMF_DIAG_EVENTS"] = "1"
+os.environ["IMFNET_DIAG_EVENTS"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
