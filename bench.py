@@ -336,7 +336,7 @@ def median(vals):
     return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
 
-def host_span_leg(model, dev, args, barrier, sync, pts, imgs, voxel, f32_valued=False):
+def host_span_leg(model, dev, args, barrier, sync, pts, imgs, voxel, f32_valued=False, batch=None):
     """SURVEY 8(d)'s span as a stream: host arrays in -> xyz_down + descriptors on the host, two fragments per forward
     (one `step` = the pair), through imf_pipeline_* (worker thread, transfers on the copy engines under the neighbouring
     forwards).  Timed like the headline: exactly --steps steps between barrier + synchronize, median of the repeats."""
@@ -349,7 +349,7 @@ def host_span_leg(model, dev, args, barrier, sync, pts, imgs, voxel, f32_valued=
     def run(n_steps):
         gen = (frags[s % R][k] for s in range(n_steps) for k in range(len(pts)))
         m = 0
-        for xd, Fh in extract_features_stream(model, gen, voxel, dev, depth=3, copy=False, batch=len(pts)):
+        for xd, Fh in extract_features_stream(model, gen, voxel, dev, depth=3, copy=False, batch=batch or len(pts)):
             m += Fh.shape[0]
         return m
 
@@ -377,7 +377,7 @@ def host_span_leg(model, dev, args, barrier, sync, pts, imgs, voxel, f32_valued=
            "ms_per_step_all": [round(v / args.steps * 1e3, 4) for v in sorted(rep)],
            "span": "host float64 point arrays + host images -> (voxelise, pyramid, rulebooks, image branch, 23 convolutions, "
                    "fusion) -> xyz_down float64 and descriptors float32 as host arrays (views of the pinned block), "
-                   "PCIe both ways; extract_features_stream(batch=%d, depth=3, copy=False)" % len(pts),
+                   "PCIe both ways; extract_features_stream(batch=%s, depth=3, copy=False)" % (batch or len(pts)),
            "points": "float32-valued float64 (a PLY's points: uploaded as float32)" if f32_valued else
                      "arbitrary float64 (fixture x 1.7: uploaded as float64)",
            "transfers": "copy engines (hipMemcpyAsync, ROC_CPU_WAIT_FOR_SIGNAL=0)" if streamer.sdma_copies else "copy kernels"}
@@ -862,6 +862,14 @@ def extra_legs(model, dev, args, sync):
     hs32, _ = host_span_leg(model, dev, args, lambda: None, sync, pts2, imgs2, voxel, f32_valued=True)
     hs32.pop("per_job_ms", None)
     out["host_span_f32_valued"] = hs32
+    import copy
+    a2 = copy.copy(args)
+    a2.steps = max(args.steps, 60)                     # (five fragments per forward: enough forwards per timed region)
+    hsa, _ = host_span_leg(model, dev, a2, lambda: None, sync, pts2, imgs2, voxel, batch="auto")
+    hsa.pop("per_job_ms", None)
+    hsa["note"] = ("the same stream with batch='auto': fragments grouped per forward up to extract.POINT_BUDGET points (five of "
+                   "these); ms_per_step is still per PAIR of fragments")
+    out["host_span_auto_batch"] = hsa
 
     wl2 = Workload(model, dev, pts2, imgs2, voxel)
     wl2.prepare_graph()

@@ -174,7 +174,10 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image):
     return sel, F
 
 
-def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, copy=True, batch=2):
+POINT_BUDGET = 1_100_000          # batch="auto": points per forward (four S50k fragments)
+
+
+def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, copy=True, batch=2, point_budget=None):
     """`extract_features` over a STREAM of host fragments (SURVEY 8d's span -- host arrays in, descriptors back on the
     host -- pipelined): yields (xyz_down float64 [M,3], F float32 [M,32] numpy) per fragment, in order.  `fragments`:
     iterable of (xyz [N,3] host array, image [1,3,H,W] host array).  Every forward is a job of the library's pipeline
@@ -183,7 +186,10 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
     job k's kernels.  Up to `depth` jobs are in flight.
     batch: consecutive fragments per forward (the model's batched call, model/resunet.py:241-250: rows grouped by
     fragment, one image each) -- the stride-4/8 levels of ONE fragment leave half the chip idle, two fill it: 0.47 vs 0.68 ms
-    of GPU time per S50k fragment; fragments of a batch share point dtype and image size (others go alone).
+    of GPU time per S50k fragment, four 0.41, eight 0.37 (bench.py: batch_4 / batch_8); fragments of a batch share point
+    dtype and image size (others go alone).  batch="auto": consecutive fragments are grouped until their points reach
+    `point_budget` (default POINT_BUDGET, ~ four S50k fragments) or IMF_MAX_BATCH fragments -- more per forward for small
+    fragments, fewer for large ones; a fragment's results then wait for its whole group (latency for throughput).
     copy=True: the arrays of a yield are fresh host copies; copy=False: views of the pinned slot, valid until the NEXT
     item is requested (a 6.5 MB copy into newly faulted pages costs ~0.3 ms per fragment).  Fragments the capacity mode
     cannot take (no capacities yet, a flag) go through `extract_features`, in order."""
@@ -194,7 +200,11 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
     runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
     depth = max(1, int(depth))
     n_slots = depth + 2                               # in flight + the one the consumer holds (copy=False) + one being staged
-    batch = max(1, min(int(batch), MAX_BATCH))
+    auto = isinstance(batch, str)
+    if auto and batch != "auto":
+        raise ValueError("batch: an integer or 'auto'")
+    budget = int(point_budget or POINT_BUDGET)
+    batch = MAX_BATCH if auto else max(1, min(int(batch), MAX_BATCH))
 
     def state(runner):
         """(streamer, pinned slots) of this runner and device; pinned blocks are expensive to create: kept with the runner."""
@@ -290,7 +300,7 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
             if group and (host[0].dtype != group[0][0].dtype or host[1].shape != group[0][1].shape):
                 yield from flush()
             group.append(host)
-            if len(group) >= batch:
+            if len(group) >= batch or (auto and sum(len(x) for x, _ in group) >= budget):
                 yield from flush()
         yield from flush()
         while inflight:

@@ -55,13 +55,15 @@ def load_fragment(ply_path, config):
     return xyz, image_to_nchw(img)
 
 
-def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, device, workers, depth=None):
+def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, device, workers, depth=None, batch_points=None):
     """The batch loop without the host in the GPU's way (SURVEY 8 f-4 / 8e "bound by host-side decode"): loader threads
     decode PLY + PNG; the main thread only stages each fragment into a pinned HostSlot and hands it to the library's
     streaming pipeline (stream.py: upload kernel, capacity-mode forward, xyz_down = xyz[inds] gathered on the device,
     download kernel -- issued by the pipeline's worker thread, transfers under the neighbouring forwards); ONE thread waits
-    for the jobs in order and fans the NPZ writes (straight from the slot's pinned views) out to the writer pool.  A
-    fragment the runner flags (capacity / f16 range) is redone by the caller on the exact path.
+    for the jobs in order and fans the NPZ writes (straight from the slot's pinned views) out to the writer pool.
+    Consecutive fragments share a forward until their points reach extract.POINT_BUDGET (the model's batched call,
+    model/resunet.py:241-250: the stride-4 / 8 levels of one fragment leave half the chip idle -- 0.50 ms per S50k fragment
+    in pairs, 0.40 in fives).  A fragment the runner flags (capacity / f16 range) is redone by the caller on the exact path.
     Returns (seconds per fragment, redo list)."""
     import queue
     import threading
@@ -87,15 +89,19 @@ def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, devic
         scene, fi = job
         return read_ply_points(fi), np.ascontiguousarray(load_image(fi, config), dtype=np.float32)
 
-    def write(job, slot, xyz, n0, v):
+    def write(job, slot, xyz, r0, n0, v, left):
         scene, fi = job
         try:
             out_dir = os.path.join(target_path, os.path.basename(scene), "seq-01")
             ensure_dir(out_dir)
-            save_descriptors(os.path.join(out_dir, os.path.basename(fi).replace(".ply", ".npz")), xyz, v["sel"][:n0],
-                             v["F"][:n0])
+            save_descriptors(os.path.join(out_dir, os.path.basename(fi).replace(".ply", ".npz")), xyz, v["sel"][r0:r0 + n0],
+                             v["F"][r0:r0 + n0])
         finally:
-            slots.put(slot)
+            with left[1]:
+                left[0] -= 1
+                last = left[0] == 0
+            if last:                                    # the slot's last fragment is on disk
+                slots.put(slot)
 
     def waiter():
         # ONE thread waits for the jobs, in submission order (many threads blocked in hipEventSynchronize slowed the
@@ -111,17 +117,22 @@ def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, devic
                 if held is None:
                     return
                 continue
-            job, sj, xyz = item
+            group, sj = item
             try:
                 if failure:
                     raise failure[0]
                 res = sj.wait()
                 if res.flags:
-                    redo.append(job)
+                    if len(group) > 1 and (res.flags & 4):      # the batch's bounding box outgrew the grid: size the next one by it
+                        runner.observe_batch(len(group), res.bbox)
+                    redo.extend(job for job, _ in group)
                     slots.put(sj.slot)
                 else:
-                    times[job[1]] = sum(sj.ms) * 1e-3
-                    writes.append(writer.submit(write, job, sj.slot, xyz, res.counts[0], sj.views))
+                    spans = res.items() if len(group) > 1 else [(0, res.counts[0])]
+                    left = [len(group), threading.Lock()]
+                    for (job, xyz), (r0, n0) in zip(group, spans):
+                        times[job[1]] = sum(sj.ms) * 1e-3 / len(group)
+                        writes.append(writer.submit(write, job, sj.slot, xyz, r0, n0, sj.views, left))
             except BaseException as e:                  # noqa: BLE001 -- re-raised by the main thread after the join
                 if not failure:
                     failure.append(e)
@@ -138,35 +149,52 @@ def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, devic
             job = todo.popleft()
             inflight.append((job, loader.submit(load, job)))
 
+    from .extract import POINT_BUDGET
+    from ._lib import MAX_BATCH
+    budget = POINT_BUDGET if batch_points is not None and batch_points < 0 else int(batch_points or 0)   # 0: one fragment per forward
+
+    def submit(group):
+        """One forward for `group` = [(job, xyz, image)]; fragments the runner cannot take go to the redo list."""
+        while True:                                         # blocks only when `depth` jobs are on the GPU / being written
+            try:
+                slot = slots.get(timeout=5.0)
+                break
+            except queue.Empty:
+                if failure or not wt.is_alive():
+                    raise failure[0] if failure else RuntimeError("generate_desc: the waiter thread died")
+        sj = streamer.submit([(xyz, image) for _, xyz, image in group], voxel_size, slot, more_follow=True)
+        if sj is None:                                      # no capacities known (e.g. the bit grid never fitted): exact path
+            redo.extend(job for job, _, _ in group)
+            slots.put(slot)
+            return
+        done_q.put(([(job, xyz) for job, xyz, _ in group], sj))
+        if slot.grown:                                      # a new size: grow every FREE slot now (HostSlot.reserve)
+            idle = []
+            while True:
+                try:
+                    idle.append(slots.get_nowait())
+                except queue.Empty:
+                    break
+            for other in idle:
+                other.reserve_like(slot, device)
+                slots.put(other)
+
     try:
         top_up()
+        group = []
         while inflight and not failure:
             job, fut = inflight.popleft()
             xyz, image = fut.result()
             top_up()
-            while True:                                         # blocks only when `depth` fragments are on the GPU / being written
-                try:
-                    slot = slots.get(timeout=5.0)
-                    break
-                except queue.Empty:
-                    if failure or not wt.is_alive():
-                        raise failure[0] if failure else RuntimeError("generate_desc: the waiter thread died")
-            sj = streamer.submit([(xyz, image)], voxel_size, slot, more_follow=True)
-            if sj is None:                                      # no capacities known (e.g. the bit grid never fitted): exact path
-                redo.append(job)
-                slots.put(slot)
-                continue
-            done_q.put((job, sj, xyz))
-            if slot.grown:                                      # a new size: grow every FREE slot now (HostSlot.reserve)
-                idle = []
-                while True:
-                    try:
-                        idle.append(slots.get_nowait())
-                    except queue.Empty:
-                        break
-                for other in idle:
-                    other.reserve_like(slot, device)
-                    slots.put(other)
+            if group and (xyz.dtype != group[0][1].dtype or image.shape != group[0][2].shape):
+                submit(group)
+                group = []
+            group.append((job, xyz, image))
+            if len(group) >= MAX_BATCH or sum(len(x) for _, x, _ in group) >= budget:
+                submit(group)
+                group = []
+        if group and not failure:
+            submit(group)
     finally:
         done_q.put(None)
         wt.join()
@@ -204,12 +232,18 @@ def load_image(ply_path, config):
     return image_to_nchw(img)
 
 
-def extract_features_batch(model, config, source_path, target_path, voxel_size, device, gather=False, workers=4):
+def extract_features_batch(model, config, source_path, target_path, voxel_size, device, gather=False, workers=4,
+                           batch_points=None):
     """scripts/generate_desc.py:44-133.  The reference decodes, computes and writes one fragment at a
     time; at ~1 ms of GPU work per fragment the PLY/PNG decode (tens of ms) and the zlib write
     (~0.1 s) would leave the GPU idle, so `workers` loader threads run ahead of the GPU and as many
     writer threads take the device-to-host copy + `savez_compressed` behind it (numpy / PIL / zlib
-    release the GIL).  workers=0 is the reference's sequential order; outputs are identical."""
+    release the GIL).  workers=0 is the reference's sequential order; outputs are identical, whatever the
+    workers and however the fragments are sharded over ranks.  batch_points > 0 (opt-in; -1 = extract.POINT_BUDGET): the
+    pipelined loop puts consecutive fragments into one forward until their points reach it (the model's batched call,
+    model/resunet.py:241-250: +25 % GPU throughput at ~5 fragments per forward) -- points and xyz stay identical, descriptors
+    agree to rounding (<= 2e-6: a row's partial sums are grouped by its 64-row tile's active offsets, and its tile-mates
+    differ in a batch), so they then depend on the grouping."""
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) \
@@ -242,7 +276,8 @@ def extract_features_batch(model, config, source_path, target_path, voxel_size, 
         # re-fetched AFTER the head fragment: an fp32 recompute or a refresh rebuilds the plans the runner points into
         runner = model.fragment_runner()
         if runner is not None and runner.ratios is not None and runner.grid_words > 0:
-            t_pipe, redo = _batch_pipelined(model, runner, config, pending, target_path, voxel_size, device, workers)
+            t_pipe, redo = _batch_pipelined(model, runner, config, pending, target_path, voxel_size, device, workers,
+                                            batch_points=batch_points)
             t_all += t_pipe
             pending = redo                                  # flagged fragments (capacity / f16 range): exact path
         for job in pending:                                 # also everything, when the runner turned out unusable
@@ -329,6 +364,10 @@ def main(argv=None):
     p.add_argument("--workers", type=int, default=None,
                    help="loader / writer threads around the GPU (0 = the reference's sequential order; default: from "
                         "os.cpu_count() // world_size -- 4..16)")
+    p.add_argument("--batch_points", type=int, default=None,
+                   help="opt-in: consecutive fragments share a forward up to this many points (-1: ~1.1 M = four to five 3DMatch "
+                        "fragments, +25 %% GPU throughput); descriptors then agree with the default's to 2e-6 instead of bit "
+                        "for bit.  Default 0: one fragment per forward, files identical whatever the workers / ranks")
     p.add_argument("--npz_threads", type=int, default=None,
                    help="host threads of ONE descriptor file's block-parallel deflate (imf_npz_write_mt; default: from "
                         "os.cpu_count() // world_size // workers -- 1..16, or $IMFNET_NPZ_THREADS)")
@@ -375,7 +414,7 @@ def main(argv=None):
     t_wall = time.time()
     with torch.no_grad():
         times, n = extract_features_batch(model, config, args.source, args.target, config.voxel_size, device,
-                                          gather=args.gather, workers=args.workers)
+                                          gather=args.gather, workers=args.workers, batch_points=args.batch_points)
     t_wall = time.time() - t_wall
     if times:
         print(f"[rank {rank}] All Time:{np.sum(times)},AVG:{np.sum(times) / len(times)} "

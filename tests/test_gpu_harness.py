@@ -40,12 +40,17 @@ def test_generate_desc_cli_matches_oracle(tmp_path, clouds, seeded_sd):
     torch.save({"state_dict": seeded_sd, "config": dict(Config(voxel_size=0.05)), "epoch": 1}, ckpt)
     gd.main(["--source", str(src), "--target", str(dst), "-m", str(ckpt)])
     assert sorted(os.listdir(dst)) == ["sceneA", "sceneB"]
-    dst_seq = tmp_path / "dst_sequential"                                 # loader/writer threads change nothing
+    dst_seq = tmp_path / "dst_sequential"                                 # the reference's sequential order
     gd.main(["--source", str(src), "--target", str(dst_seq), "-m", str(ckpt), "--workers", "0"])
+    dst_grp = tmp_path / "dst_grouped"                                    # opt-in: fragments share forwards (batched call)
+    gd.main(["--source", str(src), "--target", str(dst_grp), "-m", str(ckpt), "--batch_points", "-1"])
     for scene, k in frags:
         a = np.load(dst / scene / "seq-01" / f"cloud_bin_{k}.npz")
         b = np.load(dst_seq / scene / "seq-01" / f"cloud_bin_{k}.npz")
-        assert all((a[key] == b[key]).all() for key in ("points", "xyz", "feature"))
+        c = np.load(dst_grp / scene / "seq-01" / f"cloud_bin_{k}.npz")
+        assert all((a[key] == b[key]).all() for key in ("points", "xyz", "feature"))       # threads change nothing
+        assert (c["points"] == b["points"]).all() and (c["xyz"] == b["xyz"]).all()
+        assert np.abs(c["feature"] - b["feature"]).max() < 2e-6                              # batching: rounding only
     for (scene, k), (pts, img) in frags.items():
         out = np.load(dst / scene / "seq-01" / f"cloud_bin_{k}.npz")
         assert sorted(out.files) == ["feature", "points", "xyz"]

@@ -33,13 +33,13 @@ dev = torch.device("cuda:0")
 res = {}
 with torch.no_grad():
     gd.extract_features_batch(model, cfg, os.path.join(root, "src"), os.path.join(root, "warm"), cfg.voxel_size, dev, workers=8)
-    for level, workers, threads in ((1, 0, 1), (1, 8, 1), (1, 8, 8), (1, 16, 8), (1, 16, 16), (1, 32, 4), (6, 16, 16), (0, 8, 1), (0, 16, 1)):
+    for level, workers, threads, bp in ((1, 0, 1, 0), (1, 8, 1, 0), (1, 8, 8, 0), (1, 16, 8, 0), (1, 16, 16, 0), (1, 16, 8, -1), (6, 16, 16, 0), (0, 8, 1, 0), (0, 16, 1, 0), (0, 16, 1, -1)):
         dataio.NPZ_LEVEL, dataio.NPZ_THREADS = level, threads
-        dst = os.path.join(root, f"dst{level}_{workers}_{threads}")
+        dst = os.path.join(root, f"dst{level}_{workers}_{threads}" + ("_grouped" if bp else ""))
         t = time.time()
-        times, _ = gd.extract_features_batch(model, cfg, os.path.join(root, "src"), dst, cfg.voxel_size, dev, workers=workers)
+        times, _ = gd.extract_features_batch(model, cfg, os.path.join(root, "src"), dst, cfg.voxel_size, dev, workers=workers, batch_points=bp)
         dt = time.time() - t
-        res[f"npz_level={level} workers={workers} npz_threads={threads}"] = {
+        res[f"npz_level={level} workers={workers} npz_threads={threads}" + (" grouped forwards" if bp else "")] = {
             "fragments_per_s": round(n / dt, 1), "wall_s": round(dt, 2), "gpu_ms_per_fragment": round(float(np.mean(times)) * 1e3, 3)}
 a = np.load(os.path.join(root, "dst1_0_1", "scene", "seq-01", "cloud_bin_3.npz"))
 b = np.load(os.path.join(root, "dst0_16_1", "scene", "seq-01", "cloud_bin_3.npz"))
@@ -47,6 +47,8 @@ c = np.load(os.path.join(root, "dst1_16_16", "scene", "seq-01", "cloud_bin_3.npz
 assert all((a[k] == c[k]).all() for k in ("points", "xyz", "feature"))
 assert open(os.path.join(root, "dst1_0_1", "scene", "seq-01", "cloud_bin_3.npz"), "rb").read() == \
        open(os.path.join(root, "dst1_16_16", "scene", "seq-01", "cloud_bin_3.npz"), "rb").read(), "bytes depend on the thread count"
+g = np.load(os.path.join(root, "dst1_16_8_grouped", "scene", "seq-01", "cloud_bin_3.npz"))
+assert all((a[k] == g[k]).all() for k in ("points", "xyz")) and np.abs(a["feature"] - g["feature"]).max() < 2e-6
 same = all((a[k] == b[k]).all() for k in ("points", "xyz", "feature"))
 print(json.dumps({"fragments": n, "images": "640x480" if big else "160x120", "identical_arrays_across_settings": bool(same), **res}, indent=1))
 shutil.rmtree(root)

@@ -8,10 +8,11 @@ import numpy as np, torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--sdma", type=int, default=-1, help="1 copy engines, 0 copy kernels, -1 the package default"); ap.add_argument("--blocks", type=int, default=0)
 ap.add_argument("--buckets", type=int, default=3); ap.add_argument("--depth", type=int, default=3)
-ap.add_argument("--batch", type=int, default=2); ap.add_argument("--n", type=int, default=60)
+ap.add_argument("--batch", default="2"); ap.add_argument("--n", type=int, default=60)
 ap.add_argument("--f32", action="store_true", help="hand float32 point arrays in (no narrowing pass)")
 ap.add_argument("--check", action="store_true")
 args = ap.parse_args()
+args.batch = args.batch if args.batch == "auto" else int(args.batch)
 dev = torch.device("cuda:0")
 from bench import load_workload, build_model
 import imf_oracle as O
@@ -53,7 +54,7 @@ with torch.no_grad():
     st = r.streamer(dev)
     from imfnet_amd.model.graph import HostSlot
     slots = [HostSlot() for _ in range(4)]
-    jobs = [st.submit([(xyz, img)] * args.batch, voxel, slots[i], more_follow=True) for i in range(3)]
+    jobs = [st.submit([(xyz, img)] * (4 if args.batch == 'auto' else args.batch), voxel, slots[i], more_follow=True) for i in range(3)]
     for j in jobs:
         j.wait()
         print("  job legs (upload, forward incl. queueing, download) ms:", ["%.3f" % v for v in j.ms], "host", ["%.3f" % v for v in j.host_ms])
