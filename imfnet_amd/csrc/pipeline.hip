@@ -363,12 +363,12 @@ int imf_pipeline_wait(void *handle, int ticket, float *ms) {
     volatile int32_t *mark = p->marks + 16 * ticket;
     hipError_t e = hipSuccess;
     for (uint64_t spins = 1; *mark != t.seq; ++spins) {
-      if (spins < 2000) {
+      if (spins < 100000) {   // ~1-2 ms of polling before the first sleep (a sleep costs >= 50 us of timer slack on wake-up)
         _mm_pause();
       } else {
         struct timespec ts = {0, 20000};
         nanosleep(&ts, nullptr);
-        if (spins % 20000 == 0) {   // ~ every 0.5 s
+        if (spins % 20000 == 0) {   // ~ every 1.5 s of sleeping
           e = hipEventQuery(t.e_done);
           if (e == hipSuccess) break;   // complete as far as the runtime knows: the mark is there or never will be
           if (e != hipErrorNotReady) break;
