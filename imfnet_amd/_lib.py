@@ -79,7 +79,8 @@ class ResunetDesc(C.Structure):
     _fields_ = [("channels", C.c_int32 * 5), ("tr_channels", C.c_int32 * 5), ("in_channels", C.c_int32),
                 ("out_channels", C.c_int32), ("first_ksize", C.c_int32), ("small_first", C.c_int32),
                 ("conv", NetConv * 23), ("first_kernel", C.c_void_p), ("first_scale", C.c_void_p),
-                ("first_shift", C.c_void_p), ("fusion", FusionWeights), ("fusion_scale", C.c_float)]
+                ("first_shift", C.c_void_p), ("fusion", FusionWeights), ("fusion_scale", C.c_float),
+                ("first_kernel_image", C.c_void_p)]
 
 
 class ImageDesc(C.Structure):
@@ -218,6 +219,8 @@ SIGNATURES = {
     "imf_packed_weight_floats": (_L, [_I, _I, _I]),
     "imf_packed_weight_floats_split16": (_L, [_I, _I, _I]),
     "imf_pack_weights": (_I, [_P, _I, _I, _I, _P, _P]),
+    "imf_first_kernel_image_floats": (_L, [_I, _I]),
+    "imf_pack_first_kernel": (_I, [_P, _I, _I, _P, _P]),
     "imf_pack_weights_split16": (_I, [_P, _I, _I, _I, _P, _P]),
     "imf_spconv_auto_split": (_I, [_L, _I, _I]),
     "imf_spconv_max_split": (_I, [_I, _I]),

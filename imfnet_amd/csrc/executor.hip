@@ -393,11 +393,11 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
       rc = conv_first_and_map_dyn(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
                                   io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale, net->first_shift, 0,
                                   buf[ebuf(0, 0)], first_split, io->level[0].table, io->level[0].capacity, rb_k3[0].tile_rows,
-                                  rb_k3[0].nbr, rb_k3[0].tile_mask, main);
+                                  rb_k3[0].nbr, rb_k3[0].tile_mask, main, net->first_kernel_image);
     } else if (dyn && pyr) {   // imf_fragment_forward zeroed the grid before the level-0 pyramid
       rc = conv_first_bitgrid_dyn_cleared(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
                                           io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale,
-                                          net->first_shift, 0, buf[ebuf(0, 0)], main, first_split);
+                                          net->first_shift, 0, buf[ebuf(0, 0)], main, first_split, net->first_kernel_image);
     } else if (dyn) {
       rc = conv_first_bitgrid_dyn_fmt(io->level[0].coords, s.n[0], meta, meta + kMetaBBox, err, net->first_ksize, bitgrid,
                                       io->bitgrid_words, net->first_kernel, s.ch[1], net->first_scale,

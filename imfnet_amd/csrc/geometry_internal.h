@@ -31,6 +31,7 @@ struct DynGrid {
   const int32_t *n_dev, *bbox_dev;
   int32_t *err;
   unsigned long long words_cap;
+  const float *w_image = nullptr;   // conv1's hi / lo f16 weight image (imf_pack_first_kernel), or NULL: split in the kernel
 };
 
 __device__ __forceinline__ bool dyn_grid(const DynGrid &d, int ksize, GridDesc &g, long long &n) {

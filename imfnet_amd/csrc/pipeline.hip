@@ -2,25 +2,29 @@
 // arrays in -> voxelise -> forward -> xyz_down and descriptors back on the host, for a STREAM of fragments.
 //
 // The reference moves every fragment through pageable copies on the one stream its kernels run on.  Here a fragment's
-// inputs arrive in a pinned block and leave in a pinned block, and neither transfer is a copy COMMAND of the compute
-// stream: both are small copy kernels that read / write the pinned (device-visible) host block directly over PCIe.  They run
-// in the IDLE HALVES of the two streams a forward already has besides its main stream -- HIP maps streams onto four hardware
-// queues and a fifth / sixth stream would share a queue with one of these anyway (measured: profiles/r04_stream_timeline_5streams.txt,
-// GPU_MAX_HW_QUEUES=8 makes everything 2x slower), so the placement is made explicit:
+// inputs arrive in a pinned block and leave in a pinned block, and both transfers run in the IDLE HALVES of the two streams a
+// forward already has besides its main stream -- HIP maps streams onto four hardware queues and a fifth / sixth stream would
+// share a queue with one of these anyway, in an order nobody chose (measured: a download queued ahead of the next forward's
+// coarse levels delayed that forward by the whole transfer; GPU_MAX_HW_QUEUES=8 made everything 2x slower) -- so the
+// placement is explicit:
 //
 //     image stream: [image branch k ][ upload k+1 ]      [image branch k+1][ upload k+2 ]
 //     main stream : [ forward k .................. ]      [ forward k+1 ................. ]
 //     side stream : [levels, maps k ][ download k-1 ]    [levels, maps k+1][ download k  ]
 //
-// so the ~0.25 ms + ~0.3 ms of PCIe time per S50k pair sit under the neighbouring forwards' kernels (a copy kernel holds a
-// few wavefronts that wait on PCIe; it needs no LDS and 16 VGPRs, so it shares CUs with the convolutions).  Measured on
-// this stack (round 4, tools/e2e_probe.py): a hipMemcpyAsync issued behind queued kernels BLOCKS the calling host thread
-// for ~0.9 ms -- the launches of the next forward then start late and the GPU idles; a kernel launch never blocks.  The
-// device-to-host kernel reads the row count from the forward's meta block, so only the rows that exist cross PCIe.
+// and the ~0.25 ms + ~0.3 ms of PCIe time per S50k pair sit under the neighbouring forwards' kernels.  Two transfer
+// mechanisms (DESIGN.md 4e has the measurements):
+//   * the copy engines (hipMemcpyAsync, IMF_PIPELINE_SDMA_COPIES): leave the CUs alone (forward 0.975 ms under both
+//     transfers), but with the HIP runtime's default ROC_CPU_WAIT_FOR_SIGNAL=1 the call BLOCKS its thread behind the
+//     stream's queued kernels (~0.9 ms); the Python package sets the variable to 0 at import and then selects this mode;
+//   * copy kernels that address the pinned (device-visible) blocks directly over PCIe: never block the issuing thread and
+//     move only the rows that exist (the download kernel reads the row count from the forward's meta block), but their
+//     wavefronts wait ~2 us per access in the same CUs' vector-memory pipes as the convolutions' LDS-DMA and slow the
+//     forward they run under by 25-50 % -- the fallback when the runtime was started without the variable.
 //
 // All HIP calls of a job are made by ONE worker thread of the pipeline (imf_pipeline_submit only queues the job
 // descriptor): the ~150 launches of a forward overlap the caller's staging of the next fragment, and no interpreter is on
-// the issue path.  imf_pipeline_wait blocks on the job's completion event.
+// the issue path.  imf_pipeline_wait polls the job's completion mark (k_signal below), never the runtime.
 #include <immintrin.h>
 #include <string.h>
 #include <time.h>

@@ -487,6 +487,55 @@ constexpr int kBitsRows = 64;
 typedef _Float16 f16x8_b __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2_b __attribute__((ext_vector_type(2)));
 
+// conv1's weights as hi / lo f16 B fragments: max |w| (block reduce over 256 threads) -> power-of-two scale -> split.  Writes
+// [nkc][CBN][hi, lo][64 lanes] float4 (8 halves each) to `W_l` (LDS or global) and returns the factor that undoes the scale.
+template <int COUT>
+__device__ __forceinline__ float first_kernel_split(const float *__restrict__ w, int kvol, int nkc, float4 *W_l, unsigned *red,
+                                                    int tid) {
+  constexpr int CBN = COUT / 16;
+  const int wave = tid >> 6, lane = tid & 63;
+  unsigned amax = 0u;
+  for (int i = tid; i < kvol * COUT; i += 256) {
+    const unsigned bits = __float_as_uint(fabsf(w[i]));
+    if (bits < 0x7F800000u) amax = bits > amax ? bits : amax;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = __shfl_xor(amax, o, 64);
+    amax = t > amax ? t : amax;
+  }
+  if (lane == 0) red[wave] = amax;
+  __syncthreads();
+  amax = max(max(red[0], red[1]), max(red[2], red[3]));
+  int wshift = 0;
+  if (amax != 0u) {
+    wshift = 13 - ((int)(amax >> 23) - 127);             // the scaled kernel peaks in [2^13, 2^14): lo halves stay normal
+    wshift = wshift < -40 ? -40 : (wshift > 100 ? 100 : wshift);
+  }
+  for (int i = tid; i < nkc * CBN * 64; i += 256) {
+    const int ln = i & 63, cb = (i >> 6) % CBN, kc = i / (64 * CBN);
+    f16x8_b hi, lo;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = 32 * kc + 16 * (t >> 2) + 4 * (ln >> 4) + (t & 3);
+      const float x = k < kvol ? ldexpf(w[k * COUT + 16 * cb + (ln & 15)], wshift) : 0.f;
+      const _Float16 h = (_Float16)x;
+      hi[t] = h;
+      lo[t] = (_Float16)(x - (float)h);
+    }
+    W_l[((kc * CBN + cb) * 2 + 0) * 64 + ln] = __builtin_bit_cast(float4, hi);
+    W_l[((kc * CBN + cb) * 2 + 1) * 64 + ln] = __builtin_bit_cast(float4, lo);
+  }
+  return ldexpf(1.f, -wshift);
+}
+
+template <int COUT>
+__global__ void __launch_bounds__(256) k_pack_first_kernel(const float *__restrict__ w, int kvol, float *__restrict__ image) {
+  __shared__ unsigned red[4];
+  const int nkc = (kvol + 31) >> 5;
+  const float un = first_kernel_split<COUT>(w, kvol, nkc, reinterpret_cast<float4 *>(image), red, threadIdx.x);
+  if (threadIdx.x == 0) image[(size_t)nkc * (COUT / 16) * 2 * 64 * 4] = un;
+}
+
 // conv1 for the all-ones occupancy feature: out[v] = sum_k occ(v + off_k) * W[k], a [64, kvol] x [kvol, COUT] product per
 // workgroup whose left operand is BINARY.  Round 3: the occupancy window of a voxel is kept as a 128-bit mask (one thread
 // per (voxel, 32-offset word): no LDS atomics, no 33 KiB float matrix, no bank conflicts) and expanded to f16 0 / 1
@@ -537,39 +586,17 @@ __device__ __forceinline__ void conv_first_bits_body(const int32_t *__restrict__
     w0[j] = pr[0];
     w1[j] = pr[1];
   }
-  // ---- weights: max |w| (block reduce) -> power-of-two scale -> hi / lo f16 B fragments in the MFMA's lane order
-  //      [kc][cb][h][lane][t]: offset k = 32 kc + 16 (t >> 2) + 4 (lane >> 4) + (t & 3), column 16 cb + (lane & 15)
-  unsigned amax = 0u;
-  for (int i = tid; i < kvol * COUT; i += 256) {
-    const unsigned bits = __float_as_uint(fabsf(w[i]));
-    if (bits < 0x7F800000u) amax = bits > amax ? bits : amax;
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned t = __shfl_xor(amax, o, 64);
-    amax = t > amax ? t : amax;
-  }
-  if (lane == 0) red[wave] = amax;
-  __syncthreads();
-  amax = max(max(red[0], red[1]), max(red[2], red[3]));
-  int wshift = 0;
-  if (amax != 0u) {
-    wshift = 13 - ((int)(amax >> 23) - 127);             // the scaled kernel peaks in [2^13, 2^14): lo halves stay normal
-    wshift = wshift < -40 ? -40 : (wshift > 100 ? 100 : wshift);
-  }
-  const float un = ldexpf(1.f, -wshift);
-  for (int i = tid; i < nkc * CBN * 64; i += 256) {
-    const int ln = i & 63, cb = (i >> 6) % CBN, kc = i / (64 * CBN);
-    f16x8_b hi, lo;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int k = 32 * kc + 16 * (t >> 2) + 4 * (ln >> 4) + (t & 3);
-      const float x = k < kvol ? ldexpf(w[k * COUT + 16 * cb + (ln & 15)], wshift) : 0.f;
-      const _Float16 h = (_Float16)x;
-      hi[t] = h;
-      lo[t] = (_Float16)(x - (float)h);
-    }
-    W_l[((kc * CBN + cb) * 2 + 0) * 64 + ln] = __builtin_bit_cast(float4, hi);
-    W_l[((kc * CBN + cb) * 2 + 1) * 64 + ln] = __builtin_bit_cast(float4, lo);
+  // ---- weights: the hi / lo f16 B fragments in the MFMA's lane order, [kc][cb][h][lane][t]: offset k = 32 kc + 16 (t >> 2) +
+  //      4 (lane >> 4) + (t & 3), column 16 cb + (lane & 15).  From the image imf_pack_first_kernel wrote once per model
+  //      (16 KiB verbatim: round 4 -- every one of the ~1 600 workgroups of a launch used to redo the 4 096 splits, 1.5 k of its
+  //      1.7 k VALU instructions per wavefront), or, without one, split here: max |w| -> power-of-two scale -> hi / lo.
+  float un;
+  if (dg.w_image) {
+    const float4 *img = reinterpret_cast<const float4 *>(dg.w_image);
+    for (int i = tid; i < nkc * CBN * 2 * 64; i += 256) W_l[i] = img[i];
+    un = dg.w_image[(size_t)nkc * CBN * 2 * 64 * 4];
+  } else {
+    un = first_kernel_split<COUT>(w, kvol, nkc, W_l, red, tid);
   }
   // ---- combine the windows into this thread's mask word
   {
@@ -1013,12 +1040,12 @@ int conv_first_bitgrid_dyn_fmt(const int32_t *coords, int64_t n_cap, const int32
 int conv_first_and_map_dyn(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev, int32_t *err,
                            int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout, const float *scale,
                            const float *shift, int relu, float *out, int out_split, const imf_slot *table, int64_t capacity,
-                           int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, hipStream_t st) {
+                           int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, hipStream_t st, const float *w_image) {
   IMF_REQUIRE(coords && n_dev && bbox_dev && err && grid && grid_words > 0 && w && out && table && tile_rows && nbr && tile_mask,
               "conv_first_and_map_dyn: null pointer");
   IMF_REQUIRE((ksize == 3 || ksize == 5) && (cout == 32 || cout == 64) && n_cap > 0, "conv_first_and_map_dyn: ksize / cout / n");
   IMF_REQUIRE((capacity & (capacity - 1)) == 0, "conv_first_and_map_dyn: capacity not a power of 2");
-  DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words};
+  DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words, w_image};
   GridDesc g;
   memset(&g, 0, sizeof(g));
   const int kvol = ksize * ksize * ksize;
@@ -1038,10 +1065,25 @@ int conv_first_and_map_dyn(const int32_t *coords, int64_t n_cap, const int32_t *
 int conv_first_bitgrid_dyn_cleared(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
                                    int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
                                    const float *scale, const float *shift, int relu, float *out, hipStream_t stream,
-                                   int out_split) {
+                                   int out_split, const float *w_image) {
   IMF_REQUIRE(n_dev && bbox_dev && err && grid_words > 0, "imf_conv_first_bitgrid_dyn: null pointer");
-  DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words};
+  DynGrid dg{n_dev, bbox_dev, err, (unsigned long long)grid_words, w_image};
   return conv_first_bitgrid_impl(coords, n_cap, nullptr, dg, ksize, grid, grid_words, w, cout, scale, shift, relu, out,
                                  stream, true, out_split);
 }
 }  // namespace imf
+
+extern "C" {
+/* conv1's hi / lo f16 weight image (see first_kernel_split): [ceil(kvol / 32)][cout / 16][2][64][8 halves] + the unscale factor. */
+int64_t imf_first_kernel_image_floats(int kvol, int cout) { return (int64_t)((kvol + 31) / 32) * (cout / 16) * 2 * 64 * 4 + 4; }
+
+int imf_pack_first_kernel(const float *w, int kvol, int cout, float *image, void *stream) {
+  IMF_REQUIRE(w && image, "imf_pack_first_kernel: null pointer");
+  IMF_REQUIRE((kvol == 27 || kvol == 125) && (cout == 32 || cout == 64), "imf_pack_first_kernel: kvol=%d cout=%d", kvol, cout);
+  IMF_REQUIRE(((uintptr_t)image & 15) == 0, "imf_pack_first_kernel: image must be 16-byte aligned");
+  if (cout == 32) imf::k_pack_first_kernel<32><<<1, 256, 0, (hipStream_t)stream>>>(w, kvol, image);
+  else            imf::k_pack_first_kernel<64><<<1, 256, 0, (hipStream_t)stream>>>(w, kvol, image);
+  IMF_CHECK_LAUNCH("k_pack_first_kernel");
+  return IMF_OK;
+}
+}

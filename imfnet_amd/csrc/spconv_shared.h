@@ -371,10 +371,11 @@ int conv_first_bitgrid_dyn_fmt(const int32_t *coords, int64_t n_cap, const int32
 int conv_first_and_map_dyn(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev, int32_t *err,
                            int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout, const float *scale,
                            const float *shift, int relu, float *out, int out_split, const imf_slot *table, int64_t capacity,
-                           int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, hipStream_t st);
+                           int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, hipStream_t st,
+                           const float *w_image = nullptr);
 int conv_first_bitgrid_dyn_cleared(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, const int32_t *bbox_dev,
                                    int32_t *err, int ksize, uint32_t *grid, size_t grid_words, const float *w, int cout,
                                    const float *scale, const float *shift, int relu, float *out, hipStream_t stream,
-                                   int out_split = 0);
+                                   int out_split = 0, const float *w_image = nullptr);
 
 }  // namespace imf

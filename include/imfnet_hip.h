@@ -500,7 +500,14 @@ typedef struct imf_resunet_desc {
   const float *first_kernel, *first_scale, *first_shift;   /* conv1 [kvol][cin][cout] unpacked + norm1 */
   imf_fusion_weights fusion;
   float fusion_scale;
+  const float *first_kernel_image;     /* optional: imf_pack_first_kernel(first_kernel) -- conv1's hi / lo f16 weight image, so
+                                          that the fragment forward's conv1 workgroups copy 16 KiB instead of re-splitting the
+                                          kernel each (same bits either way); NULL: split in the kernel */
 } imf_resunet_desc;
+/* conv1 (k = 3 or 5, Cin = 1, Cout 32 / 64, model/resunet.py:42-49) as the f16 matrix pipe reads it: image of
+ * imf_first_kernel_image_floats(kvol, cout) floats, 16-byte aligned.  One-time re-layout at model load; replaces nothing. */
+int64_t imf_first_kernel_image_floats(int kvol, int cout);
+int imf_pack_first_kernel(const float *w /* [kvol][1][cout] */, int kvol, int cout, float *image, void *stream);
 
 typedef struct imf_net_trace {         /* optional per-convolution measurement record (index = conv id) */
   void *ev_begin, *ev_end;             /* in: hipEvent_t pair recorded around the main kernel */

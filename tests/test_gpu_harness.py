@@ -258,3 +258,34 @@ def test_extract_features_numpy_points_with_a_device_image(clouds, images, seede
                                    image=images[0])                                # CUDA points, host image
     assert (xd0 == xd1).all() and (xd0 == xd2).all()
     assert torch.equal(F0, F1) and torch.equal(F0, F2)
+
+
+@pytest.mark.parametrize("sdma", [False, True])
+def test_pipeline_transfer_modes_agree(clouds, images, seeded_sd, sdma):
+    """The streaming pipeline's two transfer mechanisms -- copy kernels that address the pinned blocks directly (the
+    fallback when the HIP runtime was started without ROC_CPU_WAIT_FOR_SIGNAL=0) and the copy engines (hipMemcpyAsync) --
+    deliver the same bytes: xyz_down and descriptors of streamed fragments equal the per-fragment calls', for float64
+    points that are float32 values (uploaded narrowed), arbitrary float64 and float32 inputs."""
+    from imfnet_amd.extract import extract_features, extract_features_stream
+    from imfnet_amd.model import load_model
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.eval().cuda()
+    dev = torch.device("cuda:0")
+    frs = [(clouds[0][::3].astype(np.float64), images[0]),                 # float32-valued float64: narrowed on upload
+           (clouds[1][::3].astype(np.float64) * 1.1, images[1]),           # arbitrary float64
+           (clouds[0][1::4].copy(), images[0]),                            # float32
+           (clouds[1][2::3].astype(np.float64), images[1])]
+    with torch.no_grad():
+        ref = [extract_features(m, x, voxel_size=0.05, device=dev, skip_check=True, image=i) for x, i in frs]
+        ref = [(xd, F.cpu().numpy()) for xd, F in ref]
+        runner = m.fragment_runner()
+        runner._streamers.pop(dev, None)                                   # (a streamer of the default mode may exist already)
+        st = runner.streamer(dev, sdma_copies=sdma)
+        assert st.sdma_copies == sdma
+        got = list(extract_features_stream(m, iter(frs), 0.05, dev, depth=2, batch=1))
+        got += list(extract_features_stream(m, iter(frs), 0.05, dev, depth=3, batch=1))
+    assert runner.stats["redone"] == 0
+    for (xd, F), (xr, Fr) in zip(got, ref + ref):
+        assert (xd == xr).all() and xd.dtype == np.float64
+        assert (F == Fr).all()
