@@ -417,8 +417,10 @@ def main(argv=None):
                                           gather=args.gather, workers=args.workers, batch_points=args.batch_points)
     t_wall = time.time() - t_wall
     if times:
+        r = model.fragment_runner() if hasattr(model, "fragment_runner") else None
         print(f"[rank {rank}] All Time:{np.sum(times)},AVG:{np.sum(times) / len(times)} "
-              f"({len(times)} of {n} fragments); wall {t_wall:.2f} s = {len(times) / t_wall:.1f} fragments/s end to end")
+              f"({len(times)} of {n} fragments); wall {t_wall:.2f} s = {len(times) / t_wall:.1f} fragments/s end to end"
+              + (f"; capacity buckets {len(r.buckets)}, redone {r.stats['redone']}" if r is not None else ""))
     if world > 1:
         torch.distributed.destroy_process_group()
 

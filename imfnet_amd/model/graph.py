@@ -245,7 +245,7 @@ class FragmentRunner:
     """Capacity-mode / hipGraph front end of one model (eval mode, IMFNet's configuration)."""
 
     MARGIN = 1.2          # head room over the largest voxel-per-point ratio seen
-    MAX_BUCKETS = 24      # (the streaming pipeline keeps up to three of one capacity key in flight: `lane`)
+    MAX_BUCKETS = 32      # (the streaming pipeline keeps up to three of one capacity key in flight: `lane`)
 
     def __init__(self, model):
         from .plan import FusedPlan, NativePlan
@@ -296,7 +296,10 @@ class FragmentRunner:
         npc = _grid_up(n_points, 1.25, 65536)
         rows, prev = [], npc
         for l in range(4):
-            want = self.ratios[l] * n_points * self.MARGIN
+            # from the POINT capacity, not the point count: fragments of one point-capacity class then share ONE key (a
+            # test set's fragments vary continuously in size; keyed by their own counts the 433-fragment emulation went
+            # through more buckets than MAX_BUCKETS holds and rebuilt them over and over: 107 -> see DESIGN 4e)
+            want = self.ratios[l] * npc * self.MARGIN
             c = min(_grid_up(want, 1.125, (4096, 1024, 256, 128)[l]), prev)
             rows.append(c)
             prev = c
