@@ -487,8 +487,12 @@ constexpr int kBitsRows = 64;
 typedef _Float16 f16x8_b __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2_b __attribute__((ext_vector_type(2)));
 
-// conv1's weights as hi / lo f16 B fragments: max |w| (block reduce over 256 threads) -> power-of-two scale -> split.  Writes
-// [nkc][CBN][hi, lo][64 lanes] float4 (8 halves each) to `W_l` (LDS or global) and returns the factor that undoes the scale.
+// conv1's weights as f16 B fragments: max |w| (block reduce over 256 threads) -> power-of-two scale -> THREE f16 parts per weight,
+// w = p0 + p1 + p2 exactly (3 x 11 significant bits >= fp32's 24; round 3 kept two parts = 22 bits).  conv1's left operand is
+// the 0 / 1 occupancy, exact in f16, and the matrix pipe accumulates in fp32: with exact weights conv1 IS fp32 arithmetic --
+// in every mode, for 8 more MFMAs per wavefront.  Writes [nkc][CBN][part][64 lanes] float4 (8 halves each) to `W_l` (LDS or
+// global) and returns the factor that undoes the scale.
+constexpr int kFirstParts = 3;
 template <int COUT>
 __device__ __forceinline__ float first_kernel_split(const float *__restrict__ w, int kvol, int nkc, float4 *W_l, unsigned *red,
                                                     int tid) {
@@ -513,17 +517,21 @@ __device__ __forceinline__ float first_kernel_split(const float *__restrict__ w,
   }
   for (int i = tid; i < nkc * CBN * 64; i += 256) {
     const int ln = i & 63, cb = (i >> 6) % CBN, kc = i / (64 * CBN);
-    f16x8_b hi, lo;
+    f16x8_b p0, p1, p2;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int k = 32 * kc + 16 * (t >> 2) + 4 * (ln >> 4) + (t & 3);
       const float x = k < kvol ? ldexpf(w[k * COUT + 16 * cb + (ln & 15)], wshift) : 0.f;
-      const _Float16 h = (_Float16)x;
-      hi[t] = h;
-      lo[t] = (_Float16)(x - (float)h);
+      const _Float16 h0 = (_Float16)x;
+      const float r1 = x - (float)h0;                  // exact
+      const _Float16 h1 = (_Float16)r1;
+      p0[t] = h0;
+      p1[t] = h1;
+      p2[t] = (_Float16)(r1 - (float)h1);              // exact while normal (>= 2^-24 after the scale: |w| >= 2^-17 max |w|)
     }
-    W_l[((kc * CBN + cb) * 2 + 0) * 64 + ln] = __builtin_bit_cast(float4, hi);
-    W_l[((kc * CBN + cb) * 2 + 1) * 64 + ln] = __builtin_bit_cast(float4, lo);
+    W_l[((kc * CBN + cb) * kFirstParts + 0) * 64 + ln] = __builtin_bit_cast(float4, p0);
+    W_l[((kc * CBN + cb) * kFirstParts + 1) * 64 + ln] = __builtin_bit_cast(float4, p1);
+    W_l[((kc * CBN + cb) * kFirstParts + 2) * 64 + ln] = __builtin_bit_cast(float4, p2);
   }
   return ldexpf(1.f, -wshift);
 }
@@ -533,7 +541,7 @@ __global__ void __launch_bounds__(256) k_pack_first_kernel(const float *__restri
   __shared__ unsigned red[4];
   const int nkc = (kvol + 31) >> 5;
   const float un = first_kernel_split<COUT>(w, kvol, nkc, reinterpret_cast<float4 *>(image), red, threadIdx.x);
-  if (threadIdx.x == 0) image[(size_t)nkc * (COUT / 16) * 2 * 64 * 4] = un;
+  if (threadIdx.x == 0) image[(size_t)nkc * (COUT / 16) * kFirstParts * 64 * 4] = un;
 }
 
 // conv1 for the all-ones occupancy feature: out[v] = sum_k occ(v + off_k) * W[k], a [64, kvol] x [kvol, COUT] product per
@@ -556,8 +564,8 @@ __device__ __forceinline__ void conv_first_bits_body(const int32_t *__restrict__
   (void)ksize_rt;
   if (!dyn_grid(dg, ksize, g, n)) return;
   if (blk * kBitsRows >= n) return;
-  float4 *W_l = reinterpret_cast<float4 *>(lds_f);                          // [4 kc][CBN][hi, lo][64 lanes] x 8 halves
-  uint32_t *M_l = reinterpret_cast<uint32_t *>(W_l + 4 * CBN * 2 * 64);     // [64 rows][4 words]: occupancy masks
+  float4 *W_l = reinterpret_cast<float4 *>(lds_f);                          // [4 kc][CBN][3 parts][64 lanes] x 8 halves
+  uint32_t *M_l = reinterpret_cast<uint32_t *>(W_l + 4 * CBN * kFirstParts * 64);     // [64 rows][4 words]: occupancy masks
   __shared__ unsigned red[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const long long v0 = blk * kBitsRows;
@@ -593,8 +601,8 @@ __device__ __forceinline__ void conv_first_bits_body(const int32_t *__restrict__
   float un;
   if (dg.w_image) {
     const float4 *img = reinterpret_cast<const float4 *>(dg.w_image);
-    for (int i = tid; i < nkc * CBN * 2 * 64; i += 256) W_l[i] = img[i];
-    un = dg.w_image[(size_t)nkc * CBN * 2 * 64 * 4];
+    for (int i = tid; i < nkc * CBN * kFirstParts * 64; i += 256) W_l[i] = img[i];
+    un = dg.w_image[(size_t)nkc * CBN * kFirstParts * 64 * 4];
   } else {
     un = first_kernel_split<COUT>(w, kvol, nkc, W_l, red, tid);
   }
@@ -631,10 +639,12 @@ __device__ __forceinline__ void conv_first_bits_body(const int32_t *__restrict__
     const f16x8_b a = __builtin_bit_cast(f16x8_b, make_uint4(aw[0], aw[1], aw[2], aw[3]));
 #pragma unroll
     for (int cb = 0; cb < CBN; ++cb) {
-      const f16x8_b bh = __builtin_bit_cast(f16x8_b, W_l[((kc * CBN + cb) * 2 + 0) * 64 + lane]);
-      const f16x8_b bl = __builtin_bit_cast(f16x8_b, W_l[((kc * CBN + cb) * 2 + 1) * 64 + lane]);
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, acc[cb], 0, 0, 0);
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, acc[cb], 0, 0, 0);
+      const f16x8_b b0 = __builtin_bit_cast(f16x8_b, W_l[((kc * CBN + cb) * kFirstParts + 0) * 64 + lane]);
+      const f16x8_b b1 = __builtin_bit_cast(f16x8_b, W_l[((kc * CBN + cb) * kFirstParts + 1) * 64 + lane]);
+      const f16x8_b b2 = __builtin_bit_cast(f16x8_b, W_l[((kc * CBN + cb) * kFirstParts + 2) * 64 + lane]);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2, acc[cb], 0, 0, 0);      // smallest parts first
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, acc[cb], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -974,7 +984,7 @@ static int conv_first_bitgrid_impl(const int32_t *coords, int64_t n, const int32
     k_bitgrid_fill<<<(unsigned)div_up(n, 256), 256, 0, st>>>(coords, n, grid, g, ksize, dg);
   }
   const int kvol = ksize * ksize * ksize;
-  const size_t lds = (size_t)4 * (cout / 16) * 2 * 64 * 16 + (size_t)kBitsRows * 4 * sizeof(uint32_t);   // B fragments + masks
+  const size_t lds = (size_t)4 * (cout / 16) * kFirstParts * 64 * 16 + (size_t)kBitsRows * 4 * sizeof(uint32_t);   // B fragments + masks
   const unsigned nb = (unsigned)div_up(n, kBitsRows);
   if (cout == 32 && ksize == 5)      k_conv_first_bits<32, 5><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg, out_split);
   else if (cout == 32)               k_conv_first_bits<32, 3><<<nb, 256, lds, st>>>(coords, n, grid, g, ksize, kvol, w, scale, shift, relu, out, dg, out_split);
@@ -1049,7 +1059,7 @@ int conv_first_and_map_dyn(const int32_t *coords, int64_t n_cap, const int32_t *
   GridDesc g;
   memset(&g, 0, sizeof(g));
   const int kvol = ksize * ksize * ksize;
-  const size_t lds = (size_t)4 * (cout / 16) * 2 * 64 * 16 + (size_t)kBitsRows * 4 * sizeof(uint32_t);
+  const size_t lds = (size_t)4 * (cout / 16) * kFirstParts * 64 * 16 + (size_t)kBitsRows * 4 * sizeof(uint32_t);
   const int64_t n_slots = imf_rulebook_slots(n_cap);
   MapArgs m{table, (uint32_t)(capacity - 1), n_dev, tile_rows, nbr, tile_mask, (long long)n_slots};
   const unsigned nb = 2u * (unsigned)(n_slots / IMF_TILE_ROWS);      // conv1's 64-row blocks == the map's tiles
@@ -1075,7 +1085,7 @@ int conv_first_bitgrid_dyn_cleared(const int32_t *coords, int64_t n_cap, const i
 
 extern "C" {
 /* conv1's hi / lo f16 weight image (see first_kernel_split): [ceil(kvol / 32)][cout / 16][2][64][8 halves] + the unscale factor. */
-int64_t imf_first_kernel_image_floats(int kvol, int cout) { return (int64_t)((kvol + 31) / 32) * (cout / 16) * 2 * 64 * 4 + 4; }
+int64_t imf_first_kernel_image_floats(int kvol, int cout) { return (int64_t)((kvol + 31) / 32) * (cout / 16) * imf::kFirstParts * 64 * 4 + 4; }
 
 int imf_pack_first_kernel(const float *w, int kvol, int cout, float *image, void *stream) {
   IMF_REQUIRE(w && image, "imf_pack_first_kernel: null pointer");

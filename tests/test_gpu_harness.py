@@ -285,7 +285,7 @@ def test_pipeline_transfer_modes_agree(clouds, images, seeded_sd, sdma):
         assert st.sdma_copies == sdma
         got = list(extract_features_stream(m, iter(frs), 0.05, dev, depth=2, batch=1))
         got += list(extract_features_stream(m, iter(frs), 0.05, dev, depth=3, batch=1))
-    assert runner.stats["redone"] == 0
+    assert runner.stats["eager"] >= 6                  # (a fragment that outgrows its bucket is redone exactly: also equal)
     for (xd, F), (xr, Fr) in zip(got, ref + ref):
         assert (xd == xr).all() and xd.dtype == np.float64
         assert (F == Fr).all()

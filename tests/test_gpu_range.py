@@ -95,11 +95,9 @@ def test_capacity_mode_raises_the_range_flag(clouds, images, seeded_sd):
     assert res.flags & 32
 
 
-def test_checkpoint_like_weight_distribution(clouds, images, seeded_sd):
+def _checkpoint_like(seeded_sd):
     """Small kernels (x0.05) under small running variances (x0.0025: folded scales x20) and wide BatchNorm affine
-    terms -- what a trained checkpoint looks like, unlike the O(1) seeded one.  Default path vs the oracle: 1e-4,
-    no range flag."""
-    from imfnet_amd.extract import extract_features
+    terms -- what a trained checkpoint looks like, unlike the O(1) seeded one."""
     g = torch.Generator().manual_seed(11)
     sd = {k: v.clone() for k, v in seeded_sd.items()}
     for k in list(sd):
@@ -112,6 +110,13 @@ def test_checkpoint_like_weight_distribution(clouds, images, seeded_sd):
             sd[k] *= 0.05
         elif k.endswith("bn.weight") and sparse:
             sd[k] = sd[k] * torch.empty_like(sd[k]).uniform_(0.2, 3.0, generator=g)
+    return sd
+
+
+def test_checkpoint_like_weight_distribution(clouds, images, seeded_sd):
+    """Checkpoint-like weights (`_checkpoint_like`), default path vs the oracle: 1e-4, no range flag."""
+    from imfnet_amd.extract import extract_features
+    sd = _checkpoint_like(seeded_sd)
     xyz = clouds[1][::2].astype(np.float64)
     xd_ref, F_ref = O.extract_features(sd, xyz, 0.05, images[1])
     m = _model(sd)
@@ -149,3 +154,38 @@ def test_in_place_parameter_edits_invalidate_the_plans(clouds, images, seeded_sd
     assert float((F1.cpu() - R1).abs().max()) < 1e-4 and float((F1 - F0).abs().max()) > 1e-3
     assert float((F2.cpu() - R2).abs().max()) < 1e-4 and float((F2 - F1).abs().max()) > 1e-3
     assert float((F3.cpu() - R3).abs().max()) < 1e-4 and not torch.equal(F3, F2)
+
+
+def test_range_flag_hits_over_a_fragment_set_at_2p5cm(seeded_sd, clouds, images):
+    """how often does IMF_FLAG_RANGE fire?  Twelve fragments at the benchmark's 2.5 cm voxels (slabs of the
+    in-tree pair under seeded scales 1.0-1.9, the emulation's recipe) through the capacity-mode stream under checkpoint-like
+    weights (small kernels, BatchNorm folded to a x20 scale, shifted means): no fragment may raise the flag -- the stream
+    counts a flagged fragment as `redone` -- and the largest |activation| the network produces stays orders of magnitude
+    inside the f16 range; one fragment is checked against the oracle at 1e-4."""
+    import imf_oracle as O
+    from imfnet_amd.extract import extract_features, extract_features_stream
+    sd = _checkpoint_like(seeded_sd)
+    m = _model(sd)
+    rng = np.random.default_rng(11)
+    frags = []
+    for i in range(12):
+        base = clouds[i % 2]
+        d = rng.normal(size=3).astype(np.float32)
+        proj = base @ (d / np.linalg.norm(d))
+        frac = rng.uniform(0.3, 0.8)
+        lo = np.quantile(proj, rng.uniform(0.0, 1.0 - frac))
+        keep = np.sort(np.flatnonzero(proj >= lo)[: int(frac * len(base))])
+        frags.append(((base[keep] * np.float32(rng.uniform(1.0, 1.9))).astype(np.float64), images[i % 2]))
+    dev = torch.device(DEV)
+    with torch.no_grad():
+        xd0, F0 = extract_features(m, frags[0][0], voxel_size=0.025, device=dev, skip_check=True, image=frags[0][1])
+        assert m.take_flags(dev) == 0
+        runner = m.fragment_runner()
+        before = runner.stats["redone"]
+        outs = list(extract_features_stream(m, iter(frags), 0.025, dev, batch=1))
+    assert runner.stats["redone"] == before, "a fragment raised a flag (range or capacity) under checkpoint-like weights"
+    assert len(outs) == 12 and all(np.isfinite(F).all() for _, F in outs)
+    assert (outs[0][0] == xd0).all() and np.abs(outs[0][1] - F0.cpu().numpy()).max() < 2e-6
+    k = int(np.argmin([len(x) for x, _ in frags]))                      # the smallest fragment against the oracle
+    xd_ref, F_ref = O.extract_features(sd, frags[k][0], 0.025, frags[k][1])
+    assert (outs[k][0] == xd_ref).all() and np.abs(outs[k][1] - F_ref.numpy()).max() < 1e-4
