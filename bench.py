@@ -889,12 +889,23 @@ def extra_legs(model, dev, args, sync):
     wl0 = Workload(m0, dev, pts2, imgs2, voxel)
     for _ in range(3):
         F0 = wl0.exact_step()
-    dt = timed(wl0.exact_step, 10, sync)
+    dt_exact = timed(wl0.exact_step, 10, sync)
+    F0 = F0.clone()
+    wl0.prepare_graph()
+    assert wl0.runner.variant == 0
+    wl0.runner.use_graph = False
+    for _ in range(3):
+        r0 = wl0.graph_step()
+    sync()
+    assert r0.flags == 0 and torch.equal(r0.F, F0), "strict-fp32 capacity mode differs from its exact mode"
+    dt = timed(wl0.graph_step, 10, sync)
     out["strict_fp32"] = {"descriptors_per_s": round(F0.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+                          "exact_mode_ms_per_step": round(dt_exact * 1e3, 4), "equals_exact_mode_bitwise": True,
                           "dtype": "f32 (v_mfma_f32_16x16x4_f32, fp32 operands and accumulation)",
-                          "note": "the pair, exact mode (one count readback), every convolution, the image trunk and the fusion "
-                                  "feed-forward on true-fp32 matrix instructions (IMF_CONV_VARIANT=0): the arithmetic of the "
-                                  "reference's fp32 path, and what a fragment flagged IMF_FLAG_RANGE is redone with"}
+                          "note": "the pair in capacity mode (imf_fragment_forward, no readback), every convolution, the image trunk "
+                                  "and the fusion feed-forward on true-fp32 matrix instructions (variant 0; conv1 is exact fp32 in "
+                                  "every mode): the arithmetic of the reference's fp32 path, and what a fragment flagged "
+                                  "IMF_FLAG_RANGE is redone with"}
     del m0, wl0
     return out
 

@@ -207,8 +207,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     IMF_REQUIRE(meta && io->bitgrid_words > 0, "imf_resunet_forward: capacity mode needs meta and a bit-grid capacity");
     IMF_REQUIRE(s.small_first && io->x_all_ones && net->in_channels == 1 && (net->first_ksize == 3 || net->first_ksize == 5),
                 "imf_resunet_forward: capacity mode covers the occupancy-feature first convolution only");
-    for (int i = 0; i < 23; ++i)
-      IMF_REQUIRE(!net->conv[i].w_packed || net->conv[i].variant == 6, "imf_resunet_forward: capacity mode needs variant 6");
+    for (int i = 0; i < 23; ++i)   // variant 6, or variant 0 throughout (the strict-fp32 recompute of a range-flagged fragment)
+      IMF_REQUIRE(!net->conv[i].w_packed || net->conv[i].variant == net->conv[12].variant,
+                  "imf_resunet_forward: capacity mode needs ONE convolution variant (6 or 0) for all layers");
+    IMF_REQUIRE(net->conv[12].variant == 6 || net->conv[12].variant == 0, "imf_resunet_forward: capacity mode: variant 6 or 0");
     IMF_REQUIRE(io->int_arena_bytes >= imf_resunet_int_arena_bytes_cap(net, io->n, io->bitgrid_words),
                 "imf_resunet_forward: int arena %zu < %zu bytes", io->int_arena_bytes,
                 imf_resunet_int_arena_bytes_cap(net, io->n, io->bitgrid_words));
@@ -483,7 +485,8 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   if (dyn)
     rc = fusion_attention_dyn_fmt(buf[ebuf(3, 2)], s.n[3], meta + 6, meta + kMetaStarts + IMF_MAX_BATCH * 3, io->n_items,
                                   err, io->kt_packed, io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
-                                  net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4, main, fused_split);
+                                  net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4, main, fused_split,
+                                  net->conv[12].variant == 6 ? 6 : 0);
   else
     rc = fusion_attention_batched_fmt(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
                                       io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,

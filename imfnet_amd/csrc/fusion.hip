@@ -294,18 +294,18 @@ static int run_feed_forward(const imf_fusion_weights *w, long long n, const int3
   const long long slots = (n + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
   imf_conv_args a;
   if (variant != 6) {   // the network runs on fp32 MFMA (the f16-range recompute): so does the feed-forward, on fp32 images
-    IMF_REQUIRE(variant == 0 && w->w1_f32 && w->w2_f32 && !n_dev && !out_split,
-                "imf_fusion_attention: variant %d needs the fp32 feed-forward images (w1_f32 / w2_f32), exact mode", variant);
+    IMF_REQUIRE(variant == 0 && w->w1_f32 && w->w2_f32 && !out_split,
+                "imf_fusion_attention: variant %d needs the fp32 feed-forward images (w1_f32 / w2_f32) and fp32 buffers", variant);
     memset(&a, 0, sizeof(a));
     a.in_a = n2; a.c_a = kFD; a.w_packed = w->w1_f32; a.kvol = 1; a.cout = 2 * kFH;
     a.n_slots = slots; a.n_out = n; a.shift = w->b1; a.out = g; a.split_k = 1; a.variant = 0; a.geglu = 1;
-    a.dyn_err = err;
+    a.n_out_dev = n_dev; a.dyn_err = err;
     int rc0 = imf_spconv_fwd(&a, st);
     if (rc0) return rc0;
     memset(&a, 0, sizeof(a));
     a.in_a = g; a.c_a = kFH; a.w_packed = w->w2_f32; a.kvol = 1; a.cout = kFD;
     a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = 0;
-    a.dyn_err = err;
+    a.n_out_dev = n_dev; a.dyn_err = err;
     return imf_spconv_fwd(&a, st);
   }
   memset(&a, 0, sizeof(a));
@@ -354,7 +354,7 @@ namespace imf {
 int fusion_attention_dyn_fmt(const float *x, int64_t n_cap, const int32_t *n_dev, const int32_t *item_starts_dev,
                              int n_items, int32_t *err, const float *const *kt_packed, const float *const *v_packed,
                              int n_tokens, int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
-                             void *workspace, size_t workspace_bytes, void *stream, int out_split) {
+                             void *workspace, size_t workspace_bytes, void *stream, int out_split, int variant) {
   IMF_REQUIRE(x && n_dev && item_starts_dev && err && kt_packed && v_packed && w && out && workspace,
               "imf_fusion_attention_dyn: null pointer");
   IMF_REQUIRE(n_items >= 1 && n_items <= IMF_MAX_BATCH && n_cap > 0, "imf_fusion_attention_dyn: n_items=%d", n_items);
@@ -375,7 +375,7 @@ int fusion_attention_dyn_fmt(const float *x, int64_t n_cap, const int32_t *n_dev
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_attn(p, st);
   if (rc) return rc;
-  return run_feed_forward(w, n_cap, n_dev, (float *)workspace, out, err, st, out_split);
+  return run_feed_forward(w, n_cap, n_dev, (float *)workspace, out, err, st, out_split, variant);
 }
 }  // namespace imf
 

@@ -54,6 +54,7 @@ k_spconv_mfma_simple(const ConvParams p) {
   __shared__ float4 wlds[STAGE_F4];
 
   const int tile = blockIdx.x, y = blockIdx.y;
+  if (p.n_out_dev && (long long)tile * IMF_TILE_ROWS >= conv_slots(p, conv_rows(p))) return;   // capacity mode: beyond the rows
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
   const int cin = p.c_a + p.c_b;
   const int ncc = cin / (16 * J);
@@ -128,6 +129,7 @@ k_spconv_mfma(const ConvParams p) {
   __shared__ int klist[kKCache];
 
   const int tile = blockIdx.x, y = blockIdx.y, z = blockIdx.z, S = gridDim.z;
+  if (p.n_out_dev && (long long)tile * IMF_TILE_ROWS >= conv_slots(p, conv_rows(p))) return;   // capacity mode: beyond the rows
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
   const int cin = p.c_a + p.c_b;
   const int ncc = cin / (16 * J);
@@ -817,7 +819,8 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   p.slots_extra = a->slots_extra;
   p.split_min_blocks = split_min_blocks();
   p.split_target = split_target();
-  IMF_REQUIRE(!a->n_out_dev || a->variant == 6, "imf_spconv_fwd: n_out_dev (capacity mode) needs variant 6");
+  IMF_REQUIRE(!a->n_out_dev || a->variant == 6 || split == 1,
+              "imf_spconv_fwd: n_out_dev (capacity mode) on the fp32-MFMA kernels needs an unsplit launch (split_k = 1)");
   p.err = a->dyn_err;
   p.geglu = a->geglu;
   p.a_split = (a->operand_format & IMF_FMT_A_SPLIT) ? 1 : 0;

@@ -355,7 +355,7 @@ void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t
 int fusion_attention_dyn_fmt(const float *x, int64_t n_cap, const int32_t *n_dev, const int32_t *item_starts_dev,
                              int n_items, int32_t *err, const float *const *kt_packed, const float *const *v_packed,
                              int n_tokens, int tokens_padded, const imf_fusion_weights *w, float scale, float *out,
-                             void *workspace, size_t workspace_bytes, void *stream, int out_split);
+                             void *workspace, size_t workspace_bytes, void *stream, int out_split, int variant = 6);
 int fusion_attention_batched_fmt(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
                                  const float *const *kt_packed, const float *const *v_packed, int n_tokens,
                                  int tokens_padded, const imf_fusion_weights *w, float scale, float *out,

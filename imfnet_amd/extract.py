@@ -255,6 +255,7 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
             yield from outs
             return
         runner.stats["redone"] += len(items)
+        runner.stats["redone_flags"] = runner.stats.get("redone_flags", 0) | res.flags   # which flags asked for the redo
         if len(items) > 1 and (res.flags & 4):        # the batch's bounding box outgrew the grid: size the next one by it
             runner.observe_batch(len(items), res.bbox)
         free.append(job.slot)

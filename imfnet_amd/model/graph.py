@@ -60,7 +60,9 @@ class FragmentResult:
 
     @property
     def flags(self):
-        return int(self.sync()[1]) | int(self.sync()[3]) | int(self.sync()[5]) | int(self.sync()[7])
+        m = self.sync()
+        # (a variant-0 bucket computes in fp32 throughout: a value beyond the f16 range is a value there, not an error)
+        return (int(m[1]) | int(m[3]) | int(m[5]) | int(m[7])) & ~getattr(self.bucket, "ignore_flags", 0)
 
     @property
     def counts(self):
@@ -147,6 +149,7 @@ class _Bucket:
         L = self.L = runner.L
         n_points, rows, n_items, H, W, grid_words, voxel, is_f64 = caps_tuple
         self.key, self.dev = caps_tuple, dev
+        self.ignore_flags = _lib.FLAG_RANGE if runner.variant == 0 else 0
         net, img = runner.net_desc, runner.img_plan
         c = self.caps = FragmentCaps()
         c.n_points, c.n_items, c.img_h, c.img_w, c.bitgrid_words = n_points, n_items, H, W, grid_words
@@ -262,9 +265,11 @@ class FragmentRunner:
         self.net_desc = model._native_plan.desc
         self.img_plan = model._native_image()
         fw = model._fusion_weights()
+        variants = {c.variant for c in self.net_desc.conv if c.w_packed}
+        # one arithmetic throughout: variant 6 (split-f16, the default) or variant 0 (fp32 MFMA: the strict-fp32 path)
+        self.variant = variants.pop() if len(variants) == 1 else None
         self.supported = bool(self.img_plan.supported and self.img_plan.with_kv and fw.supported and
-                              model._plan.small_first and model.conv1.in_channels == 1 and
-                              all(c.variant == 6 for c in self.net_desc.conv if c.w_packed))
+                              model._plan.small_first and model.conv1.in_channels == 1 and self.variant in (0, 6))
         # imf_fragment_forward calls imf_image_branch (csrc/image.hip) itself: a runner exists only when that plan is usable
         self.image_branch_mode = "native-hip (csrc/image.hip, inside imf_fragment_forward)" if self.supported else None
         self.ratios = None            # max rows_l / n_points seen (4 levels)
@@ -357,6 +362,10 @@ class FragmentRunner:
                 del self.buckets[victim]
             with torch.cuda.stream(stream or torch.cuda.current_stream(dev)):   # static tables are built on it
                 b = self.buckets[bk] = _Bucket(self, key, dev)
+                # the zero fills of the new blocks are queued on THIS stream, behind whatever forwards are in flight; the
+                # pipeline uploads a job's inputs on the image stream, which does not wait for this one: without the wait
+                # a fill could land on top of the first upload (seen once in ~20 runs as a spurious capacity redo)
+                torch.cuda.current_stream(dev).synchronize()
         return b
 
     def _stream_for(self, dev, stream):

@@ -241,7 +241,7 @@ typedef struct imf_conv_args {
                              variant 6 in diagnostic builds only (measured slower than the second launch) */
   void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded on `stream` immediately around the
                               main MFMA kernel (not the split-K reduce): live roofline timing     */
-  /* Capacity mode (variant 6), for launch sequences captured once and replayed on fragments of different
+  /* Capacity mode (variant 6; variant 0 with split_k == 1), for launch sequences captured once and replayed on fragments of different
    * size: n_out / n_slots (and the rulebook) are sized for a CAPACITY and the actual row count is read from
    * device memory; tiles beyond it exit at once.  dyn_split_kvol != 0: the number of kernel-offset partitions
    * is imf_spconv_auto_split(actual slots, cout, dyn_split_kvol) evaluated on the device -- split_k then only
@@ -556,8 +556,9 @@ typedef struct imf_resunet_io {        /* per fragment */
    * writes (item_row0 / item_rows / bbox above are ignored); flags raised by the kernels are OR-ed into meta[1]:
    * 1 coordinate out of range, 2 a level exceeded its capacity, 4 bounding box larger than the bit grid, 8 an item
    * without rows, 16 fewer rows than a quarter of the capacity (split cover exceeded).  A flagged result must be
-   * discarded and the fragment redone with larger capacities or in exact mode.  Needs variant 6, the all-ones
-   * occupancy input and in_channels 1.  Bit-identical to the exact mode. */
+   * discarded and the fragment redone with larger capacities or in exact mode.  Needs ONE convolution variant for all
+   * layers (6, or 0 = the strict-fp32 arithmetic), the all-ones occupancy input and in_channels 1.  Bit-identical to the
+   * exact mode of the same variant. */
   int32_t dyn;
   const int32_t *meta;
   size_t bitgrid_words;                /* capacity (uint32 words) of the conv1 occupancy grid inside the int arena */

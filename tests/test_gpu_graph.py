@@ -163,3 +163,32 @@ def test_pyramid_dyn_matches_exact_pyramid(clouds):
         got = arena[off:off + 16 * lv[l].n].view(torch.int32).view(-1, 4)
         assert torch.equal(got, lv[l].coords)
         assert [int(v) for v in m[16 + 8 * l:16 + 8 * l + 2]] == [s for s, _ in lv[l].items]
+
+
+def test_strict_fp32_capacity_mode_equals_its_exact_mode(seeded_sd, clouds, images):
+    """Variant 0 (v_mfma_f32_16x16x4_f32 in every convolution, the image trunk and the fusion feed-forward) through
+    imf_fragment_forward: bit-identical to the variant-0 exact mode, within 1e-4 of the oracle and within 2e-6 of the
+    default split-f16 path; a variant-0 bucket does not report IMF_FLAG_RANGE (nothing there is an f16 operand)."""
+    import bench
+    import imf_oracle as O
+    from imfnet_amd.model.graph import FragmentRunner
+    dev = torch.device(DEV)
+    m0, sd = bench.build_model(dev, variant=0)
+    pts = [clouds[0][::3].astype(np.float64), clouds[1][::4].astype(np.float64)]
+    imgs = np.concatenate([images[0], images[1]], 0)
+    wl = bench.Workload(m0, dev, pts, imgs, 0.05)
+    with torch.no_grad():
+        F_exact = wl.prepare_graph().clone()
+        assert wl.runner.variant == 0 and wl.runner.supported and wl.bucket.ignore_flags == 32
+        wl.runner.use_graph = False
+        res = wl.graph_step()
+        torch.cuda.synchronize()
+        assert res.flags == 0 and torch.equal(res.F, F_exact)
+        wl.runner.use_graph = True                                   # and as a replayed hipGraph
+        assert torch.equal(wl.graph_step().F, F_exact)
+        m6, _ = bench.build_model(dev)
+        F6 = bench.Workload(m6, dev, pts, imgs, 0.05).exact_step()
+    assert float((F6 - F_exact).abs().max()) < 2e-6
+    n0 = res.items()[0][1]
+    _, F_ref = O.extract_features(sd, pts[0], 0.05, images[0])
+    assert np.abs(F_exact[:n0].cpu().numpy() - F_ref.numpy()).max() < 1e-4

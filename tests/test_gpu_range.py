@@ -183,7 +183,8 @@ def test_range_flag_hits_over_a_fragment_set_at_2p5cm(seeded_sd, clouds, images)
         runner = m.fragment_runner()
         before = runner.stats["redone"]
         outs = list(extract_features_stream(m, iter(frags), 0.025, dev, batch=1))
-    assert runner.stats["redone"] == before, "a fragment raised a flag (range or capacity) under checkpoint-like weights"
+    assert runner.stats["redone"] == before, ("a fragment raised a flag (range: 32, or capacity) under checkpoint-like "
+                                              "weights: flags %d" % runner.stats.get("redone_flags", -1))
     assert len(outs) == 12 and all(np.isfinite(F).all() for _, F in outs)
     assert (outs[0][0] == xd0).all() and np.abs(outs[0][1] - F0.cpu().numpy()).max() < 2e-6
     k = int(np.argmin([len(x) for x, _ in frags]))                      # the smallest fragment against the oracle
