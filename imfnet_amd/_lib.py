@@ -133,7 +133,8 @@ class FragmentIO(C.Structure):
                 ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p), ("events", C.c_void_p * 16),
                 ("main_stream", C.c_void_p), ("side_stream", C.c_void_p), ("image_stream", C.c_void_p),
                 ("trace", C.POINTER(NetTrace)), ("levels", LevelDesc * 4), ("serialize", C.c_int32),
-                ("fp32_buffers", C.c_int32)]
+                ("fp32_buffers", C.c_int32), ("head_on_side", C.c_int32), ("reserved0", C.c_int32),
+                ("inputs_event", C.c_void_p), ("reuse_event", C.c_void_p)]
 
 
 class Job(C.Structure):
@@ -168,6 +169,7 @@ SIGNATURES = {
     "imf_stream_destroy": (None, [_P]),
     "imf_event_create": (_P, []),
     "imf_event_destroy": (None, [_P]),
+    "imf_event_record": (_I, [_P, _P]),
     "imf_event_elapsed_ms": (C.c_float, [_P, _P]),
     "imf_nn_workspace_bytes": (_Z, [_L, _L]),
     "imf_nn_search": (_I, [_P, _L, _P, _L, _I, _P, _P, _P, _Z, _P]),

@@ -25,6 +25,11 @@ void *imf_event_create(void) {
 void imf_event_destroy(void *ev) {
   if (ev) (void)hipEventDestroy((hipEvent_t)ev);
 }
+int imf_event_record(void *ev, void *stream) {
+  IMF_REQUIRE(ev, "imf_event_record: null event");
+  IMF_CHECK_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+  return IMF_OK;
+}
 /* Streams owned by the library's callers but created here: a framework's stream pool may hand the same stream out
  * twice (torch.cuda.Stream() wraps around after 32), and imf_fragment_forward needs three DISTINCT ones. */
 void *imf_stream_create(void) {

@@ -136,6 +136,7 @@ struct FragmentCtx {
   const imf_fragment_caps *caps;
   imf_fragment_io *fio;
   hipStream_t imgs;
+  bool head_on_side;   // level 0 was issued on the SIDE stream (imf_fragment_io.head_on_side): the main stream joins it
 };
 
 int fork_image_branch(const FragmentCtx &c, hipStream_t main) {
@@ -280,7 +281,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   const bool first_and_map = dyn && pyr && s.small_first && side != main;
   int items_event = -1;
   bool image_joined_side = false;
-  if (pyr) {   // level 0 was built on the main stream: the side stream (coarse levels, rulebooks) starts after it
+  if (pyr && fctx->head_on_side) {   // level 0 was built on the side stream, ahead of the main stream: main joins here
+    IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[7], side));
+    IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->events[7], 0));
+  } else if (pyr) {   // level 0 was built on the main stream: the side stream (coarse levels, rulebooks) starts after it
     IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[7], main));
     IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->events[7], 0));
   }
@@ -575,18 +579,26 @@ int imf_fragment_forward(const imf_resunet_desc *net, const imf_image_desc *img,
     // k_bitgrid_fill launch between the pyramid and conv1
     pb.grid = bitgrid; pb.grid_words = caps->bitgrid_words; pb.grid_ksize = net->first_ksize;
   }
-  if ((rc = pyramid_init(pb, main))) return rc;
+  // the head (table reset, level 0, image fork): on the main stream, or -- head_on_side -- on the side stream, where it
+  // does not queue behind the previous forward's decoder (include/imfnet_hip.h, imf_fragment_io.head_on_side)
+  const bool head_on_side = fio->head_on_side && !fio->serialize;
+  hipStream_t head = head_on_side ? side : main;
+  if (head_on_side) {
+    if (fio->reuse_event) IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)fio->reuse_event, 0));
+    if (fio->inputs_event) IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)fio->inputs_event, 0));
+  }
+  if ((rc = pyramid_init(pb, head))) return rc;
 
   // image branch on its own stream, forked from and later joined to the main one (events 9 / 10), ahead of the pyramid:
   // its ~50 small launches (~0.2 ms as a chain) must be done by the fusion block.  Forking it later in the step -- after
   // block1 / conv2 / block2 / conv3 / block3, beside the levels that leave CUs idle -- was measured slower (1.07 ->
   // 1.15 ... 1.23 ms, round 3): the chain then ends after the encoder and the fusion waits for it.
   const int fork_env = -1;
-  FragmentCtx fctx{&pb, fio->serialize ? -1 : fork_env, img, caps, fio, imgs};
-  if (fctx.fork_after < 0 && (rc = fork_image_branch(fctx, main))) return rc;
+  FragmentCtx fctx{&pb, fio->serialize ? -1 : fork_env, img, caps, fio, imgs, head_on_side};
+  if (fctx.fork_after < 0 && (rc = fork_image_branch(fctx, head))) return rc;
 
-  // level 0 of the pyramid on the main stream (conv1 needs it first); the coarse levels go to the side stream
-  if ((rc = pyramid_level0(pb, main, false))) return rc;
+  // level 0 of the pyramid on the head's stream (conv1 needs it first); the coarse levels go to the side stream
+  if ((rc = pyramid_level0(pb, head, false))) return rc;
 
   imf_resunet_io io;
   memset(&io, 0, sizeof(io));

@@ -143,7 +143,12 @@ int issue_upload(Pipeline &p, Ticket &t) {
 
 int issue_forward(Pipeline &p, Ticket &t) {
   const imf_job &j = t.job;
-  IMF_CHECK_HIP(hipStreamWaitEvent(p.main, t.e_in, 0));
+  if (j.io->head_on_side) {   // the head runs on the side stream, ahead of the main one: IT waits for the upload; the bucket
+    j.io->inputs_event = t.e_in;      // is free (its previous job has been waited for: imf_pipeline_wait's contract)
+    j.io->reuse_event = nullptr;
+  } else {
+    IMF_CHECK_HIP(hipStreamWaitEvent(p.main, t.e_in, 0));
+  }
   IMF_CHECK_HIP(hipEventRecord(t.e_begin, p.main));
   j.io->main_stream = p.main;
   int rc = imf_fragment_forward(j.net, j.img, j.caps, j.io);

@@ -30,6 +30,11 @@
 // (csrc/spconv_g.hip): DMA row images with the conflict-free lane swizzle, `lo*hi, hi*lo, hi*hi` per 32 channels.
 #include "spconv_shared.h"
 
+#ifndef IMF_W_ABL
+#define IMF_W_ABL 0   // timing experiments only (wrong results; tools/w_ablations.sh): 1 no main loop, 2 no neighbour-table loads,
+                      // 4 no combine / epilogue, 8 leave right after the tile test (launch + dispatch only)
+#endif
+
 namespace imf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -102,6 +107,7 @@ k_spconv_w(const ConvParams p) {
     tile = (int)(j * (8u / ns) + xcd / ns);
   }
   if ((long long)tile * IMF_TILE_ROWS >= slots_act) return;
+  if (IMF_W_ABL & 8) return;
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cin = p.c_a + (CAT ? p.c_b : 0);
@@ -124,6 +130,7 @@ k_spconv_w(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < kPer; ++i) {
         const int j = j0 + JSTEP * i;
+        if (IMF_W_ABL & 2) { v[i] = srow + j; continue; }
         v[i] = src[(long long)klist[j < nk ? j : 0] * p.n_slots];
       }
     } else {                                         // kvol == 1 (a pointwise layer): the slot's own row
@@ -197,7 +204,7 @@ k_spconv_w(const ConvParams p) {
   }
 
   // this wavefront's range of the tile's sub-stages
-  const int t0 = (int)((long long)wave * n_sub / W), t1 = (int)((long long)(wave + 1) * n_sub / W);
+  const int t0 = (int)((long long)wave * n_sub / W), t1 = (IMF_W_ABL & 1) ? t0 : (int)((long long)(wave + 1) * n_sub / W);
   unsigned e_cur = 0, e_nxt = 0;
   Rows rows_nxt;
   if (t0 < t1) {
@@ -272,6 +279,7 @@ k_spconv_w(const ConvParams p) {
 #undef IMF_W_DMA
 #undef IMF_W_ROWS
 
+  if ((IMF_W_ABL & 4) && acc[0][0][0] != 12345.f) return;
   // ---- the W partial tiles meet in LDS (each wavefront's own 16 KiB: its DMAs have all landed and been read) ----
   // element (row, col) of wavefront w at float index  w * 4096 + row * 64 + (((col >> 2) ^ f(row)) << 2) + (col & 3),
   // f(row) = 4 * ((row >> 2) & 1): conflict-free for the ds_write_b32 of the accumulator layout and the ds_read_b128 below

@@ -40,8 +40,11 @@ class FragmentStreamer:
     """Capacity buckets (device) + the library pipeline of one FragmentRunner on one device.  `n_buckets` forwards of one
     capacity key can be in flight (upload of k+1, forward of k, download of k-1); pinned HostSlots belong to the caller."""
 
-    def __init__(self, runner, device, n_buckets=3, sdma_copies=None, copy_blocks=0):
+    def __init__(self, runner, device, n_buckets=3, sdma_copies=None, copy_blocks=0, head_on_side=True):
         self.runner, self.device, self.n_buckets = runner, device, max(1, int(n_buckets))
+        # a job's table reset / level-0 pyramid / image fork on the side stream, under the previous job's last convolutions
+        # (imf_fragment_io.head_on_side); the pipeline hands the upload's event in, buckets are reused only after wait()
+        self.head_on_side = bool(head_on_side)
         self.L = runner.L
         main = runner.main_stream(device)
         if sdma_copies is None:                       # copy engines when hipMemcpyAsync cannot block the worker (see __init__.py)
@@ -156,6 +159,7 @@ class FragmentStreamer:
         job.out_offset, job.out_row_bytes = b.lay["F"], int(b.out.shape[1]) * 4
         job.defer_download = 1 if more_follow else 0
         b.io.trace = None
+        b.io.head_on_side = 1 if self.head_on_side else 0
         ticket = self.L.imf_pipeline_submit(self.handle, C.byref(job))
         if ticket < 0:
             with self._lock:

@@ -616,6 +616,17 @@ typedef struct imf_fragment_io {       /* [host]; all buffers device memory owne
   imf_level levels[4];                 /* out [host]: where the levels live inside pyramid_arena */
   int32_t serialize;                   /* measurement aid: issue everything on main_stream (no overlap between branches) */
   int32_t fp32_buffers;                /* as imf_resunet_io.fp32_buffers */
+  /* Head on the side stream (a STREAM of forwards over several buckets).  0: the table reset, the level-0 pyramid and the
+   * image fork are issued on main_stream, i.e. behind everything the main stream still holds -- the previous forward's
+   * decoder.  1: they are issued on side_stream, which is idle from the middle of the previous forward on, and the main
+   * stream joins in front of conv1: forward k+1's first ~60 us run under forward k's last convolutions (same kernels,
+   * same results).  The head then no longer inherits the main stream's order, so the caller states its two dependencies:
+   * inputs_event (NULL: none) = after which xyz / dyn / image are in place; reuse_event (NULL: none) = after which earlier
+   * work on ANY stream no longer touches this bucket's buffers (the end of its previous forward and of whatever read its
+   * outputs).  Not inside a hipGraph capture. */
+  int32_t head_on_side;
+  int32_t reserved0;
+  void *inputs_event, *reuse_event;
 } imf_fragment_io;
 
 size_t imf_fragment_pyramid_bytes(const imf_fragment_caps *caps);
@@ -772,6 +783,7 @@ void *imf_stream_create(void);     /* non-blocking hipStream_t, distinct from an
 void imf_stream_destroy(void *stream);
 void *imf_event_create(void);
 void imf_event_destroy(void *ev);
+int imf_event_record(void *ev, void *stream);                 /* hipEventRecord */
 float imf_event_elapsed_ms(void *ev_begin, void *ev_end);   /* < 0 on error (e.g. not completed) */
 
 #ifdef __cplusplus

@@ -260,9 +260,10 @@ def test_extract_features_numpy_points_with_a_device_image(clouds, images, seede
     assert torch.equal(F0, F1) and torch.equal(F0, F2)
 
 
-@pytest.mark.parametrize("sdma", [False, True])
-def test_pipeline_transfer_modes_agree(clouds, images, seeded_sd, sdma):
-    """The streaming pipeline's two transfer mechanisms -- copy kernels that address the pinned blocks directly (the
+@pytest.mark.parametrize("sdma,head", [(False, True), (True, True), (True, False)])
+def test_pipeline_transfer_modes_agree(clouds, images, seeded_sd, sdma, head):
+    """(head: a job's table reset / level-0 pyramid / image fork on the side stream, under the previous job's last
+    convolutions -- imf_fragment_io.head_on_side -- or on the main stream.)  The streaming pipeline's two transfer mechanisms -- copy kernels that address the pinned blocks directly (the
     fallback when the HIP runtime was started without ROC_CPU_WAIT_FOR_SIGNAL=0) and the copy engines (hipMemcpyAsync) --
     deliver the same bytes: xyz_down and descriptors of streamed fragments equal the per-fragment calls', for float64
     points that are float32 values (uploaded narrowed), arbitrary float64 and float32 inputs."""
@@ -281,8 +282,8 @@ def test_pipeline_transfer_modes_agree(clouds, images, seeded_sd, sdma):
         ref = [(xd, F.cpu().numpy()) for xd, F in ref]
         runner = m.fragment_runner()
         runner._streamers.pop(dev, None)                                   # (a streamer of the default mode may exist already)
-        st = runner.streamer(dev, sdma_copies=sdma)
-        assert st.sdma_copies == sdma
+        st = runner.streamer(dev, sdma_copies=sdma, head_on_side=head)
+        assert st.sdma_copies == sdma and st.head_on_side == head
         got = list(extract_features_stream(m, iter(frs), 0.05, dev, depth=2, batch=1))
         got += list(extract_features_stream(m, iter(frs), 0.05, dev, depth=3, batch=1))
     assert runner.stats["eager"] >= 6                  # (a fragment that outgrows its bucket is redone exactly: also equal)

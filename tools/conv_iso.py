@@ -56,7 +56,7 @@ for name, ca, cb, cout, kind, i in SHAPES:
         e1.record(); torch.cuda.synchronize()
         cols.append(e0.elapsed_time(e1) * 1e3 / REPS)
     split = ops._lib.lib().imf_spconv_auto_split(rb.n_slots, cout, rb.max_active) if rb.kvol > 1 else 1
-    tot = [a + (b if b is not None else cols[0]) for a, b in zip(tot if isinstance(tot, list) else [0.0] * len(cols), cols)]
+    tot = [a + (b if b is not None else (cols[0] or 0.0)) for a, b in zip(tot if isinstance(tot, list) else [0.0] * len(cols), cols)]
     print("%-10s k=%2d %3d->%3d slots=%6d split=%d  " % (name, rb.kvol, ca + cb, cout, rb.n_slots, split) +
           "  ".join("%7.1f us" % c if c is not None else "      -   " for c in cols))
 print("sum (missing = first column):  " + "  ".join("%7.1f us" % t for t in tot) + "   [" + ", ".join(str(s) for s in stagings) + "]")

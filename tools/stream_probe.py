@@ -11,6 +11,7 @@ ap.add_argument("--buckets", type=int, default=3); ap.add_argument("--depth", ty
 ap.add_argument("--batch", default="2"); ap.add_argument("--n", type=int, default=60)
 ap.add_argument("--f32", action="store_true", help="hand float32 point arrays in (no narrowing pass)")
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--head", type=int, default=1, help="1: a job's level-0 head on the side stream (default), 0: on the main stream")
 args = ap.parse_args()
 args.batch = args.batch if args.batch == "auto" else int(args.batch)
 dev = torch.device("cuda:0")
@@ -21,7 +22,7 @@ xyz, img, voxel = load_workload(1.7, 0.025)
 xyz = xyz.astype(np.float32 if args.f32 else np.float64)
 model, sd = build_model(dev)
 with torch.no_grad():
-    model.fragment_runner().streamer(dev, n_buckets=args.buckets, sdma_copies=None if args.sdma < 0 else bool(args.sdma), copy_blocks=args.blocks)
+    model.fragment_runner().streamer(dev, n_buckets=args.buckets, sdma_copies=None if args.sdma < 0 else bool(args.sdma), copy_blocks=args.blocks, head_on_side=bool(args.head))
     xd0, F0 = extract_features(model, xyz, voxel_size=voxel, device=dev, skip_check=True, image=img)   # exact path: teaches the runner
     F0 = F0.cpu().numpy()
     r = model.fragment_runner()
