@@ -432,11 +432,14 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
     wgs = tiles * grid.y * (s_est < (int)grid.z ? s_est : (int)grid.z);
   }
   const bool deep = nb_env ? nb_env >= 4 : wgs <= nb_wgs;
+#ifndef IMF_G_NB_WIDE
+#define IMF_G_NB_WIDE 2   // ring depth of the launches that fill the chip (experiment: 3)
+#endif
 #define IMF_G_LAUNCH(CB, USE, CAT)                                                         \
   do {                                                                                     \
     if (p.a_split) {   /* operand images: the ResUNet's own layers (label 0) */            \
       if (deep) k_spconv_g<CB, 0, CAT, 4, 1, true><<<grid, 256, 0, st>>>(p);               \
-      else      k_spconv_g<CB, 0, CAT, 2, 1, true><<<grid, 256, 0, st>>>(p);               \
+      else      k_spconv_g<CB, 0, CAT, IMF_G_NB_WIDE, 1, true><<<grid, 256, 0, st>>>(p);   \
     } else if (deep) k_spconv_g<CB, USE, CAT, 4, 1><<<grid, 256, 0, st>>>(p);              \
     else             k_spconv_g<CB, USE, CAT, 2, 1><<<grid, 256, 0, st>>>(p);              \
   } while (0)
