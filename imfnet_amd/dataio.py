@@ -105,15 +105,19 @@ def read_image_pil(path):
 
 
 def process_image(image, aim_H=480, aim_W=640, mode="resize", clip_mode="center"):
-    """util/uio.py:18-99, `resize` branch (the only one on the path, generate_desc.py:94-95):
-    cv2.resize(image, (aim_W, aim_H), INTER_LINEAR) == bilinear with half-pixel centres and no
-    anti-aliasing; returns float32 HWC.  Already-sized images are returned unchanged."""
+    """util/uio.py:18-99.  `resize` (the only branch on the path, generate_desc.py:94-95): cv2.resize(image, (aim_W, aim_H),
+    INTER_LINEAR) == bilinear with half-pixel centres and no anti-aliasing; returns float32 HWC.  Already-sized images are
+    returned unchanged.  `clip` and `padding`: _process_clip / _process_padding below (host-side numpy, off the path)."""
     img = np.asarray(image)
     H, W, _ = img.shape
     if H == aim_H and W == aim_W:
         return img
+    if mode == "clip":
+        return _process_clip(img, aim_H, aim_W, clip_mode)
+    if mode == "padding":
+        return _process_padding(img, aim_H, aim_W)
     if mode != "resize":
-        raise NotImplementedError("only mode='resize' is on the descriptor-generation path (SURVEY §8a H2)")
+        return img                                    # (the reference falls through its if / elif chain: unchanged)
     if img.dtype == np.uint8:
         # cv2.resize on 8-bit input (the .jpg branch of generate_desc.py:88-95) interpolates in fixed point and returns
         # uint8: 11-bit coefficients, result rounded to the nearest integer (OpenCV resize.cpp, INTER_RESIZE_COEF_BITS = 11;
@@ -127,6 +131,101 @@ def process_image(image, aim_H=480, aim_W=640, mode="resize", clip_mode="center"
     if rc != 0:
         raise ValueError(_native().imf_last_error().decode())
     return out
+
+
+# ---- the modes that are NOT on the descriptor-generation path (util/uio.py:41-99), restated for completeness ----------
+def _reflect101(i, n):
+    """cv2.BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba) for indices one or two beyond the edge."""
+    if n == 1:
+        return np.zeros_like(i)
+    i = np.abs(i)
+    return np.where(i >= n, 2 * (n - 1) - i, i)
+
+
+def _pyr_down(img):
+    """cv2.pyrDown: 5x5 Gaussian ([1 4 6 4 1] / 16 per axis, BORDER_REFLECT_101), then every second row / column ->
+    ((H + 1) // 2, (W + 1) // 2).  8-bit images: integer sums, (s + 128) >> 8.  [RECALLED from the OpenCV documentation and
+    pyramids.cpp; OpenCV is absent here, so this branch is UNPINNED -- it is not on the generate_desc path.]"""
+    H, W, _ = img.shape
+    k = np.array([1, 4, 6, 4, 1], dtype=np.int64)
+    src = img.astype(np.int64) if img.dtype == np.uint8 else img.astype(np.float64)
+    oy, ox = np.arange((H + 1) // 2) * 2, np.arange((W + 1) // 2) * 2
+    rows = sum(k[t] * src[:, _reflect101(ox + t - 2, W)] for t in range(5))
+    out = sum(k[t] * rows[_reflect101(oy + t - 2, H)] for t in range(5))
+    if img.dtype == np.uint8:
+        return np.clip((out + 128) >> 8, 0, 255).astype(np.uint8)
+    return (out / 256.0).astype(img.dtype)
+
+
+def _pyr_up(img):
+    """cv2.pyrUp: zero-interleave to (2H, 2W), the same Gaussian times 4.  Per axis: even outputs (s[i-1] + 6 s[i] + s[i+1]) / 8,
+    odd outputs (s[i] + s[i+1]) / 2, borders reflected (101) on the left and replicated on the right; 8-bit: (s + 32) >> 6.
+    [RECALLED, unpinned: see _pyr_down.]"""
+    H, W, _ = img.shape
+    src = img.astype(np.int64) if img.dtype == np.uint8 else img.astype(np.float64)
+
+    def up(a, n, axis):
+        i = np.arange(n)
+        prev, nxt = _reflect101(i - 1, n), np.minimum(i + 1, n - 1)
+        a_p, a_n = np.take(a, prev, axis), np.take(a, nxt, axis)
+        even, odd = a_p + 6 * a + a_n, 4 * (a + a_n)
+        shape = list(a.shape)
+        shape[axis] = 2 * n
+        out = np.empty(shape, dtype=a.dtype)
+        sl_e, sl_o = [slice(None)] * a.ndim, [slice(None)] * a.ndim
+        sl_e[axis], sl_o[axis] = slice(0, None, 2), slice(1, None, 2)
+        out[tuple(sl_e)], out[tuple(sl_o)] = even, odd
+        return out
+
+    out = up(up(src, W, 1), H, 0)
+    if img.dtype == np.uint8:
+        return np.clip((out + 32) >> 6, 0, 255).astype(np.uint8)
+    return (out / 64.0).astype(img.dtype)
+
+
+def _process_clip(img, aim_H, aim_W, clip_mode):
+    """util/uio.py:41-62: double the image until it covers the target, halve it once when it is more than twice as large in
+    both directions, then cut an aim_H x aim_W window (centre / top-left / uniformly random offset from numpy's global RNG)."""
+    H, W, _ = img.shape
+    while H < aim_H or W < aim_W:
+        img = _pyr_up(img)
+        H, W, _ = img.shape
+    if H > aim_H * 2 and W > aim_W * 2:
+        img = _pyr_down(img)
+        H, W, _ = img.shape
+    if clip_mode == "center":
+        top, left = int((H - aim_H) / 2), int((W - aim_W) / 2)
+        return img[top:top + aim_H, left:left + aim_W]
+    if clip_mode == "normal":
+        return img[0:aim_H, 0:aim_W]
+    if clip_mode == "random":
+        top = int(np.random.random() * (H - aim_H))          # (two draws, rows first: the reference's order)
+        left = int(np.random.random() * (W - aim_W))
+        return img[top:top + aim_H, left:left + aim_W]
+    return img                                               # unknown clip_mode: the reference returns the pyramid image
+
+
+def _process_padding(img, aim_H, aim_W):
+    """util/uio.py:64-97 AS WRITTEN, quirks included: its four cases compare the wrong way round, so
+      * an image larger than the target in both directions asks numpy for a block of negative height and raises ValueError;
+      * larger in one direction only: that direction is cut, the other one gets a zero block of (target - size) rows or
+        columns -- ValueError again unless the image is smaller there;
+      * not larger in either direction: returned as it is (the slice is a no-op), float64 is NOT forced.
+    Zero blocks are float64, so a padded result is float64 (np.concatenate promotes)."""
+    H, W, C = img.shape
+    chw = np.transpose(img, (2, 0, 1))
+    if aim_H < H and aim_W < W:
+        chw = np.concatenate([chw, np.zeros((C, aim_H - H, W))], axis=1)     # raises: negative dimension
+        chw = np.concatenate([chw, np.zeros((C, aim_H, aim_W - W))], axis=2)
+    elif aim_H < H:
+        chw = chw[:, 0:aim_H, :]
+        chw = np.concatenate([chw, np.zeros((C, aim_H, aim_W - W))], axis=2)
+    elif aim_W < W:
+        chw = chw[:, :, 0:aim_W]
+        chw = np.concatenate([chw, np.zeros((C, aim_H - H, W))], axis=1)
+    else:
+        chw = chw[:, 0:aim_H, 0:aim_W]
+    return np.transpose(chw, (1, 2, 0))
 
 
 def process_image_torch(image, aim_H, aim_W):

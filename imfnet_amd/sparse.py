@@ -331,7 +331,12 @@ class MinkowskiBatchNorm(nn.Module):
 
 
 class MinkowskiInstanceNorm(nn.Module):
-    """Constructible for the *IN* model variants' state_dict; not on the ResUNetBN2C path."""
+    """ME.MinkowskiInstanceNorm (the `IN` blocks of ResUNetIN2*, model/common.py:7-8): per batch item and channel,
+    (x - mean) / sqrt(var + 1e-8) over that item's rows (biased variance: ME computes both with a global average pooling),
+    then weight * x + bias with [1, C] parameters.  Plain torch on the rows -- these variants are not the checkpoint's
+    (ResUNetBN2C) and take the per-layer path, not the fused plan.  [ME 0.5.4 conventions RECALLED: eps, biased variance.]"""
+
+    EPS = 1e-8
 
     def __init__(self, num_features, dimension=-1):
         super().__init__()
@@ -339,7 +344,22 @@ class MinkowskiInstanceNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, num_features))
 
     def forward(self, x):
-        raise ImfError("MinkowskiInstanceNorm is outside the descriptor hot path (SURVEY §8)")
+        f = x.F
+        item = x.C[:, 0].long()
+        n_items = int(item.max().item()) + 1 if item.numel() else 0
+        if n_items <= 1:
+            mean = f.mean(0, keepdim=True)
+            cen = f - mean
+            var = (cen * cen).mean(0, keepdim=True)
+            out = cen * torch.rsqrt(var + self.EPS)
+        else:
+            cnt = torch.zeros(n_items, 1, dtype=f.dtype, device=f.device).index_add_(
+                0, item, torch.ones(f.shape[0], 1, dtype=f.dtype, device=f.device)).clamp_(min=1)
+            mean = torch.zeros(n_items, f.shape[1], dtype=f.dtype, device=f.device).index_add_(0, item, f) / cnt
+            cen = f - mean[item]
+            var = torch.zeros_like(mean).index_add_(0, item, cen * cen) / cnt
+            out = cen * torch.rsqrt(var + self.EPS)[item]
+        return x._like(out * self.weight + self.bias)
 
 
 class MinkowskiFunctional:

@@ -200,12 +200,35 @@ def batchnorm_eval(x, sd, prefix, eps=1e-5):
                         sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"], False, 0.0, eps)
 
 
-def basic_block(x, sd, prefix, nbr):
-    """model/residual_block.py:37-53."""
+def instance_norm(x, item, weight, bias, eps=1e-8):
+    """ME.MinkowskiInstanceNorm (model/common.py:7-8, the `IN` blocks of ResUNetIN2*): per batch item and channel
+    (x - mean) / sqrt(var + eps), mean and (biased) variance over the item's rows -- ME computes both with a global average
+    pooling -- then weight * x + bias.  float64 inside.  [RECALLED: ME 0.5.4's eps = 1e-8 and the biased variance.]"""
+    x64 = x.double().numpy()
+    out = np.empty_like(x64)
+    item = np.asarray(item)
+    for b in np.unique(item):
+        rows = item == b
+        v = x64[rows]
+        cen = v - v.mean(0, keepdims=True)
+        out[rows] = cen / np.sqrt((cen * cen).mean(0, keepdims=True) + eps)
+    out = out * weight.double().numpy().reshape(1, -1) + bias.double().numpy().reshape(1, -1)
+    return torch.from_numpy(out).float()
+
+
+def block_norm(x, sd, prefix, item):
+    """The block's norm layer by what the state dict holds: BatchNorm ('<prefix>.bn.*') or InstanceNorm ('<prefix>.weight')."""
+    if prefix + ".bn.weight" in sd:
+        return batchnorm_eval(x, sd, prefix)
+    return instance_norm(x, item, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def basic_block(x, sd, prefix, nbr, item=None):
+    """model/residual_block.py:37-53 (BasicBlockBN / BasicBlockIN; `item`: the rows' batch indices, for IN)."""
     out = spconv(x, sd[prefix + ".conv1.kernel"], nbr)
-    out = F.relu(batchnorm_eval(out, sd, prefix + ".norm1"))
+    out = F.relu(block_norm(out, sd, prefix + ".norm1", item))
     out = spconv(out, sd[prefix + ".conv2.kernel"], nbr)
-    out = batchnorm_eval(out, sd, prefix + ".norm2")
+    out = block_norm(out, sd, prefix + ".norm2", item)
     return F.relu(out + x)
 
 
@@ -278,19 +301,19 @@ def resunet_forward(sd, coords, image, feats=None, normalize_feature=True,
     tap("image_feat", img)
 
     out = batchnorm_eval(spconv(x, sd["conv1.kernel"], g.k_first), sd, "norm1")     # :168-169
-    out_s1 = basic_block(out, sd, "block1", g.k3[0])
+    out_s1 = basic_block(out, sd, "block1", g.k3[0], g.levels[0][:, 0])
     out = F.relu(out_s1)
     tap("out_s1", out_s1)
     out = batchnorm_eval(spconv(out, sd["conv2.kernel"], g.down[0]), sd, "norm2")   # :173-174
-    out_s2 = basic_block(out, sd, "block2", g.k3[1])
+    out_s2 = basic_block(out, sd, "block2", g.k3[1], g.levels[1][:, 0])
     out = F.relu(out_s2)
     tap("out_s2", out_s2)
     out = batchnorm_eval(spconv(out, sd["conv3.kernel"], g.down[1]), sd, "norm3")   # :178-179
-    out_s4 = basic_block(out, sd, "block3", g.k3[2])
+    out_s4 = basic_block(out, sd, "block3", g.k3[2], g.levels[2][:, 0])
     out = F.relu(out_s4)
     tap("out_s4", out_s4)
     out = batchnorm_eval(spconv(out, sd["conv4.kernel"], g.down[2]), sd, "norm4")   # :183-184
-    out_s8 = basic_block(out, sd, "block4", g.k3[3])
+    out_s8 = basic_block(out, sd, "block4", g.k3[3], g.levels[3][:, 0])
     out = F.relu(out_s8)
     tap("out_s8", out)
 
@@ -306,13 +329,13 @@ def resunet_forward(sd, coords, image, feats=None, normalize_feature=True,
     tap("fused", out)
 
     out = batchnorm_eval(spconv(out, sd["conv4_tr.kernel"], g.up[2]), sd, "norm4_tr")
-    out = F.relu(basic_block(out, sd, "block4_tr", g.k3[2]))
+    out = F.relu(basic_block(out, sd, "block4_tr", g.k3[2], g.levels[2][:, 0]))
     out = torch.cat([out, out_s4], 1)                                     # ME.cat :197
     out = batchnorm_eval(spconv(out, sd["conv3_tr.kernel"], g.up[1]), sd, "norm3_tr")
-    out = F.relu(basic_block(out, sd, "block3_tr", g.k3[1]))
+    out = F.relu(basic_block(out, sd, "block3_tr", g.k3[1], g.levels[1][:, 0]))
     out = torch.cat([out, out_s2], 1)                                     # :208
     out = batchnorm_eval(spconv(out, sd["conv2_tr.kernel"], g.up[0]), sd, "norm2_tr")
-    out = F.relu(basic_block(out, sd, "block2_tr", g.k3[0]))
+    out = F.relu(basic_block(out, sd, "block2_tr", g.k3[0], g.levels[0][:, 0]))
     tap("out_s1_tr", out)
     out = torch.cat([out, out_s1], 1)                                     # :219
     out = F.relu(spconv(out, sd["conv1_tr.kernel"], None))                # :224-225

@@ -205,8 +205,7 @@ def test_ply_reader_and_image_codecs(tmp_path, clouds):
     assert small.shape == (120, 160, 3) and np.abs(small - ref).max() < 1e-6
     assert process_image(small, aim_H=120, aim_W=160) is small or np.array_equal(process_image(small, 120, 160), small)
     assert image_to_nchw(small).shape == (1, 3, 120, 160)
-    with pytest.raises(NotImplementedError):
-        process_image(img, 120, 160, mode="clip")
+    assert process_image(img, 120, 160, mode="clip").shape == (120, 160, 3)
     out = tmp_path / "o.npz"
     save_descriptors(str(out), got, got[:10], torch.ones(10, 32))
     z = np.load(out)
@@ -476,3 +475,66 @@ def test_npz_block_parallel_deflate_is_thread_count_independent(tmp_path):
     info = {i.filename: i for i in zipfile.ZipFile(str(tmp_path / "l1_t8.npz")).infolist()}
     assert info["points.npy"].compress_size < 0.8 * info["points.npy"].file_size
     assert info["feature.npy"].compress_size < info["feature.npy"].file_size
+
+
+def test_process_image_clip_and_padding_modes():
+    """util/uio.py:41-99, the branches generate_desc never takes.  No OpenCV here: the pyramid filters are checked through
+    what cv2.pyrUp / pyrDown guarantee by definition (sizes, constants stay constants, 8-bit stays 8-bit, the Gaussian's
+    weights on an impulse), the window arithmetic and the padding branch's behaviour AS WRITTEN in the reference."""
+    from imfnet_amd.dataio import _pyr_down, _pyr_up, process_image
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
+    flat = np.full((11, 13, 3), 77, np.uint8)
+    assert _pyr_up(flat).shape == (22, 26, 3) and (_pyr_up(flat) == 77).all()
+    assert _pyr_down(flat).shape == (6, 7, 3) and (_pyr_down(flat) == 77).all()
+    imp = np.zeros((9, 9, 1), np.float32)
+    imp[4, 4] = 256.0
+    assert np.array_equal(_pyr_down(imp)[1:4, 1:4, 0], np.outer([1, 6, 1], [1, 6, 1]).astype(np.float32))   # taps at distance 2, 0, 2
+    up = _pyr_up(imp)[6:11, 6:11, 0]
+    assert np.array_equal(up, np.outer([1, 4, 6, 4, 1], [1, 4, 6, 4, 1]).astype(np.float32) / 64 * 256)
+    # clip: 50x70 -> doubled twice (200x280) to cover 120x160, centre window
+    big = _pyr_up(_pyr_up(img))
+    out = process_image(img, 120, 160, mode="clip")
+    assert out.dtype == np.uint8 and np.array_equal(out, big[40:160, 60:220])
+    assert np.array_equal(process_image(img, 120, 160, mode="clip", clip_mode="normal"), big[:120, :160])
+    np.random.seed(4)
+    top, left = int(np.random.random() * 80), int(np.random.random() * 120)
+    np.random.seed(4)
+    assert np.array_equal(process_image(img, 120, 160, mode="clip", clip_mode="random"), big[top:top + 120, left:left + 160])
+    # more than twice the target in both directions: halved once
+    assert np.array_equal(process_image(img, 20, 30, mode="clip", clip_mode="normal"), _pyr_down(img)[:20, :30])
+    # padding, as the reference behaves
+    assert process_image(img, 60, 80, mode="padding").shape == (50, 70, 3)            # smaller image: returned as it is
+    cut = process_image(img, 40, 80, mode="padding")                                  # taller, narrower: cut + zero columns
+    assert cut.shape == (40, 80, 3) and cut.dtype == np.float64
+    assert np.array_equal(cut[:, :70], img[:40]) and (cut[:, 70:] == 0).all()
+    with pytest.raises(ValueError):
+        process_image(img, 40, 60, mode="padding")                                    # larger both ways: negative block
+    assert process_image(img, 40, 60, mode="something else") is not None              # unknown mode: falls through unchanged
+
+
+def test_instance_norm_module_matches_the_oracle():
+    """sparse.MinkowskiInstanceNorm against oracle.instance_norm on a ragged three-item batch (the module only touches
+    .F, .C and ._like of its input: a stand-in carrier, since SparseTensor itself lives on the GPU)."""
+    import imfnet_amd.sparse as ME
+
+    class Rows:
+        def __init__(self, F, C):
+            self.F, self.C = F, C
+
+        def _like(self, F):
+            return Rows(F, self.C)
+    g = torch.Generator().manual_seed(2)
+    n = [37, 5, 120]
+    item = np.concatenate([np.full(k, i, np.int32) for i, k in enumerate(n)])
+    coords = torch.as_tensor(np.stack([item, np.arange(len(item)), np.zeros(len(item)), np.zeros(len(item))], 1).astype(np.int32))
+    f = torch.randn(len(item), 16, generator=g) * 3 + 1
+    norm = ME.MinkowskiInstanceNorm(16)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(1, 16, generator=g) + 0.5)
+        norm.bias.copy_(torch.rand(1, 16, generator=g) - 0.5)
+        out = norm(Rows(f, coords)).F
+    ref = O.instance_norm(f, item, norm.weight.detach(), norm.bias.detach())
+    assert float((out - ref).abs().max()) < 1e-5
+    one = norm(Rows(f[:37], coords[:37])).F.detach()
+    assert float((one - ref[:37]).abs().max()) < 1e-5

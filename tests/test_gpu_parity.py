@@ -712,6 +712,46 @@ def test_batched_forward_matches_single(model, clouds, images):
     assert (Fb - torch.cat(single)).abs().max() < 2e-5
 
 
+def _in_state_dict(seeded_sd, seed=5):
+    """The seeded BN state dict with the seven residual blocks' norms replaced by InstanceNorm parameters ([1, C] weight /
+    bias, no running statistics): the schema of ResUNetIN2C (model/resunet.py:316-318)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in seeded_sd.items():
+        if k.startswith("block") and ".bn." in k:
+            if k.endswith(".bn.weight"):
+                sd[k.replace(".bn.weight", ".weight")] = (torch.rand(1, v.numel(), generator=g) + 0.5)
+            elif k.endswith(".bn.bias"):
+                sd[k.replace(".bn.bias", ".bias")] = (torch.rand(1, v.numel(), generator=g) - 0.5) * 0.2
+            continue
+        sd[k] = v
+    return sd
+
+
+def test_instance_norm_variant_matches_oracle(seeded_sd, clouds, images):
+    """ResUNetIN2C (BatchNorm after the strided convolutions, InstanceNorm inside the residual blocks: model/resunet.py:316-318,
+    model/common.py:7-8) on a batch of two fragments -- the statistics are per batch item -- against the oracle."""
+    import imfnet_amd.sparse as ME
+    from imfnet_amd.model import load_model
+    sd = _in_state_dict(seeded_sd)
+    m = load_model("ResUNetIN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().to(DEV)
+    cs = [O.voxelize(clouds[i].astype(np.float64)[::4], 0.05)[0] for i in (0, 1)]
+    coords = np.concatenate([np.concatenate([np.full((len(c), 1), i, np.int32), c[:, 1:]], 1) for i, c in enumerate(cs)])
+    img = np.concatenate([images[0], images[1]])
+    with torch.no_grad():
+        st = ME.SparseTensor(torch.ones(len(coords), 1), coordinates=torch.as_tensor(coords), device=DEV)
+        Fb = m(st, torch.as_tensor(img).to(DEV)).F.cpu()
+    Fr = O.resunet_forward(sd, coords, img)
+    assert Fb.shape == Fr.shape and float((Fb - Fr).abs().max()) < 1e-4
+    # the statistics really are per item: the first fragment alone gives the same rows
+    with torch.no_grad():
+        st0 = ME.SparseTensor(torch.ones(len(cs[0]), 1), coordinates=torch.as_tensor(coords[:len(cs[0])]), device=DEV)
+        F0 = m(st0, torch.as_tensor(images[0]).to(DEV)).F.cpu()
+    assert float((F0 - Fb[:len(cs[0])]).abs().max()) < 2e-5
+
+
 def test_determinism_end_to_end(model, clouds, images):
     from imfnet_amd.extract import extract_features
     with torch.no_grad():
