@@ -424,6 +424,7 @@ def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=12):
             extract_features(model, frags[0][0], voxel_size=voxel, device=dev, skip_check=True, image=frags[0][1])
         for _ in extract_features_stream(model, (frags[i] for i in mine), voxel, dev, batch=2):
             pass                                         # untimed pass: the capacity buckets of these sizes exist afterwards
+        model.fragment_runner().streamer(dev).fill_lanes()   # ... all three lanes of each (created on demand otherwise)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -96,6 +96,16 @@ class FragmentStreamer:
                 raise ImfError("streamer: no bucket of this capacity is free and none is in flight")
             self._complete(old)                       # (outside the lock: it blocks on the GPU)
 
+    def fill_lanes(self):
+        """Create every lane still missing for the capacity keys seen so far (lanes are otherwise created on demand -- when
+        all existing ones of a key are in flight -- which depends on timing; a measurement wants them all to exist)."""
+        with self._lock:
+            for key in list(self._made):
+                while self._made[key] < self.n_buckets:
+                    lane = self._made[key]
+                    self._made[key] = lane + 1
+                    self._free.setdefault(key, []).append(self.runner.bucket(key, self.device, self.main, lane=lane))
+
     # -- submit / wait ------------------------------------------------------------------------------------------------
     def submit(self, items, voxel_size, slot, more_follow=False):
         """Queue `items` = [(xyz [N,3] host float32/float64 array, image [1,3,H,W] host float32 array)] as ONE forward
