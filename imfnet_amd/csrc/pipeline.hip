@@ -152,6 +152,7 @@ int issue_forward(Pipeline &p, Ticket &t) {
   IMF_CHECK_HIP(hipEventRecord(t.e_begin, p.main));
   j.io->main_stream = p.main;
   int rc = imf_fragment_forward(j.net, j.img, j.caps, j.io);
+  j.io->inputs_event = nullptr;       // (the ticket's event: not the caller's to keep)
   if (rc) return rc;
   if (j.sel) {
     rc = imf_gather_points(j.io->xyz, j.io->xyz_is_f64, (const int32_t *)j.io->levels[0].first_idx, j.io->meta,

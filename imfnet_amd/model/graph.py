@@ -209,6 +209,9 @@ class _Bucket:
         """All launches of one fragment on `stream` (+ the bucket's side / image streams), eagerly."""
         self.io.main_stream = stream.cuda_stream
         self.io.trace = trace
+        # (the streaming pipeline shares these buckets and sets head_on_side per job: a direct launch inherits the main
+        # stream's order instead -- the bucket's previous forward may still be running on it)
+        self.io.head_on_side, self.io.inputs_event, self.io.reuse_event = 0, None, None
         check(self.L.imf_fragment_forward(C.byref(runner.net_desc), C.byref(runner.img_plan.desc), C.byref(self.caps),
                                           C.byref(self.io)), "imf_fragment_forward")
 

@@ -290,3 +290,38 @@ def test_pipeline_transfer_modes_agree(clouds, images, seeded_sd, sdma, head):
     for (xd, F), (xr, Fr) in zip(got, ref + ref):
         assert (xd == xr).all() and xd.dtype == np.float64
         assert (F == Fr).all()
+
+
+def test_direct_launches_after_a_stream_keep_the_main_stream_order(clouds, images, seeded_sd):
+    """The streaming pipeline runs a job's head on the side stream (imf_fragment_io.head_on_side) and shares its lane-0
+    buckets with the direct capacity-mode launches (device tensors in).  A direct launch must not inherit the setting: its
+    bucket's previous forward may still be running on the main stream, and with head_on_side = 1 and no reuse_event the
+    header's contract gives the head no ordering against it.  Checked deterministically: after a direct launch the shared
+    bucket's io says head_on_side = 0 with no stale events (this assertion fails without the reset in _Bucket.enqueue).
+    Checked empirically: ten back-to-back direct launches after a stream pass, no synchronisation in between, every result
+    equal to the first -- NOTE this part passed 3 / 3 runs even WITHOUT the reset (the corruption the contract allows was
+    not reproduced on the hardware), so it guards the results, not the race."""
+    from imfnet_amd.extract import extract_features, extract_features_stream
+    from imfnet_amd.model import load_model
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.eval().cuda()
+    dev = torch.device("cuda:0")
+    xyz = clouds[0].astype(np.float64) * 1.3
+    with torch.no_grad():
+        xd0, F0 = extract_features(m, xyz, voxel_size=0.025, device=dev, skip_check=True, image=images[0])
+        F0 = F0.cpu()
+        for _ in extract_features_stream(m, ((xyz, images[0]) for _ in range(6)), 0.025, dev, batch=1):
+            pass
+        runner = m.fragment_runner()
+        assert runner.streamer(dev).head_on_side
+        xyz_d, img_d = torch.as_tensor(xyz).to(dev), torch.as_tensor(images[0]).to(dev)
+        eager0 = runner.stats["eager"]
+        outs = [extract_features(m, xyz_d, voxel_size=0.025, device=dev, skip_check=True, image=img_d)[1] for _ in range(10)]
+        torch.cuda.synchronize()
+    assert runner.stats["eager"] - eager0 == 10                      # capacity-mode launches on the shared bucket
+    key = runner.caps_for(len(xyz), 1, images[0].shape[2], images[0].shape[3], 0.025, True)
+    b = runner.buckets[key]                                          # lane 0: what the stream's first job used as well
+    assert b.launches >= 11 and b.io.head_on_side == 0 and not b.io.inputs_event and not b.io.reuse_event
+    assert all(torch.equal(F.cpu(), F0) for F in outs)
+    assert m.take_flags(dev) == 0
