@@ -162,7 +162,7 @@ using namespace imf;
 extern "C" {
 
 int imf_resunet_conv_kernel_tag(int level, int kvol, int cout, int variant) {
-  if (variant != 6 || kvol <= 1 || cout % 64 != 0 || level <= 0) return 0;
+  if ((variant != 6 && variant != 0) || kvol <= 1 || cout % 64 != 0 || level <= 0) return 0;   // (variant 0: the same kernels, AR = kArF32)
   // measured on the S50k pair / single fragment (profiles/r03_conv_isolated.txt): level 1 (438 / 219 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
   return level == 1 ? 8 : 4;

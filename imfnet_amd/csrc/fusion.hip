@@ -305,6 +305,7 @@ static int run_feed_forward(const imf_fusion_weights *w, long long n, const int3
     memset(&a, 0, sizeof(a));
     a.in_a = g; a.c_a = kFH; a.w_packed = w->w2_f32; a.kvol = 1; a.cout = kFD;
     a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = 0;
+    a.kernel_tag = 4;                                // wave-split like the variant-6 launch below (AR = kArF32)
     a.n_out_dev = n_dev; a.dyn_err = err;
     return imf_spconv_fwd(&a, st);
   }

@@ -793,9 +793,15 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   IMF_REQUIRE(a->variant != 6 || (a->kvol * (cin / 32) < kSubTab && a->c_a <= 1024 && a->c_b <= 1024),
               "imf_spconv_fwd: variant 6 needs kvol * cin / 32 < %d and <= 1024 channels per source (kvol=%d cin=%d): use variant 0",
               kSubTab, a->kvol, cin);
-  // variant 6, kernel_tag bits 2 / 3: the wave-split kernel (spconv_w.hip) with 8 / 4 wavefronts per workgroup -- the
-  // whole tile in one workgroup, no split-K partitions, no reduce launch
-  const int wsplit = a->variant == 6 ? ((a->kernel_tag & 4) ? 8 : ((a->kernel_tag & 8) ? 4 : 0)) : 0;
+  // Variant 0 (fp32 MFMA) runs on the LDS-DMA kernels too since round 5 (k_spconv_g / k_spconv_w with AR = kArF32: the
+  // fp32 weight image has the split-f16 image's sub-stage addressing) wherever their tables cover the shape; kernel_tag
+  // bit 1 or `tickets` keep the register-staged round-1 kernel k_spconv_mfma (A/B, the in-launch split-K combine).
+  const bool dma0 = a->variant == 0 && !simple && !(a->kernel_tag & 2) && !a->tickets && a->kvol < kKCache &&
+                    a->kvol * (cin / 32) < kSubTab && a->c_a <= 1024 && a->c_b <= 1024;
+  const bool dma = a->variant == 6 || dma0;
+  // kernel_tag bits 2 / 3 (variant 6, variant 0 on the DMA kernels): the wave-split kernel (spconv_w.hip) with 8 / 4
+  // wavefronts per workgroup -- the whole tile in one workgroup, no split-K partitions, no reduce launch
+  const int wsplit = dma ? ((a->kernel_tag & 4) ? 8 : ((a->kernel_tag & 8) ? 4 : 0)) : 0;
   if (wsplit) {
     IMF_REQUIRE(a->cout % 64 == 0 && (a->kvol > 1 || cin >= 256),
                 "imf_spconv_fwd: the wave-split kernel needs cout %% 64 == 0 and kvol > 1 or cin >= 256 (kvol=%d cin=%d cout=%d)",
@@ -814,12 +820,13 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
                ((a->variant == 0 && !simple) || a->variant == 6) ? a->tickets : nullptr, 0};
   p.tail_begin = p.tail_split = 0;
   p.w_unscale = a->variant == 6 ? a->w_packed + (long long)a->kvol * cin * a->cout + 1 : nullptr;
+  p.arith = dma0 ? kArF32 : kArF16x2;
   p.n_out_dev = a->n_out_dev;
   p.dyn_split_kvol = (a->n_out_dev && !wsplit) ? a->dyn_split_kvol : 0;
   p.slots_extra = a->slots_extra;
   p.split_min_blocks = split_min_blocks();
   p.split_target = split_target();
-  IMF_REQUIRE(!a->n_out_dev || a->variant == 6 || split == 1,
+  IMF_REQUIRE(!a->n_out_dev || dma || split == 1,
               "imf_spconv_fwd: n_out_dev (capacity mode) on the fp32-MFMA kernels needs an unsplit launch (split_k = 1)");
   p.err = a->dyn_err;
   p.geglu = a->geglu;
@@ -831,7 +838,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   IMF_REQUIRE(!p.out_split || !a->l2norm, "imf_spconv_fwd: IMF_FMT_OUT_SPLIT not with l2norm");
   IMF_REQUIRE(!p.res_split || a->residual, "imf_spconv_fwd: IMF_FMT_RES_SPLIT without a residual");
   IMF_REQUIRE(!a->geglu || ((a->variant == 6 || (a->variant == 0 && !simple)) && !wsplit && a->kvol == 1 && a->cout % 64 == 0 &&
-                            split == 1 && !a->scale && !a->residual && !a->relu && !a->l2norm && !(a->kernel_tag & 2)),
+                            split == 1 && !a->scale && !a->residual && !a->relu && !a->l2norm && (dma0 || !(a->kernel_tag & 2))),
               "imf_spconv_fwd: geglu needs variant 6 (k_spconv_g) or 0, kvol 1, cout %% 64 == 0, an unsplit launch and no other epilogue");
   // XCD-contiguous tile order of k_spconv_g (IMF_G_XCD: bit 0 = the 64-column launches, bit 1 = the 32-column ones; default
   // both): workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2.  In launch order each XCD gathers from ALL input
@@ -843,7 +850,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   const int xcd = 3;
   // (not for parity-grouped transposed maps: a range of consecutive tiles there is one parity class spread over the whole
   // level -- no locality to win, measured 43 -> 54 us for conv2_tr)
-  const bool g_xcd = a->variant == 6 && !wsplit && ((CB == 4 && (xcd & 1)) || (CB == 2 && (xcd & 2))) &&
+  const bool g_xcd = dma && !wsplit && ((CB == 4 && (xcd & 1)) || (CB == 2 && (xcd & 2))) &&
                      a->n_slots == imf_rulebook_slots(a->n_out);
   p.no_xcd_swizzle = !g_xcd;
   IMF_REQUIRE(!p.dyn_split_kvol || (!p.tickets && a->split_k >= 1), "imf_spconv_fwd: dyn_split_kvol needs an explicit split_k cover and no tickets");
@@ -860,6 +867,8 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
   if (wsplit) {
     launch_spconv_w(p, grid.x, wsplit, st);
+  } else if (dma0) {
+    launch_spconv_g(p, grid, CB, st, 0);
   } else if (a->variant == 6) {
     // Balanced tail: with >= 2 full rounds of workgroups per CU and a partial last round (801 tiles on
     // 256 CUs: 33 CUs get a 4th tile and set the kernel time), the tail tiles are split over their

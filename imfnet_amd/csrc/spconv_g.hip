@@ -99,9 +99,15 @@ __device__ __forceinline__ f16x8 lds_read_f16x8(const float4 *__restrict__ src) 
 //
 // PRE (round 3): the input rows are split-f16 operand images written by their producer (ConvParams::a_split) -- the two
 // 16-byte pieces a lane reads ARE its hi and lo A fragments, no conversion in the loop.  Same DMA, same sums.
-template <int CO_BLK, int USE, bool CAT, int NB, int RB, bool PRE = false>
+//
+// AR (spconv_shared.h) = the arithmetic: kArF16x2 / kArF16x2Pre as above, or kArF32 (round 5) -- the fp32 weight image
+// (imf_pack_weights; its (k, 32-channel) sub-stage is the same 8 / 4 KiB block at the same address as the split-f16
+// image's) and fp32 rows through the same DMA pieces and LDS images, 8 x v_mfma_f32_16x16x4_f32 per 32 channels and
+// column block, no conversion: variant 0, the reference's arithmetic, on this kernel's skeleton.
+template <int CO_BLK, int USE, bool CAT, int NB, int RB, int AR = kArF16x2>
 __global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? 4 : 2)
 k_spconv_g(const ConvParams p) {
+  constexpr bool PRE = AR == kArF16x2Pre;
   constexpr int ROWS = IMF_TILE_ROWS * RB;           // output rows per workgroup
   constexpr int SUB_F4 = 2 * CO_BLK * 64;            // float4 of weights per sub-stage: 512 or 256
   constexpr int SUB_SHIFT = CO_BLK == 4 ? 13 : 12;   // log2(bytes per weight sub-stage)
@@ -324,12 +330,33 @@ k_spconv_g(const ConvParams p) {
     const float4 *const abuf = wbuf + SUB_F4 + wave * AW_F4;
     slot_rd = slot_rd + 1 == NB ? 0 : slot_rd + 1;
     slot_wr = slot_wr + 1 == NB ? 0 : slot_wr + 1;
-    f16x8 ah[RB], al[RB];
     if (ABL & 32) {
 #pragma unroll
       for (int cb = 0; cb < CO_BLK; ++cb) acc[0][cb][0] += (float)t + (float)e_b;
       continue;
     }
+    if constexpr (AR == kArF32) {
+      float4 a0[RB], a1[RB], b0[CO_BLK], b1[CO_BLK];
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        a0[b] = lds_read16(&abuf[128 * b + rd_slot]);
+        a1[b] = lds_read16(&abuf[128 * b + 64 + rd_slot]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) {      // quad (j, cb) of the fp32 image: W[16 j + 4 q4 + t][16 cb + r16]
+        b0[cb] = lds_read16(&wbuf[cb * 64 + lane]);
+        b1[cb] = lds_read16(&wbuf[(CO_BLK + cb) * 64 + lane]);
+      }
+#define IMF_G_STEP(AV, BV, C)                                                                          \
+  _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                       \
+      _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                            \
+          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[b].C, BV[cb].C, acc[b][cb], 0, 0, 0);
+      IMF_G_STEP(a0, b0, x) IMF_G_STEP(a0, b0, y) IMF_G_STEP(a0, b0, z) IMF_G_STEP(a0, b0, w)
+      IMF_G_STEP(a1, b1, x) IMF_G_STEP(a1, b1, y) IMF_G_STEP(a1, b1, z) IMF_G_STEP(a1, b1, w)
+#undef IMF_G_STEP
+      continue;
+    }
+    f16x8 ah[RB], al[RB];
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
       if ((ABL & 2) || PRE) {
@@ -437,9 +464,12 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
 #endif
 #define IMF_G_LAUNCH(CB, USE, CAT)                                                         \
   do {                                                                                     \
-    if (p.a_split) {   /* operand images: the ResUNet's own layers (label 0) */            \
-      if (deep) k_spconv_g<CB, 0, CAT, 4, 1, true><<<grid, 256, 0, st>>>(p);               \
-      else      k_spconv_g<CB, 0, CAT, IMF_G_NB_WIDE, 1, true><<<grid, 256, 0, st>>>(p);   \
+    if (p.arith == kArF32) {   /* variant 0 (label 0: every caller) */                     \
+      if (deep) k_spconv_g<CB, 0, CAT, 4, 1, kArF32><<<grid, 256, 0, st>>>(p);             \
+      else      k_spconv_g<CB, 0, CAT, 2, 1, kArF32><<<grid, 256, 0, st>>>(p);             \
+    } else if (p.a_split) {   /* operand images: the ResUNet's own layers (label 0) */     \
+      if (deep) k_spconv_g<CB, 0, CAT, 4, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);        \
+      else      k_spconv_g<CB, 0, CAT, IMF_G_NB_WIDE, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);   \
     } else if (deep) k_spconv_g<CB, USE, CAT, 4, 1><<<grid, 256, 0, st>>>(p);              \
     else             k_spconv_g<CB, USE, CAT, 2, 1><<<grid, 256, 0, st>>>(p);              \
   } while (0)

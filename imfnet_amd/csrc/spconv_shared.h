@@ -6,6 +6,11 @@ namespace imf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Arithmetic of the LDS-DMA convolution kernels' main loops (template argument AR of k_spconv_g / k_spconv_w).
+constexpr int kArF16x2 = 0;      // variant 6: fp32 rows split into f16 hi + lo in registers
+constexpr int kArF16x2Pre = 1;   // variant 6 on split-f16 operand images (ConvParams::a_split)
+constexpr int kArF32 = 2;        // variant 0: fp32 operands, v_mfma_f32_16x16x4_f32 (the reference's arithmetic)
+
 struct ConvParams {
   const float *in_a, *in_b;
   int c_a, c_b;
@@ -52,6 +57,7 @@ struct ConvParams {
   int a_split;              // in_a (and in_b) are operand images
   int res_split;            // `residual` is an operand image
   int out_split;            // write `out` as an operand image (not with l2norm / geglu)
+  int arith;                // kArF16x2 (with a_split: kArF16x2Pre) or kArF32: which weight image w_packed is and which MFMAs run
   int32_t *err;             // flag word (optional): 16 = the rule wanted more partitions than the launch covers
                             // (capacity mode); 32 = an output value left the f16 range (|y| >= 65504 or NaN): the
                             // next split-f16 convolution would turn it into inf -- see IMF_FLAG_RANGE

@@ -68,10 +68,17 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 
 }  // namespace
 
-// PRE: the input rows are split-f16 operand images (ConvParams::a_split; see spconv_g.hip) -- no conversion in the loop.
-template <bool CAT, int W, bool PRE = false>
+// AR (spconv_shared.h): the arithmetic of the main loop.
+//   kArF16x2      fp32 rows split into f16 hi + lo in registers, 3 x v_mfma_f32_16x16x32_f16 per 32 channels (variant 6)
+//   kArF16x2Pre   the same products; the input rows are split-f16 operand images (ConvParams::a_split) -- no conversion
+//   kArF32        fp32 rows and the fp32 weight image (imf_pack_weights) straight into 8 x v_mfma_f32_16x16x4_f32 per 32
+//                 channels (variant 0: the reference's arithmetic).  Same DMA pieces, same LDS images, no conversion at all:
+//                 lane (r16, q4) reads channels {4 q4 .. + 3} and {16 + 4 q4 .. + 3} of its row as two float4 -- the A
+//                 operands of the 8 k-steps -- and the image's [j][cb][lane] quads are the matching B operands.
+template <bool CAT, int W, int AR = kArF16x2>
 __global__ void __launch_bounds__(64 * W, 2)
 k_spconv_w(const ConvParams p) {
+  constexpr bool PRE = AR == kArF16x2Pre;
   constexpr int NT = 64 * W;
   constexpr int REG_F4 = 1024;                       // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512
   constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
@@ -235,12 +242,35 @@ k_spconv_w(const ConvParams p) {
     // sub-stage t has landed: the region is private, the wavefront's own counter is the only wait
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float4 a0[4], a1[4];
-    f16x8 bh[4], bl[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       a0[b] = w_lds16(&areg[128 * b + rd_slot]);
       a1[b] = w_lds16(&areg[128 * b + 64 + rd_slot]);
     }
+    if constexpr (AR == kArF32) {
+      // B operands: quad (j, cb) of the fp32 image = W[16 j + 4 q4 + t][16 cb + r16], t = 0 .. 3
+      float4 b0[4], b1[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        b0[cb] = w_lds16(&wreg[cb * 64 + lane]);
+        b1[cb] = w_lds16(&wreg[(4 + cb) * 64 + lane]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (t + 1 < t1) {
+        IMF_W_DMA(e_nxt, rows_nxt)                      // lands under the 128 MFMAs below
+        e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 2 < kSubTab ? t + 2 : kSubTab - 1]));
+        IMF_W_ROWS(rows_nxt, e_nxt)
+      }
+      // k-step (j, t): channel 16 j + 4 q4 + t; sixteen independent accumulators between two MFMAs of one accumulator
+#define IMF_W_STEP(AV, BV, C)                                                                            \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                          \
+      _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                   \
+          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[b].C, BV[cb].C, acc[b][cb], 0, 0, 0);
+      IMF_W_STEP(a0, b0, x) IMF_W_STEP(a0, b0, y) IMF_W_STEP(a0, b0, z) IMF_W_STEP(a0, b0, w)
+      IMF_W_STEP(a1, b1, x) IMF_W_STEP(a1, b1, y) IMF_W_STEP(a1, b1, z) IMF_W_STEP(a1, b1, w)
+#undef IMF_W_STEP
+    } else {
+    f16x8 bh[4], bl[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       bh[cb] = w_lds_f16x8(&wreg[(2 * cb) * 64 + lane]);
@@ -275,6 +305,7 @@ k_spconv_w(const ConvParams p) {
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
         acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bh[cb], acc[b][cb], 0, 0, 0);
+    }
   }
 #undef IMF_W_DMA
 #undef IMF_W_ROWS
@@ -354,21 +385,21 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
   const unsigned slabs = (unsigned)(p.cout / 64);
   const dim3 grid(p.w_xcd == 2 && slabs <= 8 && (slabs & (slabs - 1)) == 0 ? (tiles + 7u) / 8u * 8u : tiles, slabs, 1);
   const bool cat = p.c_b > 0;
-  if (p.a_split) {
-    if (waves == 8) {
-      if (cat) k_spconv_w<true, 8, true><<<grid, 512, 0, st>>>(p);
-      else     k_spconv_w<false, 8, true><<<grid, 512, 0, st>>>(p);
-    } else {
-      if (cat) k_spconv_w<true, 4, true><<<grid, 256, 0, st>>>(p);
-      else     k_spconv_w<false, 4, true><<<grid, 256, 0, st>>>(p);
-    }
-  } else if (waves == 8) {
-    if (cat) k_spconv_w<true, 8><<<grid, 512, 0, st>>>(p);
-    else     k_spconv_w<false, 8><<<grid, 512, 0, st>>>(p);
-  } else {
-    if (cat) k_spconv_w<true, 4><<<grid, 256, 0, st>>>(p);
-    else     k_spconv_w<false, 4><<<grid, 256, 0, st>>>(p);
-  }
+  const int ar = p.arith == kArF32 ? kArF32 : (p.a_split ? kArF16x2Pre : kArF16x2);
+#define IMF_W_LAUNCH(AR)                                                    \
+  do {                                                                      \
+    if (waves == 8) {                                                       \
+      if (cat) k_spconv_w<true, 8, AR><<<grid, 512, 0, st>>>(p);            \
+      else     k_spconv_w<false, 8, AR><<<grid, 512, 0, st>>>(p);           \
+    } else {                                                                \
+      if (cat) k_spconv_w<true, 4, AR><<<grid, 256, 0, st>>>(p);            \
+      else     k_spconv_w<false, 4, AR><<<grid, 256, 0, st>>>(p);           \
+    }                                                                       \
+  } while (0)
+  if (ar == kArF32) IMF_W_LAUNCH(kArF32);
+  else if (ar == kArF16x2Pre) IMF_W_LAUNCH(kArF16x2Pre);
+  else IMF_W_LAUNCH(kArF16x2);
+#undef IMF_W_LAUNCH
 }
 
 }  // namespace imf

@@ -402,13 +402,20 @@ H3_DMA = int(os.environ.get("IMF_H3_GLDS", "1")) != 0
 
 
 def conv_kernel_name(variant, cin, cout, staging=None, kernel_tag=0):
+    """Label of the kernel family a launch runs on (bench.py groups by it).  Variant 0 (fp32 MFMA) runs on the LDS-DMA
+    kernels too since round 5 (AR = kArF32, csrc/spconv_g.hip / spconv_w.hip): same family names with an `/f32` suffix;
+    kernel_tag bit 1 / staging="regs" selects round 1's register-staged k_spconv_mfma."""
     if kernel_tag & 16:
         return "k_pointwise_head"
-    if variant == 6 and (kernel_tag & 12 or staging in ("wave8", "wave4")):
-        return f"k_spconv_w<{8 if (kernel_tag & 4 or staging == 'wave8') else 4}>"
+    suffix = "/f32" if variant == 0 else ""
+    regs0 = variant == 0 and (kernel_tag & 2 or staging == "regs")
+    if variant in (0, 6) and not regs0 and (kernel_tag & 12 or staging in ("wave8", "wave4")):
+        return f"k_spconv_w<{8 if (kernel_tag & 4 or staging == 'wave8') else 4}>" + suffix
     if variant == 6:
         dma = H3_DMA if staging is None else staging == "dma"
         return f"k_spconv_{'g' if dma else 'h3'}<{4 if cout % 64 == 0 else 2}, 0>"
+    if variant == 0 and not regs0:
+        return f"k_spconv_g<{4 if cout % 64 == 0 else 2}, 0>" + suffix
     return f"k_spconv_mfma<{4 if cout % 64 == 0 else 2},{4 if cin % 64 == 0 else 2}>"
 
 
@@ -477,8 +484,11 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
         if fused_reduce and variant in (0, 6):
             tk = torch.zeros(rb.n_slots // TILE_ROWS * max(1, cout // 32), dtype=torch.int32, device=in_a.device)
             a.tickets = tk.data_ptr()
-    if variant == 6 and max(in_a.numel(), 0 if in_b is None else in_b.numel()) * 4 >= 2 ** 31:
+    big = max(in_a.numel(), 0 if in_b is None else in_b.numel()) * 4 >= 2 ** 31
+    if variant == 6 and big:
         raise ImfError("variant 6 addresses its inputs through a 2 GiB buffer window: use variant 0 for larger matrices")
+    if variant == 0 and big:
+        a.kernel_tag = 2                                  # the LDS-DMA kernels share that window: the register-staged kernel
     need = (L.imf_packed_weight_floats_split16 if variant == 6 else L.imf_packed_weight_floats)(rb.kvol, a.c_a + a.c_b, cout)
     if w_packed.numel() != need:
         raise ImfError(f"packed weight has {w_packed.numel()} floats, expected {need} "

@@ -172,7 +172,8 @@ def _rb_and_ref(cm, g, which):
     return cm.conv_rulebook(1, 1, 1), None, len(g.levels[0])
 
 
-@pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple",
+@pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple", "f32_regs", "f32_regs_split5",
+                                  "f32_wave8", "f32_wave4",
                                   "h3", "h3_split1", "h3_split5", "h3_wave8", "h3_wave4"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
@@ -183,16 +184,21 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
     kvol = 1 if nbr_ref is None else nbr_ref.shape[1]
     fa, fb = _rand((n_in, ca), 10), (_rand((n_in, cb), 11) if cb else None)
     w = _rand((kvol, ca + cb, cout), 12, 1.0 / np.sqrt(kvol * (ca + cb)))
+    # variant 0 (fp32 MFMA, the reference's arithmetic) runs on the LDS-DMA kernels since round 5 (AR = kArF32): "auto" /
+    # "split1" / "split5" = k_spconv_g, "f32_wave8" / "f32_wave4" = k_spconv_w; "f32_regs*" / "split5_fused" = round 1's
+    # register-staged k_spconv_mfma (kernel_tag bit 1, or the in-launch combine it alone implements)
     kw = {"auto": {}, "split1": {"split_k": 1}, "split5": {"split_k": 5}, "simple": {"variant": 1},
           "split5_fused": {"split_k": 5, "fused_reduce": True},
+          "f32_regs": {"staging": "regs"}, "f32_regs_split5": {"staging": "regs", "split_k": 5},
+          "f32_wave8": {"staging": "wave8"}, "f32_wave4": {"staging": "wave4"},
           "h3": {"variant": 6},
           "h3_split1": {"variant": 6, "split_k": 1}, "h3_split5": {"variant": 6, "split_k": 5},
           # variant 6 = the LDS-DMA kernel k_spconv_g (the register-staged k_spconv_h3 lives in diagnostic builds only)
           # the wave-split kernel of the coarse levels (csrc/spconv_w.hip): whole tile per workgroup, 8 / 4 wavefronts
           "h3_wave8": {"variant": 6, "staging": "wave8"}, "h3_wave4": {"variant": 6, "staging": "wave4"}}[mode]
-    if mode in ("h3_wave8", "h3_wave4") and (kvol == 1 or cout % 64):
+    if mode in ("h3_wave8", "h3_wave4", "f32_wave8", "f32_wave4") and (kvol == 1 or cout % 64):
         pytest.skip("the wave-split kernel covers kvol > 1 and cout % 64 == 0")
-    if mode in ("split5", "split5_fused", "h3_split5") and kvol == 1:
+    if mode in ("split5", "split5_fused", "h3_split5", "f32_regs_split5") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")
     out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV), split16=mode.startswith("h3")), cout, rb,
                      in_b=None if fb is None else fb.to(DEV), **kw).cpu()
@@ -230,14 +236,18 @@ def test_spconv_chip_filling_launches_match_fp32_mfma(ops, clouds):
         wp6, wp0 = ops.pack_weights(w, split16=True), ops.pack_weights(w)
         fin = (fa if fb is None else torch.cat([fa, fb], 1)).abs()
         bound = ops.spconv(fin[:, :ca].contiguous(), ops.pack_weights(w.abs()), cout, rb,
-                           in_b=None if fb is None else fin[:, ca:].contiguous(), split_k=1, variant=0) * 4e-6 + 1e-6
+                           in_b=None if fb is None else fin[:, ca:].contiguous(), split_k=1, variant=0, staging="regs") * 4e-6 + 1e-6
         sc, sh = (_rand((cout,), 63).abs() + 0.5).to(DEV), _rand((cout,), 64).to(DEV)
         a = ops.spconv(fa, wp6, cout, rb, in_b=fb, variant=6, split_k=1, staging=staging)
-        b = ops.spconv(fa, wp0, cout, rb, in_b=fb, variant=0, split_k=1)
+        b = ops.spconv(fa, wp0, cout, rb, in_b=fb, variant=0, split_k=1, staging="regs")
+        c = ops.spconv(fa, wp0, cout, rb, in_b=fb, variant=0, split_k=1, staging=staging)   # fp32 on the DMA kernels (round 5)
         assert ((a - b).abs() <= bound).all(), (ca, cb, cout, float((a - b).abs().max()))
+        assert ((c - b).abs() <= bound).all(), (ca, cb, cout, float((c - b).abs().max()))
         a = ops.spconv(fa, wp6, cout, rb, in_b=fb, variant=6, split_k=1, scale=sc, shift=sh, relu=True, staging=staging)
-        b = ops.spconv(fa, wp0, cout, rb, in_b=fb, variant=0, split_k=1, scale=sc, shift=sh, relu=True)
+        b = ops.spconv(fa, wp0, cout, rb, in_b=fb, variant=0, split_k=1, scale=sc, shift=sh, relu=True, staging="regs")
+        c = ops.spconv(fa, wp0, cout, rb, in_b=fb, variant=0, split_k=1, scale=sc, shift=sh, relu=True, staging=staging)
         assert ((a - b).abs() <= bound * sc + 1e-6).all(), (ca, cb, cout, float((a - b).abs().max()))
+        assert ((c - b).abs() <= bound * sc + 1e-6).all(), (ca, cb, cout, float((c - b).abs().max()))
 
 
 def test_spconv_operand_images(ops, clouds):
