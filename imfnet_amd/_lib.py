@@ -224,6 +224,8 @@ SIGNATURES = {
     "imf_first_kernel_image_floats": (_L, [_I, _I]),
     "imf_pack_first_kernel": (_I, [_P, _I, _I, _P, _P]),
     "imf_pack_weights_split16": (_I, [_P, _I, _I, _I, _P, _P]),
+    "imf_packed_weight_floats_bf16x3": (_L, [_I, _I, _I]),
+    "imf_pack_weights_bf16x3": (_I, [_P, _I, _I, _I, _P, _P]),
     "imf_spconv_auto_split": (_I, [_L, _I, _I]),
     "imf_spconv_max_split": (_I, [_I, _I]),
     "imf_spconv_occupancy": (_I, [_I, _I, _I]),

@@ -59,7 +59,7 @@ class SparseConvFunction(torch.autograd.Function):
             out = ops.spconv_small_cin(feat_c, k3.detach(), rb)
         else:
             variant = ops.conv_variant_for(module.kernel_volume)
-            out = ops.spconv(feat_c, ops.pack_weights(k3.detach(), split16=(variant == 6)), module.out_channels, rb,
+            out = ops.spconv(feat_c, ops.pack_weights(k3.detach(), variant=variant), module.out_channels, rb,
                              variant=variant)
         ctx.save_for_backward(feat_c, kernel)
         ctx.module, ctx.x, ctx.rb = module, x, rb
@@ -86,7 +86,7 @@ class SparseConvFunction(torch.autograd.Function):
                 if not m._transposed and m.stride == 1:
                     wt = wt.flip(0)
                 variant = ops.conv_variant_for(K)
-                grad_feat = ops.spconv(g, ops.pack_weights(wt.contiguous(), split16=(variant == 6)), m.in_channels, rbt,
+                grad_feat = ops.spconv(g, ops.pack_weights(wt.contiguous(), variant=variant), m.in_channels, rbt,
                                        variant=variant)
         if ctx.needs_input_grad[1]:
             dw = spconv_wgrad(feat, g, rb, K)

@@ -162,7 +162,7 @@ using namespace imf;
 extern "C" {
 
 int imf_resunet_conv_kernel_tag(int level, int kvol, int cout, int variant) {
-  if ((variant != 6 && variant != 0) || kvol <= 1 || cout % 64 != 0 || level <= 0) return 0;   // (variant 0: the same kernels, AR = kArF32)
+  if ((variant != 6 && variant != 0 && variant != 3) || kvol <= 1 || cout % 64 != 0 || level <= 0) return 0;   // (variant 0: the same kernels, AR = kArF32)
   // measured on the S50k pair / single fragment (profiles/r03_conv_isolated.txt): level 1 (438 / 219 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
   return level == 1 ? 8 : 4;
@@ -211,7 +211,8 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     for (int i = 0; i < 23; ++i)   // variant 6, or variant 0 throughout (the strict-fp32 recompute of a range-flagged fragment)
       IMF_REQUIRE(!net->conv[i].w_packed || net->conv[i].variant == net->conv[12].variant,
                   "imf_resunet_forward: capacity mode needs ONE convolution variant (6 or 0) for all layers");
-    IMF_REQUIRE(net->conv[12].variant == 6 || net->conv[12].variant == 0, "imf_resunet_forward: capacity mode: variant 6 or 0");
+    IMF_REQUIRE(net->conv[12].variant == 6 || net->conv[12].variant == 0 || net->conv[12].variant == 3,
+                "imf_resunet_forward: capacity mode: variant 6, 3 or 0");
     IMF_REQUIRE(io->int_arena_bytes >= imf_resunet_int_arena_bytes_cap(net, io->n, io->bitgrid_words),
                 "imf_resunet_forward: int arena %zu < %zu bytes", io->int_arena_bytes,
                 imf_resunet_int_arena_bytes_cap(net, io->n, io->bitgrid_words));
@@ -485,17 +486,18 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   if (io->image_ready && !image_joined_side) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
   if (items_event >= 0) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->events[items_event], 0));
   const int fused_split = wants_split(FUSED) ? 1 : 0;   // the block's output: conv4_tr's operand image
+  const int fusion_variant = (net->conv[12].variant == 6 || net->conv[12].variant == 3) ? net->conv[12].variant : 0;
   is_split[FUSED] = fused_split != 0;
   if (dyn)
     rc = fusion_attention_dyn_fmt(buf[ebuf(3, 2)], s.n[3], meta + 6, meta + kMetaStarts + IMF_MAX_BATCH * 3, io->n_items,
                                   err, io->kt_packed, io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
                                   net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4, main, fused_split,
-                                  net->conv[12].variant == 6 ? 6 : 0);
+                                  fusion_variant);
   else
     rc = fusion_attention_batched_fmt(buf[ebuf(3, 2)], io->n_items, io->item_row0, io->item_rows, io->kt_packed,
                                       io->v_packed, io->n_tokens, io->tokens_padded, &net->fusion,
                                       net->fusion_scale, buf[FUSED], fusion_ws, fusion_ws_floats * 4,
-                                      err, main, fused_split, net->conv[12].variant == 6 ? 6 : 0);
+                                      err, main, fused_split, fusion_variant);
   if (rc) return rc;
   if (io->fusion_done) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->fusion_done, main));
   if (diag_marks) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[12], main));

@@ -293,7 +293,7 @@ static int run_feed_forward(const imf_fusion_weights *w, long long n, const int3
   float *y = ws, *n2 = ws + (size_t)n * kFD, *g = ws + (size_t)n * 2 * kFD;
   const long long slots = (n + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
   imf_conv_args a;
-  if (variant != 6) {   // the network runs on fp32 MFMA (the f16-range recompute): so does the feed-forward, on fp32 images
+  if (variant != 6 && variant != 3) {   // the network runs on fp32 MFMA (the f16-range recompute): so does the feed-forward, on fp32 images
     IMF_REQUIRE(variant == 0 && w->w1_f32 && w->w2_f32 && !out_split,
                 "imf_fusion_attention: variant %d needs the fp32 feed-forward images (w1_f32 / w2_f32) and fp32 buffers", variant);
     memset(&a, 0, sizeof(a));
@@ -309,19 +309,23 @@ static int run_feed_forward(const imf_fusion_weights *w, long long n, const int3
     a.n_out_dev = n_dev; a.dyn_err = err;
     return imf_spconv_fwd(&a, st);
   }
+  // variant 6: split-f16 images, the GEGLU output travels as an operand image.  variant 3: bf16x3 images (w1_p / w2_p packed
+  // by imf_pack_weights_bf16x3), fp32 buffers throughout
+  const bool b3 = variant == 3;
+  IMF_REQUIRE(!b3 || !out_split, "imf_fusion_attention: variant 3 writes fp32 rows");
   memset(&a, 0, sizeof(a));
   a.in_a = n2; a.c_a = kFD; a.w_packed = w->w1_p; a.kvol = 1; a.cout = 2 * kFH;
-  a.n_slots = slots; a.n_out = n; a.shift = w->b1; a.out = g; a.split_k = 1; a.variant = 6; a.geglu = 1;
+  a.n_slots = slots; a.n_out = n; a.shift = w->b1; a.out = g; a.split_k = 1; a.variant = variant; a.geglu = 1;
   a.n_out_dev = n_dev; a.dyn_err = err;
-  a.operand_format = IMF_FMT_OUT_SPLIT;
+  a.operand_format = b3 ? 0 : IMF_FMT_OUT_SPLIT;
   int rc = imf_spconv_fwd(&a, st);
   if (rc) return rc;
   memset(&a, 0, sizeof(a));
   a.in_a = g; a.c_a = kFH; a.w_packed = w->w2_p; a.kvol = 1; a.cout = kFD;
-  a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = 6;
+  a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = variant;
   a.kernel_tag = 4;                                  // wave-split, 8 wavefronts: K = 1024 is 32 sub-stages per tile
   a.n_out_dev = n_dev; a.dyn_err = err;              // z feeds conv4_tr (split-f16): range guard
-  a.operand_format = IMF_FMT_A_SPLIT | (out_split ? IMF_FMT_OUT_SPLIT : 0);
+  a.operand_format = b3 ? 0 : (IMF_FMT_A_SPLIT | (out_split ? IMF_FMT_OUT_SPLIT : 0));
   return imf_spconv_fwd(&a, st);
 }
 

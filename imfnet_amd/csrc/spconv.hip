@@ -313,7 +313,7 @@ k_spconv_reduce(const ConvParams p, int S, long long slot0) {
       x[e] = v;
     }
     s = make_float4(x[0], x[1], x[2], x[3]);
-    if (p.err && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) || out_of_f16_range(s.w)))
+    if (range_guard(p) && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) || out_of_f16_range(s.w)))
       atomicOr(p.err, 32);
   }
   if (p.l2norm) {   // cout in {32, 64}: a row = 8 or 16 consecutive lanes (all lanes take part)
@@ -785,20 +785,22 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   const int cin = a->c_a + a->c_b;
   const int J = ci_chunk_of(cin) / 16, CB = co_blk_of(a->cout);
   IMF_REQUIRE(!a->l2norm || a->cout == 16 * CB, "imf_spconv_fwd: l2norm needs cout in {32, 64}");
-  IMF_REQUIRE(a->variant == 0 || a->variant == 1 || a->variant == 6,
-              "imf_spconv_fwd: variant=%d (0 = fp32 MFMA, 1 = fp32 MFMA without the pipeline, 6 = split-f16 MFMA)", a->variant);
-  const bool simple = a->variant != 6 && (a->variant == 1 || a->kvol >= kKCache || (a->c_b > 0 && a->c_a % (16 * J) != 0));
-  IMF_REQUIRE(a->variant != 6 || a->kvol < kKCache,
-              "imf_spconv_fwd: variant 6 (split-f16 weights) needs kvol <= %d", kKCache - 1);
-  IMF_REQUIRE(a->variant != 6 || (a->kvol * (cin / 32) < kSubTab && a->c_a <= 1024 && a->c_b <= 1024),
-              "imf_spconv_fwd: variant 6 needs kvol * cin / 32 < %d and <= 1024 channels per source (kvol=%d cin=%d): use variant 0",
+  IMF_REQUIRE(a->variant == 0 || a->variant == 1 || a->variant == 3 || a->variant == 6,
+              "imf_spconv_fwd: variant=%d (0 = fp32 MFMA, 1 = fp32 MFMA without the pipeline, 3 = bf16x3 MFMA, 6 = split-f16 MFMA)", a->variant);
+  const bool v16 = a->variant == 6 || a->variant == 3;   // the 16-bit matrix pipe: LDS-DMA kernels only
+  const bool simple = !v16 && (a->variant == 1 || a->kvol >= kKCache || (a->c_b > 0 && a->c_a % (16 * J) != 0));
+  IMF_REQUIRE(!v16 || a->kvol < kKCache,
+              "imf_spconv_fwd: variants 6 / 3 (split-f16 / bf16x3 weights) need kvol <= %d", kKCache - 1);
+  IMF_REQUIRE(!v16 || (a->kvol * (cin / 32) < kSubTab && a->c_a <= 1024 && a->c_b <= 1024),
+              "imf_spconv_fwd: variants 6 / 3 need kvol * cin / 32 < %d and <= 1024 channels per source (kvol=%d cin=%d): use variant 0",
               kSubTab, a->kvol, cin);
+  IMF_REQUIRE(a->variant != 3 || (!(a->kernel_tag & 2) && !a->tickets), "imf_spconv_fwd: variant 3 has no register-staged kernel / tickets");
   // Variant 0 (fp32 MFMA) runs on the LDS-DMA kernels too since round 5 (k_spconv_g / k_spconv_w with AR = kArF32: the
   // fp32 weight image has the split-f16 image's sub-stage addressing) wherever their tables cover the shape; kernel_tag
   // bit 1 or `tickets` keep the register-staged round-1 kernel k_spconv_mfma (A/B, the in-launch split-K combine).
   const bool dma0 = a->variant == 0 && !simple && !(a->kernel_tag & 2) && !a->tickets && a->kvol < kKCache &&
                     a->kvol * (cin / 32) < kSubTab && a->c_a <= 1024 && a->c_b <= 1024;
-  const bool dma = a->variant == 6 || dma0;
+  const bool dma = v16 || dma0;
   // kernel_tag bits 2 / 3 (variant 6, variant 0 on the DMA kernels): the wave-split kernel (spconv_w.hip) with 8 / 4
   // wavefronts per workgroup -- the whole tile in one workgroup, no split-K partitions, no reduce launch
   const int wsplit = dma ? ((a->kernel_tag & 4) ? 8 : ((a->kernel_tag & 8) ? 4 : 0)) : 0;
@@ -820,7 +822,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
                ((a->variant == 0 && !simple) || a->variant == 6) ? a->tickets : nullptr, 0};
   p.tail_begin = p.tail_split = 0;
   p.w_unscale = a->variant == 6 ? a->w_packed + (long long)a->kvol * cin * a->cout + 1 : nullptr;
-  p.arith = dma0 ? kArF32 : kArF16x2;
+  p.arith = a->variant == 6 ? kArF16x2 : (a->variant == 3 ? kArBf16x3 : kArF32);
   p.n_out_dev = a->n_out_dev;
   p.dyn_split_kvol = (a->n_out_dev && !wsplit) ? a->dyn_split_kvol : 0;
   p.slots_extra = a->slots_extra;
@@ -837,7 +839,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
               "imf_spconv_fwd: operand_format needs variant 6 and an unsplit launch (split_k=%d)", split);
   IMF_REQUIRE(!p.out_split || !a->l2norm, "imf_spconv_fwd: IMF_FMT_OUT_SPLIT not with l2norm");
   IMF_REQUIRE(!p.res_split || a->residual, "imf_spconv_fwd: IMF_FMT_RES_SPLIT without a residual");
-  IMF_REQUIRE(!a->geglu || ((a->variant == 6 || (a->variant == 0 && !simple)) && !wsplit && a->kvol == 1 && a->cout % 64 == 0 &&
+  IMF_REQUIRE(!a->geglu || ((v16 || (a->variant == 0 && !simple)) && !wsplit && a->kvol == 1 && a->cout % 64 == 0 &&
                             split == 1 && !a->scale && !a->residual && !a->relu && !a->l2norm && (dma0 || !(a->kernel_tag & 2))),
               "imf_spconv_fwd: geglu needs variant 6 (k_spconv_g) or 0, kvol 1, cout %% 64 == 0, an unsplit launch and no other epilogue");
   // XCD-contiguous tile order of k_spconv_g (IMF_G_XCD: bit 0 = the 64-column launches, bit 1 = the 32-column ones; default
@@ -867,7 +869,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
   if (wsplit) {
     launch_spconv_w(p, grid.x, wsplit, st);
-  } else if (dma0) {
+  } else if (dma0 || a->variant == 3) {
     launch_spconv_g(p, grid, CB, st, 0);
   } else if (a->variant == 6) {
     // Balanced tail: with >= 2 full rounds of workgroups per CU and a partial last round (801 tiles on

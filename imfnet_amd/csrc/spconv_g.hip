@@ -109,9 +109,13 @@ __global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? 4 : 2)
 k_spconv_g(const ConvParams p) {
   constexpr bool PRE = AR == kArF16x2Pre;
   constexpr int ROWS = IMF_TILE_ROWS * RB;           // output rows per workgroup
-  constexpr int SUB_F4 = 2 * CO_BLK * 64;            // float4 of weights per sub-stage: 512 or 256
-  constexpr int SUB_SHIFT = CO_BLK == 4 ? 13 : 12;   // log2(bytes per weight sub-stage)
-  constexpr int QPS = SUB_F4 / 256;                  // weight DMAs per thread per sub-stage: 2 or 1
+  constexpr int SUB_F4 = (AR == kArBf16x3 ? 3 : 2) * CO_BLK * 64;   // float4 of weights per sub-stage: 512 / 256 (bf16x3: 768 / 384)
+  constexpr unsigned SUB_BYTES = SUB_F4 * 16;        // bytes per weight sub-stage
+  constexpr int QPS = (SUB_F4 + 255) / 256;          // weight DMAs per thread per sub-stage: 2 or 1 (bf16x3: 3 or 2)
+  // bf16x3 with 32-column slabs: 384 float4 = one and a half passes of the 256 threads; in the last pass wavefronts 2, 3
+  // repeat the pieces of wavefronts 0, 1 (same bytes to the same LDS addresses) so that every wavefront issues the same
+  // number of DMA instructions -- the counted vmcnt waits below rely on it
+  constexpr bool W_PARTIAL = SUB_F4 % 256 != 0;
   constexpr int AW_F4 = 128 * RB;                    // gathered rows per wavefront and sub-stage: RB x 2 KiB
   constexpr int BUF_F4 = SUB_F4 + 4 * AW_F4;
   constexpr int NBR_F4 = kKCache * ROWS / 4;
@@ -251,6 +255,8 @@ k_spconv_g(const ConvParams p) {
       const_cast<float *>(CAT ? p.in_b : p.in_a), (short)0, 0x7FFFF000, 0x00020000);
   const unsigned stride_a = (unsigned)p.c_a * 4u, stride_b = (unsigned)(CAT ? p.c_b : p.c_a) * 4u;
   const unsigned woff0 = (unsigned)tid * 16u;
+  const int wave_last = W_PARTIAL ? (wave & 1) : wave;                              // wavefront whose piece the last weight DMA copies
+  const unsigned woff_last = (unsigned)(wave_last * 64 + lane) * 16u;
   const unsigned wslab = (unsigned)((long long)y * p.kvol * ncc * SUB_F4 * 16);     // bytes (image < 2 GiB)
   // writer role of the lane in the row gather: row lane >> 2 of a 16-row block, piece (lane & 3) ^ f(row >> 2)
   const int row_w = lane >> 2;
@@ -273,12 +279,14 @@ k_spconv_g(const ConvParams p) {
 #define IMF_DMA(e, rows, b)                                                                                      \
   {                                                                                                              \
     const unsigned ee = (unsigned)__builtin_amdgcn_readfirstlane((int)(e));                                      \
-    const unsigned wso = wslab + ((ee & 511u) << SUB_SHIFT);                                                     \
+    const unsigned wso = wslab + (ee & 511u) * SUB_BYTES;                                                        \
     float4 *const wb = smem + (b) * BUF_F4;                                                                      \
     if (!(ABL & 8)) {                                                                                            \
-    _Pragma("unroll") for (int j = 0; j < QPS; ++j)                                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wb + j * 256 + wave * 64), 16,              \
-                                                 woff0 + (unsigned)j * 4096u, wso, 0, 0);                        \
+    _Pragma("unroll") for (int j = 0; j < QPS; ++j) {                                                            \
+        const bool last_ = W_PARTIAL && j == QPS - 1;                                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wb + j * 256 + (last_ ? wave_last : wave) * 64), 16, \
+                                                 (last_ ? woff_last : woff0) + (unsigned)j * 4096u, wso, 0, 0);  \
+    }                                                                                                            \
     }                                                                                                            \
     const bool second = CAT && ((ee >> 14) & 1u);                                                                \
     const unsigned soff = (ee >> 15) << 7;                                                                       \
@@ -354,6 +362,24 @@ k_spconv_g(const ConvParams p) {
       IMF_G_STEP(a0, b0, x) IMF_G_STEP(a0, b0, y) IMF_G_STEP(a0, b0, z) IMF_G_STEP(a0, b0, w)
       IMF_G_STEP(a1, b1, x) IMF_G_STEP(a1, b1, y) IMF_G_STEP(a1, b1, z) IMF_G_STEP(a1, b1, w)
 #undef IMF_G_STEP
+      continue;
+    }
+    if constexpr (AR == kArBf16x3) {
+      // fp32 rows -> three bf16 parts in registers; the image's quads (3 cb + part) are the matching B parts
+      bf16x8 ap[RB][3], bp[CO_BLK][3];
+#pragma unroll
+      for (int b = 0; b < RB; ++b)
+        split_b3(lds_read16(&abuf[128 * b + rd_slot]), lds_read16(&abuf[128 * b + 64 + rd_slot]), ap[b][0], ap[b][1], ap[b][2]);
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb)
+#pragma unroll
+        for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, lds_read16(&wbuf[(3 * cb + h) * 64 + lane]));
+#define IMF_G_TERM(I, J)                                                                               \
+  _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                       \
+      _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                            \
+          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], bp[cb][J], acc[b][cb], 0, 0, 0);
+      IMF_B3_TERMS(IMF_G_TERM)
+#undef IMF_G_TERM
       continue;
     }
     f16x8 ah[RB], al[RB];
@@ -467,6 +493,9 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
     if (p.arith == kArF32) {   /* variant 0 (label 0: every caller) */                     \
       if (deep) k_spconv_g<CB, 0, CAT, 4, 1, kArF32><<<grid, 256, 0, st>>>(p);             \
       else      k_spconv_g<CB, 0, CAT, 2, 1, kArF32><<<grid, 256, 0, st>>>(p);             \
+    } else if (p.arith == kArBf16x3) {   /* variant 3: 12 / 6 KiB of weights per sub-stage -- ring of 3 where the f16 kernels take 4 */ \
+      if (deep) k_spconv_g<CB, 0, CAT, 3, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);          \
+      else      k_spconv_g<CB, 0, CAT, 2, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);          \
     } else if (p.a_split) {   /* operand images: the ResUNet's own layers (label 0) */     \
       if (deep) k_spconv_g<CB, 0, CAT, 4, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);        \
       else      k_spconv_g<CB, 0, CAT, IMF_G_NB_WIDE, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);   \

@@ -80,9 +80,59 @@ k_pack_weights_h3(const float *__restrict__ w, int kvol, int cin, int cout, _Flo
   packed[(q0 + 64) * 8 + t] = lo;
 }
 
+// ---- variant 3 ("bf16x3"): fp32 operands carried EXACTLY by three bf16 parts ---------------------------------------
+// w = p0 + p1 + p2 with p0 = bf16(w), p1 = bf16(w - p0), p2 = bf16(w - p0 - p1), round-to-nearest-even: the residuals are
+// exact fp32 differences with <= 16 and <= 8 significant bits, so the third part closes the sum -- three 8-bit significands
+// carry fp32's 24, and bf16 has fp32's exponent range (no pre-scaling, no range guard, unlike the split-f16 image).  The
+// kernels multiply with six v_mfma_f32_16x16x32_bf16 per 32 channels (a0 w2, a1 w1, a2 w0, a0 w1, a1 w0, a0 w0: every
+// term down to 2^-16 relative; the three dropped ones are <= 2^-26 |a| |w| together), fp32 accumulation in the MFMA.
+// Image: [y][k][cc][q = 3 cb + part][lane][t] -- the split-f16 image's lane / channel mapping with three parts per
+// column block: ci = 32 cc + 16 (t >> 2) + 4 (lane >> 4) + (t & 3), co = y CW + 16 cb + (lane & 15); 1.5 x the fp32 size.
+__global__ void __launch_bounds__(256)
+k_pack_weights_b3(const float *__restrict__ w, int kvol, int cin, int cout, __bf16 *__restrict__ packed) {
+  const long long total = (long long)kvol * cin * cout;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int CB = co_blk_of(cout), CW = 16 * CB, ncc = cin / 32;
+  long long r = idx;
+  const int t = r & 7; r >>= 3;
+  const int lane = r & 63; r >>= 6;
+  const int cb = r % CB; r /= CB;
+  const int cc = r % ncc; r /= ncc;
+  const int k = r % kvol; r /= kvol;
+  const int y = (int)r;
+  const int ci = cc * 32 + 16 * (t >> 2) + 4 * (lane >> 4) + (t & 3);
+  const int co = y * CW + 16 * cb + (lane & 15);
+  const float v = w[((long long)k * cin + ci) * cout + co];
+  const __bf16 p0 = (__bf16)v;
+  const float r1 = v - (float)p0;
+  const __bf16 p1 = (__bf16)r1;
+  const __bf16 p2 = (__bf16)(r1 - (float)p1);
+  const long long q0 = ((((long long)y * kvol + k) * ncc + cc) * (3 * CB) + 3 * cb) * 64 + lane;
+  packed[q0 * 8 + t] = p0;
+  packed[(q0 + 64) * 8 + t] = p1;
+  packed[(q0 + 128) * 8 + t] = p2;
+}
+
 }  // namespace imf
 
 using namespace imf;
+
+extern "C" int64_t imf_packed_weight_floats_bf16x3(int kvol, int cin, int cout) {
+  return (int64_t)kvol * cin * cout / 2 * 3;
+}
+
+extern "C" int imf_pack_weights_bf16x3(const float *w, int kvol, int cin, int cout, float *packed, void *stream) {
+  IMF_REQUIRE(w && packed, "imf_pack_weights_bf16x3: null pointer");
+  IMF_REQUIRE(kvol >= 1 && kvol <= IMF_MAX_KVOL, "imf_pack_weights_bf16x3: kvol=%d", kvol);
+  IMF_REQUIRE(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0,
+              "imf_pack_weights_bf16x3: cin=%d cout=%d must be multiples of 32", cin, cout);
+  const long long total = (long long)kvol * cin * cout;
+  k_pack_weights_b3<<<(unsigned)div_up(total, 256), 256, 0, (hipStream_t)stream>>>(w, kvol, cin, cout,
+                                                                                   reinterpret_cast<__bf16 *>(packed));
+  IMF_CHECK_LAUNCH("k_pack_weights_b3");
+  return IMF_OK;
+}
 
 extern "C" int imf_pack_weights_split16(const float *w, int kvol, int cin, int cout, float *packed,
                                         void *stream) {

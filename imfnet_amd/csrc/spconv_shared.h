@@ -10,6 +10,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kArF16x2 = 0;      // variant 6: fp32 rows split into f16 hi + lo in registers
 constexpr int kArF16x2Pre = 1;   // variant 6 on split-f16 operand images (ConvParams::a_split)
 constexpr int kArF32 = 2;        // variant 0: fp32 operands, v_mfma_f32_16x16x4_f32 (the reference's arithmetic)
+constexpr int kArBf16x3 = 3;     // variant 3: fp32 operands as three bf16 parts each (exact), six v_mfma_f32_16x16x32_bf16
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// Eight fp32 values -> three bf16 parts each, x = p0 + p1 + p2 EXACTLY: p0 = bf16(x), p1 = bf16(x - p0), p2 = x - p0 - p1
+// (round-to-nearest-even; the residuals are exact fp32 differences of <= 16 and <= 8 significant bits).  hipcc emits
+// v_cvt_pk_bf16_f32 / v_pk_add_f32: ~4.5 VALU instructions per value.
+__device__ __forceinline__ void split_b3(const float4 &x0, const float4 &x1, bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const __bf16 h0 = (__bf16)v[t];
+    const float r1 = v[t] - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    p0[t] = h0;
+    p1[t] = h1;
+    p2[t] = (__bf16)(r1 - (float)h1);
+  }
+}
+// The six products of one (row block, column block, 32-channel chunk), smallest terms first; a = {a0, a1, a2}, b likewise.
+#define IMF_B3_TERMS(X) X(0, 2) X(1, 1) X(2, 0) X(0, 1) X(1, 0) X(0, 0)
 
 struct ConvParams {
   const float *in_a, *in_b;
@@ -62,6 +82,9 @@ struct ConvParams {
                             // (capacity mode); 32 = an output value left the f16 range (|y| >= 65504 or NaN): the
                             // next split-f16 convolution would turn it into inf -- see IMF_FLAG_RANGE
 };
+
+// IMF_FLAG_RANGE is raised by split-f16 launches only: with fp32 / bf16x3 operands a large value is a value, not an error
+__device__ __forceinline__ bool range_guard(const ConvParams &p) { return p.err && p.arith <= kArF16x2Pre; }
 
 constexpr float kF16Max = 65504.f;
 // true when y cannot be carried by the split-f16 operands of the next convolution (also for NaN)
@@ -172,7 +195,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (
         }
       }
     }
-    if (p.err && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(p.err, 32);
+    if (range_guard(p) && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(p.err, 32);
     return;
   }
 
@@ -191,7 +214,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const f32x4 (
       v[cb][r] = x;
     }
   }
-  if (p.err) {      // range guard for the consumer's f16 operands: one atomic per offending wavefront, none normally
+  if (range_guard(p)) {      // range guard for the consumer's f16 operands: one atomic per offending wavefront, none normally
     bool bad = false;
 #pragma unroll
     for (int cb = 0; cb < CO_BLK; ++cb)
@@ -300,7 +323,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvParams &p, const 
       *reinterpret_cast<float4 *>(p.out + orow * p.cout + col + 16) = make_float4(x[4], x[5], x[6], x[7]);
     }
   }
-  if (p.err && __ballot(bad) != 0ull && lane == 0) atomicOr(p.err, 32);
+  if (range_guard(p) && __ballot(bad) != 0ull && lane == 0) atomicOr(p.err, 32);
 }
 
 // Sum of the S partial slabs of one 64-row tile (ascending partition order) + epilogue, by the 256
@@ -330,7 +353,7 @@ __device__ __forceinline__ void fused_reduce_tile(const ConvParams &p, int S, lo
         s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
       }
       if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-      if (p.err && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) || out_of_f16_range(s.w)))
+      if (range_guard(p) && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) || out_of_f16_range(s.w)))
         atomicOr(p.err, 32);
     }
     if (p.l2norm) {

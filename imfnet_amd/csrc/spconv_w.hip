@@ -75,10 +75,15 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 //                 channels (variant 0: the reference's arithmetic).  Same DMA pieces, same LDS images, no conversion at all:
 //                 lane (r16, q4) reads channels {4 q4 .. + 3} and {16 + 4 q4 .. + 3} of its row as two float4 -- the A
 //                 operands of the 8 k-steps -- and the image's [j][cb][lane] quads are the matching B operands.
+//   kArBf16x3     fp32 rows split into three bf16 parts in registers (exact), the bf16x3 weight image (12 KiB per sub-stage),
+//                 6 x v_mfma_f32_16x16x32_bf16 per 32 channels (variant 3).  The wavefront's weight region stays 8 KiB: a
+//                 sub-stage's weights arrive in two halves of 6 KiB (column blocks 0-1, then 2-3), each landing under the
+//                 48 MFMAs of the other; the rows of sub-stage t + 1 are requested as soon as those of t sit in registers.
 template <bool CAT, int W, int AR = kArF16x2>
 __global__ void __launch_bounds__(64 * W, 2)
 k_spconv_w(const ConvParams p) {
   constexpr bool PRE = AR == kArF16x2Pre;
+  constexpr unsigned SUB_BYTES = AR == kArBf16x3 ? 12288u : 8192u;   // weight image bytes per (offset, 32-channel) sub-stage
   constexpr int NT = 64 * W;
   constexpr int REG_F4 = 1024;                       // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512
   constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
@@ -177,7 +182,7 @@ k_spconv_w(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(CAT ? p.in_b : p.in_a), (short)0, 0x7FFFF000, 0x00020000);
   const unsigned stride_a = (unsigned)p.c_a * 4u, stride_b = (unsigned)(CAT ? p.c_b : p.c_a) * 4u;
-  const unsigned wslab = (unsigned)((long long)y * p.kvol * ncc * 512 * 16);       // bytes (image < 2 GiB)
+  const unsigned wslab = (unsigned)((long long)y * p.kvol * ncc * SUB_BYTES);      // bytes (image < 2 GiB)
   const unsigned woff = (unsigned)lane * 16u;
   // writer role of the lane in a 16-row block's gather: row lane >> 2, piece (lane & 3) ^ f(row >> 2)   (spconv_g.hip)
   const int row_w = lane >> 2;
@@ -197,7 +202,7 @@ k_spconv_w(const ConvParams p) {
 #define IMF_W_DMA(e, rows)                                                                                         \
   {                                                                                                                \
     const unsigned ee = (unsigned)(e);                                                                             \
-    const unsigned wso = wslab + ((ee & 511u) << 13);                                                              \
+    const unsigned wso = wslab + (ee & 511u) * SUB_BYTES;                                                          \
     _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wreg + 64 * j), 16, woff + 1024u * j, wso, 0, 0); \
     const bool second = CAT && ((ee >> 14) & 1u);                                                                  \
@@ -210,6 +215,26 @@ k_spconv_w(const ConvParams p) {
     }                                                                                                              \
   }
 
+  // bf16x3: the gathered rows of a sub-stage (8 pieces) and one 6 KiB half of its weights (6 pieces) as separate requests
+#define IMF_W_DMA_ROWS(e, rows)                                                                                    \
+  {                                                                                                                \
+    const unsigned ee = (unsigned)(e);                                                                             \
+    const bool second = CAT && ((ee >> 14) & 1u);                                                                  \
+    const unsigned soff = (ee >> 15) << 7;                                                                         \
+    const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                        \
+    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) {                                                             \
+      const unsigned voff = __umul24((rows).r[b_], second ? stride_b : stride_a) + wr_byte;                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(areg + 128 * b_), 16, voff, soff, 0, 0);           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(areg + 128 * b_ + 64), 16, voff + 64u, soff, 0, 0); \
+    }                                                                                                              \
+  }
+#define IMF_W_DMA_WHALF(e, h)                                                                                      \
+  {                                                                                                                \
+    const unsigned wso = wslab + ((unsigned)(e) & 511u) * SUB_BYTES + (unsigned)(h) * 6144u;                       \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                                  \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wreg + 64 * j), 16, woff + 1024u * j, wso, 0, 0); \
+  }
+
   // this wavefront's range of the tile's sub-stages
   const int t0 = (int)((long long)wave * n_sub / W), t1 = (IMF_W_ABL & 1) ? t0 : (int)((long long)(wave + 1) * n_sub / W);
   unsigned e_cur = 0, e_nxt = 0;
@@ -218,7 +243,12 @@ k_spconv_w(const ConvParams p) {
     e_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t0]));
     Rows rows0;
     IMF_W_ROWS(rows0, e_cur)
-    IMF_W_DMA(e_cur, rows0)
+    if constexpr (AR == kArBf16x3) {
+      IMF_W_DMA_ROWS(e_cur, rows0)
+      IMF_W_DMA_WHALF(e_cur, 0)
+    } else {
+      IMF_W_DMA(e_cur, rows0)
+    }
     e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t0 + 1 < kSubTab ? t0 + 1 : kSubTab - 1]));
     IMF_W_ROWS(rows_nxt, e_nxt)
   }
@@ -237,6 +267,57 @@ k_spconv_w(const ConvParams p) {
   //   * one extra load per sub-stage that touches a line per lane of the weight block two sub-stages ahead (a software
   //     prefetch towards L2 / L1): the stride-4 / 8 launches 35.8 -> 38.3 us, the stride-2 ones 29.3 -> 34.6 us -- every
   //     additional vector-memory instruction costs the wavefront more than the shorter DMA latency returns.
+  if constexpr (AR == kArBf16x3) {
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+      const bool more = t + 1 < t1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // rows of t and weight half A of t have landed
+      float4 a0[4], a1[4];
+      bf16x8 bp[2][3];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        a0[b] = w_lds16(&areg[128 * b + rd_slot]);
+        a1[b] = w_lds16(&areg[128 * b + 64 + rd_slot]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, w_lds16(&wreg[(3 * cb + h) * 64 + lane]));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // both regions are free
+      IMF_W_DMA_WHALF(e_cur, 1)                                   // half B of t: lands under the first 48 MFMAs
+      if (more) IMF_W_DMA_ROWS(e_nxt, rows_nxt)                   // rows of t + 1: a whole sub-stage to land
+      bf16x8 ap[4][3];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) split_b3(a0[b], a1[b], ap[b][0], ap[b][1], ap[b][2]);
+#define IMF_W_TERM(I, J)                                                                                 \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                          \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                   \
+          acc[b][CB0 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], bp[cb][J], acc[b][CB0 + cb], 0, 0, 0);
+      {
+        constexpr int CB0 = 0;
+        IMF_B3_TERMS(IMF_W_TERM)
+      }
+      // half B has landed (the 8 row pieces of t + 1 issued after it may still be in flight)
+      if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, w_lds16(&wreg[(3 * cb + h) * 64 + lane]));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (more) {
+        IMF_W_DMA_WHALF(e_nxt, 0)                                 // half A of t + 1: lands under the second 48 MFMAs
+        e_cur = e_nxt;
+        e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 2 < kSubTab ? t + 2 : kSubTab - 1]));
+        IMF_W_ROWS(rows_nxt, e_nxt)
+      }
+      {
+        constexpr int CB0 = 2;
+        IMF_B3_TERMS(IMF_W_TERM)
+      }
+#undef IMF_W_TERM
+    }
+  } else {
 #pragma unroll 1
   for (int t = t0; t < t1; ++t) {
     // sub-stage t has landed: the region is private, the wavefront's own counter is the only wait
@@ -307,6 +388,9 @@ k_spconv_w(const ConvParams p) {
         acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bh[cb], acc[b][cb], 0, 0, 0);
     }
   }
+  }
+#undef IMF_W_DMA_ROWS
+#undef IMF_W_DMA_WHALF
 #undef IMF_W_DMA
 #undef IMF_W_ROWS
 
@@ -352,7 +436,7 @@ k_spconv_w(const ConvParams p) {
       s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
     }
     if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-    if (p.err) {                                     // range guard for the consumer's f16 operands
+    if (range_guard(p)) {                            // range guard for the consumer's f16 operands
       const bool bad = orow >= 0 && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) ||
                                      out_of_f16_range(s.w));
       if (__ballot(bad) != 0ull && lane == 0) atomicOr(p.err, 32);
@@ -385,7 +469,7 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
   const unsigned slabs = (unsigned)(p.cout / 64);
   const dim3 grid(p.w_xcd == 2 && slabs <= 8 && (slabs & (slabs - 1)) == 0 ? (tiles + 7u) / 8u * 8u : tiles, slabs, 1);
   const bool cat = p.c_b > 0;
-  const int ar = p.arith == kArF32 ? kArF32 : (p.a_split ? kArF16x2Pre : kArF16x2);
+  const int ar = (p.arith == kArF32 || p.arith == kArBf16x3) ? p.arith : (p.a_split ? kArF16x2Pre : kArF16x2);
 #define IMF_W_LAUNCH(AR)                                                    \
   do {                                                                      \
     if (waves == 8) {                                                       \
@@ -397,6 +481,7 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
     }                                                                       \
   } while (0)
   if (ar == kArF32) IMF_W_LAUNCH(kArF32);
+  else if (ar == kArBf16x3) IMF_W_LAUNCH(kArBf16x3);
   else if (ar == kArF16x2Pre) IMF_W_LAUNCH(kArF16x2Pre);
   else IMF_W_LAUNCH(kArF16x2);
 #undef IMF_W_LAUNCH

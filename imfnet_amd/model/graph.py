@@ -149,7 +149,7 @@ class _Bucket:
         L = self.L = runner.L
         n_points, rows, n_items, H, W, grid_words, voxel, is_f64 = caps_tuple
         self.key, self.dev = caps_tuple, dev
-        self.ignore_flags = _lib.FLAG_RANGE if runner.variant == 0 else 0
+        self.ignore_flags = _lib.FLAG_RANGE if runner.variant in (0, 3) else 0   # fp32 / bf16x3 operands: no f16 range
         net, img = runner.net_desc, runner.img_plan
         c = self.caps = FragmentCaps()
         c.n_points, c.n_items, c.img_h, c.img_w, c.bitgrid_words = n_points, n_items, H, W, grid_words
@@ -269,10 +269,10 @@ class FragmentRunner:
         self.img_plan = model._native_image()
         fw = model._fusion_weights()
         variants = {c.variant for c in self.net_desc.conv if c.w_packed}
-        # one arithmetic throughout: variant 6 (split-f16, the default) or variant 0 (fp32 MFMA: the strict-fp32 path)
+        # one arithmetic throughout: variant 6 (split-f16), 3 (bf16x3) or 0 (fp32 MFMA: the strict-fp32 path)
         self.variant = variants.pop() if len(variants) == 1 else None
         self.supported = bool(self.img_plan.supported and self.img_plan.with_kv and fw.supported and
-                              model._plan.small_first and model.conv1.in_channels == 1 and self.variant in (0, 6))
+                              model._plan.small_first and model.conv1.in_channels == 1 and self.variant in (0, 3, 6))
         # imf_fragment_forward calls imf_image_branch (csrc/image.hip) itself: a runner exists only when that plan is usable
         self.image_branch_mode = "native-hip (csrc/image.hip, inside imf_fragment_forward)" if self.supported else None
         self.ratios = None            # max rows_l / n_points seen (4 levels)

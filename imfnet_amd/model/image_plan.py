@@ -33,7 +33,6 @@ class ImagePlan:
         if not self.supported:
             return
         self.variant = int(variant)
-        split16 = self.variant == 6
         self._keep = []
         d = self.desc = ImageDesc()
         d.variant = self.variant
@@ -45,12 +44,12 @@ class ImagePlan:
         def pack(w):                                   # torch [co,ci,kh,kw] -> [kh*kw, ci, co] -> fragment-major
             co, ci, kh, kw = w.shape
             k = w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, ci, co).contiguous()
-            return keep(ops.pack_weights(k, split16=split16))
+            return keep(ops.pack_weights(k, variant=self.variant))
 
         w = bb.conv1.weight.detach().float().permute(2, 3, 1, 0).reshape(147, 64)
         stem = torch.zeros((1, 160, 64), dtype=torch.float32, device=w.device)
         stem[0, :147] = w
-        d.stem_w = keep(ops.pack_weights(stem, split16=split16))
+        d.stem_w = keep(ops.pack_weights(stem, variant=self.variant))
         sc, sh = _fold(bb.bn1)
         d.stem_scale, d.stem_shift = keep(sc), keep(sh)
 
@@ -83,7 +82,7 @@ class ImagePlan:
                             att.to_kv.weight.shape == (256, 128) and att.to_kv.bias is None)
         if self.with_kv:
             d.ln_g, d.ln_b = keep(nc.weight.detach().float().contiguous()), keep(nc.bias.detach().float().contiguous())
-            d.kv_w = keep(ops.pack_weights(att.to_kv.weight.detach().float().t().contiguous().unsqueeze(0), split16=split16))
+            d.kv_w = keep(ops.pack_weights(att.to_kv.weight.detach().float().t().contiguous().unsqueeze(0), variant=self.variant))
         self._shapes = {}
 
     def buffers(self, dev, B, H, W, private=False):

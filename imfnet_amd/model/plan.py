@@ -322,7 +322,7 @@ class NativePlan:
             d.first_scale, d.first_shift = (t.data_ptr() for t in fused.first_bn)
             k = fused.first_kernel
             if k.is_cuda and k.shape[1] == 1 and k.shape[0] in (27, 125) and k.shape[2] in (32, 64) and \
-                    all(c.variant == 6 for c in d.conv if c.w_packed):
+                    all(c.variant in (6, 3) for c in d.conv if c.w_packed):
                 # conv1's weights as the f16 matrix pipe reads them, split once here instead of by every workgroup
                 self.first_image = torch.empty(self.L.imf_first_kernel_image_floats(k.shape[0], k.shape[2]),
                                                dtype=torch.float32, device=k.device)

@@ -236,13 +236,17 @@ class ResUNet2(ME.MinkowskiNetwork):
         return w
 
     def take_flags(self, device):
-        """Read and clear the flag word (one 4-byte readback: synchronises with the current stream)."""
+        """Read and clear the flag word (one 4-byte readback: synchronises with the current stream).  IMF_FLAG_RANGE is
+        only meaningful while the convolutions run on split-f16 operands (variant 6): the fp32 / bf16x3 variants carry any
+        fp32 value, so the bit (which the fusion kernel raises in every mode) is dropped for them."""
         w = self._flag_words.get(_norm_device(device))
         if w is None:
             return 0
         v = int(w.item())
         if v:
             w.zero_()
+        if ops.CONV_VARIANT != 6:
+            v &= ~32                                   # IMF_FLAG_RANGE (_lib.FLAG_RANGE)
         return v
 
     def forward_fp32(self, fn):

@@ -374,24 +374,29 @@ MAX_PIPELINED_KVOL = 27
 
 
 def conv_variant_for(kvol):
-    """Variant 6 needs kvol <= 27 (its split-f16 weight image is only read by the pipelined kernel)."""
-    return CONV_VARIANT if (CONV_VARIANT != 6 or kvol <= MAX_PIPELINED_KVOL) else 0
+    """Variants 6 and 3 need kvol <= 27 (their 16-bit weight images are only read by the LDS-DMA kernels)."""
+    return CONV_VARIANT if (CONV_VARIANT not in (6, 3) or kvol <= MAX_PIPELINED_KVOL) else 0
 
 
-def pack_weights(kernel, out=None, split16=False):
+def pack_weights(kernel, out=None, split16=False, variant=None):
     """ME kernel tensor [kvol,cin,cout] (or [cin,cout]) -> MFMA fragment-major image: fp32 B
-    fragments (variants 0 and 1) or, with split16, the hi/lo f16 fragments of variant 6 (same size)."""
+    fragments (variants 0 and 1), with split16 / variant=6 the hi/lo f16 fragments of variant 6 (same size + trailer), with
+    variant=3 the three bf16 parts of variant 3 (1.5 x the size)."""
+    if variant is not None:
+        split16 = variant == 6
     k = kernel.detach()
     if k.dim() == 2:
         k = k.unsqueeze(0)
     k = _req(k.contiguous().float(), torch.float32, "kernel", 3)
     kvol, cin, cout = k.shape
     L = _lib.lib()
-    need = (L.imf_packed_weight_floats_split16 if split16 else L.imf_packed_weight_floats)(kvol, cin, cout)
+    b3 = variant == 3
+    need = (L.imf_packed_weight_floats_bf16x3 if b3 else L.imf_packed_weight_floats_split16 if split16
+            else L.imf_packed_weight_floats)(kvol, cin, cout)
     packed = out if out is not None else torch.empty(need, dtype=torch.float32, device=k.device)
     if packed.numel() < need:
         raise ImfError(f"packed weight buffer has {packed.numel()} floats, needs {need}")
-    fn = L.imf_pack_weights_split16 if split16 else L.imf_pack_weights
+    fn = L.imf_pack_weights_bf16x3 if b3 else L.imf_pack_weights_split16 if split16 else L.imf_pack_weights
     check(fn(k.data_ptr(), kvol, cin, cout, packed.data_ptr(), _stream()), "imf_pack_weights")
     return packed
 
@@ -407,10 +412,12 @@ def conv_kernel_name(variant, cin, cout, staging=None, kernel_tag=0):
     kernel_tag bit 1 / staging="regs" selects round 1's register-staged k_spconv_mfma."""
     if kernel_tag & 16:
         return "k_pointwise_head"
-    suffix = "/f32" if variant == 0 else ""
+    suffix = {0: "/f32", 3: "/b3"}.get(variant, "")
     regs0 = variant == 0 and (kernel_tag & 2 or staging == "regs")
-    if variant in (0, 6) and not regs0 and (kernel_tag & 12 or staging in ("wave8", "wave4")):
+    if variant in (0, 3, 6) and not regs0 and (kernel_tag & 12 or staging in ("wave8", "wave4")):
         return f"k_spconv_w<{8 if (kernel_tag & 4 or staging == 'wave8') else 4}>" + suffix
+    if variant == 3:
+        return f"k_spconv_g<{4 if cout % 64 == 0 else 2}, 0>" + suffix
     if variant == 6:
         dma = H3_DMA if staging is None else staging == "dma"
         return f"k_spconv_{'g' if dma else 'h3'}<{4 if cout % 64 == 0 else 2}, 0>"
@@ -485,11 +492,12 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
             tk = torch.zeros(rb.n_slots // TILE_ROWS * max(1, cout // 32), dtype=torch.int32, device=in_a.device)
             a.tickets = tk.data_ptr()
     big = max(in_a.numel(), 0 if in_b is None else in_b.numel()) * 4 >= 2 ** 31
-    if variant == 6 and big:
-        raise ImfError("variant 6 addresses its inputs through a 2 GiB buffer window: use variant 0 for larger matrices")
+    if variant in (6, 3) and big:
+        raise ImfError("variants 6 / 3 address their inputs through a 2 GiB buffer window: use variant 0 for larger matrices")
     if variant == 0 and big:
         a.kernel_tag = 2                                  # the LDS-DMA kernels share that window: the register-staged kernel
-    need = (L.imf_packed_weight_floats_split16 if variant == 6 else L.imf_packed_weight_floats)(rb.kvol, a.c_a + a.c_b, cout)
+    need = (L.imf_packed_weight_floats_split16 if variant == 6 else L.imf_packed_weight_floats_bf16x3 if variant == 3
+            else L.imf_packed_weight_floats)(rb.kvol, a.c_a + a.c_b, cout)
     if w_packed.numel() != need:
         raise ImfError(f"packed weight has {w_packed.numel()} floats, expected {need} "
                        f"({rb.kvol}x{a.c_a + a.c_b}x{cout}, variant {variant})")
@@ -611,8 +619,10 @@ class FusionKernelWeights:
         w1t = f(ff[0].weight)[perm].t().contiguous()                       # [256, 2048], packed column order
         self.t = dict(ln1_g=f(blk0.norm.weight), ln1_b=f(blk0.norm.bias), wq_p=pack_weights(f(att.to_q.weight).t()),
                       wo_p=pack_weights(f(att.to_out.weight).t()), bo=f(att.to_out.bias), ln2_g=f(blk1.norm.weight),
-                      ln2_b=f(blk1.norm.bias), w1_p=pack_weights(w1t, split16=True), b1=f(ff[0].bias)[perm].contiguous(),
-                      w2_p=pack_weights(f(ff[2].weight).t(), split16=True), b2=f(ff[2].bias),
+                      # (w1_p / w2_p: the image of the 16-bit variant the process runs -- split-f16 for 6, three bf16 parts for 3)
+                      ln2_b=f(blk1.norm.bias), w1_p=pack_weights(w1t, variant=3 if CONV_VARIANT == 3 else 6),
+                      b1=f(ff[0].bias)[perm].contiguous(),
+                      w2_p=pack_weights(f(ff[2].weight).t(), variant=3 if CONV_VARIANT == 3 else 6), b2=f(ff[2].bias),
                       # the same two matrices as fp32 images: the feed-forward of the variant-0 (fp32 MFMA) recompute
                       w1_f32=pack_weights(w1t), w2_f32=pack_weights(f(ff[2].weight).t()))
         self.c = FusionWeights(**{k: v.data_ptr() for k, v in self.t.items()})
@@ -627,7 +637,7 @@ def fusion_attention_batched(x, items, kt_packed, v_packed, n_tokens, tokens_pad
     if out is None:
         out = torch.empty_like(x)
     if variant is None:
-        variant = 6 if CONV_VARIANT == 6 else 0
+        variant = CONV_VARIANT if CONV_VARIANT in (6, 3) else 0
     B = len(items)
     L = _lib.lib()
     r0 = (C.c_int64 * B)(*[int(a) for a, _ in items])

@@ -250,9 +250,9 @@ class _ConvBase(nn.Module):
 
     def packed(self):
         variant = ops.conv_variant_for(self.kernel_volume)
-        tag = (self.kernel.data_ptr(), self.kernel._version, variant == 6)
+        tag = (self.kernel.data_ptr(), self.kernel._version, variant)
         if self._packed is None or self._packed[0] != tag:
-            self._packed = (tag, ops.pack_weights(self.kernel, split16=(variant == 6)))
+            self._packed = (tag, ops.pack_weights(self.kernel, variant=variant))
         return self._packed[1]
 
     def rulebook(self, x):

@@ -208,6 +208,15 @@ int imf_pack_weights(const float *w, int kvol, int cin, int cout, float *packed,
  * imf_packed_weight_floats_split16 floats: the fp32 image's size + a 64-float trailer holding 2^-s. */
 int64_t imf_packed_weight_floats_split16(int kvol, int cin, int cout);
 int imf_pack_weights_split16(const float *w, int kvol, int cin, int cout, float *packed, void *stream);
+/* The same weights as THREE bf16 parts per value for imf_conv_args.variant == 3 ("bf16x3", round 5): w = p0 + p1 + p2
+ * EXACTLY (p0 = bf16(w), p1 = bf16(w - p0), p2 = bf16(w - p0 - p1), round-to-nearest-even: three 8-bit significands carry
+ * fp32's 24 bits, and bf16 has fp32's exponent range -- no pre-scaling, no range restriction).  The convolution splits its
+ * fp32 input rows the same way in registers and forms a0 w2 + a1 w1 + a2 w0 + a0 w1 + a1 w0 + a0 w0 on the bf16 matrix
+ * pipe with fp32 accumulation: every product term down to 2^-16 relative; the three dropped terms are together
+ * <= 2^-26 |a| |w|, a quarter of an fp32 ulp of the product.  1.5 x the fp32 image's size.  Same reference as
+ * imf_pack_weights (the '*.kernel' tensors of model/resunet.py:42-158, model/residual_block.py:23-33). */
+int64_t imf_packed_weight_floats_bf16x3(int kvol, int cin, int cout);
+int imf_pack_weights_bf16x3(const float *w, int kvol, int cin, int cout, float *packed, void *stream);
 
 typedef struct imf_conv_args {
   const float *in_a;      /* [n_in, c_a]                                                      */
@@ -226,9 +235,16 @@ typedef struct imf_conv_args {
   int32_t l2norm;         /* y /= ||y||_2 over the row (requires cout <= 64)                      */
   float *out;             /* [n_out, cout]                                                        */
   int32_t split_k;        /* 0 = choose automatically; >= 1 = number of kernel-offset partitions  */
-  int32_t variant;        /* 0 = pipelined workgroup kernel on the fp32 MFMA; 1 = the same arithmetic without the
-                             pipeline (simple reference kernel; any kvol); 2..5 = retired round-1 experiments
-                             (their measurements: DESIGN.md 4), rejected with IMF_EINVAL;
+  int32_t variant;        /* 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32: the reference's arithmetic), since round 5 on the LDS-DMA
+                                 kernels k_spconv_g / k_spconv_w (AR = kArF32) wherever their tables cover the shape
+                                 (kvol <= 27, kvol * cin / 32 < 224, <= 1024 channels per source, inputs < 2 GiB), else --
+                                 or with kernel_tag bit 1 / `tickets` -- on round 1's register-staged k_spconv_mfma;
+                             1 = the same arithmetic without any pipeline (simple reference kernel; any kvol);
+                             2, 4, 5 = retired round-1 experiments (their measurements: DESIGN.md 4), IMF_EINVAL;
+                             3 = "bf16x3": fp32 operands carried exactly by three bf16 parts each, six
+                                 v_mfma_f32_16x16x32_bf16 per 32 channels, fp32 accumulation (w_packed from
+                                 imf_pack_weights_bf16x3; fp32 rows in, fp32 rows out, no range restriction; kvol <= 27;
+                                 in_a / in_b smaller than 2 GiB each).  k_spconv_g / k_spconv_w with AR = kArBf16x3;
                              6 = fp32-class arithmetic on the f16 matrix pipe with split operands, both operands staged
                                  global -> LDS by DMA (k_spconv_g; see kernel_tag for the register-staged twin)
                                  (w_packed from imf_pack_weights_split16; kvol <= 27; |input| < 65504;
@@ -251,10 +267,11 @@ typedef struct imf_conv_args {
    * imf_rulebook_transpose's parity classes, else 0). */
   const int32_t *n_out_dev;
   int32_t dyn_split_kvol, slots_extra;
-  int32_t kernel_tag;     /* variant 6 only.  bit 0: profiling label -- the identical kernel under a second symbol
+  int32_t kernel_tag;     /* variants 6, 3 and 0.  bit 0: profiling label -- the identical kernel under a second symbol
                              (k_spconv_g<.., 1>: the image branch's dense convolutions).  bit 1: the register-staged twin
                              k_spconv_h3 (csrc/spconv_h3.hip; same sums bit for bit) -- DIAGNOSTIC builds only (make h3 /
-                             stamps): the product library answers IMF_EUNSUPPORTED, as it does for variant 6 + `tickets`.
+                             stamps): the product library answers IMF_EUNSUPPORTED, as it does for variant 6 + `tickets`;
+                             with variant 0: round 1's register-staged fp32 kernel k_spconv_mfma (always built).
                              bit 2 (4) / bit 3 (8): the wave-split kernel k_spconv_w (csrc/spconv_w.hip) with 8 / 4
                              wavefronts per workgroup -- for levels of a few hundred 64-row tiles or fewer: one workgroup
                              owns a (tile, 64-column slab) for all kernel offsets, its wavefronts split the tile's

@@ -173,7 +173,7 @@ def _rb_and_ref(cm, g, which):
 
 
 @pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple", "f32_regs", "f32_regs_split5",
-                                  "f32_wave8", "f32_wave4",
+                                  "f32_wave8", "f32_wave4", "b3", "b3_split1", "b3_split5", "b3_wave8", "b3_wave4",
                                   "h3", "h3_split1", "h3_split5", "h3_wave8", "h3_wave4"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
@@ -191,16 +191,19 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
           "split5_fused": {"split_k": 5, "fused_reduce": True},
           "f32_regs": {"staging": "regs"}, "f32_regs_split5": {"staging": "regs", "split_k": 5},
           "f32_wave8": {"staging": "wave8"}, "f32_wave4": {"staging": "wave4"},
+          # variant 3 = bf16x3: fp32 operands as three bf16 parts each (exact), six bf16 MFMAs per 32 channels
+          "b3": {"variant": 3}, "b3_split1": {"variant": 3, "split_k": 1}, "b3_split5": {"variant": 3, "split_k": 5},
+          "b3_wave8": {"variant": 3, "staging": "wave8"}, "b3_wave4": {"variant": 3, "staging": "wave4"},
           "h3": {"variant": 6},
           "h3_split1": {"variant": 6, "split_k": 1}, "h3_split5": {"variant": 6, "split_k": 5},
           # variant 6 = the LDS-DMA kernel k_spconv_g (the register-staged k_spconv_h3 lives in diagnostic builds only)
           # the wave-split kernel of the coarse levels (csrc/spconv_w.hip): whole tile per workgroup, 8 / 4 wavefronts
           "h3_wave8": {"variant": 6, "staging": "wave8"}, "h3_wave4": {"variant": 6, "staging": "wave4"}}[mode]
-    if mode in ("h3_wave8", "h3_wave4", "f32_wave8", "f32_wave4") and (kvol == 1 or cout % 64):
+    if mode.endswith(("wave8", "wave4")) and (kvol == 1 or cout % 64):
         pytest.skip("the wave-split kernel covers kvol > 1 and cout % 64 == 0")
-    if mode in ("split5", "split5_fused", "h3_split5", "f32_regs_split5") and kvol == 1:
+    if mode in ("split5", "split5_fused", "h3_split5", "f32_regs_split5", "b3_split5") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")
-    out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV), split16=mode.startswith("h3")), cout, rb,
+    out = ops.spconv(fa.to(DEV), ops.pack_weights(w.to(DEV), variant=kw.get("variant", 0)), cout, rb,
                      in_b=None if fb is None else fb.to(DEV), **kw).cpu()
     fin = fa if fb is None else torch.cat([fa, fb], 1)
     wk = w if kvol > 1 else w[0]
@@ -248,6 +251,58 @@ def test_spconv_chip_filling_launches_match_fp32_mfma(ops, clouds):
         c = ops.spconv(fa, wp0, cout, rb, in_b=fb, variant=0, split_k=1, scale=sc, shift=sh, relu=True, staging=staging)
         assert ((a - b).abs() <= bound * sc + 1e-6).all(), (ca, cb, cout, float((a - b).abs().max()))
         assert ((c - b).abs() <= bound * sc + 1e-6).all(), (ca, cb, cout, float((c - b).abs().max()))
+
+
+def test_pack_weights_bf16x3_is_an_exact_split(ops):
+    """imf_pack_weights_bf16x3: every weight as three bf16 parts whose sum IS the fp32 value (three 8-bit significands carry
+    fp32's 24 bits; bf16 has fp32's exponent range, so magnitudes from 1e-30 to 1e30 survive), in the split-f16 image's lane
+    order with three parts per column block."""
+    for kvol, cin, cout in ((27, 32, 32), (3, 64, 128), (1, 96, 64)):
+        w = _rand((kvol, cin, cout), 5) * torch.pow(10.0, _rand((kvol, cin, cout), 6) * 8)      # ~16 decades
+        w[0, 0, 0], w[0, 1, 1], w[0, 2, 2] = 1e-30, -3e30, 0.0
+        CB = 4 if cout % 64 == 0 else 2
+        img = ops.pack_weights(w.to(DEV), variant=3).cpu().view(torch.bfloat16)
+        assert img.numel() == kvol * cin * cout * 3
+        parts = img.view(cout // (16 * CB), kvol, cin // 32, CB, 3, 64, 8).float()               # y k cc cb part lane t
+        total = parts.double().sum(4)                                                            # exact in fp64
+        ref = (w.view(kvol, cin // 32, 2, 4, 4, cout // (16 * CB), CB, 16)                        # k cc t>>2 q t&3 y cb c
+                .permute(5, 0, 1, 6, 3, 7, 2, 4).reshape(cout // (16 * CB), kvol, cin // 32, CB, 64, 8))   # lane = 16 q + c
+        assert torch.equal(total, ref.double())
+        p0 = parts[:, :, :, :, 0]
+        assert torch.equal(p0, ref.to(torch.bfloat16).float())                                   # first part = bf16(w), nearest-even
+
+
+def test_spconv_bf16x3_is_fp32_class(ops, clouds):
+    """Variant 3 against the fp32-MFMA kernel on the chip-filling and coarse shapes, errors measured against fp64: the
+    bf16x3 products drop three terms of <= 2^-26 |a||w| together and accumulate in fp32 like the fp32 MFMA does, so its
+    error must be of the fp32 kernel's own size (<= 1.5 x its worst element + roundoff floor), with no range restriction:
+    inputs of magnitude 1e6 and weights of 1e-6 (either overflows / underflows an f16 operand)."""
+    xyz = clouds[0].astype(np.float64) * 1.7
+    cm = _build_levels(ops, ops.voxelize(torch.as_tensor(xyz).to(DEV), 0.025))
+    n0, n1 = cm.level(1).n, cm.level(2).n
+    for ca, cb, cout, rb, n_in, staging, amp in ((64, 0, 64, cm.conv_rulebook(1, 3, 1), n0, None, 1.0),
+                                                 (32, 0, 32, cm.conv_rulebook(1, 3, 1), n0, None, 1e6),
+                                                 (64, 64, 64, cm.transpose_rulebook(2, 3, 2), n1, None, 1.0),
+                                                 (64, 32, 64, cm.conv_rulebook(1, 1, 1), n0, None, 1.0),
+                                                 (64, 0, 128, cm.conv_rulebook(2, 3, 1), n1, "wave4", 1e6),
+                                                 (64, 64, 128, cm.conv_rulebook(2, 3, 1), n1, "wave8", 1.0)):
+        fa, fb = _rand((n_in, ca), 90).to(DEV) * amp, (_rand((n_in, cb), 91).to(DEV) * amp if cb else None)
+        w = _rand((rb.kvol, ca + cb, cout), 92, 0.05).to(DEV) / amp
+        b3 = ops.spconv(fa, ops.pack_weights(w, variant=3), cout, rb, in_b=fb, variant=3, split_k=1, staging=staging)
+        f32 = ops.spconv(fa, ops.pack_weights(w), cout, rb, in_b=fb, variant=0, split_k=1, staging=staging)
+        fin = fa if fb is None else torch.cat([fa, fb], 1)
+        nbr = rb.nbr.view(rb.kvol, -1)[:, :rb.n_slots] if rb.nbr is not None else None
+        # fp64 reference on the device: gather-GEMM per offset through the rulebook's own neighbour table
+        ref = torch.zeros((rb.n_out, cout), dtype=torch.float64, device=DEV)
+        rows = rb.tile_rows[:rb.n_slots].long() if rb.tile_rows is not None else torch.arange(rb.n_out, device=DEV)
+        for k in range(rb.kvol):
+            idx = nbr[k].long() if nbr is not None else rows
+            ok = (idx >= 0) & (rows >= 0)
+            ref.index_add_(0, rows[ok], fin[idx[ok]].double() @ w[k].double())
+        e3, e0 = (b3.double() - ref).abs().max().item(), (f32.double() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert e3 <= 1.5 * e0 + 1e-7 * scale, (ca, cb, cout, staging, e3, e0, scale)
+        assert e0 <= 2e-6 * scale * 8, (ca, cb, cout, staging, e0, scale)                        # (the reference itself is sane)
 
 
 def test_spconv_operand_images(ops, clouds):
