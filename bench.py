@@ -46,9 +46,29 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md: aggregate L2 bandwidth
-PMC_FILE = "r04_pmc_traffic.json"
-STATS_FILE = "r04_kernel_stats.txt"
-COUNTERS_FILE = "r04_pmc_counters.txt"
+# The three arithmetics the convolutions can run on (imfnet_amd/ops.py CONV_VARIANT; imf_conv_args.variant).  `peak_tf` = the
+# dense matrix peak of MI355X_MICROARCH.md for the instruction used, divided by the matrix instructions one fp32
+# multiply-add block costs: the fp32-EQUIVALENT matrix roofline of the arithmetic.
+ARITH = {
+    "bf16x3": {"variant": 3, "suffix": "/b3", "ar": "3", "peak_tf": 2500.0 / 6, "mfma_flops": 16384,
+               "dtype": "f32 (each fp32 operand split EXACTLY into 3 bf16 parts = 24 significant bits, fp32 exponent range; "
+                        "6 x v_mfma_f32_16x16x32_bf16 per 32 channels, fp32 accumulate)",
+               "arithmetic": "a = a0 + a1 + a2, w = w0 + w1 + w2 exactly (bf16 parts, round-to-nearest residuals); products a0w2 + "
+                             "a1w1 + a2w0 + a0w1 + a1w0 + a0w0 with fp32 accumulation in the MFMA; the three dropped terms are "
+                             "together <= 2^-26 |a||w| (a quarter of an fp32 ulp of the product); fp32 buffers between layers, no "
+                             "range restriction, no recompute path"},
+    "f16x2": {"variant": 6, "suffix": "", "ar": "(0|1)", "peak_tf": 2500.0 / 3, "mfma_flops": 16384,
+              "dtype": "f32 (2xf16-split operands, 22-bit, 3 x v_mfma_f32_16x16x32_f16; fp32 accumulate) -- FAST mode, narrower "
+                       "operands than the reference's fp32",
+              "arithmetic": "fp32 operands split into f16 hi + lo (weights pre-scaled by a power of two), lo*hi + hi*lo + hi*hi "
+                            "with fp32 accumulation; activations outside the f16 range raise IMF_FLAG_RANGE and the fragment "
+                            "is redone on fp32 MFMA"},
+    "f32": {"variant": 0, "suffix": "/f32", "ar": "2", "peak_tf": 157.3, "mfma_flops": 2048,
+            "dtype": "f32 (v_mfma_f32_16x16x4_f32: fp32 operands and accumulation, the reference's arithmetic)",
+            "arithmetic": "fp32 rows and fp32 weights through the same LDS-DMA kernels into v_mfma_f32_16x16x4_f32"},
+}
+VARIANT_NAME = {v["variant"]: k for k, v in ARITH.items()}
+PROFILE_TAG = "r05"          # profiles/<tag>_kernel_stats_<arith>.txt, <tag>_pmc_traffic_<arith>.json, <tag>_pmc_counters_<arith>.txt
 
 
 def load_pair(scale):
@@ -81,30 +101,43 @@ def algorithmic_bytes(rec):
     return pairs * (rec["cin"] + rec["cout"]) * 4 + pairs * 8 + rec["kvol"] * rec["cin"] * rec["cout"] * 4, pairs
 
 
-def pmc_traffic(kernel):
+def _family_regex(label, arith):
+    """Regex over demangled kernel symbols (without the imf:: prefix and the argument list) for a bench label.  Labels come
+    from ops.conv_kernel_name: `k_spconv_w<W>` / `k_spconv_g<CB, 0>` (+ `/b3`, `/f32`) name a template FAMILY -- every
+    (CAT, NB, RB) instance of the arithmetic AR (last template argument: 0 / 1 split-f16 without / with operand images,
+    2 fp32, 3 bf16x3); anything else is a plain symbol."""
+    ar = ARITH[arith]["ar"]
+    base = label.split("/")[0]
+    if arith == "f16x2":
+        ar = "1"                                          # the ResUNet's launches read operand images; 0 = the image trunk's
+    m = re.match(r"k_spconv_w<(\d)>$", base)
+    if m:
+        return r"k_spconv_w<(true|false), %s, %s, 0>$" % (m.group(1), ar)     # (label 0; 1 = the image trunk's launches)
+    m = re.match(r"k_spconv_g<(\d), (\d)>$", base)
+    if m:
+        return r"k_spconv_g<%s, %s, (true|false), \d, \d, %s>$" % (m.group(1), m.group(2), ar)
+    return re.escape(base) + r"(<.*>)?$"
+
+
+def _profile(kind, arith):
+    """profiles/<PROFILE_TAG>_<kind>_<arith>.<ext> (this round's passes of this same command per arithmetic)."""
+    ext = "json" if kind == "pmc_traffic" else "txt"
+    path = os.path.join(ROOT, "profiles", "%s_%s_%s.%s" % (PROFILE_TAG, kind, arith, ext))
+    return path if os.path.exists(path) else None
+
+
+def pmc_traffic(kernel, arith):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r03_pmc_traffic.json, produced by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
+    (profiles/r05_pmc_traffic_<arith>.json, produced by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
     separate runs; read side doubled per the gfx950 FETCH_SIZE correction).  None if absent."""
-    for name in (PMC_FILE, "r03_pmc_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            break
-    else:
-        return None, "no PMC profile committed"
+    path = _profile("pmc_traffic", arith)
+    if not path:
+        return None, "no PMC profile committed for %s" % arith
     ks = json.load(open(path))["kernels"]
-    # `kernel` names a template FAMILY (k_spconv_g<4, 0> = every (CAT, NB, RB) instance of the 64-column sparse
-    # launches, which is what the live timing above groups too): launch-weighted average over its symbols
-    key = "imf::" + kernel
-    if kernel.startswith("k_spconv_w<"):              # k_spconv_w<W> = the symbols k_spconv_w<CAT, W>
-        # the ResUNet's launches read operand images (third argument true); the two-argument symbols of the same kernel
-        # are the image trunk's small dense convolutions, which the live timing above does not group either
-        w = kernel[len("k_spconv_w<"):-1]
-        fam = [v for k, v in ks.items() if re.match(r"imf::k_spconv_w<(true|false), %s, true>" % w, k)] or \
-              [v for k, v in ks.items() if re.match(r"imf::k_spconv_w<(true|false), %s>" % w, k)]
-    else:
-        fam = [v for k, v in ks.items() if k == key or k.startswith(key[:-1] + ",") or k.startswith(key + "<")]
+    rx = re.compile(_family_regex(kernel, arith))
+    fam = [v for k, v in ks.items() if rx.match(k[len("imf::"):] if k.startswith("imf::") else k)]
     if not fam:
-        return None, f"{key} not in {os.path.basename(path)}"
+        return None, f"{kernel} not in {os.path.basename(path)}"
     n = sum(v["launches"] for v in fam)
     avg = lambda f: sum(v[f] * v["launches"] for v in fam) / n
     hit = sum(v["l2_hit_rate"] * v["launches"] for v in fam) / n
@@ -114,51 +147,37 @@ def pmc_traffic(kernel):
                                             f"bytes because feature rows are re-gathered from L2 / Infinity Cache, not HBM")
 
 
-def rocprof_avg_us(kernel, name=None):
+def rocprof_avg_us(kernel, arith):
     """Launch-weighted average duration of `kernel`'s symbols in the committed `rocprofv3 --kernel-trace --stats` summary of
-    this same command (profiles/r03_kernel_stats.txt, tools/profile_round.sh) -- printed beside the live HIP-event timing so
-    that roofline.frac can be recomputed from profiles/ alone.  (n, avg_us) or None."""
-    for cand in ([name] if name else [STATS_FILE, "r03_kernel_stats.txt"]):
-        path = os.path.join(ROOT, "profiles", cand)
-        if os.path.exists(path):
-            break
-    else:
+    this same command (profiles/r05_kernel_stats_<arith>.txt, tools/profile_round.sh) -- printed beside the live HIP-event
+    timing so that roofline.frac can be recomputed from profiles/ alone.  (n, avg_us, file) or None."""
+    path = _profile("kernel_stats", arith)
+    if not path:
         return None
     rows = []
     for line in open(path):
         m = re.match(r"(?:void )?imf::(.*?)\(.*\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s+[\d.]+\s*$", line)
         if m:
             rows.append((m.group(1), int(m.group(2)), float(m.group(3))))
-    if kernel.startswith("k_spconv_w<"):   # (operand-image symbols if the profile has them: see pmc_traffic)
-        w = kernel[len("k_spconv_w<"):-1]
-        fam = [r for r in rows if re.match(r"k_spconv_w<(true|false), %s, true>$" % w, r[0])] or \
-              [r for r in rows if re.match(r"k_spconv_w<(true|false), %s>$" % w, r[0])]
-    else:
-        fam = [r for r in rows if r[0] == kernel or r[0].startswith(kernel[:-1] + ",") or r[0].startswith(kernel + "<")]
+    rx = re.compile(_family_regex(kernel, arith))
+    fam = [r for r in rows if rx.match(r[0])]
     n, tot = sum(r[1] for r in fam), sum(r[2] for r in fam)
     return (n, tot / n, os.path.basename(path)) if n else None
 
 
-def pmc_counters(kernel):
+def pmc_counters(kernel, arith):
     """(matrix-pipe busy %, MFMA instructions per launch, file) of `kernel`'s family from the committed counter table
-    (profiles/r04_pmc_counters.txt, tools/pmc_table.py), launch-weighted; None if absent."""
-    for cand in (COUNTERS_FILE, "r03_pmc_counters.txt"):
-        path = os.path.join(ROOT, "profiles", cand)
-        if os.path.exists(path):
-            break
-    else:
+    (profiles/r05_pmc_counters_<arith>.txt, tools/pmc_table.py), launch-weighted; None if absent."""
+    path = _profile("pmc_counters", arith)
+    if not path:
         return None
     rows = []
     for line in open(path):
         m = re.match(r"(k_\S.*?)\s+(\d+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+\d+\s+(\d+) /", line)
         if m:
             rows.append((m.group(1).strip(), int(m.group(2)), float(m.group(5)), int(m.group(7))))
-    if kernel.startswith("k_spconv_w<"):
-        w = kernel[len("k_spconv_w<"):-1]
-        fam = [r for r in rows if re.match(r"k_spconv_w<(true|false), %s, true>$" % w, r[0])]
-    else:
-        fam = [r for r in rows if r[0] == kernel or r[0].startswith(kernel[:-1] + ",") or r[0].startswith(kernel + "<")]
-        fam = [r for r in fam if r[0].endswith("true>")] or fam      # the ResUNet's launches read operand images
+    rx = re.compile(_family_regex(kernel, arith))
+    fam = [r for r in rows if rx.match(r[0])]
     n = sum(r[1] for r in fam)
     if not n:
         return None
@@ -222,6 +241,104 @@ def cpu_baseline(xyz, img, voxel, sd, seconds_budget=12.0):
                       f"({med * 1e3:.0f} ms each), {best[impl][0]} threads (best of a probe on a {ncpu}-cpu host; one run "
                       f"on 1 thread: {one_t * 1e3:.0f} ms): C hash-map voxelise / pyramid / rulebooks (OpenMP) + the "
                       f"convolutions as {names[impl]} + torch-CPU image encoder and attention"}
+
+
+def group_trace(records):
+    """Traced launches (HIP events recorded by the library right around each convolution kernel on its launch stream) grouped
+    by kernel family: total ms, algorithmic bytes (SURVEY 8(d)) and useful flops."""
+    groups, cache = {}, {}
+    for rec in records:
+        ms = rec["ev"].elapsed_ms()
+        assert ms >= 0.0
+        key = id(rec["rb"]) if "arena" not in rec else (rec["rb"].nbr, rec["rb"].n_slots), rec["cin"], rec["cout"]
+        if key not in cache:
+            cache[key] = algorithmic_bytes(rec)
+        g = groups.setdefault(rec["kernel"], {"ms": 0.0, "bytes": 0, "n": 0, "flops": 0})
+        g["ms"] += ms
+        g["bytes"] += cache[key][0]
+        g["flops"] += 2 * cache[key][1] * rec["cin"] * rec["cout"]
+        g["n"] += 1
+    return groups
+
+
+def build_roofline(groups, arith, traced_steps, ms_per_step, iso_groups=None):
+    """The `roofline` object of one arithmetic.  The dominant kernel family (by time) against BOTH rooflines:
+      * the matrix pipe -- `bound: "mfma"` -- useful fp32 flops (2 * pairs * Cin * Cout, no padding) per launch / launch time
+        against the fp32-EQUIVALENT matrix peak of the arithmetic (dense 16-bit peak / matrix instructions per fp32
+        multiply-add block; 157.3 TF for the fp32 MFMA), with the counter-measured matrix-pipe occupancy beside it;
+      * HBM, notionally: SURVEY 8(d)'s algorithmic bytes per launch / launch time / 8 TB/s (`notional_hbm_frac`; measured HBM
+        traffic is a third of those bytes -- rows are re-gathered from L2 -- so HBM is not what binds, VERDICT r4 #9)."""
+    A = ARITH[arith]
+    dom = max(groups, key=lambda k: groups[k]["ms"])
+    g = groups[dom]
+    sec = g["ms"] * 1e-3
+    tf = g["flops"] / sec / 1e12
+    gbs = g["bytes"] / sec / 1e9
+    conv_ms = sum(v["ms"] for v in groups.values()) / traced_steps
+    conv_bytes = sum(v["bytes"] for v in groups.values()) / traced_steps
+    conv_flops = sum(v["flops"] for v in groups.values()) / traced_steps
+    traffic, traffic_note = pmc_traffic(dom, arith)
+
+    def counters(kernel, avg_us):
+        pc = pmc_counters(kernel, arith)
+        if not pc:
+            return {}
+        busy, mfma, src = pc
+        return {"mfma_busy": round(busy / 100.0, 4), "mfma_per_launch": int(mfma),
+                "issued_tflops": round(mfma * A["mfma_flops"] / (avg_us * 1e-6) / 1e12, 1),
+                "counters": "profiles/" + src}
+
+    def per_kernel_entry(k, v):
+        avg_us = v["ms"] * 1e3 / v["n"]
+        e = {"launches_per_step": v["n"] // traced_steps, "avg_launch_us": round(avg_us, 2),
+             "useful_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+             "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / A["peak_tf"], 4),
+             "notional_hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        e.update(counters(k, avg_us))
+        rp = rocprof_avg_us(k, arith)
+        if rp:
+            e["rocprof_avg_launch_us"] = round(rp[1], 2)
+        return e
+
+    avg_us = g["ms"] * 1e3 / g["n"]
+    r = {"bound": "mfma", "kernel": dom, "arithmetic": arith,
+         "achieved": round(tf, 2), "peak": round(A["peak_tf"], 1), "unit": "TFLOP/s", "frac": round(tf / A["peak_tf"], 4),
+         "peak_note": ("fp32-equivalent matrix peak of this arithmetic: MI355X dense 16-bit matrix peak 2500 TFLOP/s / %d matrix "
+                       "instructions per fp32 multiply-add block" % (6 if arith == "bf16x3" else 3)) if arith != "f32" else
+                      "fp32 matrix peak (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md",
+         "achieved_note": "USEFUL flops (2 * pairs * Cin * Cout of the rulebook's occupied pairs; the 64-row tiles also multiply "
+                          "their empty (row, offset) slots, ~48 % of the issued matrix work: `issued_tflops`) / launch time",
+         "traffic": traffic, "traffic_note": traffic_note,
+         "notional_hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                          "note": "SURVEY 8(d)'s algorithmic bytes per launch / launch time / 8 TB/s: the contract's HBM roofline. "
+                                  "Notional -- the counter traffic above is a fraction of these bytes (rows are re-gathered "
+                                  "from L2 / Infinity Cache), so HBM is not the binding resource"},
+         "launches_per_step": g["n"] // traced_steps,
+         "avg_launch_us": round(avg_us, 2),
+         "algorithmic_bytes_per_launch": g["bytes"] // g["n"],
+         "algorithmic_flops_per_launch": g["flops"] // g["n"],
+         "all_sparse_conv_ms_per_step": round(conv_ms, 3),
+         "step_frac": round(conv_flops / (ms_per_step * 1e-3) / 1e12 / A["peak_tf"], 4),
+         "step_notional_hbm_frac": round(conv_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "step_frac_note": "sum of the convolutions' useful flops (algorithmic bytes) per step / ms_per_step / peak: the whole "
+                           "step against the roofline -- geometry, image branch and fusion count as time only",
+         "per_kernel": {k: per_kernel_entry(k, v) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
+         "timing": "HIP events around each launch on its launch stream, in situ (other streams' kernels of the same "
+                   "step overlap), %d steps after the timed regions" % traced_steps}
+    r.update(counters(dom, avg_us))
+    rp = rocprof_avg_us(dom, arith)
+    if rp:
+        r["rocprof_avg_launch_us"] = round(rp[1], 2)
+        r["rocprof_frac"] = round(g["flops"] / g["n"] / (rp[1] * 1e-6) / 1e12 / A["peak_tf"], 4)
+        r["rocprof_notional_hbm_frac"] = round(g["bytes"] / g["n"] / (rp[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        r["rocprof_note"] = ("%d launches of the family in profiles/%s (rocprofv3 --kernel-trace --stats of this command with "
+                             "IMF_CONV_VARIANT=%d; kernel tracing serialises the streams and carries no event records)"
+                             % (rp[0], rp[2], A["variant"]))
+    if iso_groups and dom in iso_groups:
+        gi = iso_groups[dom]
+        r["isolated_avg_launch_us"] = round(gi["ms"] * 1e3 / gi["n"], 2)
+        r["isolated_frac"] = round(gi["flops"] / (gi["ms"] * 1e-3) / 1e12 / A["peak_tf"], 4)
+    return r
 
 
 def self_launch(args):
@@ -394,20 +511,27 @@ def host_span_leg(model, dev, args, barrier, sync, pts, imgs, voxel, f32_valued=
     return out, trace
 
 
-def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=12):
-    """SURVEY 8(e) as a measurement: a synthetic test set (slabs of the in-tree pair, seeded scales and sizes, the same on
-    every rank) is LPT-sharded over the ranks (imfnet_amd.dist.shard_fragments), every rank streams ITS fragments through
-    the host-array pipeline, then ONE variable-length gather brings all [M_i, 32] blocks to rank 0 (RCCL send / recv under
-    nccl).  Rank 0 checks counts, order and every block bit for bit against the CRC its producer took."""
+def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=96, distinct=24, passes=3, min_region_s=1.2):
+    """SURVEY 8(e) as a measurement: a synthetic test set (`distinct` seeded slabs of the in-tree pair -- scales and sizes
+    the same on every rank, float32-valued like a PLY's points -- repeated to `per_rank` x world fragments) is LPT-sharded
+    over the ranks (imfnet_amd.dist.shard_fragments); every rank streams ITS fragments through the host-array pipeline
+    (xyz_down + descriptors back on the host, as generate_desc needs them) while each fragment's descriptors are ALSO
+    copied device-to-device from the capacity bucket into the rank's send buffer (extract_features_stream(device_sink=...));
+    then ONE variable-length gather brings all [M_i, 32] blocks to rank 0: one all_gather of the row counts + one grouped
+    ncclSend / ncclRecv exchange under RCCL, every receive posted at once (dist.gather_fragment_descriptors(packed=...)) --
+    nothing goes through the host on the way.  Rank 0 checks counts, order and every block bit for bit against the CRC
+    its producer took from the host copy.
+    Reproducibility: capacity keys, lanes and pinned slots are created by two full untimed passes over the
+    SAME fragment list (the second is what a timed pass looks like); then `passes` timed passes of >= per_rank fragments
+    each, the median is reported, every pass listed."""
     import zlib
     from imfnet_amd import dist as idist
     from imfnet_amd.extract import extract_features, extract_features_stream
     z = np.load(os.path.join(ROOT, "tests", "golden", "fixture_clouds.npz"))
     im = np.load(os.path.join(ROOT, "tests", "golden", "fixture_images.npz"))
     rng = np.random.default_rng(7)
-    n_frag = per_rank * world
-    frags = []
-    for i in range(n_frag):
+    protos = []
+    for i in range(distinct):
         base = z[f"cloud_bin_{i % 2}"]
         scale = np.float32(rng.uniform(1.0, 1.9))
         d = rng.normal(size=3).astype(np.float32)
@@ -416,55 +540,97 @@ def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=12):
         lo = np.quantile(proj, rng.uniform(0.0, 1.0 - frac))
         keep = np.flatnonzero(proj >= lo)[: int(frac * len(base))]
         pts = (base[np.sort(keep)] * scale).astype(np.float64)           # float32-valued, as a PLY's points
-        frags.append((pts, np.transpose(im[f"image_{i % 2}"], (2, 0, 1))[None].copy()))
-    shards = idist.shard_fragments([len(p) for p, _ in frags], world)
+        protos.append((pts, np.transpose(im[f"image_{i % 2}"], (2, 0, 1))[None].copy()))
+    n_frag = per_rank * world
+    frag = lambda i: protos[i % distinct]                 # fragment i of the test set
+    shards = idist.shard_fragments([len(frag(i)[0]) for i in range(n_frag)], world)
     mine = shards[rank]
+    coll = idist._collective_device()
+    main = None
+
+    def one_pass(sink_buf, crcs):
+        """Stream this rank's shard once; returns the rows per fragment (shard order)."""
+        rows, at = [], [0]
+
+        def sink(F_dev):                                  # D2D, on the runner's main stream: bucket -> send buffer
+            if sink_buf is not None:
+                sink_buf[at[0]:at[0] + F_dev.shape[0]].copy_(F_dev, non_blocking=True)
+            at[0] += F_dev.shape[0]
+        gen = extract_features_stream(model, (frag(i) for i in mine), voxel, dev, batch=2, copy=False, device_sink=sink)
+        for i, (xd, Fh) in zip(mine, gen):
+            rows.append(Fh.shape[0])
+            if crcs is not None:
+                crcs[i, 0], crcs[i, 1] = zlib.crc32(Fh.tobytes()), Fh.shape[0]
+        return rows
+
     with torch.no_grad():
         if model.fragment_runner().ratios is None:       # (teach the runner: one fragment on the exact path)
-            extract_features(model, frags[0][0], voxel_size=voxel, device=dev, skip_check=True, image=frags[0][1])
-        for _ in extract_features_stream(model, (frags[i] for i in mine), voxel, dev, batch=2):
-            pass                                         # untimed pass: the capacity buckets of these sizes exist afterwards
-        model.fragment_runner().streamer(dev).fill_lanes()   # ... all three lanes of each (created on demand otherwise)
+            extract_features(model, frag(0)[0], voxel_size=voxel, device=dev, skip_check=True, image=frag(0)[1])
+        rows = one_pass(None, None)                      # untimed: every capacity key of this shard exists afterwards ...
+        model.fragment_runner().streamer(dev).fill_lanes()   # ... and every lane of each key
+        send_buf = torch.empty((sum(rows), 32), dtype=torch.float32, device=dev)
+        crcs = torch.zeros((n_frag, 2), dtype=torch.int64)
+        assert one_pass(send_buf, crcs) == rows          # untimed: what a timed pass does, slot for slot (+ the CRCs)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
         t0 = time.perf_counter()
-        results, crcs = {}, torch.zeros((n_frag, 2), dtype=torch.int64)
-        coll = idist._collective_device()
-        for i, (xd, Fh) in zip(mine, extract_features_stream(model, (frags[i] for i in mine), voxel, dev, batch=2)):
-            crcs[i, 0], crcs[i, 1] = zlib.crc32(Fh.tobytes()), Fh.shape[0]
-            results[i] = torch.from_numpy(Fh).to(coll, non_blocking=False)
+        one_pass(send_buf, None)                         # untimed probe of one pass
         torch.cuda.synchronize()
-        t_stream = time.perf_counter() - t0
+        # a timed region = `reps` passes over the shard, >= min_region_s long on the slowest rank's probe (same on all ranks)
+        reps = torch.tensor([max(1, int(np.ceil(min_region_s / max(time.perf_counter() - t0, 1e-3))))], device=coll)
         if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        gathered = idist.gather_fragment_descriptors(results, n_frag, shards, dst=0, device=coll)
-        if coll.type == "cuda":
+            dist.all_reduce(reps, op=dist.ReduceOp.MAX)
+        reps = int(reps.item())
+        st = model.fragment_runner().stats
+        redone0 = st.get("redone", 0)
+        t_pass = []
+        for _ in range(passes):
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                one_pass(send_buf, None)
             torch.cuda.synchronize()
-        t_gather = time.perf_counter() - t1
-    tt = torch.tensor([t_stream, t_gather], dtype=torch.float64, device=coll)
+            t_pass.append((time.perf_counter() - t0) / reps)
+        redone = st.get("redone", 0) - redone0
+        packed = (rows, send_buf if coll.type == "cuda" else send_buf.cpu())   # (gloo test hook: the collective is on the host)
+        t_gather = []
+        for _ in range(passes):
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            gathered = idist.gather_fragment_descriptors(None, n_frag, shards, dst=0, device=coll, packed=packed)
+            if coll.type == "cuda":
+                torch.cuda.synchronize()
+            t_gather.append(time.perf_counter() - t1)
+    tt = torch.tensor([t_pass, t_gather], dtype=torch.float64, device=coll)
     crcs = crcs.to(coll)
     if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)        # per pass: the slowest rank
         dist.all_reduce(crcs, op=dist.ReduceOp.MAX)      # every entry is written by exactly one rank, zero elsewhere
     if rank != 0:
         return None
     crcs = crcs.cpu()
     assert gathered is not None and sorted(gathered) == list(range(n_frag)), "gather: fragments missing / out of order"
-    rows = 0
+    total_rows = 0
     for i in range(n_frag):
         blk = gathered[i].cpu().numpy()
         assert blk.shape == (int(crcs[i, 1]), 32), f"gather: fragment {i} has {blk.shape} rows, producer said {int(crcs[i, 1])}"
         assert zlib.crc32(blk.tobytes()) == int(crcs[i, 0]), f"gather: fragment {i} differs from what its rank computed"
-        rows += blk.shape[0]
-    ts, tg = float(tt[0]), float(tt[1])
-    return {"fragments": n_frag, "ranks": world, "backend": backend, "descriptors": rows,
-            "fragments_per_s": round(n_frag / ts, 1), "descriptors_per_s": round(rows / ts, 1),
-            "stream_s_max_over_ranks": round(ts, 4), "gather_ms": round(tg * 1e3, 3),
-            "gather_bytes": rows * 128, "verified": "every block on rank 0: rows and CRC-32 equal to its producer's",
-            "note": "host-array pipeline per rank (LPT shards by point count) + one variable-length gather of the [M_i,32] blocks "
-                    "to rank 0; fragments of %d-%d k points" % (min(len(p) for p, _ in frags) // 1000, max(len(p) for p, _ in frags) // 1000)}
+        total_rows += blk.shape[0]
+    ts, tg = median(tt[0].tolist()), median(tt[1].tolist())
+    sizes = [len(p) for p, _ in protos]
+    return {"fragments": n_frag, "fragments_per_rank": per_rank, "ranks": world, "backend": backend, "descriptors": total_rows,
+            "fragments_per_s": round(n_frag / ts, 1), "descriptors_per_s": round(total_rows / ts, 1),
+            "stream_s_max_over_ranks": round(ts, 4), "stream_s_all_passes": [round(v, 4) for v in tt[0].tolist()],
+            "timed_region": "%d passes over the shard (%d fragments per rank) = %.2f s per region, %d regions, median" % (reps, reps * per_rank, ts * reps, passes),
+            "gather_ms": round(tg * 1e3, 3), "gather_ms_all": [round(v * 1e3, 3) for v in tt[1].tolist()],
+            "gather_bytes": total_rows * 128, "fragments_redone_on_the_exact_path": redone,
+            "gather": "device-resident: D2D copy from the capacity bucket into the rank's send buffer as each fragment completes, "
+                      "one all_gather of row counts + one grouped send / recv exchange (all receives posted at once)",
+            "verified": "every block on rank 0: rows and CRC-32 equal to its producer's host copy",
+            "note": "host-array pipeline per rank (LPT shards by point count; %d distinct fragments of %d-%d k points, repeated) "
+                    "+ one variable-length gather of the [M_i,32] blocks to rank 0; median of %d timed passes after two untimed "
+                    "passes over the same list" % (distinct, min(sizes) // 1000, max(sizes) // 1000, passes)}
 
 
 def main():
@@ -490,10 +656,16 @@ def main():
                     help="untimed steps run for at least this long before the first timed region (clock / power settle)")
     ap.add_argument("--trace-steps", type=int, default=3,
                     help="steps AFTER the timed regions that carry HIP events around every convolution (live roofline)")
+    ap.add_argument("--arith", default=None, choices=tuple(ARITH),
+                    help="arithmetic of the convolutions for the headline (`value`): bf16x3 (default: fp32 operands split exactly "
+                         "into three bf16 parts), f16x2 (the 22-bit FAST mode), f32 (fp32 MFMA).  The other two are measured "
+                         "too and reported with their own roofline under `arithmetics` (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-fragment / batch / fp32-MFMA / graph legs")
     ap.add_argument("--no-host-span", action="store_true", help="skip the host-array stream leg (profiling runs)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-pipeline + gather leg")
+    ap.add_argument("--sharded-per-rank", type=int, default=96, help="fragments per rank of the sharded-pipeline leg")
+    ap.add_argument("--sharded-region-s", type=float, default=1.2, help="minimum length of one timed region of that leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -501,6 +673,9 @@ def main():
 
     from imfnet_amd import dist as idist
     from imfnet_amd import ops
+    if args.arith is None:
+        args.arith = VARIANT_NAME.get(ops.CONV_VARIANT, "bf16x3")
+    ops.CONV_VARIANT = ARITH[args.arith]["variant"]      # process-wide: every leg below runs on the headline's arithmetic
 
     # test hooks (single-GPU box): IMF_DIST_BACKEND=gloo IMF_FORCE_DEVICE=0 run N ranks on one device
     backend = os.environ.get("IMF_DIST_BACKEND", "nccl")
@@ -625,7 +800,8 @@ def main():
             host_span, host_trace = host_span_leg(model, dev, args, barrier, sync, pts2, imgs2, voxel)
         sharded = None
         if not args.no_sharded and dyn:
-            sharded = sharded_pipeline_leg(model, dev, voxel, rank, world, backend)
+            sharded = sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=args.sharded_per_rank,
+                                           min_region_s=args.sharded_region_s)
 
     t = torch.tensor(rep, dtype=torch.float64, device=dev)
     hs = torch.tensor([host_span["ms_per_step"] if host_span else 0.0, float(M)], dtype=torch.float64, device=dev)
@@ -647,76 +823,10 @@ def main():
 
     if rank == 0:
         # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
-        def group(records):
-            groups, cache = {}, {}
-            for rec in records:
-                ms = rec["ev"].elapsed_ms()
-                assert ms >= 0.0
-                key = id(rec["rb"]) if "arena" not in rec else (rec["rb"].nbr, rec["rb"].n_slots), rec["cin"], rec["cout"]
-                if key not in cache:
-                    cache[key] = algorithmic_bytes(rec)
-                g = groups.setdefault(rec["kernel"], {"ms": 0.0, "bytes": 0, "n": 0, "flops": 0})
-                g["ms"] += ms
-                g["bytes"] += cache[key][0]
-                g["flops"] += 2 * cache[key][1] * rec["cin"] * rec["cout"]
-                g["n"] += 1
-            return groups
-
-        groups = group(trace)
-        dom = max(groups, key=lambda k: groups[k]["ms"])
-        g = groups[dom]
-        achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
-        conv_ms = sum(v["ms"] for v in groups.values()) / traced_steps
-        conv_bytes = sum(v["bytes"] for v in groups.values()) / traced_steps
-        traffic, traffic_note = pmc_traffic(dom)
-
-        def binding(kernel, avg_us):
-            """What actually binds a variant-6 kernel: the L2 -> LDS DMA stream.  Every 48 MFMAs (one sub-stage of a
-            64 x 64 tile) move 16 KiB (8 KiB of gathered rows + 8 KiB of weights); MFMA count and matrix-pipe busy from the
-            committed counter table."""
-            pc = pmc_counters(kernel)
-            if not pc:
-                return {}
-            busy, mfma, src = pc
-            l2_bytes = mfma / 48.0 * 16384.0
-            return {"mfma_busy": round(busy / 100.0, 4), "mfma_per_launch": int(mfma),
-                    "l2_lds_bytes_per_launch": int(l2_bytes),
-                    "l2_lds_frac": round(l2_bytes / (avg_us * 1e-6) / 1e9 / L2_PEAK_GBS, 4), "counters": "profiles/" + src}
-
-        def per_kernel_entry(v):
-            avg_us = v["ms"] * 1e3 / v["n"]
-            frac = v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            e = {"launches_per_step": v["n"] // traced_steps, "avg_launch_us": round(avg_us, 2), "frac": round(frac, 4)}
-            if frac > 1.0:
-                e["note"] = "served from cache: the gathers' algorithmic bytes come from L2 / LDS reuse, not HBM"
-            return e
-
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_note": traffic_note,
-                    "launches_per_step": g["n"] // traced_steps,
-                    "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),
-                    "algorithmic_bytes_per_launch": g["bytes"] // g["n"],
-                    "achieved_tflops_useful": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2),
-                    "all_sparse_conv_ms_per_step": round(conv_ms, 3),
-                    "step_frac": round(conv_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                    "step_frac_note": "sum of the convolutions' algorithmic bytes per step / ms_per_step / 8 TB/s (the whole "
-                                      "step against the contract's roofline: geometry, image branch and fusion count as time only)",
-                    "per_kernel": {k: {**per_kernel_entry(v), **binding(k, v["ms"] * 1e3 / v["n"])}
-                                   for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
-                    "timing": "HIP events around each launch on its launch stream, in situ (other streams' kernels of the same "
-                              "step overlap), %d steps after the timed regions" % traced_steps}
-        roofline.update({"binding_resource": binding(dom, g["ms"] * 1e3 / g["n"]),
-                         "binding_note": "bound: hbm is the contract's notional roofline; every variant-6 kernel is bound by its "
-                                         "L2 -> LDS DMA stream (l2_lds_frac of 34.5 TB/s) at the matrix-pipe occupancy mfma_busy"})
-        rp = rocprof_avg_us(dom)
-        if rp:
-            roofline["rocprof_avg_launch_us"] = round(rp[1], 2)
-            roofline["rocprof_frac"] = round(roofline["algorithmic_bytes_per_launch"] / (rp[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-            roofline["rocprof_note"] = ("%d launches of the family in profiles/%s (rocprofv3 --kernel-trace --stats of "
-                                        "this command; kernel tracing serialises the streams and carries no event records)" % (rp[0], rp[2]))
-        extras = {}
+        groups = group_trace(trace)
+        extras, arithmetics = {}, None
         with torch.no_grad():
+            iso_groups = None
             if dyn and world == 1:
                 # the same launches with nothing else on the GPU: every stream collapsed onto one (serialised)
                 iso = []
@@ -727,12 +837,11 @@ def main():
                     finally:
                         wl.bucket.io.serialize = 0
                     sync()
-                gi = group(iso).get(dom)
-                if gi:
-                    roofline["isolated_avg_launch_us"] = round(gi["ms"] * 1e3 / gi["n"], 2)
-                    roofline["isolated_frac"] = round(gi["bytes"] / (gi["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                iso_groups = group_trace(iso)
+            roofline = build_roofline(groups, args.arith, traced_steps, elapsed / args.steps * 1e3, iso_groups)
             if world == 1 and not args.no_extras:
                 extras = extra_legs(model, dev, args, sync)
+                arithmetics = other_arithmetics(dev, args, sync, F_ref)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(xyz1, img1, voxel, sd)
@@ -755,7 +864,7 @@ def main():
                        "settle_steps": settle_steps, "settle_ms": args.settle_ms,
                        "traced_steps_in_timed_region": 0},
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (3xf16-split operands, 22-bit; fp32 accumulate)" if ops.CONV_VARIANT == 6 else "f32",
+            "dtype": ARITH[args.arith]["dtype"],
             "data": ("synthetic (reference fixture fragment%s scaled x%.2f, seeded random weights)"
                      % (" PAIR cloud_bin_0 + cloud_bin_1" + (" x%d" % (args.batch // 2) if args.batch > 2 else "")
                         if args.batch >= 2 else " cloud_bin_0", args.scale)),
@@ -779,13 +888,12 @@ def main():
                                      "exact": "exact mode: row-count readback + native executor (imf_resunet_forward)"}[run_mode],
                        "capacity_mode": graph_info,
                        "image_branch": model.image_branch_mode if not dyn else wl.runner.image_branch_mode,
-                       "conv_arithmetic": ("fp32 operands split into f16 hi+lo (weights pre-scaled by a power of two), "
-                                           "3x v_mfma_f32_16x16x32_f16 with fp32 accumulation (fp32-class: max |dF| 3e-7 vs "
-                                           "an fp64-accumulated network); activations outside the f16 range raise a flag and the "
-                                           "fragment is redone on fp32 MFMA (strict_fp32 below)" if ops.CONV_VARIANT == 6 else "fp32 MFMA"),
+                       "arithmetic": args.arith, "conv_arithmetic": ARITH[args.arith]["arithmetic"],
                        "sharded_pipeline": sharded,
                        **extras},
             "roofline": roofline, "cpu_baseline": cpu,
+            # the same pair step on the other two arithmetics, each timed and rooflined like the headline (N = 1)
+            "arithmetics": arithmetics,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -798,7 +906,7 @@ def extra_legs(model, dev, args, sync):
       batch_4 / batch_8      the pair twice / four times in ONE forward (IMF_MAX_BATCH = 8): the coarse levels fill the chip
       e2e_extract_features   SURVEY 8(d)'s span, one synchronous call at a time
       host_span_f32_valued   the stream leg on float32-valued points (what a PLY holds): uploaded as float32
-      strict_fp32            the same pair with true-fp32 matrix instructions (v_mfma_f32_16x16x4_f32) everywhere"""
+    (the other arithmetics -- f16x2 fast mode, strict fp32 -- are `arithmetics` of the line: other_arithmetics below)"""
     from imfnet_amd.extract import extract_features
     xyz1, img1, voxel = load_workload(args.scale, args.voxel)
     out = {}
@@ -886,29 +994,53 @@ def extra_legs(model, dev, args, sync):
     r.use_graph = prev
     del wl2
 
-    m0, _ = build_model(dev, variant=0)
-    wl0 = Workload(m0, dev, pts2, imgs2, voxel)
-    for _ in range(3):
-        F0 = wl0.exact_step()
-    dt_exact = timed(wl0.exact_step, 10, sync)
-    F0 = F0.clone()
-    wl0.prepare_graph()
-    assert wl0.runner.variant == 0
-    wl0.runner.use_graph = False
-    for _ in range(3):
-        r0 = wl0.graph_step()
-    sync()
-    assert r0.flags == 0 and torch.equal(r0.F, F0), "strict-fp32 capacity mode differs from its exact mode"
-    dt = timed(wl0.graph_step, 10, sync)
-    out["strict_fp32"] = {"descriptors_per_s": round(F0.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 4),
-                          "exact_mode_ms_per_step": round(dt_exact * 1e3, 4), "equals_exact_mode_bitwise": True,
-                          "dtype": "f32 (v_mfma_f32_16x16x4_f32, fp32 operands and accumulation)",
-                          "note": "the pair in capacity mode (imf_fragment_forward, no readback), every convolution, the image trunk "
-                                  "and the fusion feed-forward on true-fp32 matrix instructions (variant 0; conv1 is exact fp32 in "
-                                  "every mode): the arithmetic of the reference's fp32 path, and what a fragment flagged "
-                                  "IMF_FLAG_RANGE is redone with"}
-    del m0, wl0
     return out
+
+
+def other_arithmetics(dev, args, sync, F_headline):
+    """The same pair step on the arithmetics the headline does NOT run, each measured like the headline: capacity mode
+    (imf_fragment_forward, no readback), exactly --steps steps between synchronize per repeat, median of 5 repeats after a
+    settle, input replicas beyond the Infinity Cache; then three traced steps -> its own `roofline` (dominant kernel, useful
+    TFLOP/s against the arithmetic's matrix peak, notional HBM fraction, counters / rocprofv3 averages from
+    profiles/r05_*_<arith>.*).  Capacity mode is asserted bit-identical to the arithmetic's own exact mode."""
+    from imfnet_amd import ops
+    pts2, imgs2 = load_pair(args.scale)
+    res = {}
+    prev = ops.CONV_VARIANT
+    for name, A in ARITH.items():
+        if name == args.arith:
+            continue
+        ops.CONV_VARIANT = A["variant"]
+        try:
+            m, _ = build_model(dev, variant=A["variant"])
+            wl = Workload(m, dev, pts2 * (args.batch // 2) if args.batch >= 2 else pts2[:1],
+                          np.concatenate([imgs2] * (args.batch // 2), 0) if args.batch >= 2 else imgs2[:1], args.voxel)
+            F_exact = wl.prepare_graph(replicate=True).clone()
+            assert wl.runner.variant == A["variant"]
+            wl.runner.use_graph = False
+            t_s = time.perf_counter()
+            while (time.perf_counter() - t_s) * 1e3 < min(args.settle_ms, 300.0):
+                for _ in range(10):
+                    r = wl.graph_step()
+                sync()
+            assert r.flags == 0 and torch.equal(r.F, F_exact), "%s: capacity mode differs from its exact mode" % name
+            rep = sorted(timed(wl.graph_step, args.steps, sync) for _ in range(5))
+            dt = rep[len(rep) // 2]
+            M = wl.last_res.counts[0]
+            tr = []
+            for _ in range(3):
+                wl.graph_step(tr)
+            sync()
+            res[name] = {"value": round(M / dt, 1), "unit": "descriptors/s", "ms_per_step": round(dt * 1e3, 4),
+                         "ms_per_step_all": [round(v * 1e3, 4) for v in rep], "steps": args.steps,
+                         "dtype": A["dtype"], "conv_arithmetic": A["arithmetic"],
+                         "equals_exact_mode_bitwise": True,
+                         "max_abs_diff_vs_headline_descriptors": float((r.F - F_headline).abs().max()),
+                         "roofline": build_roofline(group_trace(tr), name, 3, dt * 1e3)}
+            del m, wl
+        finally:
+            ops.CONV_VARIANT = prev
+    return res
 
 
 if __name__ == "__main__":

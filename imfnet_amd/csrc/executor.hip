@@ -162,7 +162,11 @@ using namespace imf;
 extern "C" {
 
 int imf_resunet_conv_kernel_tag(int level, int kvol, int cout, int variant) {
-  if ((variant != 6 && variant != 0 && variant != 3) || kvol <= 1 || cout % 64 != 0 || level <= 0) return 0;   // (variant 0: the same kernels, AR = kArF32)
+  if ((variant != 6 && variant != 0 && variant != 3) || kvol <= 1 || cout % 64 != 0) return 0;   // (variants 0 / 3: the same kernels, other AR)
+  // (bf16x3 at stride 1: the wave-split kernel reads the 12 KiB of B fragments once per 96 MFMAs where k_spconv_g reads them
+  // once per 24, and measured 150 -> 140 us for the 64 -> 64 layers in isolation (tools/conv_iso.py, VARIANT=3) -- but in situ
+  // the pair step went 1.27 -> 1.33 ms: its 73 KiB workgroups leave no room for the side streams' kernels.  Not used.)
+  if (level <= 0) return 0;
   // measured on the S50k pair / single fragment (profiles/r03_conv_isolated.txt): level 1 (438 / 219 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
   return level == 1 ? 8 : 4;

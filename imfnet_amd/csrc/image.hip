@@ -323,8 +323,8 @@ int imf_image_branch(const imf_image_desc *net, const float *image, int B, int H
     // cuts the sub-stage ranges, csrc/spconv_w.hip), so it is a static choice per layer -- never a function of the batch or
     // image size, or an image's features would differ in the last bits between batch sizes.
     const int waves = c.kvol == 9 && (c.variant == 6 || c.variant == 0 || c.variant == 3) && c.cout % 64 == 0 ? 8 : 0;
-    if (waves == 8) a.kernel_tag = 4;
-    else if (waves == 4) a.kernel_tag = 8;
+    if (waves == 8) a.kernel_tag = 4 | 1;
+    else if (waves == 4) a.kernel_tag = 8 | 1;
     if (waves) a.split_k = 1;
     a.workspace = p.splitk; a.workspace_bytes = p.splitk_bytes;
     return imf_spconv_fwd(&a, st);

@@ -105,7 +105,7 @@ __device__ __forceinline__ f16x8 lds_read_f16x8(const float4 *__restrict__ src) 
 // image's) and fp32 rows through the same DMA pieces and LDS images, 8 x v_mfma_f32_16x16x4_f32 per 32 channels and
 // column block, no conversion: variant 0, the reference's arithmetic, on this kernel's skeleton.
 template <int CO_BLK, int USE, bool CAT, int NB, int RB, int AR = kArF16x2>
-__global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? 4 : 2)
+__global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? (AR == kArBf16x3 && CO_BLK == 4 ? 3 : 4) : 2)
 k_spconv_g(const ConvParams p) {
   constexpr bool PRE = AR == kArF16x2Pre;
   constexpr int ROWS = IMF_TILE_ROWS * RB;           // output rows per workgroup
@@ -469,6 +469,11 @@ k_spconv_g(const ConvParams p) {
 }
 
 void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use) {
+  // use bit 1: two 64-row tiles per workgroup (RB 2; the caller halved grid.x): every wavefront takes two row blocks against
+  // one read of the B fragments.  Measured slower on split-f16 (above); instantiated for bf16x3, whose 12 KiB of B fragments
+  // per sub-stage make the LDS fragment reads (14 KiB per wavefront and sub-stage) a co-bound of the 24 MFMAs
+  const bool rb2 = (use & 2) != 0;
+  use &= 1;
   // deep ring (NB 4, two workgroups per CU) when the whole launch is resident at once that way (<= 512 workgroups);
   // measured (tools/layer_times.py): 438 unsplit workgroups of a pair's stride-2 level 43 -> 33 us, but 544 workgroups
   // 28 -> 33 us (a second round of 32), and every launch that fills the chip is faster with four workgroups per CU
@@ -494,8 +499,9 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
       if (deep) k_spconv_g<CB, 0, CAT, 4, 1, kArF32><<<grid, 256, 0, st>>>(p);             \
       else      k_spconv_g<CB, 0, CAT, 2, 1, kArF32><<<grid, 256, 0, st>>>(p);             \
     } else if (p.arith == kArBf16x3) {   /* variant 3: 12 / 6 KiB of weights per sub-stage -- ring of 3 where the f16 kernels take 4 */ \
-      if (deep) k_spconv_g<CB, 0, CAT, 3, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);          \
-      else      k_spconv_g<CB, 0, CAT, 2, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);          \
+      if (rb2)       k_spconv_g<CB, 0, CAT, 2, 2, kArBf16x3><<<grid, 256, 0, st>>>(p);     \
+      else if (deep) k_spconv_g<CB, 0, CAT, 3, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);     \
+      else           k_spconv_g<CB, 0, CAT, 2, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);     \
     } else if (p.a_split) {   /* operand images: the ResUNet's own layers (label 0) */     \
       if (deep) k_spconv_g<CB, 0, CAT, 4, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);        \
       else      k_spconv_g<CB, 0, CAT, IMF_G_NB_WIDE, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);   \

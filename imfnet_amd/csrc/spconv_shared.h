@@ -377,7 +377,7 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
 
 // spconv_w.hip: variant 6 for the coarse levels -- one workgroup per (tile, 64-column slab), the tile's sub-stages split
 // over its `waves` (8 or 4) wavefronts, partial tiles combined through LDS, epilogue in the same launch
-void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t st);
+void launch_spconv_w(const ConvParams &p, unsigned tiles, int waves, hipStream_t st, int use = 0);
 
 // spconv.hip: imf_conv_first_bitgrid_dyn on a grid the caller already zeroed and filled (geometry.hip: k_emit_unique)
 // the fusion block with its output optionally written as a split-f16 operand image (fusion.hip; for imf_resunet_forward)

@@ -79,7 +79,9 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 //                 6 x v_mfma_f32_16x16x32_bf16 per 32 channels (variant 3).  The wavefront's weight region stays 8 KiB: a
 //                 sub-stage's weights arrive in two halves of 6 KiB (column blocks 0-1, then 2-3), each landing under the
 //                 48 MFMAs of the other; the rows of sub-stage t + 1 are requested as soon as those of t sit in registers.
-template <bool CAT, int W, int AR = kArF16x2>
+// USE: profiling label only (the identical kernel under a second symbol; 1 = the image trunk's dense 3 x 3 convolutions, so that
+// per-kernel statistics keep them apart from the ResUNet's launches -- imf_conv_args.kernel_tag bit 0, as k_spconv_g's USE).
+template <bool CAT, int W, int AR = kArF16x2, int USE = 0>
 __global__ void __launch_bounds__(64 * W, 2)
 k_spconv_w(const ConvParams p) {
   constexpr bool PRE = AR == kArF16x2Pre;
@@ -458,7 +460,7 @@ k_spconv_w(const ConvParams p) {
 }
 
 // grid = (tiles, cout / 64); `waves` = 8 (512 threads, one workgroup per CU) or 4 (256 threads, two per CU)
-void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st) {
+void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st, int use) {
   // w_xcd 1 = slab by XCD, tiles interleaved (pair step 1.092 -> 1.074 ms, round 3); 2 = slab by XCD AND one range of
   // consecutive tiles per XCD (0.953 -> 0.940 ms on top: the XCD's L2 serves a fraction of the input rows)
   const int xcd_env = 2;
@@ -472,7 +474,9 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
   const int ar = (p.arith == kArF32 || p.arith == kArBf16x3) ? p.arith : (p.a_split ? kArF16x2Pre : kArF16x2);
 #define IMF_W_LAUNCH(AR)                                                    \
   do {                                                                      \
-    if (waves == 8) {                                                       \
+    if (use == 1 && waves == 8 && !cat) {                                   \
+      k_spconv_w<false, 8, AR, 1><<<grid, 512, 0, st>>>(p);                 \
+    } else if (waves == 8) {                                                \
       if (cat) k_spconv_w<true, 8, AR><<<grid, 512, 0, st>>>(p);            \
       else     k_spconv_w<false, 8, AR><<<grid, 512, 0, st>>>(p);           \
     } else {                                                                \

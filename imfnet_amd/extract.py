@@ -177,7 +177,8 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image):
 POINT_BUDGET = 1_100_000          # batch="auto": points per forward (four S50k fragments)
 
 
-def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, copy=True, batch=2, point_budget=None):
+def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, copy=True, batch=2, point_budget=None,
+                            device_sink=None):
     """`extract_features` over a STREAM of host fragments (SURVEY 8d's span -- host arrays in, descriptors back on the
     host -- pipelined): yields (xyz_down float64 [M,3], F float32 [M,32] numpy) per fragment, in order.  `fragments`:
     iterable of (xyz [N,3] host array, image [1,3,H,W] host array).  Every forward is a job of the library's pipeline
@@ -192,7 +193,12 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
     fragments, fewer for large ones; a fragment's results then wait for its whole group (latency for throughput).
     copy=True: the arrays of a yield are fresh host copies; copy=False: views of the pinned slot, valid until the NEXT
     item is requested (a 6.5 MB copy into newly faulted pages costs ~0.3 ms per fragment).  Fragments the capacity mode
-    cannot take (no capacities yet, a flag) go through `extract_features`, in order."""
+    cannot take (no capacities yet, a flag) go through `extract_features`, in order.
+    device_sink: optional callable(F_dev) called once per fragment, in order, BEFORE its yield, with the fragment's
+    descriptors as a DEVICE tensor [M, 32] (a view of the capacity bucket's output block, or the exact path's tensor) while
+    the runner's main stream is torch's current stream: a copy the sink enqueues there (e.g. into a per-rank send buffer for
+    the RCCL gather, dist.gather_fragment_descriptors(packed=...)) is ordered before any later forward that reuses the
+    bucket -- the descriptors go from the bucket to the collective without a host round trip."""
     from collections import deque
     device = _cuda_device(device or 'cuda:0')
     if model.training:
@@ -226,6 +232,8 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
         for xyz, image in items:
             with torch.no_grad():
                 xd, F = extract_features(model, xyz, voxel_size=voxel_size, device=device, skip_check=True, image=image)
+            if device_sink is not None:
+                device_sink(F)
             Fh = getattr(F, "host", None)
             yield xd, (Fh.copy() if Fh is not None else F.cpu().numpy())
 
@@ -246,6 +254,10 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
                 st["stream_" + k] = st.get("stream_" + k, 0.0) + job.host_ms[i]
             v = job.views
             spans = res.items() if len(items) > 1 else [(0, res.counts[0])]
+            if device_sink is not None:               # the bucket's device rows, on the stream its forwards run on
+                with torch.cuda.stream(runner.main_stream(device)):
+                    for r0, m in spans:
+                        device_sink(job.bucket.out[r0:r0 + m])
             if copy:
                 outs = [(v["sel"][r0:r0 + m].copy(), v["F"][r0:r0 + m].copy()) for r0, m in spans]
                 free.append(job.slot)

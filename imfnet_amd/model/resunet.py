@@ -120,10 +120,12 @@ class ResUNet2(ME.MinkowskiNetwork):
         self._invalidate()
 
     def _refresh(self):
-        if self._stale():
+        # (packed weights, plans and runners are built for ONE arithmetic: a changed ops.CONV_VARIANT rebuilds them too)
+        if self._stale() or getattr(self, "_built_variant", ops.CONV_VARIANT) != ops.CONV_VARIANT:
             self._invalidate()
 
     def _invalidate(self):
+        self._built_variant = ops.CONV_VARIANT
         self._plan = None
         self._native_plan = None
         self._folded = None
@@ -422,6 +424,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         return out
 
     def _fusion_weights(self):
+        self._refresh()
         if self._fw is None:
             self._fw = ops.FusionKernelWeights(self.attention_fusion)
         return self._fw

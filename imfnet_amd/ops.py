@@ -367,9 +367,13 @@ def rulebook_identity(n_out, device):
     return Rulebook(None, None, None, _lib.lib().imf_rulebook_slots(n_out), n_out, 1)
 
 
-# Sparse-conv kernel variant used by the model layers (include/imfnet_hip.h, imf_conv_args.variant):
-# 6 = split-f16 MFMA (fp32-class accuracy, ~5x fewer matrix-pipe cycles), 0 = fp32 MFMA.
-CONV_VARIANT = int(os.environ.get("IMF_CONV_VARIANT", "6"))
+# Sparse-conv arithmetic used by the model layers (include/imfnet_hip.h, imf_conv_args.variant; env IMF_CONV_VARIANT):
+#   3 (default since round 5) = "bf16x3": every fp32 operand as three bf16 parts (exact), six bf16 MFMAs per 32 channels,
+#       fp32 accumulation -- fp32 operand precision and range on the 16-bit matrix pipe, fp32 buffers, no range guard;
+#   6 = split-f16 MFMA: two f16 parts per operand (22 bits), three MFMAs, operand images between layers, ~27 % faster,
+#       activations must stay below 65504 (IMF_FLAG_RANGE -> the fragment is redone on variant 0): the FAST mode;
+#   0 = fp32 MFMA (v_mfma_f32_16x16x4_f32): the reference's own arithmetic, ~1.6x slower than 3.
+CONV_VARIANT = int(os.environ.get("IMF_CONV_VARIANT", "3"))
 MAX_PIPELINED_KVOL = 27
 
 
@@ -479,9 +483,9 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     a.split_k, a.variant = split, int(variant)
     a.operand_format = int(operand_format)
     a.dyn_err = None if flags is None else flags.data_ptr()
-    if staging not in (None, "dma", "regs", "wave8", "wave4"):
+    if staging not in (None, "dma", "dma2", "regs", "wave8", "wave4"):
         raise ImfError(f"spconv: staging={staging!r}")
-    a.kernel_tag = {"regs": 2, "wave8": 4, "wave4": 8}.get(staging, 0)
+    a.kernel_tag = {"regs": 2, "wave8": 4, "wave4": 8, "dma2": 32}.get(staging, 0)
     ws = None
     nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)   # split-K partials / balanced-tail partials
     if nbytes:

@@ -43,3 +43,15 @@ def head_map():
 def seeded_sd():
     import imf_oracle as O
     return O.seeded_state_dict(seed=0, with_unused_image_layers=True)
+
+
+@pytest.fixture
+def fast_mode():
+    """The split-f16 FAST mode (imf_conv_args.variant 6: two f16 parts per operand, operand images between layers, the fused
+    head, IMF_FLAG_RANGE + fp32 recompute) for the duration of one test.  The process default since round 5 is variant 3
+    (bf16x3: exact fp32 operands, fp32 buffers, no range guard); the tests of variant 6's own machinery pin it with this."""
+    from imfnet_amd import ops
+    prev = ops.CONV_VARIANT
+    ops.CONV_VARIANT = 6
+    yield
+    ops.CONV_VARIANT = prev

@@ -51,16 +51,22 @@ def _worker(rank, world, port, out_dir):
 
     mine = {i: desc(i) for i in shards[rank]}
     got = idist.gather_fragment_descriptors(mine, n_frag, shards, dst=0)
+    # the shard's blocks already packed in one buffer (what the sharded bench leg sends: filled from the capacity buckets
+    # as the fragments complete) -- same result, nothing concatenated inside
+    rows = [sizes[i] for i in shards[rank]]
+    buf = torch.cat([mine[i] for i in shards[rank]], 0) if rows else torch.empty((0, 32))
+    got_packed = idist.gather_fragment_descriptors(None, n_frag, shards, dst=0, packed=(rows, buf))
     blocks = idist.gather_blocks(torch.full((rank + 2, 3), float(rank)), dst=0)
     if rank == 0:
-        assert sorted(got) == list(range(n_frag))
+        assert sorted(got) == list(range(n_frag)) == sorted(got_packed)
         for i in range(n_frag):
             assert torch.equal(got[i], desc(i)), i                 # bit-exact, right order, right counts
+            assert torch.equal(got_packed[i], desc(i)), i
         assert [b.shape[0] for b in blocks] == [r + 2 for r in range(world)]
         assert all(float(b.mean()) == r for r, b in enumerate(blocks))
         np.save(os.path.join(out_dir, "ok.npy"), np.array([1]))
     else:
-        assert got is None and blocks is None
+        assert got is None and blocks is None and got_packed is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,8 +82,12 @@ def _worker_more_ranks(rank, world, port, out_dir):
     assert sum(1 for s in shards if not s) == world - 2
     mine = {i: torch.full((i + 3, 32), float(i)) for i in shards[rank]}
     got = idist.gather_fragment_descriptors(mine, 2, shards, dst=0)
+    rows = [i + 3 for i in shards[rank]]
+    buf = torch.cat([mine[i] for i in shards[rank]], 0) if rows else torch.empty((0, 32))
+    got_packed = idist.gather_fragment_descriptors(None, 2, shards, dst=0, packed=(rows, buf), device=torch.device("cpu"))
     if rank == 0:
         assert sorted(got) == [0, 1] and got[0].shape == (3, 32) and float(got[1].mean()) == 1.0
+        assert all(torch.equal(got[i], got_packed[i]) for i in (0, 1))
         np.save(os.path.join(out_dir, "ok2.npy"), np.array([1]))
     dist.barrier()
     dist.destroy_process_group()

@@ -19,7 +19,8 @@ def test_bench_two_ranks_share_one_gpu_under_gloo():
     env = dict(os.environ, IMF_DIST_BACKEND="gloo", IMF_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--repeats", "2", "--settle-ms", "50", "--mode", "capacity", "--no-cpu-baseline", "--no-extras"]
+           "--repeats", "2", "--settle-ms", "50", "--mode", "capacity", "--no-cpu-baseline", "--no-extras",
+           "--sharded-per-rank", "12", "--sharded-region-s", "0.05"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -30,3 +31,4 @@ def test_bench_two_ranks_share_one_gpu_under_gloo():
     sp = d["config"]["sharded_pipeline"]
     assert sp["ranks"] == 2 and sp["backend"] == "gloo" and sp["fragments"] == 24
     assert sp["verified"].startswith("every block") and sp["descriptors"] > 0 and sp["gather_ms"] > 0
+    assert sp["gather"].startswith("device-resident") and len(sp["stream_s_all_passes"]) == 3

@@ -633,10 +633,10 @@ def test_fused_fusion_kernel_matches_reference_module(ops, model, golden):
     assert (out0 - out).abs().max() < 5e-6
 
 
-def test_fusion_range_flag_in_both_variants(ops, model, golden):
-    """the feed-forward's f16 range guard is armed whatever the plan's variant.  Rows scaled until the GEGLU
-    hidden passes 65504: variant 6 must raise IMF_FLAG_RANGE (its operands would be inf); variant 0 raises it too (its
-    output would feed conv4_tr's f16 operands) but computes finite fp32 values."""
+def test_fusion_range_flag_in_both_variants(ops, model, golden, fast_mode):
+    """The feed-forward's f16 range guard.  Rows scaled until the GEGLU hidden passes 65504: variant 6 must raise
+    IMF_FLAG_RANGE (its operands would be inf); variant 0 -- what the flagged fragment is redone with, fp32 throughout -- computes
+    finite fp32 values (round 5: its convolution launches no longer raise the bit, a large value is a value in fp32)."""
     fw = model._fusion_weights()
     x = torch.as_tensor(golden["af_in"]).to(DEV)
     ctx = torch.as_tensor(golden["af_ctx"]).to(DEV)
@@ -655,9 +655,18 @@ def test_fusion_range_flag_in_both_variants(ops, model, golden):
                 flags = torch.zeros(1, dtype=torch.int32, device=DEV)
                 out = ops.fusion_attention(x, ops.pack_weights(kt), ops.pack_weights(vp), 300, 320, big, flags=flags,
                                            variant=variant)
-                assert int(flags.item()) & 32, f"variant {variant}: no range flag"
-                if variant == 0:
+                if variant == 6:
+                    assert int(flags.item()) & 32, "variant 6: no range flag"
+                else:
                     assert torch.isfinite(out).all()
+                    out_f32 = out
+            # the default arithmetic (bf16x3) on the same rows: finite, no flag from its convolution launches, = fp32 to roundoff
+            O_ = ops
+            O_.CONV_VARIANT = 3
+            big3 = FusionKernelWeights(model.attention_fusion)
+            out3 = ops.fusion_attention(x, ops.pack_weights(kt), ops.pack_weights(vp), 300, 320, big3, variant=3)
+            O_.CONV_VARIANT = 6
+            assert torch.isfinite(out3).all() and ((out3 - out_f32).abs() <= 1e-5 * out_f32.abs().max()).all()
         finally:
             ff[0].weight.copy_(w0); ff[0].bias.copy_(b0)
 
@@ -710,11 +719,44 @@ def test_fused_equals_layerwise(model, clouds, images):
     assert (a - b).abs().max() < 2e-5
 
 
-def test_native_executor_equals_python_plan(model, clouds, images, monkeypatch):
-    """imf_resunet_forward (one C call per fragment) issues the launches of the Python arena executor:
+@pytest.fixture
+def model6(model, fast_mode):
+    """The module's model with its plans rebuilt for the split-f16 fast mode (variant 6), back on the default afterwards."""
+    model._invalidate()
+    yield model
+    model._invalidate()
+
+
+def test_native_executor_equals_python_plan_bf16x3(model, clouds, images, monkeypatch):
+    """The default arithmetic (variant 3): imf_resunet_forward issues exactly the launches of the op-by-op Python executor on
+    fp32 buffers -- bit-identical descriptors; 23 convolution launches traced (no fused head in this arithmetic)."""
+    from imfnet_amd import ops as O_
+    from imfnet_amd.extract import sparse_tensor_from_points
+    assert O_.CONV_VARIANT == 3
+    for k, voxel in ((0, 0.05), (1, 0.025)):
+        xyz = clouds[k].astype(np.float64)
+        img = torch.as_tensor(images[k]).to(DEV)
+        with torch.no_grad():
+            monkeypatch.setenv("IMFNET_PYTHON_EXECUTOR", "1")
+            st, _ = sparse_tensor_from_points(xyz, voxel, torch.device(DEV))
+            a = model(st, img).F.clone()
+            monkeypatch.delenv("IMFNET_PYTHON_EXECUTOR")
+            O_.TRACE = []
+            st2, _ = sparse_tensor_from_points(xyz, voxel, torch.device(DEV))
+            b = model(st2, img).F.clone()
+            torch.cuda.synchronize()
+            trace, O_.TRACE = O_.TRACE, None
+        assert model._native_plan is not None
+        assert torch.equal(a, b)
+        assert len(trace) == 22 and all(r["kernel"].endswith("/b3") for r in trace)
+
+
+def test_native_executor_equals_python_plan(model6, clouds, images, monkeypatch):
+    """Fast mode (variant 6).  imf_resunet_forward (one C call per fragment) issues the launches of the Python arena executor:
     with fp32 feature buffers (what the op-by-op executor has) descriptors must be bit-identical, for both fragments
     and two voxel sizes, also when traced; in its default mode -- layers hand split-f16 operand images on, residual
     reads see 22 of 24 bits -- within 2e-6."""
+    model = model6
     from imfnet_amd import ops as O_
     from imfnet_amd.extract import sparse_tensor_from_points
     for k, voxel in ((0, 0.05), (1, 0.05), (0, 0.025)):

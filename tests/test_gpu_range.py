@@ -59,7 +59,7 @@ def _huge_bottleneck_sd(seeded_sd):
     return sd
 
 
-def test_out_of_range_fragment_is_recomputed_in_fp32(clouds, images, seeded_sd, monkeypatch):
+def test_out_of_range_fragment_is_recomputed_in_fp32(clouds, images, seeded_sd, monkeypatch, fast_mode):
     from imfnet_amd.extract import extract_features
     sd = _huge_bottleneck_sd(seeded_sd)
     xyz = clouds[0][::4].astype(np.float64)
@@ -85,7 +85,7 @@ def test_out_of_range_fragment_is_recomputed_in_fp32(clouds, images, seeded_sd, 
     assert float((F3.cpu() - F_ref).abs().max()) > 1e-3          # 10x the 1e-4 tolerance the guarded path meets
 
 
-def test_capacity_mode_raises_the_range_flag(clouds, images, seeded_sd):
+def test_capacity_mode_raises_the_range_flag(clouds, images, seeded_sd, fast_mode):
     from imfnet_amd.model.graph import FragmentRunner
     m = _model(_huge_bottleneck_sd(seeded_sd))
     r = FragmentRunner(m)
@@ -93,6 +93,32 @@ def test_capacity_mode_raises_the_range_flag(clouds, images, seeded_sd):
     r.ratios, r.grid_words = [0.2, 0.06, 0.02, 0.006], 1 << 16
     res = r.run(xyz, [0], torch.as_tensor(images[0]).to(DEV), 0.05, stream=torch.cuda.Stream())
     assert res.flags & 32
+
+
+def test_bf16x3_needs_no_range_guard(clouds, images, seeded_sd):
+    """The default arithmetic (variant 3, bf16x3) carries every fp32 value: the fragment that sends variant 6 to its fp32
+    recompute (activations ~1e5 in the bottleneck) is simply computed -- no flag, no warning, no second pass -- on the
+    per-layer path, the exact path and in capacity mode, within the same 1e-4 of the oracle."""
+    from imfnet_amd import ops
+    from imfnet_amd.extract import extract_features
+    from imfnet_amd.model.graph import FragmentRunner
+    assert ops.CONV_VARIANT == 3
+    sd = _huge_bottleneck_sd(seeded_sd)
+    xyz = clouds[0][::4].astype(np.float64)
+    xd_ref, F_ref = O.extract_features(sd, xyz, 0.05, images[0])
+    m = _model(sd)
+    for _ in range(2):                                   # first call: exact path (teaches the runner); second: capacity mode
+        with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            xd, F = extract_features(m, xyz, voxel_size=0.05, device=torch.device(DEV), skip_check=True, image=images[0])
+        assert not any("f16 range" in str(w.message) for w in rec)
+        assert (xd == xd_ref).all() and float((F.cpu() - F_ref).abs().max()) < 1e-4
+    st = m.fragment_runner().stats
+    assert st.get("redone", 0) == 0 and st["eager"] >= 1
+    r = FragmentRunner(m)
+    r.ratios, r.grid_words = [0.2, 0.06, 0.02, 0.006], 1 << 16
+    res = r.run(torch.as_tensor(xyz).to(DEV), [0], torch.as_tensor(images[0]).to(DEV), 0.05, stream=torch.cuda.Stream())
+    assert res.flags == 0 and float((res.F.cpu() - F_ref).abs().max()) < 1e-4
 
 
 def _checkpoint_like(seeded_sd):

@@ -1,6 +1,6 @@
 """Isolated timing of the network's sparse-convolution shapes (nothing else on the GPU): each shape is launched
 REPS times back to back on one stream and timed with one event pair (main kernel + split-K reduce).
-usage: [BATCH=2] [IMF_LIB=...] conv_iso.py [staging ...]      staging: dma (default) | regs | wave8 | wave4
+usage: [BATCH=2] [VARIANT=6|3|0] [IMF_LIB=...] conv_iso.py [staging ...]      staging: dma (default) | dma2 | regs | wave8 | wave4
 Several stagings print one column each (a shape a staging does not serve prints "-")."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +10,7 @@ from imfnet_amd import ops
 from imfnet_amd import sparse as ME
 from bench import load_workload, load_pair
 stagings = sys.argv[1:] or [None]
+VARIANT = int(os.environ.get("VARIANT", "6"))
 REPS = 20
 dev = torch.device("cuda:0")
 xyz, img, voxel = load_workload(1.7, 0.025)
@@ -37,7 +38,7 @@ for name, ca, cb, cout, kind, i in SHAPES:
         rb, n_in = cm.conv_rulebook(1, 1, 1), levels[0].n
     fa = torch.randn(n_in, ca, generator=g).to(dev)
     fb = torch.randn(n_in, cb, generator=g).to(dev) if cb else None
-    w = ops.pack_weights((torch.randn(rb.kvol, ca + cb, cout, generator=g) * 0.05).to(dev), split16=True)
+    w = ops.pack_weights((torch.randn(rb.kvol, ca + cb, cout, generator=g) * 0.05).to(dev), variant=VARIANT)
     sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
     out = torch.empty(rb.n_out, cout, device=dev)
     cols = []
@@ -45,7 +46,7 @@ for name, ca, cb, cout, kind, i in SHAPES:
         if staging in ("wave8", "wave4") and (rb.kvol == 1 or cout % 64):
             cols.append(None)
             continue
-        kw = dict(in_b=fb, scale=sc, shift=sh, relu=True, variant=6, out=out, staging=staging)
+        kw = dict(in_b=fb, scale=sc, shift=sh, relu=True, variant=VARIANT, out=out, staging=staging)
         for _ in range(3):
             ops.spconv(fa, w, cout, rb, **kw)
         torch.cuda.synchronize()
