@@ -368,6 +368,7 @@ def build_model(dev, variant=None):
         model.load_state_dict(sd, strict=True)
         model = model.eval().to(dev)
         if variant is not None:                        # plans pack their weights lazily: force it under this variant
+            model.pinned_variant = variant             # (and keep them when the process default is another one)
             from imfnet_amd.model.plan import FusedPlan
             model._plan = FusedPlan(model)
             model._native_image()

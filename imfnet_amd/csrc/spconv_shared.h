@@ -17,6 +17,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // (round-to-nearest-even; the residuals are exact fp32 differences of <= 16 and <= 8 significant bits).  hipcc emits
 // v_cvt_pk_bf16_f32 / v_pk_add_f32: ~4.5 VALU instructions per value.
 __device__ __forceinline__ void split_b3(const float4 &x0, const float4 &x1, bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
+#ifdef IMF_B3_NOSPLIT_ABL   // timing experiment only (wrong results): what the in-register split costs
+  p0 = __builtin_bit_cast(bf16x8, x0); p1 = __builtin_bit_cast(bf16x8, x1); p2 = __builtin_bit_cast(bf16x8, x0);
+  return;
+#endif
   const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
   for (int t = 0; t < 8; ++t) {

@@ -14,6 +14,7 @@ on a geometric grid so that fragments of similar size share a bucket).  A fragme
 meta[1]) is redone on the exact path, which also updates the ratios.
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -130,10 +131,13 @@ class HostSlot:
             self._views = {}
             self._np = (self.inbuf.numpy(), self.outbuf.numpy())
         v = self._views.get(id(b))
-        if v is not None and v["bucket"] is b:
+        if v is not None and v["bucket"]() is b:
             return v
+        for k in [k for k, w in self._views.items() if w["bucket"]() is None]:     # views of evicted buckets
+            del self._views[k]
         L, (hi, ho) = b.lay, self._np
-        v = dict(bucket=b, dyn=hi[:4 * DYN_WORDS].view(np.int32),
+        # (a WEAK reference: a slot must not keep an evicted bucket's device blocks alive)
+        v = dict(bucket=weakref.ref(b), dyn=hi[:4 * DYN_WORDS].view(np.int32),
                  image=hi[L["img"]:L["img"] + b.image.numel() * 4].view(np.float32).reshape(tuple(b.image.shape)),
                  xyz=hi[L["xyz"]:L["xyz"] + b.xyz.numel() * b.xyz.element_size()]
                      .view(np.float64 if b.xyz.dtype == torch.float64 else np.float32).reshape(-1, 3),
@@ -197,6 +201,8 @@ class _Bucket:
         self.graph = C.c_void_p()
         self.n_nodes = 0
         self.launches = 0
+        self.last_use = 0            # FragmentRunner's use counter at the last bucket() / acquire: eviction is LRU
+        self.in_flight = False       # owned by a streaming job right now (FragmentStreamer): never evicted
         self._first_view = None
 
     def first_idx_view(self):
@@ -357,19 +363,31 @@ class FragmentRunner:
         """The capacity bucket of `key`; lane > 0: further buckets of the same capacities (forwards in flight side by side
         in the streaming pipeline need their own buffers)."""
         bk = key if lane == 0 else (key, lane)
+        self._use_tick = getattr(self, "_use_tick", 0) + 1
         b = self.buckets.get(bk)
         if b is None:
-            if len(self.buckets) >= self.MAX_BUCKETS:           # drop the least used
-                victim = min(self.buckets, key=lambda k: self.buckets[k].launches)
-                torch.cuda.synchronize(dev)
-                del self.buckets[victim]
+            if len(self.buckets) >= self.MAX_BUCKETS:           # drop the least RECENTLY used bucket no job is using
+                idle = [k for k, v in self.buckets.items() if not v.in_flight]
+                if idle:
+                    victim = min(idle, key=lambda k: self.buckets[k].last_use)
+                    torch.cuda.synchronize(dev)                 # (a direct launch on it may still be running)
+                    self.drop_bucket(victim)
             with torch.cuda.stream(stream or torch.cuda.current_stream(dev)):   # static tables are built on it
                 b = self.buckets[bk] = _Bucket(self, key, dev)
                 # the zero fills of the new blocks are queued on THIS stream, behind whatever forwards are in flight; the
                 # pipeline uploads a job's inputs on the image stream, which does not wait for this one: without the wait
                 # a fill could land on top of the first upload (seen once in ~20 runs as a spurious capacity redo)
                 torch.cuda.current_stream(dev).synchronize()
+        b.last_use = self._use_tick
         return b
+
+    def drop_bucket(self, bk):
+        """Forget bucket `bk` (= key, or (key, lane)): its device blocks are released once the last holder lets go (the
+        streamers drop theirs in `FragmentStreamer._evict`; pinned slots only hold weak references)."""
+        b = self.buckets.pop(bk, None)
+        if b is not None:
+            for st in self._streamers.values():
+                st.forget(b)
 
     def _stream_for(self, dev, stream):
         """(the runner's main stream, the caller's stream or None): work submitted on any other stream is ordered

@@ -121,11 +121,15 @@ class ResUNet2(ME.MinkowskiNetwork):
 
     def _refresh(self):
         # (packed weights, plans and runners are built for ONE arithmetic: a changed ops.CONV_VARIANT rebuilds them too)
-        if self._stale() or getattr(self, "_built_variant", ops.CONV_VARIANT) != ops.CONV_VARIANT:
+        # (`pinned_variant`: a model built for one arithmetic beside the process default -- bench.build_model(variant=...))
+        want = self.pinned_variant if self.pinned_variant is not None else ops.CONV_VARIANT
+        if self._stale() or getattr(self, "_built_variant", want) != want:
             self._invalidate()
 
+    pinned_variant = None
+
     def _invalidate(self):
-        self._built_variant = ops.CONV_VARIANT
+        self._built_variant = self.pinned_variant if self.pinned_variant is not None else ops.CONV_VARIANT
         self._plan = None
         self._native_plan = None
         self._folded = None

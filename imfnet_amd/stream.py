@@ -38,7 +38,16 @@ class StreamJob:
 
 class FragmentStreamer:
     """Capacity buckets (device) + the library pipeline of one FragmentRunner on one device.  `n_buckets` forwards of one
-    capacity key can be in flight (upload of k+1, forward of k, download of k-1); pinned HostSlots belong to the caller."""
+    capacity key can be in flight (upload of k+1, forward of k, download of k-1); pinned HostSlots belong to the caller.
+    The streamer's buckets are its OWN lanes 1 .. n_buckets of a key -- lane 0 is the bucket the direct capacity-mode
+    launches use (FragmentRunner.launch / run), which follows the main stream's order only, whereas a pipeline job's upload
+    and head run on the image / side streams (a shared bucket could be overwritten under an unsynchronised direct
+    forward).  At most MAX_KEYS capacity keys stay resident: beyond that the least recently used key with nothing in flight is
+    dropped -- its lanes leave this streamer, the runner and (weakly referenced) the pinned slots, and the device blocks go
+    back to the allocator (a re-observe after a flagged fragment changes every key and would otherwise strand the old
+    lanes: input block, output block, pyramid, arenas and image buffers per bucket, without bound over a varied data set)."""
+
+    MAX_KEYS = 8
 
     def __init__(self, runner, device, n_buckets=3, sdma_copies=None, copy_blocks=0, head_on_side=True):
         self.runner, self.device, self.n_buckets = runner, device, max(1, int(n_buckets))
@@ -59,6 +68,8 @@ class FragmentStreamer:
         self.main = main
         self._free = {}              # capacity key -> lanes not in flight
         self._made = {}              # capacity key -> lanes created so far
+        self._used = {}              # capacity key -> submit counter at its last use (eviction is LRU over keys)
+        self._tick = 0
         self._inflight = []          # StreamJobs not yet completed, in submit order
         self._lock = threading.RLock()
         self._scratch32 = None
@@ -84,17 +95,56 @@ class FragmentStreamer:
         """A bucket of capacity `key` that no job is using; completes the oldest job of that key when all are busy."""
         while True:
             with self._lock:
+                self._tick += 1
+                self._used[key] = self._tick
                 free = self._free.setdefault(key, [])
                 if free:
-                    return free.pop()
+                    b = free.pop()
+                    b.in_flight = True
+                    return b
                 if self._made.get(key, 0) < self.n_buckets:
-                    lane = self._made.get(key, 0)
-                    self._made[key] = lane + 1
-                    return self.runner.bucket(key, self.device, self.main, lane=lane)
+                    if key not in self._made:
+                        self._evict_lru(keep=key)
+                    lane = self._made.get(key, 0) + 1            # lanes 1 ..: lane 0 belongs to the direct launches
+                    self._made[key] = lane
+                    b = self.runner.bucket(key, self.device, self.main, lane=lane)
+                    b.in_flight = True
+                    return b
                 old = next((j for j in self._inflight if j.bucket.key == key), None)
             if old is None:
                 raise ImfError("streamer: no bucket of this capacity is free and none is in flight")
             self._complete(old)                       # (outside the lock: it blocks on the GPU)
+
+    def _release(self, b):
+        b.in_flight = False
+        lanes = self._free.get(b.key)
+        if lanes is not None:                         # (None: the key was evicted while this lane was out)
+            lanes.append(b)
+
+    def _evict_lru(self, keep=None):
+        """Drop least-recently-used keys with nothing in flight until fewer than MAX_KEYS remain (called under the lock)."""
+        while len(self._made) >= self.MAX_KEYS:
+            idle = [k for k in self._made if k != keep and len(self._free.get(k, ())) == self._made[k]]
+            if not idle:
+                return
+            victim = min(idle, key=lambda k: self._used.get(k, 0))
+            lanes = self._made.pop(victim)
+            self._free.pop(victim, None)
+            self._used.pop(victim, None)
+            for lane in range(1, lanes + 1):           # every job of these lanes has been waited for: nothing is queued on them
+                self.runner.drop_bucket((victim, lane))
+
+    def forget(self, b):
+        """The runner dropped bucket b (FragmentRunner.drop_bucket): it must not be handed out again."""
+        with self._lock:
+            lanes = self._free.get(b.key)
+            if lanes and b in lanes:
+                lanes.remove(b)
+                self._made[b.key] -= 1
+                if self._made[b.key] <= 0 and not any(j.bucket.key == b.key for j in self._inflight):
+                    self._made.pop(b.key, None)
+                    self._free.pop(b.key, None)
+                    self._used.pop(b.key, None)
 
     def fill_lanes(self):
         """Create every lane still missing for the capacity keys seen so far (lanes are otherwise created on demand -- when
@@ -102,8 +152,8 @@ class FragmentStreamer:
         with self._lock:
             for key in list(self._made):
                 while self._made[key] < self.n_buckets:
-                    lane = self._made[key]
-                    self._made[key] = lane + 1
+                    lane = self._made[key] + 1
+                    self._made[key] = lane
                     self._free.setdefault(key, []).append(self.runner.bucket(key, self.device, self.main, lane=lane))
 
     # -- submit / wait ------------------------------------------------------------------------------------------------
@@ -140,7 +190,7 @@ class FragmentStreamer:
                 at += n_each[j]
             if not narrowed:
                 with self._lock:
-                    self._free[key].append(b)
+                    self._release(b)
                 b = None
         if b is None:
             key = runner.caps_for(n, k, H, W, voxel_size, x0.dtype == np.float64)
@@ -173,7 +223,7 @@ class FragmentStreamer:
         ticket = self.L.imf_pipeline_submit(self.handle, C.byref(job))
         if ticket < 0:
             with self._lock:
-                self._free[key].append(b)
+                self._release(b)
             check(ticket, "imf_pipeline_submit")
         b.launches += 1
         runner.stats["eager"] += 1
@@ -190,7 +240,7 @@ class FragmentStreamer:
             rc = self.L.imf_pipeline_wait(self.handle, sj.ticket, ms)
             with self._lock:
                 self._inflight.remove(sj)
-                self._free[sj.bucket.key].append(sj.bucket)
+                self._release(sj.bucket)
             check(rc, "imf_pipeline_wait")
             sj.ms = (float(ms[0]), float(ms[1]), float(ms[2]))
             sj.stamps = tuple(float(ms[i]) for i in range(8, 21))   # device x5, host x3 (ms since the pipeline's creation)

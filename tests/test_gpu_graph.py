@@ -168,7 +168,7 @@ def test_pyramid_dyn_matches_exact_pyramid(clouds):
 def test_strict_fp32_capacity_mode_equals_its_exact_mode(seeded_sd, clouds, images):
     """Variant 0 (v_mfma_f32_16x16x4_f32 in every convolution, the image trunk and the fusion feed-forward) through
     imf_fragment_forward: bit-identical to the variant-0 exact mode, within 1e-4 of the oracle and within 2e-6 of the
-    default split-f16 path; a variant-0 bucket does not report IMF_FLAG_RANGE (nothing there is an f16 operand)."""
+    default path (bf16x3 since round 5); a variant-0 bucket does not report IMF_FLAG_RANGE (nothing there is an f16 operand)."""
     import bench
     import imf_oracle as O
     from imfnet_amd.model.graph import FragmentRunner
@@ -187,7 +187,8 @@ def test_strict_fp32_capacity_mode_equals_its_exact_mode(seeded_sd, clouds, imag
         wl.runner.use_graph = True                                   # and as a replayed hipGraph
         assert torch.equal(wl.graph_step().F, F_exact)
         m6, _ = bench.build_model(dev)
-        F6 = bench.Workload(m6, dev, pts, imgs, 0.05).exact_step()
+        F6 = bench.Workload(m6, dev, pts, imgs, 0.05).exact_step()   # (issued on the workload's own stream)
+        torch.cuda.synchronize()
     assert float((F6 - F_exact).abs().max()) < 2e-6
     n0 = res.items()[0][1]
     _, F_ref = O.extract_features(sd, pts[0], 0.05, images[0])

@@ -293,14 +293,13 @@ def test_pipeline_transfer_modes_agree(clouds, images, seeded_sd, sdma, head):
 
 
 def test_direct_launches_after_a_stream_keep_the_main_stream_order(clouds, images, seeded_sd):
-    """The streaming pipeline runs a job's head on the side stream (imf_fragment_io.head_on_side) and shares its lane-0
-    buckets with the direct capacity-mode launches (device tensors in).  A direct launch must not inherit the setting: its
-    bucket's previous forward may still be running on the main stream, and with head_on_side = 1 and no reuse_event the
-    header's contract gives the head no ordering against it.  Checked deterministically: after a direct launch the shared
-    bucket's io says head_on_side = 0 with no stale events (this assertion fails without the reset in _Bucket.enqueue).
-    Checked empirically: ten back-to-back direct launches after a stream pass, no synchronisation in between, every result
-    equal to the first -- NOTE this part passed 3 / 3 runs even WITHOUT the reset (the corruption the contract allows was
-    not reproduced on the hardware), so it guards the results, not the race."""
+    """The streaming pipeline runs a job's upload and head on the image / side streams (imf_fragment_io.head_on_side), which
+    do not wait for the main stream; the direct capacity-mode launches (device tensors in) follow the main stream's order
+    only.  Round 4 had them SHARE the lane-0 bucket of a capacity key (a pipeline job after an unsynchronised
+    direct launch could overwrite its inputs); since round 5 the streamer owns lanes 1 .. n of a key and the direct path
+    lane 0, so the two never meet on one bucket.  Checked: after a stream pass and ten back-to-back direct launches (no
+    synchronisation in between) the direct bucket has seen exactly the direct launches, carries head_on_side = 0 and no
+    stale events, the streamer's lanes are other objects, and every result equals the first."""
     from imfnet_amd.extract import extract_features, extract_features_stream
     from imfnet_amd.model import load_model
     m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
@@ -319,9 +318,12 @@ def test_direct_launches_after_a_stream_keep_the_main_stream_order(clouds, image
         eager0 = runner.stats["eager"]
         outs = [extract_features(m, xyz_d, voxel_size=0.025, device=dev, skip_check=True, image=img_d)[1] for _ in range(10)]
         torch.cuda.synchronize()
-    assert runner.stats["eager"] - eager0 == 10                      # capacity-mode launches on the shared bucket
+    assert runner.stats["eager"] - eager0 == 10                      # capacity-mode launches on the direct bucket
     key = runner.caps_for(len(xyz), 1, images[0].shape[2], images[0].shape[3], 0.025, True)
-    b = runner.buckets[key]                                          # lane 0: what the stream's first job used as well
-    assert b.launches >= 11 and b.io.head_on_side == 0 and not b.io.inputs_event and not b.io.reuse_event
+    b = runner.buckets[key]                                          # lane 0: the direct launches' own bucket
+    assert b.launches == 10 and b.io.head_on_side == 0 and not b.io.inputs_event and not b.io.reuse_event
+    st = runner.streamer(dev)
+    lanes = [runner.buckets[(k, lane)] for k in st._made for lane in range(1, st._made[k] + 1)]
+    assert lanes and all(l is not b for l in lanes) and sum(l.launches for l in lanes) >= 6
     assert all(torch.equal(F.cpu(), F0) for F in outs)
     assert m.take_flags(dev) == 0
