@@ -962,7 +962,21 @@ def extra_legs(model, dev, args, sync):
         per_call.append(time.perf_counter() - t0)
     per_call.sort()
     dt = per_call[len(per_call) // 2]
+    per_dev = []
+    for i in range(28):                               # the reference's own return: F stays a device tensor (util/misc.py:100-104)
+        t0 = time.perf_counter()
+        xd, Fd = extract_features(model, xyz_host, voxel_size=voxel, device=dev, skip_check=True, image=img1, host_descriptors=False)
+        if i >= 3:
+            per_dev.append(time.perf_counter() - t0)
+    sync()
+    assert torch.equal(Fd.cpu(), torch.as_tensor(np.asarray(Fh))) and not hasattr(Fd, "host")
+    per_dev.sort()
     out["e2e_extract_features"] = {"descriptors_per_s": round(Fh.shape[0] / dt, 1), "ms_per_fragment": round(dt * 1e3, 3),
+                                   "device_descriptors": {"ms_per_fragment": round(per_dev[len(per_dev) // 2] * 1e3, 3),
+                                                          "ms_per_fragment_min_max": [round(per_dev[0] * 1e3, 3), round(per_dev[-1] * 1e3, 3)],
+                                                          "span": "the same call with host_descriptors=False: xyz_down on the host, F "
+                                                                  "left on the device (the reference's return); the call returns "
+                                                                  "when xyz_down has arrived"},
                                    "ms_per_fragment_min_max": [round(per_call[0] * 1e3, 3), round(per_call[-1] * 1e3, 3)],
                                    "span": "extract_features(host float64 points [%d,3] + host image) -> xyz_down on the host, "
                                            "and F on the host (one job of the pipeline: stage, upload, forward, download), one "

@@ -108,7 +108,7 @@ def _host_inputs(xyz, image):
     return np.ascontiguousarray(a), np.ascontiguousarray(img, dtype=np.float32)
 
 
-def _extract_with_runner(runner, xyz, voxel_size, device, image):
+def _extract_with_runner(runner, xyz, voxel_size, device, image, host_descriptors=True):
     """extract_features through the capacity-mode graph; None = not applicable / flagged (caller runs the exact path)."""
     n = int(xyz.shape[0])
     is_f64 = (xyz.dtype == torch.float64) if torch.is_tensor(xyz) else (np.asarray(xyz).dtype != np.float32)
@@ -125,7 +125,7 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image):
         slot = slots[0] if slots else graph.HostSlot()
         if not slots:
             slots.append(slot)
-        job = runner.streamer(device).submit([host], voxel_size, slot)
+        job = runner.streamer(device).submit([host], voxel_size, slot, skip_descriptors=not host_descriptors)
         if job is None:
             return None
         res = job.wait()
@@ -142,7 +142,8 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image):
         if outer is not None:
             outer.wait_stream(stream)
             F.record_stream(outer)
-        F.host = v["F"][:m]                           # the same descriptors, already on the host (pinned; valid until the
+        if host_descriptors:
+            F.host = v["F"][:m]                       # the same descriptors, already on the host (pinned; valid until the
         return sel, F                                 # next extract_features call): saves the caller's F.cpu()
     key = runner.caps_for(n, 1, int(img.shape[2]), int(img.shape[3]), voxel_size, is_f64)
     if key is None:
@@ -323,10 +324,14 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
 
 
 def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=None,
-                     skip_check=False, is_eval=True, image=None):
+                     skip_check=False, is_eval=True, image=None, host_descriptors=True):
     """xyz: [N,3] points (numpy float64/float32, or a tensor already on the device).
     rgb in [0,1] / normal in [-1,1] are optional per-point inputs (concatenated as rgb-0.5, normal/2);
-    with neither, the input feature is a column of ones.  image: [1,3,H,W] float32."""
+    with neither, the input feature is a column of ones.  image: [1,3,H,W] float32.
+    Returns (xyz_down float64 [M,3] on the host, F float32 [M,32] ON THE DEVICE) -- util/misc.py:100-104.  With host arrays
+    in, the descriptors are ALSO brought back in the same download as xyz_down (`F.host`, a pinned view valid until the next
+    call: it spares the caller's F.cpu(), scripts/generate_desc.py:122); host_descriptors=False leaves them on the device
+    only -- exactly the reference's return, 6.5 MB less over PCIe per S50k fragment."""
     if is_eval and model.training:                   # (walking ~190 modules per fragment costs 0.7 ms)
         model.eval()
     if not skip_check:
@@ -355,7 +360,7 @@ def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=
     # fragment (it needs voxel-per-point ratios to size its capacity buckets); anything it flags is redone here.
     runner = model.fragment_runner() if (feats is None and image is not None and hasattr(model, "fragment_runner")) else None
     if runner is not None:
-        got = _extract_with_runner(runner, xyz, voxel_size, device, image)
+        got = _extract_with_runner(runner, xyz, voxel_size, device, image, host_descriptors)
         if got is not None:
             return got
     # descriptor extraction is inference: with is_eval (the reference's callers all sit under torch.no_grad())

@@ -157,7 +157,7 @@ class FragmentStreamer:
                     self._free.setdefault(key, []).append(self.runner.bucket(key, self.device, self.main, lane=lane))
 
     # -- submit / wait ------------------------------------------------------------------------------------------------
-    def submit(self, items, voxel_size, slot, more_follow=False):
+    def submit(self, items, voxel_size, slot, more_follow=False, skip_descriptors=False):
         """Queue `items` = [(xyz [N,3] host float32/float64 array, image [1,3,H,W] host float32 array)] as ONE forward
         (several items: the model's batched call, model/resunet.py:241-250) with `slot` (graph.HostSlot) as its pinned
         staging.  more_follow: another submit is coming -- this job's download is then issued behind the next job's
@@ -214,7 +214,10 @@ class FragmentStreamer:
         job.caps, job.io = C.pointer(b.caps), C.pointer(b.io)
         job.host_in, job.dev_in = slot.inbuf.data_ptr(), b.inbuf.data_ptr()
         job.in_bytes = b.lay["xyz"] + n * 3 * b.xyz.element_size()
-        job.dev_out, job.host_out, job.out_bytes = b.outbuf.data_ptr(), slot.outbuf.data_ptr(), b.outbuf.numel()
+        # skip_descriptors (copy-engine mode): the download ends in front of the descriptors -- meta + xyz_down only; the caller
+        # takes the descriptors from the bucket on the device (extract_features(host_descriptors=False))
+        out_bytes = b.lay["F"] if (skip_descriptors and self.sdma_copies) else b.outbuf.numel()
+        job.dev_out, job.host_out, job.out_bytes = b.outbuf.data_ptr(), slot.outbuf.data_ptr(), out_bytes
         job.sel, job.sel_offset = b.sel.data_ptr(), b.lay["sel"]
         job.out_offset, job.out_row_bytes = b.lay["F"], int(b.out.shape[1]) * 4
         job.defer_download = 1 if more_follow else 0

@@ -327,3 +327,24 @@ def test_direct_launches_after_a_stream_keep_the_main_stream_order(clouds, image
     assert lanes and all(l is not b for l in lanes) and sum(l.launches for l in lanes) >= 6
     assert all(torch.equal(F.cpu(), F0) for F in outs)
     assert m.take_flags(dev) == 0
+
+
+def test_extract_features_can_leave_the_descriptors_on_the_device(clouds, images, seeded_sd):
+    """util/misc.py:100-104 returns F as a device tensor; extract_features(host_descriptors=False) does exactly that -- the
+    download stops in front of the descriptor block (xyz_down + counts only cross PCIe) -- and the rows equal the default
+    call's, on the device and in its pinned host copy."""
+    from imfnet_amd.extract import extract_features
+    from imfnet_amd.model import load_model
+    m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.eval().cuda()
+    dev = torch.device("cuda:0")
+    xyz = clouds[1].astype(np.float64) * 1.2
+    with torch.no_grad():
+        extract_features(m, xyz, voxel_size=0.025, device=dev, skip_check=True, image=images[1])     # exact path: teaches the runner
+        xd1, F1 = extract_features(m, xyz, voxel_size=0.025, device=dev, skip_check=True, image=images[1])
+        host1 = np.array(F1.host)
+        xd2, F2 = extract_features(m, xyz, voxel_size=0.025, device=dev, skip_check=True, image=images[1], host_descriptors=False)
+    assert hasattr(F1, "host") and not hasattr(F2, "host") and F2.is_cuda
+    assert (xd1 == xd2).all() and torch.equal(F1, F2) and (F2.cpu().numpy() == host1).all()
+    assert m.fragment_runner().stats["eager"] >= 2
