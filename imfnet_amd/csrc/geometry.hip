@@ -87,6 +87,7 @@ __device__ __forceinline__ void block_bbox_store(int4 lo, int4 hi, int32_t *wg_b
 #define IMF_INS_PPT 4
 #endif
 constexpr int kInsThreads = 256, kInsPerThread = IMF_INS_PPT, kInsPoints = kInsThreads * kInsPerThread, kInsSlots = 2 * kInsPoints;
+static_assert(kInsPerThread % 2 == 0 && kInsSlots <= 65536, "k_insert_points_wg packs two 16-bit LDS slot numbers per word (mine[kInsPerThread / 2])");
 
 template <typename T>
 __global__ void __launch_bounds__(kInsThreads)

@@ -229,7 +229,8 @@ void work(Pipeline *p) {
     Ticket &t = p->tickets[id];
     lk.unlock();
     t.t_pop = now_s();
-    int rc = t.uploaded ? IMF_OK : issue_upload(*p, t);
+    // (t.rc: the upload-ahead of this job, issued while it was still queued, failed -- its inputs are stale: no forward)
+    int rc = t.rc ? t.rc : (t.uploaded ? IMF_OK : issue_upload(*p, t));
     if (!rc) rc = issue_forward(*p, t);
     if (rc) fail(t, rc);
     t.t_fwd = t.t_dl = now_s();
@@ -368,6 +369,15 @@ int imf_pipeline_wait(void *handle, int ticket, float *ms) {
   int rc = t.rc;
   if (rc) {
     set_error("%s", t.err);
+    // launches of this job may already be queued on the bucket's three streams (a failure after the upload, or half-way
+    // through the forward): the bucket goes back to its owner only once they have drained
+    const imf_fragment_io *io = t.job.io;
+    if (io) {
+      (void)hipStreamSynchronize(p->main);
+      if (io->side_stream) (void)hipStreamSynchronize((hipStream_t)io->side_stream);
+      if (io->image_stream) (void)hipStreamSynchronize((hipStream_t)io->image_stream);
+      (void)hipGetLastError();
+    }
   } else {
     // poll the completion mark (see k_signal); once in a while ask the runtime whether the device is still alive
     volatile int32_t *mark = p->marks + 16 * ticket;

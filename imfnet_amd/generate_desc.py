@@ -131,7 +131,10 @@ def _batch_pipelined(model, runner, config, jobs, target_path, voxel_size, devic
                     spans = res.items() if len(group) > 1 else [(0, res.counts[0])]
                     left = [len(group), threading.Lock()]
                     for (job, xyz), (r0, n0) in zip(group, spans):
-                        times[job[1]] = sum(sj.ms) * 1e-3 / len(group)
+                        # GPU time of the fragment's forward: first to last kernel (device stamps forward_begin / forward_end
+                        # of imf_pipeline_wait) -- what the reference's print times (scripts/generate_desc.py:99-110), not the
+                        # pipeline latency (queueing behind the previous forward, the deferred download): ADVICE r4
+                        times[job[1]] = max(sj.stamps[3] - sj.stamps[2], 0.0) * 1e-3 / len(group)
                         writes.append(writer.submit(write, job, sj.slot, xyz, r0, n0, sj.views, left))
             except BaseException as e:                  # noqa: BLE001 -- re-raised by the main thread after the join
                 if not failure:
