@@ -872,7 +872,7 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   if (wsplit) {
     launch_spconv_w(p, grid.x, wsplit, st, a->kernel_tag & 1);
   } else if (dma0 || a->variant == 3) {
-    launch_spconv_g(p, grid, CB, st, rb2 ? 2 : 0);
+    launch_spconv_g(p, grid, CB, st, (rb2 ? 2 : 0) | (a->kernel_tag & 1));
   } else if (a->variant == 6) {
     // Balanced tail: with >= 2 full rounds of workgroups per CU and a partial last round (801 tiles on
     // 256 CUs: 33 CUs get a 4th tile and set the kernel time), the tail tiles are split over their

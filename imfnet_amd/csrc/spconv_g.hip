@@ -495,13 +495,13 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
 #endif
 #define IMF_G_LAUNCH(CB, USE, CAT)                                                         \
   do {                                                                                     \
-    if (p.arith == kArF32) {   /* variant 0 (label 0: every caller) */                     \
-      if (deep) k_spconv_g<CB, 0, CAT, 4, 1, kArF32><<<grid, 256, 0, st>>>(p);             \
-      else      k_spconv_g<CB, 0, CAT, 2, 1, kArF32><<<grid, 256, 0, st>>>(p);             \
+    if (p.arith == kArF32) {   /* variant 0 */                                             \
+      if (deep) k_spconv_g<CB, USE, CAT, 4, 1, kArF32><<<grid, 256, 0, st>>>(p);           \
+      else      k_spconv_g<CB, USE, CAT, 2, 1, kArF32><<<grid, 256, 0, st>>>(p);           \
     } else if (p.arith == kArBf16x3) {   /* variant 3: 12 / 6 KiB of weights per sub-stage -- ring of 3 where the f16 kernels take 4 */ \
       if (rb2)       k_spconv_g<CB, 0, CAT, 2, 2, kArBf16x3><<<grid, 256, 0, st>>>(p);     \
-      else if (deep) k_spconv_g<CB, 0, CAT, 3, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);     \
-      else           k_spconv_g<CB, 0, CAT, 2, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);     \
+      else if (deep) k_spconv_g<CB, USE, CAT, 3, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);   \
+      else           k_spconv_g<CB, USE, CAT, 2, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);   \
     } else if (p.a_split) {   /* operand images: the ResUNet's own layers (label 0) */     \
       if (deep) k_spconv_g<CB, 0, CAT, 4, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);        \
       else      k_spconv_g<CB, 0, CAT, IMF_G_NB_WIDE, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);   \

@@ -682,6 +682,41 @@ def test_forward_matches_reference_golden_S5(model, clouds, images, golden):
     assert np.abs(F.cpu().numpy() - golden["S5_F"]).max() < 1e-4            # north_star tolerance
 
 
+@pytest.mark.parametrize("variant", [6, 0])
+def test_forward_matches_reference_golden_other_arithmetics(seeded_sd, clouds, images, golden, variant):
+    """The goldens of the reference's own model code against the two arithmetics that are not the default: the split-f16
+    fast mode (variant 6) and fp32 MFMA (variant 0) -- config 1 (S5) and a full 2.5 cm fragment, exact path (first call) and
+    capacity mode (second call), each within the north_star's 1e-4 and within 2e-6 of the default arithmetic (bf16x3)."""
+    from imfnet_amd import ops as O_
+    from imfnet_amd.extract import extract_features
+    from imfnet_amd.model import load_model
+
+    def run(v):
+        prev, O_.CONV_VARIANT = O_.CONV_VARIANT, v
+        try:
+            m = load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3, config=None)
+            m.load_state_dict(seeded_sd, strict=True)
+            m = m.eval().to(DEV)
+            outs = []
+            with torch.no_grad():
+                for _ in range(2):
+                    outs.append(extract_features(m, clouds[0].astype(np.float64), voxel_size=0.05, device=torch.device(DEV),
+                                                 skip_check=True, image=images[0])[1].cpu().numpy())
+                F25 = extract_features(m, clouds[0].astype(np.float64), voxel_size=0.025, device=torch.device(DEV),
+                                       skip_check=True, image=images[0])[1].cpu().numpy()
+            assert m.fragment_runner().variant == v and m.fragment_runner().stats["eager"] >= 1
+            return outs, F25
+        finally:
+            O_.CONV_VARIANT = prev
+
+    (a, b), F25 = run(variant)
+    (d, _), D25 = run(3)
+    assert np.abs(a - golden["S5_F"]).max() < 1e-4 and np.abs(b - golden["S5_F"]).max() < 1e-4
+    assert np.abs(a - d).max() < 2e-6 and np.abs(F25 - D25).max() < 2e-6
+    M = int(golden["S25_0_M"])
+    assert F25.shape == (M, 32) and np.abs(F25[:: max(1, M // 256)][:256] - golden["S25_0_rows"]).max() < 1e-4
+
+
 def test_forward_matches_reference_golden_crop(model, clouds, images, golden):
     from imfnet_amd.extract import extract_features
     crop = clouds[0].astype(np.float64)[golden["crop_sel_idx"]]
