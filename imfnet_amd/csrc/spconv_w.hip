@@ -79,6 +79,10 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 //                 6 x v_mfma_f32_16x16x32_bf16 per 32 channels (variant 3).  The wavefront's weight region stays 8 KiB: a
 //                 sub-stage's weights arrive in two halves of 6 KiB (column blocks 0-1, then 2-3), each landing under the
 //                 48 MFMAs of the other; the rows of sub-stage t + 1 are requested as soon as those of t sit in registers.
+//                 (Measured and dropped, round 5: the MFMAs in row-block-major order with the split of block b + 1 placed
+//                 between the MFMAs of block b -- the compiler interleaves them, the times do not move: 509 vs 515 us
+//                 over the network's wave-split shapes, step 1.295 vs 1.297 ms; the split's VALU work is hidden by the
+//                 SIMD's other wavefront already.  What the split costs is the g kernel's: ablated, step -8.5 %.)
 // USE: profiling label only (the identical kernel under a second symbol; 1 = the image trunk's dense 3 x 3 convolutions, so that
 // per-kernel statistics keep them apart from the ResUNet's launches -- imf_conv_args.kernel_tag bit 0, as k_spconv_g's USE).
 template <bool CAT, int W, int AR = kArF16x2, int USE = 0>
