@@ -433,7 +433,8 @@ int imf_fusion_attention_batched(const float *x, int n_items, const int64_t *ite
                                  const float *const *kt_packed, const float *const *v_packed, int n_tokens,
                                  int tokens_padded, const imf_fusion_weights *w /* [host] */, float scale, float *out,
                                  void *workspace, size_t workspace_bytes, void *stream);
-/* The same with the arithmetic of the feed-forward chosen (variant 6: split-f16 images w1_p / w2_p; variant 0: fp32 MFMA on
+/* The same with the arithmetic of the feed-forward chosen (variant 6: split-f16 images w1_p / w2_p; variant 3: w1_p / w2_p are
+ * imf_pack_weights_bf16x3 images, fp32 rows between the two GEMMs; variant 0: fp32 MFMA on
  * w1_f32 / w2_f32) and a flag word (device int32, may be NULL; caller zeroes) that receives IMF_FLAG_RANGE when a value
  * that feeds an f16 operand -- LN2's output, the GEGLU hidden, the block's output -- is NaN or >= 65504 in magnitude. */
 int imf_fusion_attention_batched_v(const float *x, int n_items, const int64_t *item_row0, const int64_t *item_rows,
@@ -536,8 +537,8 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
   int32_t kernel_tag;                  /* out: imf_conv_args.kernel_tag of the launch (imf_resunet_conv_kernel_tag) */
 } imf_net_trace;
 
-/* Which variant-6 kernel the ResUNet executors (imf_resunet_forward, imf_fragment_forward and the Python plan that
- * mirrors them) use for a convolution whose OUTPUT rows live on pyramid level `level` (0 = tensor stride 1):
+/* Which LDS-DMA kernel (variants 3, 6 and 0 alike: the arithmetic is a template argument of the same two kernels) the
+ * ResUNet executors (imf_resunet_forward, imf_fragment_forward and the Python plan that mirrors them) use for a convolution whose OUTPUT rows live on pyramid level `level` (0 = tensor stride 1):
  * the value for imf_conv_args.kernel_tag.  Level 0 (thousands of 64-row tiles): k_spconv_g, unsplit.  Level 1: the
  * wave-split kernel with 4 wavefronts per workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4).  The
  * choice is a function of the LEVEL only -- never of the row count -- so exact mode, capacity mode and a graph replay
