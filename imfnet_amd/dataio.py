@@ -271,8 +271,10 @@ NPZ_THREADS = int(os.environ.get("IMFNET_NPZ_THREADS", "0"))       # 0: chosen b
 
 def save_npz(path, level=None, threads=None, **arrays):
     """np.savez_compressed(path, **arrays) through the native ZIP writer (imf_npz_write_mt): the same members and arrays,
-    deflated at zlib level `level` (default 1: ~4x faster than numpy's 6; 0 = stored like np.savez), the deflate cut
-    into independent 256 KiB blocks over `threads` host threads (default NPZ_THREADS, else 1)."""
+    deflated at `level` (0 = stored like np.savez; 2..9 = zlib at that level, numpy uses 6; default 1 = the library's own
+    deflate producers, csrc/fast_deflate.h: value-granular matches for float64 point arrays, byte Huffman for float32
+    descriptors -- ~10x numpy's speed per file at a file no larger than zlib level 1's), the deflate cut into independent
+    256 KiB blocks over `threads` host threads (default NPZ_THREADS, else 1)."""
     import ctypes as C
     if not str(path).endswith(".npz"):
         path = str(path) + ".npz"

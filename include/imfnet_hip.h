@@ -787,12 +787,15 @@ int imf_png_read_f32(const char *path, float *out, int64_t capacity_floats, int 
 int imf_resize_bilinear_f32(const float *in, int H, int W, int C, float *out, int H_out, int W_out, int chw);
 /* np.savez (level 0) / np.savez_compressed (level 1..9, raw deflate) of n_arrays C-ordered arrays: names[i] (member
  * name), dtype[i] (numpy descr, e.g. "<f8"), ndim[i], their dims concatenated in shape, data[i].  np.load reads the
- * file; the arrays are identical to numpy's own writers'. */
+ * file; the arrays are identical to numpy's own writers'.  Levels 2..9 are zlib's; level 1 uses the library's own raw-deflate
+ * producers where the member allows (8-byte items: matches at value granularity -- the float32-valued float64 coordinates of
+ * `points` / `xyz` repeat earlier values exactly 98-99 % of the time --; members without LZ77 matches: byte-wise Huffman),
+ * zlib level 1 otherwise: scripts/generate_desc.py:118-123 at ~10x numpy's rate per core. */
 int imf_npz_write(const char *path, int n_arrays, const char *const *names, const char *const *dtype,
                   const int32_t *ndim, const int64_t *shape, const void *const *data, int level);
 /* The same with block-parallel deflate on `threads` host threads (256 KiB blocks as independent raw-deflate segments that
- * end on a byte boundary, concatenated; CRC-32s combined): the bytes differ from the single-threaded file's, the arrays
- * np.load returns do not.  threads <= 1 is imf_npz_write.  scripts/generate_desc.py:118-123 at the rate of eight GPUs. */
+ * end on a byte boundary, concatenated; CRC-32s combined): the file's bytes are a function of the arrays and the level only,
+ * never of `threads`.  threads <= 1 is imf_npz_write.  scripts/generate_desc.py:118-123 at the rate of eight GPUs. */
 int imf_npz_write_mt(const char *path, int n_arrays, const char *const *names, const char *const *dtype,
                      const int32_t *ndim, const int64_t *shape, const void *const *data, int level, int threads);
 

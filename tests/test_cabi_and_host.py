@@ -538,3 +538,58 @@ def test_instance_norm_module_matches_the_oracle():
     assert float((out - ref).abs().max()) < 1e-5
     one = norm(Rows(f[:37], coords[:37])).F.detach()
     assert float((one - ref[:37]).abs().max()) < 1e-5
+
+
+def test_fast_deflate_producers_round_trip_through_zlib(tmp_path, clouds):
+    """csrc/fast_deflate.h (level 1 of imf_npz_write_mt): every member is inflated by zlib (zipfile / np.load) to exactly the
+    input -- point-like float64 (value-granular matches), descriptor-like float32 (byte Huffman), and the corner cases of a
+    hand-written encoder: incompressible data (stored-block fallback), one repeated value (long matches at distance 8), a
+    single distinct byte (one-symbol code), frequencies that force the 15-bit length limit, lengths around the 256 KiB
+    segment and 65 535-byte stored-block boundaries, empty and one-element members.  On the in-tree fragment the file is
+    smaller than zlib level 1's (IMFNET_NPZ_ZLIB=1 in a subprocess) and np.load returns identical arrays from both."""
+    import subprocess
+    import sys
+    import zipfile
+    from imfnet_amd.dataio import save_npz
+    rng = np.random.default_rng(3)
+    pts = (clouds[0] * np.float32(1.3)).astype(np.float64)
+    F = rng.normal(size=(len(pts) // 6, 32)).astype(np.float32)
+    F /= np.linalg.norm(F, axis=1, keepdims=True)
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    skew = np.concatenate([np.full(min(f, 200000), i, np.uint8) for i, f in enumerate(fib[:34])])     # deep Huffman tree
+    rng.shuffle(skew)
+    arrays = dict(points=pts, xyz=pts[::5].copy(), feature=F,
+                  random64=rng.integers(0, 2 ** 63, size=70001, dtype=np.int64),                      # nothing repeats: stored
+                  const64=np.full(100003, 3.25), ramp64=np.arange(40000, dtype=np.float64),
+                  period64=np.tile(rng.normal(size=37), 3000),                                        # matches at distance 37 values
+                  const8=np.full((256 << 10) + 5, 7, np.uint8), skew8=skew,
+                  noise8=rng.integers(0, 256, size=(256 << 10) * 2 + 65535 + 3, dtype=np.uint8),
+                  f32zero=np.zeros(65536 * 4 + 1, np.float32), empty64=np.zeros((0, 3)), one64=np.array([1.5]),
+                  block64=np.arange((256 << 10) // 8, dtype=np.int64) % 97, i4=np.arange(5000, dtype=np.int32) % 11)
+    path = str(tmp_path / "fast.npz")
+    for threads in (1, 5):
+        save_npz(path, level=1, threads=threads, **arrays)
+        z = np.load(path)
+        assert set(z.files) == set(arrays)
+        for k, a in arrays.items():
+            assert z[k].dtype == a.dtype and z[k].shape == a.shape and (z[k] == a).all(), k
+        assert zipfile.ZipFile(path).testzip() is None
+    info = {i.filename[:-4]: i for i in zipfile.ZipFile(path).infolist()}
+    assert info["points"].compress_size < 0.16 * info["points"].file_size            # the in-tree fragment: 0.135
+    assert info["const64"].compress_size < 0.01 * info["const64"].file_size
+    assert info["period64"].compress_size < 0.05 * info["period64"].file_size
+    # stored fallback: 5 bytes per 65 535-byte stored block + the segment's sync marker, never more
+    assert info["random64"].compress_size <= info["random64"].file_size * 1.0002 + 64
+    assert info["noise8"].compress_size <= info["noise8"].file_size * 1.0002 + 64
+    assert info["feature"].compress_size < 0.95 * info["feature"].file_size
+    # against zlib level 1 on the descriptor-file members (the library reads IMFNET_NPZ_ZLIB once per process)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from imfnet_amd.dataio import save_npz; z = np.load(%r);"
+            "save_npz(%r, level=1, threads=2, points=z['points'], xyz=z['xyz'], feature=z['feature'])"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, str(tmp_path / "zlib.npz")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, IMFNET_NPZ_ZLIB="1"))
+    save_npz(str(tmp_path / "mine.npz"), level=1, threads=2, points=pts, xyz=arrays["xyz"], feature=F)
+    a, b = np.load(tmp_path / "mine.npz"), np.load(tmp_path / "zlib.npz")
+    assert all((a[k] == b[k]).all() for k in ("points", "xyz", "feature"))
+    assert os.path.getsize(tmp_path / "mine.npz") <= os.path.getsize(tmp_path / "zlib.npz")
