@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "common.h"
+#include "fast_crc32.h"
 #include "fast_deflate.h"
 
 namespace imf {
@@ -474,7 +475,8 @@ int imf_npz_write_mt(const char *path, int n_arrays, const char *const *names, c
     // deflates the array's first 64 KiB; when LZ77 finds next to nothing (float32 descriptors: 0.93 of the input at 25 MB/s
     // per core) the member is Huffman-coded only (the same 0.93 at ~95 MB/s); point arrays (0.2 at ~110 MB/s) keep it.
     m.strategy = Z_DEFAULT_STRATEGY;
-    if (level > 0 && m.nbytes >= (64 << 10)) {
+    const bool values64 = level == 1 && !zlib_only && itemsize == 8;   // (no probe needed: the producer is chosen by the item size)
+    if (level > 0 && m.nbytes >= (64 << 10) && !values64) {
       z_stream ps;
       memset(&ps, 0, sizeof(ps));
       IMF_REQUIRE(deflateInit2(&ps, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK, "imf_npz_write: deflateInit2");
@@ -487,10 +489,8 @@ int imf_npz_write_mt(const char *path, int n_arrays, const char *const *names, c
       if (prc == Z_STREAM_END && got * 100 > (size_t)(64 << 10) * 85) m.strategy = Z_HUFFMAN_ONLY;
     }
     m.producer = kZlib;
-    if (level == 1 && !zlib_only) {
-      if (itemsize == 8) m.producer = kValues64;
-      else if (m.strategy == Z_HUFFMAN_ONLY) m.producer = kHuffman;
-    }
+    if (values64) m.producer = kValues64;
+    else if (level == 1 && !zlib_only && m.strategy == Z_HUFFMAN_ONLY) m.producer = kHuffman;
     // block b covers [b * kBlock, ...) of the array's bytes; block 0 is preceded by the .npy header
     m.first_block = blocks.size();
     m.n_blocks = m.nbytes ? (m.nbytes + kBlock - 1) / kBlock : 1;
@@ -525,8 +525,8 @@ int imf_npz_write_mt(const char *path, int n_arrays, const char *const *names, c
       const Member &m = mem[(size_t)bl.member];
       const bool first = bl.lo == 0, last = b + 1 == m.first_block + m.n_blocks;
       uLong crc = crc32(0L, Z_NULL, 0);
-      if (first) crc = crc32(crc, m.head.data(), (uInt)m.head.size());
-      if (bl.len) crc = crc32(crc, m.src + bl.lo, (uInt)bl.len);
+      if (first) crc = fast_crc32(crc, m.head.data(), m.head.size());
+      if (bl.len) crc = fast_crc32(crc, m.src + bl.lo, bl.len);        // carry-less multiplies: ~15x zlib 1.2.11's table loop
       bl.crc = crc;
       bl.rc = Z_OK;
       if (level == 0) continue;
