@@ -512,7 +512,8 @@ def host_span_leg(model, dev, args, barrier, sync, pts, imgs, voxel, f32_valued=
     return out, trace
 
 
-def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=96, distinct=24, passes=3, min_region_s=1.2):
+def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=96, distinct=24, passes=3, min_region_s=1.2,
+                         barrier=None):
     """SURVEY 8(e) as a measurement: a synthetic test set (`distinct` seeded slabs of the in-tree pair -- scales and sizes
     the same on every rank, float32-valued like a PLY's points -- repeated to `per_rank` x world fragments) is LPT-sharded
     over the ranks (imfnet_amd.dist.shard_fragments); every rank streams ITS fragments through the host-array pipeline
@@ -586,7 +587,7 @@ def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=96, d
         t_pass = []
         for _ in range(passes):
             if world > 1:
-                dist.barrier()
+                (barrier or dist.barrier)()
             t0 = time.perf_counter()
             for _ in range(reps):
                 one_pass(send_buf, None)
@@ -597,7 +598,7 @@ def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=96, d
         t_gather = []
         for _ in range(passes):
             if world > 1:
-                dist.barrier()
+                (barrier or dist.barrier)()
             t1 = time.perf_counter()
             gathered = idist.gather_fragment_descriptors(None, n_frag, shards, dst=0, device=coll, packed=packed)
             if coll.type == "cuda":
@@ -802,7 +803,7 @@ def main():
         sharded = None
         if not args.no_sharded and dyn:
             sharded = sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=args.sharded_per_rank,
-                                           min_region_s=args.sharded_region_s)
+                                           min_region_s=args.sharded_region_s, barrier=barrier)
 
     t = torch.tensor(rep, dtype=torch.float64, device=dev)
     hs = torch.tensor([host_span["ms_per_step"] if host_span else 0.0, float(M)], dtype=torch.float64, device=dev)
