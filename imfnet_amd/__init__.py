@@ -20,6 +20,9 @@ def _runtime_untouched():
 # handed to the GPU instead.  The runtime reads the variable once, when it starts, so it is set here -- at import, and
 # only while the runtime has not been touched; SDMA_ASYNC tells the streaming pipeline (stream.py) whether its transfers
 # may use the copy engines (hipMemcpyAsync) or must stay copy kernels (which never block, but share CUs with the forward).
+# SIDE EFFECT of importing this package: ROC_CPU_WAIT_FOR_SIGNAL=0 in the process environment (unless already set).  The
+# variable only DECLARES the mode; stream.py measures the effective one when it creates a pipeline (a runtime started by
+# something else before this import ignores it).
 if _runtime_untouched():
     _os.environ.setdefault("ROC_CPU_WAIT_FOR_SIGNAL", "0")
     SDMA_ASYNC = _os.environ["ROC_CPU_WAIT_FOR_SIGNAL"] == "0"

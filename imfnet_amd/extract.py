@@ -120,7 +120,8 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image, host_descriptor
     if host is not None:
         # host arrays (the reference's call, scripts/generate_desc.py:100): one job of the streaming pipeline (stream.py) --
         # pinned staging both ways, float32 upload when the float64 values are float32 values, xyz_down = xyz[inds]
-        # gathered on the device, only the rows that exist copied back
+        # gathered on the device; the download is the bucket's output block (copy-engine mode: the whole capacity-sized block,
+        # or only its meta + xyz_down part with host_descriptors=False; copy-kernel mode: only the rows that exist)
         slots = runner.host_slots
         slot = slots[0] if slots else graph.HostSlot()
         if not slots:

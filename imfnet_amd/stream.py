@@ -20,6 +20,30 @@ from ._lib import META_WORDS, ImfError, Job, check
 from .model import graph
 
 
+def _copy_engine_calls_return_at_once(device, stream):
+    """`imfnet_amd.SDMA_ASYNC` only says that ROC_CPU_WAIT_FOR_SIGNAL=0 was exported before torch touched the
+    runtime; if something else started HIP earlier the variable had no effect, hipMemcpyAsync behind queued kernels blocks
+    its caller (~1 ms per call inside a forward) and the pipeline silently loses what section 4e of LAB_NOTES.md gained.
+    So the EFFECTIVE mode is measured once per streamer: ~2 ms of GPU work is queued, then one small pinned device-to-host
+    copy is issued behind it and the issue call is timed (~20 us when the dependency is handed to the GPU, the length of
+    the queued work when the CPU waits).  Any failure of the probe keeps the declared mode."""
+    import time
+    try:
+        with torch.cuda.device(device), torch.cuda.stream(stream):
+            src = torch.zeros(1 << 16, dtype=torch.uint8, device=device)
+            dst = torch.empty(1 << 16, dtype=torch.uint8).pin_memory()
+            dst.copy_(src, non_blocking=True)              # (a process's first device-to-host copy costs ~13 ms once)
+            stream.synchronize()
+            torch.cuda._sleep(4_000_000)                   # ~2 ms of queued GPU time
+            t0 = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            dt = time.perf_counter() - t0
+            stream.synchronize()
+        return dt < 0.5e-3
+    except Exception:                                      # noqa: BLE001 -- a probe must never take the pipeline down
+        return True
+
+
 class StreamJob:
     """One submitted forward: `wait()` -> FragmentResult (counts, flags, item spans); `views` are the numpy views of the
     pinned blocks (`sel` = xyz_down rows, `F` = descriptors) -- valid until the slot is handed to another submit."""
@@ -58,7 +82,7 @@ class FragmentStreamer:
         main = runner.main_stream(device)
         if sdma_copies is None:                       # copy engines when hipMemcpyAsync cannot block the worker (see __init__.py)
             from . import SDMA_ASYNC
-            sdma_copies = SDMA_ASYNC
+            sdma_copies = SDMA_ASYNC and _copy_engine_calls_return_at_once(device, main)
         self.sdma_copies = bool(sdma_copies)
         flags = (_lib.PIPELINE_SDMA_COPIES if sdma_copies else 0) | ((int(copy_blocks) & 0xFFF) << 8)
         with torch.cuda.device(device):
