@@ -8,6 +8,7 @@
  *   orc_voxelize    util/misc.py:82-87 (np.floor(xyz/voxel), ME.utils.sparse_quantize)
  *   orc_downsample  implicit coordinate_manager.stride() of the stride-2 convs, model/resunet.py:54-85
  *   orc_rulebook    kernel maps of ME.MinkowskiConvolution(Transpose), model/resunet.py:42-158
+ * (imf_cpu_twins.c holds the twins with the C ABI's own signatures and layouts.)
  */
 #include <math.h>
 #include <stdint.h>
