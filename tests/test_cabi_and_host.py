@@ -593,3 +593,32 @@ def test_fast_deflate_producers_round_trip_through_zlib(tmp_path, clouds):
     a, b = np.load(tmp_path / "mine.npz"), np.load(tmp_path / "zlib.npz")
     assert all((a[k] == b[k]).all() for k in ("points", "xyz", "feature"))
     assert os.path.getsize(tmp_path / "mine.npz") <= os.path.getsize(tmp_path / "zlib.npz")
+
+
+def test_fast_deflate_fuzz(tmp_path):
+    """Property test of csrc/fast_deflate.h through the NPZ writer: whatever the bytes -- random lengths, alphabets from one
+    symbol to all 256, heavy skew, runs, periodic values, values whose repeats sit just inside / outside the 32 KiB window --
+    numpy (zlib inflate + CRC check) reads back exactly what was written."""
+    from hypothesis import given, settings, strategies as st
+    from imfnet_amd.dataio import save_npz
+    path = str(tmp_path / "f.npz")
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(0, 2 ** 32 - 1), st.integers(0, 70000), st.integers(1, 256), st.integers(1, 5000), st.booleans())
+    def run(seed, n, alphabet, period, skew):
+        rng = np.random.default_rng(seed)
+        p = rng.dirichlet(np.full(alphabet, 0.05 if skew else 5.0))
+        u8 = rng.choice(alphabet, size=n, p=p).astype(np.uint8)
+        base = rng.normal(size=period)
+        f8 = np.tile(base, n // period + 1)[:n].copy()
+        f8[rng.integers(0, max(n, 1), size=n // 50)] = rng.normal(size=n // 50) if n else 0.0
+        far = np.arange(max(n, 1), dtype=np.float64) % 4097              # repeats at distance 4097 values: outside the window
+        near = np.arange(max(n, 1), dtype=np.float64) % 4096             # at 4096: the last distance deflate can express
+        f4 = rng.normal(size=n).astype(np.float32)
+        arrays = dict(u8=u8, f8=f8, far=far, near=near, f4=f4, i8=rng.integers(-3, 3, size=n).astype(np.int64))
+        save_npz(path, level=1, threads=1 + seed % 3, **arrays)
+        z = np.load(path)
+        for k, a in arrays.items():
+            assert z[k].dtype == a.dtype and z[k].shape == a.shape and (z[k] == a).all(), (k, seed, n)
+
+    run()
