@@ -105,7 +105,7 @@ __device__ __forceinline__ f16x8 lds_read_f16x8(const float4 *__restrict__ src) 
 // image's) and fp32 rows through the same DMA pieces and LDS images, 8 x v_mfma_f32_16x16x4_f32 per 32 channels and
 // column block, no conversion: variant 0, the reference's arithmetic, on this kernel's skeleton.
 template <int CO_BLK, int USE, bool CAT, int NB, int RB, int AR = kArF16x2>
-__global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? (AR == kArBf16x3 && CO_BLK == 4 ? 3 : 4) : 2)
+__global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? 4 : 2)
 k_spconv_g(const ConvParams p) {
   constexpr bool PRE = AR == kArF16x2Pre;
   constexpr int ROWS = IMF_TILE_ROWS * RB;           // output rows per workgroup
@@ -118,16 +118,25 @@ k_spconv_g(const ConvParams p) {
   constexpr bool W_PARTIAL = SUB_F4 % 256 != 0;
   constexpr int AW_F4 = 128 * RB;                    // gathered rows per wavefront and sub-stage: RB x 2 KiB
   constexpr int BUF_F4 = SUB_F4 + 4 * AW_F4;
+  // WS1 (bf16x3, 64-column slabs, ring of 2): the 12 KiB weight block of a sub-stage is staged in ONE buffer -- the B
+  // fragments are in registers before the next block is requested (a second barrier per sub-stage) -- and only the gathered
+  // rows are double-buffered: 28 KiB + tables instead of 40 KiB, i.e. FOUR workgroups per CU like the 16-bit-image kernels
+  // instead of three.  Same fragments, same MFMA order: bit-identical sums.
+  constexpr bool WS1 = AR == kArBf16x3 && NB == 2 && RB == 1 && CO_BLK == 4;
+  constexpr int LDS_BUFS = WS1 ? SUB_F4 + NB * 4 * AW_F4 : NB * BUF_F4;
   constexpr int NBR_F4 = kKCache * ROWS / 4;
   constexpr int TAB_F4 = (kSubTab + 3) / 4;
   constexpr int KL_F4 = (kKCache + 3) / 4;
   constexpr int ABL = IMF_G_ABL;
   constexpr int D = NB - 1;                          // sub-stages in flight
   constexpr int PER = ((IMF_G_ABL & 8) ? 0 : QPS) + ((IMF_G_ABL & 4) ? 0 : 2 * RB);   // DMA instructions per thread and sub-stage
-  __shared__ float4 smem[NB * BUF_F4 + NBR_F4 + TAB_F4 + KL_F4];
-  unsigned *const nbr_lds = reinterpret_cast<unsigned *>(smem + NB * BUF_F4);            // [kKCache][ROWS]
-  unsigned *const stab = reinterpret_cast<unsigned *>(smem + NB * BUF_F4 + NBR_F4);       // [kSubTab]
-  int *const klist = reinterpret_cast<int *>(smem + NB * BUF_F4 + NBR_F4 + TAB_F4);       // [kKCache]
+  __shared__ float4 smem[LDS_BUFS + NBR_F4 + TAB_F4 + KL_F4];
+  unsigned *const nbr_lds = reinterpret_cast<unsigned *>(smem + LDS_BUFS);               // [kKCache][ROWS]
+  unsigned *const stab = reinterpret_cast<unsigned *>(smem + LDS_BUFS + NBR_F4);          // [kSubTab]
+  int *const klist = reinterpret_cast<int *>(smem + LDS_BUFS + NBR_F4 + TAB_F4);          // [kKCache]
+  // weight block / this wavefront's row images of ring slot b
+#define IMF_WBUF(b) (WS1 ? smem : smem + (b) * BUF_F4)
+#define IMF_ABUF(b) (WS1 ? smem + SUB_F4 + (b) * (4 * AW_F4) + wave * AW_F4 : smem + (b) * BUF_F4 + SUB_F4 + wave * AW_F4)
 
   int super = blockIdx.x, z = blockIdx.z, S = gridDim.z;
   long long slots_act = p.n_slots;
@@ -280,7 +289,7 @@ k_spconv_g(const ConvParams p) {
   {                                                                                                              \
     const unsigned ee = (unsigned)__builtin_amdgcn_readfirstlane((int)(e));                                      \
     const unsigned wso = wslab + (ee & 511u) * SUB_BYTES;                                                        \
-    float4 *const wb = smem + (b) * BUF_F4;                                                                      \
+    float4 *const wb = IMF_WBUF(b);                                                                              \
     if (!(ABL & 8)) {                                                                                            \
     _Pragma("unroll") for (int j = 0; j < QPS; ++j) {                                                            \
         const bool last_ = W_PARTIAL && j == QPS - 1;                                                            \
@@ -291,7 +300,7 @@ k_spconv_g(const ConvParams p) {
     const bool second = CAT && ((ee >> 14) & 1u);                                                                \
     const unsigned soff = (ee >> 15) << 7;                                                                       \
     const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                      \
-    float4 *const ab = wb + SUB_F4 + wave * AW_F4;                                                               \
+    float4 *const ab = IMF_ABUF(b);                                                                              \
     if (!(ABL & 4)) {                                                                                            \
     _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) {                                                          \
       const unsigned rr_ = (ABL & 512) && (rows).r[b_] != kNoRow ? ((rows).r[b_] & 1023u) : (rows).r[b_];        \
@@ -330,12 +339,13 @@ k_spconv_g(const ConvParams p) {
     else                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     IMF_GSTAMP(9 + 4 * t);
     e_b = e_c; irow_b = irow_c; e_c = e_d;
-    if (t + D < n_sub) IMF_DMA(e_b, irow_b, slot_wr)
+    if (!WS1 && t + D < n_sub) IMF_DMA(e_b, irow_b, slot_wr)   // (WS1: after the fragment reads, below)
     IMF_READ_ROWS(irow_c, e_c)
     e_d = IMF_READ_E(t + D + 2);
     IMF_GSTAMP(10 + 4 * t);
-    const float4 *const wbuf = smem + slot_rd * BUF_F4;
-    const float4 *const abuf = wbuf + SUB_F4 + wave * AW_F4;
+    const float4 *const wbuf = IMF_WBUF(slot_rd);
+    const float4 *const abuf = IMF_ABUF(slot_rd);
+    const int slot_dma = slot_wr;
     slot_rd = slot_rd + 1 == NB ? 0 : slot_rd + 1;
     slot_wr = slot_wr + 1 == NB ? 0 : slot_wr + 1;
     if (ABL & 32) {
@@ -374,6 +384,10 @@ k_spconv_g(const ConvParams p) {
       for (int cb = 0; cb < CO_BLK; ++cb)
 #pragma unroll
         for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, lds_read16(&wbuf[(3 * cb + h) * 64 + lane]));
+      if constexpr (WS1) {   // every wavefront holds its fragments: the single weight buffer (and the other row buffer) may be refilled
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + D < n_sub) IMF_DMA(e_b, irow_b, slot_dma)
+      }
 #define IMF_G_TERM(I, J)                                                                               \
   _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                       \
       _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                            \
@@ -430,6 +444,8 @@ k_spconv_g(const ConvParams p) {
 #undef IMF_DMA
 #undef IMF_READ_ROWS
 #undef IMF_READ_E
+#undef IMF_WBUF
+#undef IMF_ABUF
 
   IMF_GSTAMP(2);
   if ((IMF_G_ABL & 256) && acc[0][0][0] != 12345.f) return;
