@@ -104,7 +104,7 @@ def algorithmic_bytes(rec):
 def _family_regex(label, arith):
     """Regex over demangled kernel symbols (without the imf:: prefix and the argument list) for a bench label.  Labels come
     from ops.conv_kernel_name: `k_spconv_w<W>` / `k_spconv_g<CB, 0>` (+ `/b3`, `/f32`) name a template FAMILY -- every
-    (CAT, NB, RB) instance of the arithmetic AR (last template argument: 0 / 1 split-f16 without / with operand images,
+    (CAT, NB, RB, WS1) instance of the arithmetic AR (template argument before the last of k_spconv_g, third of k_spconv_w: 0 / 1 split-f16 without / with operand images,
     2 fp32, 3 bf16x3); anything else is a plain symbol."""
     ar = ARITH[arith]["ar"]
     base = label.split("/")[0]
@@ -115,7 +115,7 @@ def _family_regex(label, arith):
         return r"k_spconv_w<(true|false), %s, %s, 0>$" % (m.group(1), ar)     # (label 0; 1 = the image trunk's launches)
     m = re.match(r"k_spconv_g<(\d), (\d)>$", base)
     if m:
-        return r"k_spconv_g<%s, %s, (true|false), \d, \d, %s>$" % (m.group(1), m.group(2), ar)
+        return r"k_spconv_g<%s, %s, (true|false), \d, \d, %s(, (true|false))?>$" % (m.group(1), m.group(2), ar)
     return re.escape(base) + r"(<.*>)?$"
 
 

@@ -864,15 +864,13 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   }
 #endif
   dim3 grid((unsigned)(a->n_slots / IMF_TILE_ROWS), (unsigned)(a->cout / (16 * CB)), (unsigned)split);
-  const bool rb2 = (a->kernel_tag & 32) && a->variant == 3 && !wsplit;   // k_spconv_g with two tiles per workgroup
-  if (rb2) grid.x = (grid.x + 1u) / 2u;
   if (g_xcd) grid.x = (grid.x + 7u) / 8u * 8u;
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
   if (wsplit) {
     launch_spconv_w(p, grid.x, wsplit, st, a->kernel_tag & 1);
   } else if (dma0 || a->variant == 3) {
-    launch_spconv_g(p, grid, CB, st, (rb2 ? 2 : 0) | (a->kernel_tag & 1));
+    launch_spconv_g(p, grid, CB, st, a->kernel_tag & 1);
   } else if (a->variant == 6) {
     // Balanced tail: with >= 2 full rounds of workgroups per CU and a partial last round (801 tiles on
     // 256 CUs: 33 CUs get a 4th tile and set the kernel time), the tail tiles are split over their

@@ -104,9 +104,21 @@ __device__ __forceinline__ f16x8 lds_read_f16x8(const float4 *__restrict__ src) 
 // (imf_pack_weights; its (k, 32-channel) sub-stage is the same 8 / 4 KiB block at the same address as the split-f16
 // image's) and fp32 rows through the same DMA pieces and LDS images, 8 x v_mfma_f32_16x16x4_f32 per 32 channels and
 // column block, no conversion: variant 0, the reference's arithmetic, on this kernel's skeleton.
-template <int CO_BLK, int USE, bool CAT, int NB, int RB, int AR = kArF16x2>
-__global__ void __launch_bounds__(256, (NB == 2 && RB == 1) ? 4 : 2)
+//
+// WS1 (round 5, bf16x3): ONE buffer for the weight block and -- at NB 1 -- one for the gathered rows: every wavefront has the
+// sub-stage's A and B fragments in registers before the next sub-stage is requested (a second barrier per sub-stage, the
+// registers are the second buffer, as in k_spconv_w), so the requests of t + 1 land under the MFMAs of t.  What it buys is
+// residency: 28.0 / 22.0 KiB of LDS per workgroup instead of 48.8 / 36.8, i.e. FIVE (64-column slabs, 96 VGPRs) or SEVEN
+// (32-column slabs, 64 VGPRs) workgroups per CU instead of three / four.  Measured on the pair (same box, tools/conv_iso.py
+// and the step): ring of 2 with both operands double-buffered, 3 per CU: 64 -> 64 at 103 k rows 150 us, step 1.30 ms; weights
+// single, rows double, 4 per CU: 140 us, 1.27 ms; both single, 5 / 7 per CU: 132-137 us, 32 -> 32 51 -> 49 us, step -1.3 %
+// and -2.9 % on two boxes.  The other direction loses every time: rows in a ring of 3 behind the single weight buffer (3
+// per CU) 149 us, two tiles per workgroup (RB 2, 2 per CU) 142 us, both 153 us; rows requested at the loop head instead of
+// after the reads (4 per CU): 141 us, no change.  Same fragments, same MFMA order in all of them: bit-identical sums.
+template <int CO_BLK, int USE, bool CAT, int NB, int RB, int AR = kArF16x2, bool WS1 = false>
+__global__ void __launch_bounds__(256, RB == 1 ? (NB == 1 ? (CO_BLK == 2 ? 7 : AR == kArBf16x3 ? 5 : 6) : NB == 2 ? 4 : (WS1 ? 3 : 2)) : 2)
 k_spconv_g(const ConvParams p) {
+  static_assert(!WS1 || NB <= 3, "single weight buffer: one or two row sub-stages in flight");
   constexpr bool PRE = AR == kArF16x2Pre;
   constexpr int ROWS = IMF_TILE_ROWS * RB;           // output rows per workgroup
   constexpr int SUB_F4 = (AR == kArBf16x3 ? 3 : 2) * CO_BLK * 64;   // float4 of weights per sub-stage: 512 / 256 (bf16x3: 768 / 384)
@@ -118,17 +130,14 @@ k_spconv_g(const ConvParams p) {
   constexpr bool W_PARTIAL = SUB_F4 % 256 != 0;
   constexpr int AW_F4 = 128 * RB;                    // gathered rows per wavefront and sub-stage: RB x 2 KiB
   constexpr int BUF_F4 = SUB_F4 + 4 * AW_F4;
-  // WS1 (bf16x3, 64-column slabs, ring of 2): the 12 KiB weight block of a sub-stage is staged in ONE buffer -- the B
-  // fragments are in registers before the next block is requested (a second barrier per sub-stage) -- and only the gathered
-  // rows are double-buffered: 28 KiB + tables instead of 40 KiB, i.e. FOUR workgroups per CU like the 16-bit-image kernels
-  // instead of three.  Same fragments, same MFMA order: bit-identical sums.
-  constexpr bool WS1 = AR == kArBf16x3 && NB == 2 && RB == 1 && CO_BLK == 4;
+  // WS1: one weight buffer, NB row buffers (see above)
   constexpr int LDS_BUFS = WS1 ? SUB_F4 + NB * 4 * AW_F4 : NB * BUF_F4;
   constexpr int NBR_F4 = kKCache * ROWS / 4;
   constexpr int TAB_F4 = (kSubTab + 3) / 4;
   constexpr int KL_F4 = (kKCache + 3) / 4;
   constexpr int ABL = IMF_G_ABL;
-  constexpr int D = NB - 1;                          // sub-stages in flight
+  constexpr int D = NB == 1 ? 1 : NB - 1;            // sub-stages in flight (NB 1, WS1 only: the registers are the second buffer)
+  static_assert(NB > 1 || WS1, "a single buffer needs the mid-iteration requests");
   constexpr int PER = ((IMF_G_ABL & 8) ? 0 : QPS) + ((IMF_G_ABL & 4) ? 0 : 2 * RB);   // DMA instructions per thread and sub-stage
   __shared__ float4 smem[LDS_BUFS + NBR_F4 + TAB_F4 + KL_F4];
   unsigned *const nbr_lds = reinterpret_cast<unsigned *>(smem + LDS_BUFS);               // [kKCache][ROWS]
@@ -285,7 +294,7 @@ k_spconv_g(const ConvParams p) {
         (dst).r[b_] = *reinterpret_cast<const unsigned *>(base_ + 64 * b_);                                      \
   }
   // LDS-DMA of one sub-stage into buffer `b`: weights verbatim, the wavefront's 16 RB rows as 1 KiB images
-#define IMF_DMA(e, rows, b)                                                                                      \
+#define IMF_DMA_W(e, b)                                                                                          \
   {                                                                                                              \
     const unsigned ee = (unsigned)__builtin_amdgcn_readfirstlane((int)(e));                                      \
     const unsigned wso = wslab + (ee & 511u) * SUB_BYTES;                                                        \
@@ -297,6 +306,10 @@ k_spconv_g(const ConvParams p) {
                                                  (last_ ? woff_last : woff0) + (unsigned)j * 4096u, wso, 0, 0);  \
     }                                                                                                            \
     }                                                                                                            \
+  }
+#define IMF_DMA_R(e, rows, b)                                                                                    \
+  {                                                                                                              \
+    const unsigned ee = (unsigned)__builtin_amdgcn_readfirstlane((int)(e));                                      \
     const bool second = CAT && ((ee >> 14) & 1u);                                                                \
     const unsigned soff = (ee >> 15) << 7;                                                                       \
     const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                      \
@@ -310,6 +323,7 @@ k_spconv_g(const ConvParams p) {
     }                                                                                                            \
     }                                                                                                            \
   }
+#define IMF_DMA(e, rows, b) { IMF_DMA_W(e, b) IMF_DMA_R(e, rows, b) }
 
   // Ring of NB buffers, D = NB - 1 sub-stages in flight.  Bookkeeping runs ahead of the DMA: the table word of
   // sub-stage t + D + 2 and the input rows of t + D + 1 are read in iteration t, the DMA of t + D is issued in it.
@@ -324,10 +338,12 @@ k_spconv_g(const ConvParams p) {
       const unsigned e0 = IMF_READ_E(d);
       Rows irow0;
       IMF_READ_ROWS(irow0, e0)
-      IMF_DMA(e0, irow0, d)
+      if (!WS1 || d == 0) IMF_DMA_W(e0, d)          // (WS1: one weight block in flight, row sub-stages 0 .. D - 1)
+      IMF_DMA_R(e0, irow0, d)
     }
   }
-  int slot_rd = 0, slot_wr = D;   // t % NB and (t + D) % NB
+  unsigned e_hist = IMF_READ_E(1);                  // WS1, D 2: the table word of sub-stage t + 1 (the next weight block)
+  int slot_rd = 0, slot_wr = D % NB;   // t % NB and (t + D) % NB
   IMF_GSTAMP(1);
 #pragma unroll 1
   for (int t = 0; t < n_sub; ++t) {
@@ -335,6 +351,12 @@ k_spconv_g(const ConvParams p) {
     // sub-stage t has landed (this thread's part, then -- barrier -- everyone's); every wavefront is past its reads
     // of buffer (t - 1) % NB, which the DMA below refills
     if (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (WS1) {
+      // issue order W(0) R(0) [R(1)] | W(1) R(D) | W(2) R(D + 1) ...: W(t) and R(t) have landed once at most the ONE row
+      // sub-stage requested after W(t) is outstanding (D 2: R(t + 1), if there is one)
+      if (D == 2 && t + 1 < n_sub) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * RB) : "memory");
+      else                         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     else if (n_sub - 1 - t >= D - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER * (D - 1)) : "memory");
     else                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     IMF_GSTAMP(9 + 4 * t);
@@ -346,12 +368,22 @@ k_spconv_g(const ConvParams p) {
     const float4 *const wbuf = IMF_WBUF(slot_rd);
     const float4 *const abuf = IMF_ABUF(slot_rd);
     const int slot_dma = slot_wr;
-    slot_rd = slot_rd + 1 == NB ? 0 : slot_rd + 1;
-    slot_wr = slot_wr + 1 == NB ? 0 : slot_wr + 1;
+    slot_rd = slot_rd + 1 >= NB ? 0 : slot_rd + 1;
+    slot_wr = slot_wr + 1 >= NB ? 0 : slot_wr + 1;
     if (ABL & 32) {
 #pragma unroll
       for (int cb = 0; cb < CO_BLK; ++cb) acc[0][cb][0] += (float)t + (float)e_b;
       continue;
+    }
+    // WS1, once the sub-stage's fragments are requested: every wavefront holds them -> the single weight buffer and the row
+    // buffer of sub-stage t + D may be refilled
+#define IMF_WS_MID                                                                                     \
+    if constexpr (WS1) {                                                                               \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                  \
+      const unsigned e_w = D == 1 ? e_b : e_hist;   /* table word of sub-stage t + 1 */                \
+      e_hist = e_b;                                                                                    \
+      if (t + 1 < n_sub) IMF_DMA_W(e_w, 0)                                                             \
+      if (t + D < n_sub) IMF_DMA_R(e_b, irow_b, slot_dma)                                              \
     }
     if constexpr (AR == kArF32) {
       float4 a0[RB], a1[RB], b0[CO_BLK], b1[CO_BLK];
@@ -365,6 +397,7 @@ k_spconv_g(const ConvParams p) {
         b0[cb] = lds_read16(&wbuf[cb * 64 + lane]);
         b1[cb] = lds_read16(&wbuf[(CO_BLK + cb) * 64 + lane]);
       }
+      IMF_WS_MID
 #define IMF_G_STEP(AV, BV, C)                                                                          \
   _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                       \
       _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                            \
@@ -384,10 +417,7 @@ k_spconv_g(const ConvParams p) {
       for (int cb = 0; cb < CO_BLK; ++cb)
 #pragma unroll
         for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, lds_read16(&wbuf[(3 * cb + h) * 64 + lane]));
-      if constexpr (WS1) {   // every wavefront holds its fragments: the single weight buffer (and the other row buffer) may be refilled
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + D < n_sub) IMF_DMA(e_b, irow_b, slot_dma)
-      }
+      IMF_WS_MID
 #define IMF_G_TERM(I, J)                                                                               \
   _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                       \
       _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                            \
@@ -412,6 +442,7 @@ k_spconv_g(const ConvParams p) {
       bh[cb] = lds_read_f16x8(&wbuf[(2 * cb) * 64 + lane]);
       bl[cb] = lds_read_f16x8(&wbuf[(2 * cb + 1) * 64 + lane]);
     }
+    IMF_WS_MID
 #ifdef IMF_G_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers (perturbs the schedule a little)
     IMF_GSTAMP(11 + 4 * t);
@@ -442,6 +473,9 @@ k_spconv_g(const ConvParams p) {
         acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bh[cb], acc[b][cb], 0, 0, 0);
   }
 #undef IMF_DMA
+#undef IMF_WS_MID
+#undef IMF_DMA_W
+#undef IMF_DMA_R
 #undef IMF_READ_ROWS
 #undef IMF_READ_E
 #undef IMF_WBUF
@@ -485,10 +519,7 @@ k_spconv_g(const ConvParams p) {
 }
 
 void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st, int use) {
-  // use bit 1: two 64-row tiles per workgroup (RB 2; the caller halved grid.x): every wavefront takes two row blocks against
-  // one read of the B fragments.  Measured slower on split-f16 (above); instantiated for bf16x3, whose 12 KiB of B fragments
-  // per sub-stage make the LDS fragment reads (14 KiB per wavefront and sub-stage) a co-bound of the 24 MFMAs
-  const bool rb2 = (use & 2) != 0;
+  // use: profiling label (bit 0)
   use &= 1;
   // deep ring (NB 4, two workgroups per CU) when the whole launch is resident at once that way (<= 512 workgroups);
   // measured (tools/layer_times.py): 438 unsplit workgroups of a pair's stride-2 level 43 -> 33 us, but 544 workgroups
@@ -506,23 +537,25 @@ void launch_spconv_g(const ConvParams &p, dim3 grid, int co_blk, hipStream_t st,
     wgs = tiles * grid.y * (s_est < (int)grid.z ? s_est : (int)grid.z);
   }
   const bool deep = nb_env ? nb_env >= 4 : wgs <= nb_wgs;
-#ifndef IMF_G_NB_WIDE
-#define IMF_G_NB_WIDE 2   // ring depth of the launches that fill the chip (experiment: 3)
-#endif
+  // launches that fill the chip.  bf16x3: single buffers (WS1: 5 / 7 workgroups per CU instead of 3 / 4).  Split-f16 and fp32
+  // (8 / 4 KiB weight blocks, four per CU with the ring of two already): single buffers for the 32-column slabs only -- A/B
+  // on one box, 32 -> 32 at 103 k rows 38.5 -> 36.8 us (f16x2), 67.8 -> 65.3 us (fp32; in situ 52.2 -> 48.7), but 64 -> 64
+  // 91.6 -> 92.9 us and 219 -> 242 us: six workgroups of the 64-column kernel per CU lose more to the second barrier per
+  // sub-stage than they gain
 #define IMF_G_LAUNCH(CB, USE, CAT)                                                         \
   do {                                                                                     \
     if (p.arith == kArF32) {   /* variant 0 */                                             \
       if (deep) k_spconv_g<CB, USE, CAT, 4, 1, kArF32><<<grid, 256, 0, st>>>(p);           \
-      else      k_spconv_g<CB, USE, CAT, 2, 1, kArF32><<<grid, 256, 0, st>>>(p);           \
+      else      k_spconv_g<CB, USE, CAT, (CB == 2 ? 1 : 2), 1, kArF32, CB == 2><<<grid, 256, 0, st>>>(p); \
     } else if (p.arith == kArBf16x3) {   /* variant 3: 12 / 6 KiB of weights per sub-stage -- ring of 3 where the f16 kernels take 4 */ \
-      if (rb2)       k_spconv_g<CB, 0, CAT, 2, 2, kArBf16x3><<<grid, 256, 0, st>>>(p);     \
-      else if (deep) k_spconv_g<CB, USE, CAT, 3, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);   \
-      else           k_spconv_g<CB, USE, CAT, 2, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);   \
+      /* (single buffers, 5 / 7 workgroups per CU, for the launches that fill the chip; the resident ones keep the ring) */ \
+      if (deep) k_spconv_g<CB, USE, CAT, 3, 1, kArBf16x3><<<grid, 256, 0, st>>>(p);        \
+      else      k_spconv_g<CB, USE, CAT, 1, 1, kArBf16x3, true><<<grid, 256, 0, st>>>(p);  \
     } else if (p.a_split) {   /* operand images: the ResUNet's own layers (label 0) */     \
       if (deep) k_spconv_g<CB, 0, CAT, 4, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);        \
-      else      k_spconv_g<CB, 0, CAT, IMF_G_NB_WIDE, 1, kArF16x2Pre><<<grid, 256, 0, st>>>(p);   \
+      else      k_spconv_g<CB, 0, CAT, (CB == 2 ? 1 : 2), 1, kArF16x2Pre, CB == 2><<<grid, 256, 0, st>>>(p); \
     } else if (deep) k_spconv_g<CB, USE, CAT, 4, 1><<<grid, 256, 0, st>>>(p);              \
-    else             k_spconv_g<CB, USE, CAT, 2, 1><<<grid, 256, 0, st>>>(p);              \
+    else             k_spconv_g<CB, USE, CAT, (CB == 2 ? 1 : 2), 1, kArF16x2, CB == 2><<<grid, 256, 0, st>>>(p); \
   } while (0)
   if (p.c_b > 0) {        // two-source input (decoder skip connections)
     if (co_blk == 4) IMF_G_LAUNCH(4, 0, true); else IMF_G_LAUNCH(2, 0, true);

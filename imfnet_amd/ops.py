@@ -483,9 +483,9 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     a.split_k, a.variant = split, int(variant)
     a.operand_format = int(operand_format)
     a.dyn_err = None if flags is None else flags.data_ptr()
-    if staging not in (None, "dma", "dma2", "regs", "wave8", "wave4"):
+    if staging not in (None, "dma", "regs", "wave8", "wave4"):
         raise ImfError(f"spconv: staging={staging!r}")
-    a.kernel_tag = {"regs": 2, "wave8": 4, "wave4": 8, "dma2": 32}.get(staging, 0)
+    a.kernel_tag = {"regs": 2, "wave8": 4, "wave4": 8}.get(staging, 0)
     ws = None
     nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)   # split-K partials / balanced-tail partials
     if nbytes:
