@@ -234,11 +234,17 @@ k_spconv_w(const ConvParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(areg + 128 * b_ + 64), 16, voff + 64u, soff, 0, 0); \
     }                                                                                                              \
   }
-#define IMF_W_DMA_WHALF(e, h)                                                                                      \
+  // ... and one 6 KiB half of its weights (column blocks 2 h, 2 h + 1) straight into REGISTERS: the image is in fragment
+  // order and the block is this wavefront's alone, so the six 1 KiB pieces are six plain buffer loads -- no LDS-DMA piece
+  // (~100 cycles of issue each in a phase that carries row pieces and fragment reads, MI355X_MICROARCH.md), no LDS write,
+  // no ds_read, no hand-counted wait (the compiler waits for the registers)
+#define IMF_W_LD_WHALF(dst, e, h)                                                                                  \
   {                                                                                                                \
     const unsigned wso = wslab + ((unsigned)(e) & 511u) * SUB_BYTES + (unsigned)(h) * 6144u;                       \
-    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                                  \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wreg + 64 * j), 16, woff + 1024u * j, wso, 0, 0); \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < 2; ++cb_)                                                            \
+        _Pragma("unroll") for (int h_ = 0; h_ < 3; ++h_)                                                           \
+            (dst)[cb_][h_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                     \
+                rs_w, woff + 1024u * (unsigned)(3 * cb_ + h_), wso, 0));                                           \
   }
 
   // this wavefront's range of the tile's sub-stages
@@ -251,7 +257,6 @@ k_spconv_w(const ConvParams p) {
     IMF_W_ROWS(rows0, e_cur)
     if constexpr (AR == kArBf16x3) {
       IMF_W_DMA_ROWS(e_cur, rows0)
-      IMF_W_DMA_WHALF(e_cur, 0)
     } else {
       IMF_W_DMA(e_cur, rows0)
     }
@@ -274,55 +279,60 @@ k_spconv_w(const ConvParams p) {
   //     prefetch towards L2 / L1): the stride-4 / 8 launches 35.8 -> 38.3 us, the stride-2 ones 29.3 -> 34.6 us -- every
   //     additional vector-memory instruction costs the wavefront more than the shorter DMA latency returns.
   if constexpr (AR == kArBf16x3) {
+    // Issue order per sub-stage t: WB(t) | [rows of t landed, 8 fragment reads] R(t + 1) | 48 MFMAs on half A | WA(t + 1) |
+    // 48 MFMAs on half B.  R = 8 LDS-DMA pieces, WA / WB = 6 register loads each.  The loop body is branch-free ON PURPOSE:
+    // the compiler's vmcnt for the register loads is the minimum over the paths that reach a use, so a request behind
+    // `if (more)` makes it wait for everything younger as well (seen: vmcnt(6) / vmcnt(3) where 14 are allowed).  The
+    // wavefront's last sub-stage therefore requests a next one too: rows that do not exist (no memory access, zeros into
+    // the free row region) and a weight half nobody reads; both are waited for before the region is reused below.
+    bf16x8 bA[2][3], bB[2][3];
+    if (t0 < t1) IMF_W_LD_WHALF(bA, e_cur, 0)
 #pragma unroll 1
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // rows of t and weight half A of t have landed
+      IMF_W_LD_WHALF(bB, e_cur, 1)                                // half B of t: lands under the first 48 MFMAs
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");           // rows of t have landed (the two weight halves may be in flight)
       float4 a0[4], a1[4];
-      bf16x8 bp[2][3];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         a0[b] = w_lds16(&areg[128 * b + rd_slot]);
         a1[b] = w_lds16(&areg[128 * b + 64 + rd_slot]);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the row region is free
+      if (!more) {
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, w_lds16(&wreg[(3 * cb + h) * 64 + lane]));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // both regions are free
-      IMF_W_DMA_WHALF(e_cur, 1)                                   // half B of t: lands under the first 48 MFMAs
-      if (more) IMF_W_DMA_ROWS(e_nxt, rows_nxt)                   // rows of t + 1: a whole sub-stage to land
+        for (int b = 0; b < 4; ++b) rows_nxt.r[b] = kNoRowW;
+      }
+      IMF_W_DMA_ROWS(e_nxt, rows_nxt)                             // rows of t + 1: a whole sub-stage to land
+      __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks the requests below ~40 MFMAs)
       bf16x8 ap[4][3];
 #pragma unroll
       for (int b = 0; b < 4; ++b) split_b3(a0[b], a1[b], ap[b][0], ap[b][1], ap[b][2]);
 #define IMF_W_TERM(I, J)                                                                                 \
   _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                          \
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                   \
-          acc[b][CB0 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], bp[cb][J], acc[b][CB0 + cb], 0, 0, 0);
+          acc[b][CB0 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], BP[cb][J], acc[b][CB0 + cb], 0, 0, 0);
       {
         constexpr int CB0 = 0;
+#define BP bA
         IMF_B3_TERMS(IMF_W_TERM)
+#undef BP
       }
-      // half B has landed (the 8 row pieces of t + 1 issued after it may still be in flight)
-      if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, w_lds16(&wreg[(3 * cb + h) * 64 + lane]));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (more) {
-        IMF_W_DMA_WHALF(e_nxt, 0)                                 // half A of t + 1: lands under the second 48 MFMAs
-        e_cur = e_nxt;
-        e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 2 < kSubTab ? t + 2 : kSubTab - 1]));
-        IMF_W_ROWS(rows_nxt, e_nxt)
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      IMF_W_LD_WHALF(bA, e_nxt, 0)                                // half A of t + 1: lands under the second 48 MFMAs
+      e_cur = e_nxt;
+      e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 2 < kSubTab ? t + 2 : kSubTab - 1]));
+      IMF_W_ROWS(rows_nxt, e_nxt)
+      __builtin_amdgcn_sched_barrier(0);
       {
         constexpr int CB0 = 2;
+#define BP bB
         IMF_B3_TERMS(IMF_W_TERM)
+#undef BP
       }
 #undef IMF_W_TERM
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the trailing requests (see above)
   } else {
 #pragma unroll 1
   for (int t = t0; t < t1; ++t) {
@@ -396,7 +406,7 @@ k_spconv_w(const ConvParams p) {
   }
   }
 #undef IMF_W_DMA_ROWS
-#undef IMF_W_DMA_WHALF
+#undef IMF_W_LD_WHALF
 #undef IMF_W_DMA
 #undef IMF_W_ROWS
 

@@ -120,10 +120,10 @@ class FusedPlan:
         a.n_slots, a.n_out = rb.n_slots, rb.n_out
         a.residual = residual or None
         a.out = out
-        # the executors' static kernel policy (csrc/executor.hip): a function of the output level only, never split-K
+        # the executors' static kernel policy (csrc/executor.hip): a function of the output level and the layer's channels only, never split-K
         split = 1
         a.split_k = split
-        a.kernel_tag = self.L.imf_resunet_conv_kernel_tag(rb.level, a.kvol, a.cout, a.variant)
+        a.kernel_tag = self.L.imf_resunet_conv_kernel_tag(rb.level, a.kvol, c_a + c_b, a.cout, a.variant)
         a.workspace, a.workspace_bytes = (ws[0] or None, ws[1])
         a.tickets = None
         a.dyn_err = self._flags if (a.variant == 6 and not a.l2norm) else None

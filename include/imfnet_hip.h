@@ -539,14 +539,15 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
 
 /* Which LDS-DMA kernel (variants 3, 6 and 0 alike: the arithmetic is a template argument of the same two kernels) the
  * ResUNet executors (imf_resunet_forward, imf_fragment_forward and the Python plan that mirrors them) use for a convolution whose OUTPUT rows live on pyramid level `level` (0 = tensor stride 1):
- * the value for imf_conv_args.kernel_tag.  Level 0 (thousands of 64-row tiles): k_spconv_g, unsplit.  Level 1: the
- * wave-split kernel with 4 wavefronts per workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4).  The
- * choice is a function of the LEVEL only -- never of the row count -- so exact mode, capacity mode and a graph replay
- * form every sum in the same order (bit-identical descriptors) without a device-side split rule; no executor launch
- * uses split-K partitions or the k_spconv_reduce pass any more.  0 for shapes the wave-split kernel does not serve
- * (kvol == 1, cout % 64 != 0, variant != 6).  Replaces: the implicit per-layer algorithm choice inside
+ * the value for imf_conv_args.kernel_tag.  Level 0 (thousands of 64-row tiles): k_spconv_g, unsplit (variant 3: the
+ * wave-split kernel with 4 wavefronts for the 64 -> 64 layers).  Level 1: the wave-split kernel with 4 wavefronts per
+ * workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4).  The choice is a function of the LEVEL and the layer's
+ * channel counts only -- never of the row count -- so exact mode, capacity mode and a graph replay form every sum in the
+ * same order (bit-identical descriptors) without a device-side split rule; no executor launch uses split-K partitions
+ * or the k_spconv_reduce pass any more.  0 for shapes the wave-split kernel does not serve (kvol == 1, cout % 64 != 0,
+ * a variant other than 6 / 3 / 0).  Replaces: the implicit per-layer algorithm choice inside
  * ME.MinkowskiConvolution (model/resunet.py:168-226). */
-int imf_resunet_conv_kernel_tag(int level, int kvol, int cout, int variant);
+int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int variant);
 
 typedef struct imf_resunet_io {        /* per fragment */
   imf_level level[4];                  /* tensor strides 1, 2, 4, 8 (imf_pyramid_build) */
