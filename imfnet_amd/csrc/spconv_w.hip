@@ -285,6 +285,9 @@ k_spconv_w(const ConvParams p) {
     // `if (more)` makes it wait for everything younger as well (seen: vmcnt(6) / vmcnt(3) where 14 are allowed).  The
     // wavefront's last sub-stage therefore requests a next one too: rows that do not exist (no memory access, zeros into
     // the free row region) and a weight half nobody reads; both are waited for before the region is reused below.
+    // (Measured and dropped: the gathered rows as register loads too -- lane (r16, q4) loading its two A-fragment pieces of
+    // row 16 b + r16 straight from global, no LDS in the main loop at all, 210 VGPRs: bit-identical, the 8-wavefront shapes
+    // 525-530 -> 542 us in sum, the 4-wavefront ones 512-518 -> 504 us, pair step 1.231-1.242 vs 1.237-1.243 ms: a wash.)
     bf16x8 bA[2][3], bB[2][3];
     if (t0 < t1) IMF_W_LD_WHALF(bA, e_cur, 0)
 #pragma unroll 1
