@@ -178,7 +178,7 @@ SIGNATURES = {
     "imf_select_keypoints": (_I, [_P, _L, _P, _L, _D, _P, _P, _P, _Z, _P]),
     "imf_resunet_int_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64), _P]),
     "imf_resunet_float_arena_bytes": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64)]),
-    "imf_resunet_conv_kernel_tag": (_I, [_I, _I, _I, _I, _I]),
+    "imf_resunet_conv_kernel_tag": (_I, [_I, _I, _I, _I, _I, _I]),
     "imf_resunet_forward": (_I, [C.POINTER(ResunetDesc), C.POINTER(ResunetIO)]),
     "imf_resunet_int_arena_bytes_cap": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64), _Z]),
     "imf_resunet_float_arena_bytes_cap": (_Z, [C.POINTER(ResunetDesc), C.POINTER(C.c_int64)]),

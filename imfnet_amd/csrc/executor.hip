@@ -161,16 +161,24 @@ using namespace imf;
 
 extern "C" {
 
-int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int variant) {
+int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int variant, int n_items) {
   if ((variant != 6 && variant != 0 && variant != 3) || kvol <= 1 || cout % 64 != 0) return 0;   // (variants 0 / 3: the same kernels, other AR)
-  // Stride-1 level: k_spconv_g, except bf16x3's two 64 -> 64 layers (block1_tr).  With its weight halves loaded straight
-  // into registers the wave-split kernel takes 128 us for such a layer in isolation where k_spconv_g takes 136-140
-  // (tools/conv_iso.py, VARIANT=3), and in situ the pair step goes 1.259 -> 1.252 ms (A/B/A/B on one box) -- these two run
-  // at the end of the step, when the side streams are idle.  The 128 -> 64 layer (conv2_tr) loses there (56 vs 49 us), and
-  // with EVERY stride-1 layer on the wave-split kernel the step was 1.27 -> 1.33 ms (its 73 KiB workgroups leave no room
-  // for the side streams' kernels under the encoder).
-  if (level <= 0) return (variant == 3 && cin == 64 && cout == 64) ? 8 : 0;
-  // measured on the S50k pair / single fragment (profiles/r03_conv_isolated.txt): level 1 (438 / 219 tiles) is fastest
+  // Stride-1 level: k_spconv_g, except bf16x3's two 64 -> 64 layers (block1_tr): with its weight halves loaded straight
+  // into registers the wave-split kernel takes 126-136 us for such a layer in isolation (half-tile / whole-tile workgroups)
+  // where k_spconv_g takes 136-140 (tools/conv_iso.py, VARIANT=3); in situ the pair step goes 1.259 -> 1.252 ms with whole
+  // tiles and a further -0.7 % with half tiles (A/B/A/B on one box each) -- these two run at the end of the step, when the
+  // side streams are idle.  The 128 -> 64 layer (conv2_tr) loses there (52-56 vs 49 us), and with EVERY stride-1 layer on
+  // the wave-split kernel the step was 1.27 -> 1.33 ms (its workgroups leave no room for the side streams' kernels under
+  // the encoder).
+  if (level <= 0) return (variant == 3 && cin == 64 && cout == 64) ? (8 | 64) : 0;
+  // ONE fragment per forward (the reference's call pattern, resunet.py:163 from generate_desc.py:99): its stride-2/4/8 levels
+  // have 219 / 61 / 17 tiles -- as half-tile workgroups of 4 wavefronts (kernel_tag 8 | 64, spconv_w.hip RB 2) they reach twice
+  // as many CUs: forward 0.93 -> 0.87 ms.  A pair's levels (438 / 120 / 34 tiles) are NOT faster that way (+0.5-1 %: the
+  // wavefronts of a half tile have half the MFMAs per request to hide its latency under) and keep whole tiles.
+  // n_items is static in every mode (the batch of a forward), so exact mode, capacity mode and a replay still agree bit
+  // for bit.
+  if (variant == 3 && n_items == 1) return 8 | 64;
+  // measured on the S50k pair (profiles/r03_conv_isolated.txt, r05_conv_isolated_*.txt): level 1 (438 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
   return level == 1 ? 8 : 4;
 }
@@ -462,7 +470,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     // one workgroup (or its wavefronts) owns a tile for all kernel offsets: no split-K partitions, no reduce launch, and
     // the kernel is a function of the level and the layer's channels only -- both modes form the same sums
     a.split_k = 1;
-    a.kernel_tag = imf_resunet_conv_kernel_tag(rb.level, c.kvol, c.cin, c.cout, c.variant);
+    a.kernel_tag = imf_resunet_conv_kernel_tag(rb.level, c.kvol, c.cin, c.cout, c.variant, io->n_items);
     a.variant = c.variant;
     a.workspace = ws; a.workspace_bytes = ws_bytes;   // split-K partials or the balanced tail's
     IMF_REQUIRE(st.in_b < 0 || fmt_of(st.in_a) == fmt_of(st.in_b), "imf_resunet_forward: conv %d concatenates an operand "

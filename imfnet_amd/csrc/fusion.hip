@@ -108,6 +108,42 @@ __device__ __forceinline__ void gemm16(f32x4 (&acc)[NC], const float *A, int lda
   }
 }
 
+// The same product in two calls, so that the B fragments of GEMM n + 1 (weights, K^T, V: none of them depends on what the
+// workgroup computes) can be REQUESTED before GEMM n runs and land under it: frags_load issues U x NC 16-byte loads,
+// frags_mma consumes them in the order gemm16 does (u ascending, 4 k-steps each, column blocks inner) -- identical sums.
+// `uact` (<= U, uniform) = the steps that exist (K / 16).
+template <int NC, int U>
+struct Frags { float4 v[U][NC]; };
+template <int NC, int U>
+__device__ __forceinline__ void frags_load(Frags<NC, U> &f, const float *packed, int kfull, const int (&cblk)[NC], int lane,
+                                           int uact = U) {
+  const int ncc = kfull / 64;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (u < uact) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) f.v[u][i] = *bfrag(packed, ncc, u, cblk[i], lane);
+    }
+}
+template <int NC, int U>
+__device__ __forceinline__ void frags_mma(f32x4 (&acc)[NC], const float *A, int lda, const Frags<NC, U> &f, int lane, int uact = U) {
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const float *arow = A + r16 * lda + 4 * q4;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (u < uact) {
+      const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * u);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const float4 b = f.v[u][i];
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[i], 0, 0, 0);
+      }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -151,6 +187,13 @@ k_fusion_attn(const FusionParams p) {
   if (row0 >= row_end) return;                                      // grid.x covers the largest item
   const float *ktp = p.ktp_b[item], *vp = p.vp_b[item];
 
+  // Every GEMM's B fragments are requested one phase ahead (round 5): W_q before x is even loaded, K^T before the q GEMM
+  // runs, V before the scores, W_o before P V -- each of the four dependent L2 round trips (~2.5 us) now lands under the
+  // previous phase instead of in front of its own MFMAs.  Same fragments, same MFMA order: bit-identical to round 4.
+  const int cb_q[1] = {wave};
+  Frags<1, 16> f_q;
+  frags_load<1, 16>(f_q, p.wq, kFD, cb_q, lane);       // K = 256: 16 steps
+
   // ---- load x, LayerNorm 1 (wave w: rows 2w, 2w+1) ------------------------------------------
   for (int rr = 0; rr < 2; ++rr) {
     const int r = 2 * wave + rr;
@@ -160,35 +203,45 @@ k_fusion_attn(const FusionParams p) {
   }
   __syncthreads();
   for (int rr = 0; rr < 2; ++rr) layer_norm_row(X + (2 * wave + rr) * kLdX, N + (2 * wave + rr) * kLdX, p.ln1g, p.ln1b, lane);
+
+  // scores: N = tokp (<= 320 -> <= 20 column blocks, round-robin over waves; a wavefront's blocks c, c + 8, c + 16 in one
+  // pass, a missing block repeats the last valid one)
+  const int ncb_s = p.tokp / 16;
+  const bool has_s = wave < ncb_s;
+  const int c0 = has_s ? wave : 0, c1 = wave + 8 < ncb_s ? wave + 8 : c0, c2 = wave + 16 < ncb_s ? wave + 16 : c1;
+  const int cb_s[3] = {c0, c1, c2};
+  Frags<3, 8> f_s;
+  frags_load<3, 8>(f_s, ktp, kFQ, cb_s, lane);        // K = 128: 8 steps x 3 blocks
   __syncthreads();
 
   // ---- q = LN(x) Wq^T : N = 128 -> column block = wave -----------------------------------------
   {
     f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-    const int cb[1] = {wave};
-    gemm16<1, 16>(acc, N, kLdX, kFD, p.wq, cb, lane);    // all 16 steps of K = 256 in flight: one L2 round trip, not two
+    frags_mma<1, 16>(acc, N, kLdX, f_q, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) Q[(4 * q4 + r) * kLdQ + wave * 16 + r16] = acc[0][r];
   }
+  // o = P V: K = tokp (16-token steps), N = 128 -> column block = wave
+  const int U_v = p.tokp / 16;
+  Frags<1, kMaxTokP / 16> f_v;
+  frags_load<1, kMaxTokP / 16>(f_v, vp, p.tokp, cb_q, lane, U_v);
   __syncthreads();
 
-  // ---- scores = q K^T * scale : N = tokp (<= 320 -> <= 20 column blocks, round-robin over waves) --
-  // The block is a chain of dependent L2 round trips (~2.5 us each: 16-row workgroups, B fragments straight from L2), so
-  // a wavefront's column blocks c, c + 8, c + 16 go through ONE gemm call with every B fragment in flight together
-  // instead of three calls (round 3: the attention half 28 -> see DESIGN 4d); a missing block repeats the last valid one.
-  const int ncb_s = p.tokp / 16;
-  if (wave < ncb_s) {
+  // ---- scores = q K^T * scale ---------------------------------------------------------------------
+  if (has_s) {
     f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    const int c1 = wave + 8 < ncb_s ? wave + 8 : wave, c2 = wave + 16 < ncb_s ? wave + 16 : c1;
-    const int cb[3] = {wave, c1, c2};
-    gemm16<3, 8>(acc, Q, kLdQ, kFQ, ktp, cb, lane);
+    frags_mma<3, 8>(acc, Q, kLdQ, f_s, lane);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      if (i > 0 && cb[i] == cb[i - 1]) continue;       // a repeated (missing) block
+      if (i > 0 && cb_s[i] == cb_s[i - 1]) continue;       // a repeated (missing) block
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S[(4 * q4 + r) * kLdS + cb[i] * 16 + r16] = acc[i][r] * p.scale;
+      for (int r = 0; r < 4; ++r) S[(4 * q4 + r) * kLdS + cb_s[i] * 16 + r16] = acc[i][r] * p.scale;
     }
   }
+  // y = o Wo^T: N = 256 -> 2 column blocks per wave, K = 128
+  const int cb_o[2] = {2 * wave, 2 * wave + 1};
+  Frags<2, 8> f_o;
+  frags_load<2, 8>(f_o, p.wo, kFQ, cb_o, lane);
   __syncthreads();
 
   // ---- softmax over the valid tokens (wave w: rows 2w, 2w+1; 5 columns per lane) ----------------
@@ -219,30 +272,22 @@ k_fusion_attn(const FusionParams p) {
   }
   __syncthreads();
 
-  // ---- o = P V : K = tokp, N = 128 -> column block = wave (written over q) -----------------------
+  // ---- o = P V (written over q: q was last read before the previous barriers) --------------------
   {
     f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-    const int cb[1] = {wave};
-    // q was last read before the previous barrier.  K = tokp: as many 16-token steps in flight as divide it
-    const int U = p.tokp / 16;
-    if (U % 20 == 0)      gemm16<1, 20>(acc, S, kLdS, p.tokp, vp, cb, lane);
-    else if (U % 16 == 0) gemm16<1, 16>(acc, S, kLdS, p.tokp, vp, cb, lane);
-    else if (U % 12 == 0) gemm16<1, 12>(acc, S, kLdS, p.tokp, vp, cb, lane);
-    else if (U % 8 == 0)  gemm16<1, 8>(acc, S, kLdS, p.tokp, vp, cb, lane);
-    else                  gemm16<1, 4>(acc, S, kLdS, p.tokp, vp, cb, lane);
+    frags_mma<1, kMaxTokP / 16>(acc, S, kLdS, f_v, lane, U_v);
 #pragma unroll
     for (int r = 0; r < 4; ++r) Q[(4 * q4 + r) * kLdQ + wave * 16 + r16] = acc[0][r];
   }
   __syncthreads();
 
-  // ---- y = o Wo^T + bo + x : N = 256 -> 2 column blocks per wave; y replaces x in place -----------
+  // ---- y = o Wo^T + bo + x; y replaces x in place -------------------------------------------------
   {
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    const int cb[2] = {2 * wave, 2 * wave + 1};
-    gemm16<2, 8>(acc, Q, kLdQ, kFQ, p.wo, cb, lane);
+    frags_mma<2, 8>(acc, Q, kLdQ, f_o, lane);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int col = cb[i] * 16 + r16;
+      const int col = cb_o[i] * 16 + r16;
       const float bias = p.bo[col];
 #pragma unroll
       for (int r = 0; r < 4; ++r) X[(4 * q4 + r) * kLdX + col] += acc[i][r] + bias;   // each element owned by one lane
@@ -289,7 +334,7 @@ constexpr size_t kWsFloatsPerRow = 2 * kFD + kFH;
 // The GEGLU output travels as a split-f16 operand image (the only reader is the second GEMM: same products, no
 // conversions in its loop); out_split: the block's output too (its reader is conv4_tr, imf_resunet_forward decides).
 static int run_feed_forward(const imf_fusion_weights *w, long long n, const int32_t *n_dev, float *ws, float *out,
-                            int32_t *err, hipStream_t st, int out_split, int variant = 6) {
+                            int32_t *err, hipStream_t st, int out_split, int variant = 6, int n_items = 0) {
   float *y = ws, *n2 = ws + (size_t)n * kFD, *g = ws + (size_t)n * 2 * kFD;
   const long long slots = (n + IMF_TILE_ROWS - 1) / IMF_TILE_ROWS * IMF_TILE_ROWS;
   imf_conv_args a;
@@ -323,7 +368,9 @@ static int run_feed_forward(const imf_fusion_weights *w, long long n, const int3
   memset(&a, 0, sizeof(a));
   a.in_a = g; a.c_a = kFH; a.w_packed = w->w2_p; a.kvol = 1; a.cout = kFD;
   a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = variant;
-  a.kernel_tag = 4;                                  // wave-split, 8 wavefronts: K = 1024 is 32 sub-stages per tile
+  // wave-split, 8 wavefronts: K = 1024 is 32 sub-stages per tile; one fragment per forward on bf16x3 (17 tiles x 4 slabs):
+  // half-tile workgroups of 4 wavefronts (imf_resunet_conv_kernel_tag's rule for the stride-8 level)
+  a.kernel_tag = (b3 && n_items == 1) ? (8 | 64) : 4;
   a.n_out_dev = n_dev; a.dyn_err = err;              // z feeds conv4_tr (split-f16): range guard
   a.operand_format = b3 ? 0 : (IMF_FMT_A_SPLIT | (out_split ? IMF_FMT_OUT_SPLIT : 0));
   return imf_spconv_fwd(&a, st);
@@ -380,7 +427,7 @@ int fusion_attention_dyn_fmt(const float *x, int64_t n_cap, const int32_t *n_dev
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_attn(p, st);
   if (rc) return rc;
-  return run_feed_forward(w, n_cap, n_dev, (float *)workspace, out, err, st, out_split, variant);
+  return run_feed_forward(w, n_cap, n_dev, (float *)workspace, out, err, st, out_split, variant, n_items);
 }
 }  // namespace imf
 
@@ -443,7 +490,7 @@ int fusion_attention_batched_fmt(const float *x, int n_items, const int64_t *ite
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_attn(p, st);
   if (rc) return rc;
-  return run_feed_forward(w, n, nullptr, (float *)workspace, out, flags, st, out_split, variant);
+  return run_feed_forward(w, n, nullptr, (float *)workspace, out, flags, st, out_split, variant, n_items);
 }
 }  // namespace imf
 

@@ -85,13 +85,20 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 //                 SIMD's other wavefront already.  What the split costs is the g kernel's: ablated, step -8.5 %.)
 // USE: profiling label only (the identical kernel under a second symbol; 1 = the image trunk's dense 3 x 3 convolutions, so that
 // per-kernel statistics keep them apart from the ResUNet's launches -- imf_conv_args.kernel_tag bit 0, as k_spconv_g's USE).
-template <bool CAT, int W, int AR = kArF16x2, int USE = 0>
-__global__ void __launch_bounds__(64 * W, 2)
+// RB (round 5): 16-row blocks per workgroup, 4 = a whole 64-row tile, 2 = HALF a tile (rows 32 h .. 32 h + 31 of tile u / 2,
+// unit u = launch index).  The stride-8 level of a fragment pair has 34 tiles x 4 slabs = 136 workgroups for 256 CUs; as
+// 272 half-tile workgroups of 4 wavefronts (40 KiB of LDS: up to three per CU) every CU works.  The rulebook is untouched --
+// a half tile walks its tile's offset list (the tile's mask is a superset of the half's) -- and a row's sums depend on
+// (W, the tile's offset list) only, as before.
+template <bool CAT, int W, int AR = kArF16x2, int USE = 0, int RB = 4>
+__global__ void __launch_bounds__(64 * W, RB == 2 ? 3 : 2)
 k_spconv_w(const ConvParams p) {
+  static_assert(RB == 4 || (RB == 2 && AR == kArBf16x3), "half tiles: bf16x3 only (its weights need no LDS region)");
+  constexpr int HPT = 4 / RB;                        // workgroups (units) per 64-row tile
   constexpr bool PRE = AR == kArF16x2Pre;
   constexpr unsigned SUB_BYTES = AR == kArBf16x3 ? 12288u : 8192u;   // weight image bytes per (offset, 32-channel) sub-stage
   constexpr int NT = 64 * W;
-  constexpr int REG_F4 = 1024;                       // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512
+  constexpr int REG_F4 = RB == 2 ? 512 : 1024;       // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512 (half tile, bf16x3: rows 256; the partial tile 512)
   constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
   constexpr int TAB_F4 = (kSubTab + 3) / 4;
   constexpr int KL_F4 = (kKCache + 3) / 4;
@@ -113,7 +120,7 @@ k_spconv_w(const ConvParams p) {
     // from the ACTUAL tiles; the launcher pads gridDim.x to a multiple of 8 so that every XCD has enough workgroups.
     const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
     const unsigned xcd = lin & 7u, j = lin >> 3;
-    const unsigned groups = 8u / ns, t_act = (unsigned)(slots_act / IMF_TILE_ROWS);
+    const unsigned groups = 8u / ns, t_act = (unsigned)(slots_act / IMF_TILE_ROWS) * HPT;   // (units)
     const unsigned chunk = (t_act + groups - 1) / groups;
     y = (int)(xcd % ns);
     if (j >= chunk) return;
@@ -124,6 +131,8 @@ k_spconv_w(const ConvParams p) {
     y = (int)(xcd % ns);
     tile = (int)(j * (8u / ns) + xcd / ns);
   }
+  const int r_off = (tile % HPT) * (16 * RB);        // first row of this workgroup inside its tile
+  tile /= HPT;
   if ((long long)tile * IMF_TILE_ROWS >= slots_act) return;
   if (IMF_W_ABL & 8) return;
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
@@ -175,9 +184,9 @@ k_spconv_w(const ConvParams p) {
   }
   __syncthreads();
 
-  f32x4 acc[4][4];
+  f32x4 acc[RB][4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < RB; ++b)
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[b][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -201,8 +210,8 @@ k_spconv_w(const ConvParams p) {
   struct Rows { unsigned r[4]; };
 #define IMF_W_ROWS(dst, e)                                                                                         \
   {                                                                                                                \
-    const unsigned *const base_ = nbr_lds + ((((unsigned)(e)) >> 9) & 31u) * IMF_TILE_ROWS + row_w;                \
-    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) (dst).r[b_] = w_lds_u32(base_ + 16 * b_);                                 \
+    const unsigned *const base_ = nbr_lds + ((((unsigned)(e)) >> 9) & 31u) * IMF_TILE_ROWS + r_off + row_w;        \
+    _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) (dst).r[b_] = w_lds_u32(base_ + 16 * b_);                    \
   }
   // LDS-DMA of one sub-stage into the wavefront's region: 8 KiB of weights verbatim, 64 rows x 128 B as 8 images
 #define IMF_W_DMA(e, rows)                                                                                         \
@@ -214,7 +223,7 @@ k_spconv_w(const ConvParams p) {
     const bool second = CAT && ((ee >> 14) & 1u);                                                                  \
     const unsigned soff = (ee >> 15) << 7;                                                                         \
     const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                        \
-    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) {                                                             \
+    _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) {                                                               \
       const unsigned voff = __umul24((rows).r[b_], second ? stride_b : stride_a) + wr_byte;                        \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(areg + 128 * b_), 16, voff, soff, 0, 0);           \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(areg + 128 * b_ + 64), 16, voff + 64u, soff, 0, 0); \
@@ -228,7 +237,7 @@ k_spconv_w(const ConvParams p) {
     const bool second = CAT && ((ee >> 14) & 1u);                                                                  \
     const unsigned soff = (ee >> 15) << 7;                                                                         \
     const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                        \
-    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) {                                                             \
+    _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) {                                                               \
       const unsigned voff = __umul24((rows).r[b_], second ? stride_b : stride_a) + wr_byte;                        \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(areg + 128 * b_), 16, voff, soff, 0, 0);           \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(areg + 128 * b_ + 64), 16, voff + 64u, soff, 0, 0); \
@@ -295,24 +304,24 @@ k_spconv_w(const ConvParams p) {
       const bool more = t + 1 < t1;
       IMF_W_LD_WHALF(bB, e_cur, 1)                                // half B of t: lands under the first 48 MFMAs
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");           // rows of t have landed (the two weight halves may be in flight)
-      float4 a0[4], a1[4];
+      float4 a0[RB], a1[RB];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < RB; ++b) {
         a0[b] = w_lds16(&areg[128 * b + rd_slot]);
         a1[b] = w_lds16(&areg[128 * b + 64 + rd_slot]);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the row region is free
       if (!more) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) rows_nxt.r[b] = kNoRowW;
+        for (int b = 0; b < RB; ++b) rows_nxt.r[b] = kNoRowW;
       }
       IMF_W_DMA_ROWS(e_nxt, rows_nxt)                             // rows of t + 1: a whole sub-stage to land
       __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks the requests below ~40 MFMAs)
-      bf16x8 ap[4][3];
+      bf16x8 ap[RB][3];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) split_b3(a0[b], a1[b], ap[b][0], ap[b][1], ap[b][2]);
+      for (int b = 0; b < RB; ++b) split_b3(a0[b], a1[b], ap[b][0], ap[b][1], ap[b][2]);
 #define IMF_W_TERM(I, J)                                                                                 \
-  _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                          \
+  _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                          \
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                   \
           acc[b][CB0 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], BP[cb][J], acc[b][CB0 + cb], 0, 0, 0);
       {
@@ -341,9 +350,9 @@ k_spconv_w(const ConvParams p) {
   for (int t = t0; t < t1; ++t) {
     // sub-stage t has landed: the region is private, the wavefront's own counter is the only wait
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float4 a0[4], a1[4];
+    float4 a0[RB], a1[RB];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < RB; ++b) {
       a0[b] = w_lds16(&areg[128 * b + rd_slot]);
       a1[b] = w_lds16(&areg[128 * b + 64 + rd_slot]);
     }
@@ -363,7 +372,7 @@ k_spconv_w(const ConvParams p) {
       }
       // k-step (j, t): channel 16 j + 4 q4 + t; sixteen independent accumulators between two MFMAs of one accumulator
 #define IMF_W_STEP(AV, BV, C)                                                                            \
-  _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                          \
+  _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                          \
       _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                   \
           acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[b].C, BV[cb].C, acc[b][cb], 0, 0, 0);
       IMF_W_STEP(a0, b0, x) IMF_W_STEP(a0, b0, y) IMF_W_STEP(a0, b0, z) IMF_W_STEP(a0, b0, w)
@@ -383,25 +392,25 @@ k_spconv_w(const ConvParams p) {
       e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 2 < kSubTab ? t + 2 : kSubTab - 1]));
       IMF_W_ROWS(rows_nxt, e_nxt)
     }
-    f16x8 ah[4], al[4];
+    f16x8 ah[RB], al[RB];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < RB; ++b) {
       if (PRE) { ah[b] = __builtin_bit_cast(f16x8, a0[b]); al[b] = __builtin_bit_cast(f16x8, a1[b]); }
       else w_split8(a0[b], a1[b], ah[b], al[b]);
     }
     // per accumulator: lo*hi, hi*lo, hi*hi (k_spconv_g's order); consecutive MFMAs on different accumulators
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < RB; ++b)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
         acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b], bh[cb], acc[b][cb], 0, 0, 0);
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < RB; ++b)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
         acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bl[cb], acc[b][cb], 0, 0, 0);
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < RB; ++b)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
         acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bh[cb], acc[b][cb], 0, 0, 0);
@@ -420,7 +429,7 @@ k_spconv_w(const ConvParams p) {
   {
     float *const mine = reinterpret_cast<float *>(areg);
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < RB; ++b)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -430,7 +439,7 @@ k_spconv_w(const ConvParams p) {
         }
   }
   __syncthreads();
-  constexpr int PT = 1024 / NT;                      // float4 per thread: 2 (W 8) / 4 (W 4)
+  constexpr int PT = 256 * RB / NT;                  // float4 per thread: 2 (W 8) / 4 (W 4)
   const float un = p.w_unscale ? *p.w_unscale : 1.f;
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
@@ -443,7 +452,7 @@ k_spconv_w(const ConvParams p) {
       const float4 v = w_lds16(&smem[w * REG_F4 + phys]);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    const int orow = row_of_slot(p, (long long)tile * IMF_TILE_ROWS + row);
+    const int orow = row_of_slot(p, (long long)tile * IMF_TILE_ROWS + r_off + row);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + col);
     if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + col);
@@ -478,6 +487,10 @@ k_spconv_w(const ConvParams p) {
 
 // grid = (tiles, cout / 64); `waves` = 8 (512 threads, one workgroup per CU) or 4 (256 threads, two per CU)
 void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st, int use) {
+  // use bit 1: half-tile workgroups (RB 2; bf16x3 with 4 wavefronts only)
+  const bool half = (use & 2) != 0 && waves == 4 && p_in.arith == kArBf16x3;
+  use &= 1;
+  if (half) tiles *= 2;
   // w_xcd 1 = slab by XCD, tiles interleaved (pair step 1.092 -> 1.074 ms, round 3); 2 = slab by XCD AND one range of
   // consecutive tiles per XCD (0.953 -> 0.940 ms on top: the XCD's L2 serves a fraction of the input rows)
   const int xcd_env = 2;
@@ -502,6 +515,10 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
     }                                                                       \
   } while (0)
   if (ar == kArF32) IMF_W_LAUNCH(kArF32);
+  else if (half) {
+    if (cat) k_spconv_w<true, 4, kArBf16x3, 0, 2><<<grid, 256, 0, st>>>(p);
+    else     k_spconv_w<false, 4, kArBf16x3, 0, 2><<<grid, 256, 0, st>>>(p);
+  }
   else if (ar == kArBf16x3) IMF_W_LAUNCH(kArBf16x3);
   else if (ar == kArF16x2Pre) IMF_W_LAUNCH(kArF16x2Pre);
   else IMF_W_LAUNCH(kArF16x2);

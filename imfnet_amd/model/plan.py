@@ -105,6 +105,7 @@ class FusedPlan:
         conv_args("final", m.final, l2norm=bool(m.normalize_feature))
         self.first_ksize = m.conv1.kernel_size
         self._trace_arena = None
+        self._n_items = 0
         self._side = {}
 
     # -------------------------------------------------------------------------------------------
@@ -123,7 +124,7 @@ class FusedPlan:
         # the executors' static kernel policy (csrc/executor.hip): a function of the output level and the layer's channels only, never split-K
         split = 1
         a.split_k = split
-        a.kernel_tag = self.L.imf_resunet_conv_kernel_tag(rb.level, a.kvol, c_a + c_b, a.cout, a.variant)
+        a.kernel_tag = self.L.imf_resunet_conv_kernel_tag(rb.level, a.kvol, c_a + c_b, a.cout, a.variant, self._n_items)
         a.workspace, a.workspace_bytes = (ws[0] or None, ws[1])
         a.tickets = None
         a.dyn_err = self._flags if (a.variant == 6 and not a.l2norm) else None
@@ -140,10 +141,11 @@ class FusedPlan:
                                   kvol=rb.kvol, cin=cin, cout=a.cout, rb=rb, split=split, ev=ev, name=name,
                                   arena=self._trace_arena))
 
-    def run(self, x, fuse, after_fuse=None):
+    def run(self, x, fuse, after_fuse=None, n_items=0):
         """x: SparseTensor at tensor stride 1 (pyramid built); fuse(F8 [n8,C]) -> [n8,C] is the
         bottleneck fusion (torch).  Returns the [M, out] descriptor tensor."""
         m, L = self.model, self.L
+        self._n_items = int(n_items)            # batch of this forward: part of the executors' static kernel policy
         cm = x.coordinate_manager
         lv = [cm.level(ts) for ts in (1, 2, 4, 8)]
         n = [l.n for l in lv]

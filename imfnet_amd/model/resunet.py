@@ -401,7 +401,7 @@ class ResUNet2(ME.MinkowskiNetwork):
                 t.record_stream(cur)
             self._fuse_done = torch.cuda.Event()
             return x._like(self._native_plan.run(x, packed, items, ev, self._fuse_done))
-        return x._like(self._plan.run(x, fuse, hook))
+        return x._like(self._plan.run(x, fuse, hook, n_items=len(items) if items else int(image_feat.shape[0])))
 
     def forward_layers(self, x, image):
         """Op-by-op order of the reference's forward (resunet.py:163-235)."""

@@ -278,7 +278,10 @@ typedef struct imf_conv_args {
                              (offset, 32-channel chunk) list into contiguous ranges and combine their partial tiles through
                              LDS in wavefront order, epilogue in the same launch.  Needs kvol > 1, cout % 64 == 0,
                              split_k <= 1.  The wavefront count is part of the summation order (deterministic; a tile's
-                             sums do not depend on the row count, so exact and capacity mode agree bit for bit) */
+                             sums do not depend on the row count, so exact and capacity mode agree bit for bit).
+                             bit 6 (64), with bit 3 and variant 3 only: HALF-TILE workgroups -- each 4-wavefront workgroup
+                             owns 32 of a tile's 64 rows (same offset list, same per-row sums as bit 3 alone): twice the
+                             workgroups for levels that leave CUs idle (one fragment per forward) */
   int32_t *dyn_err;       /* optional device flag word (any mode): IMF_FLAG_SPLIT_COVER when the rule asks for more
                              partitions than split_k covers; IMF_FLAG_RANGE when an OUTPUT value is NaN or |y| >= 65504,
                              i.e. cannot be an operand of a following variant-6 convolution */
@@ -540,14 +543,16 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
 /* Which LDS-DMA kernel (variants 3, 6 and 0 alike: the arithmetic is a template argument of the same two kernels) the
  * ResUNet executors (imf_resunet_forward, imf_fragment_forward and the Python plan that mirrors them) use for a convolution whose OUTPUT rows live on pyramid level `level` (0 = tensor stride 1):
  * the value for imf_conv_args.kernel_tag.  Level 0 (thousands of 64-row tiles): k_spconv_g, unsplit (variant 3: the
- * wave-split kernel with 4 wavefronts for the 64 -> 64 layers).  Level 1: the wave-split kernel with 4 wavefronts per
- * workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4).  The choice is a function of the LEVEL and the layer's
- * channel counts only -- never of the row count -- so exact mode, capacity mode and a graph replay form every sum in the
+ * wave-split kernel with 4 wavefronts and half-tile workgroups, kernel_tag 8 | 64, for the 64 -> 64 layers).  Level 1: the
+ * wave-split kernel with 4 wavefronts per workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4); variant 3 with
+ * ONE fragment in the forward (n_items == 1): half-tile workgroups of 4 wavefronts (8 | 64) on levels 1-3.  The choice is
+ * a function of the LEVEL, the layer's channel counts and the batch size only -- never of the row count -- so exact mode,
+ * capacity mode and a graph replay form every sum in the
  * same order (bit-identical descriptors) without a device-side split rule; no executor launch uses split-K partitions
  * or the k_spconv_reduce pass any more.  0 for shapes the wave-split kernel does not serve (kvol == 1, cout % 64 != 0,
  * a variant other than 6 / 3 / 0).  Replaces: the implicit per-layer algorithm choice inside
  * ME.MinkowskiConvolution (model/resunet.py:168-226). */
-int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int variant);
+int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int variant, int n_items);
 
 typedef struct imf_resunet_io {        /* per fragment */
   imf_level level[4];                  /* tensor strides 1, 2, 4, 8 (imf_pyramid_build) */

@@ -173,7 +173,7 @@ def _rb_and_ref(cm, g, which):
 
 
 @pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple", "f32_regs", "f32_regs_split5",
-                                  "f32_wave8", "f32_wave4", "b3", "b3_split1", "b3_split5", "b3_wave8", "b3_wave4",
+                                  "f32_wave8", "f32_wave4", "b3", "b3_split1", "b3_split5", "b3_wave8", "b3_wave4", "b3_wave4h",
                                   "h3", "h3_split1", "h3_split5", "h3_wave8", "h3_wave4"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
@@ -194,12 +194,13 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
           # variant 3 = bf16x3: fp32 operands as three bf16 parts each (exact), six bf16 MFMAs per 32 channels
           "b3": {"variant": 3}, "b3_split1": {"variant": 3, "split_k": 1}, "b3_split5": {"variant": 3, "split_k": 5},
           "b3_wave8": {"variant": 3, "staging": "wave8"}, "b3_wave4": {"variant": 3, "staging": "wave4"},
+          "b3_wave4h": {"variant": 3, "staging": "wave4h"},
           "h3": {"variant": 6},
           "h3_split1": {"variant": 6, "split_k": 1}, "h3_split5": {"variant": 6, "split_k": 5},
           # variant 6 = the LDS-DMA kernel k_spconv_g (the register-staged k_spconv_h3 lives in diagnostic builds only)
           # the wave-split kernel of the coarse levels (csrc/spconv_w.hip): whole tile per workgroup, 8 / 4 wavefronts
           "h3_wave8": {"variant": 6, "staging": "wave8"}, "h3_wave4": {"variant": 6, "staging": "wave4"}}[mode]
-    if mode.endswith(("wave8", "wave4")) and (kvol == 1 or cout % 64):
+    if mode.endswith(("wave8", "wave4", "wave4h")) and (kvol == 1 or cout % 64):
         pytest.skip("the wave-split kernel covers kvol > 1 and cout % 64 == 0")
     if mode in ("split5", "split5_fused", "h3_split5", "f32_regs_split5", "b3_split5") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")

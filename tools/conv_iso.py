@@ -1,6 +1,6 @@
 """Isolated timing of the network's sparse-convolution shapes (nothing else on the GPU): each shape is launched
 REPS times back to back on one stream and timed with one event pair (main kernel + split-K reduce).
-usage: [BATCH=2] [VARIANT=6|3|0] [IMF_LIB=...] conv_iso.py [staging ...]      staging: dma (default) | dma2 | regs | wave8 | wave4
+usage: [BATCH=2] [VARIANT=6|3|0] [IMF_LIB=...] conv_iso.py [staging ...]      staging: dma (default) | regs | wave8 | wave4 | wave4h (half-tile workgroups, bf16x3)
 Several stagings print one column each (a shape a staging does not serve prints "-")."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,7 +43,7 @@ for name, ca, cb, cout, kind, i in SHAPES:
     out = torch.empty(rb.n_out, cout, device=dev)
     cols = []
     for staging in stagings:
-        if staging in ("wave8", "wave4") and (rb.kvol == 1 or cout % 64):
+        if staging in ("wave8", "wave4", "wave4h") and (rb.kvol == 1 or cout % 64):
             cols.append(None)
             continue
         kw = dict(in_b=fb, scale=sc, shift=sh, relu=True, variant=VARIANT, out=out, staging=staging)
