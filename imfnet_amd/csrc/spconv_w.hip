@@ -297,6 +297,8 @@ k_spconv_w(const ConvParams p) {
     // (Measured and dropped: the gathered rows as register loads too -- lane (r16, q4) loading its two A-fragment pieces of
     // row 16 b + r16 straight from global, no LDS in the main loop at all, 210 VGPRs: bit-identical, the 8-wavefront shapes
     // 525-530 -> 542 us in sum, the 4-wavefront ones 512-518 -> 504 us, pair step 1.231-1.242 vs 1.237-1.243 ms: a wash.)
+    // (Also dropped: both weight halves of t + 1 requested during sub-stage t -- four register sets, 206 VGPRs, one register
+    // copy of 48 VGPRs per sub-stage: the wave-split shapes +4-5 % in sum, pair step 1.283-1.292 -> 1.335 ms.)
     bf16x8 bA[2][3], bB[2][3];
     if (t0 < t1) IMF_W_LD_WHALF(bA, e_cur, 0)
 #pragma unroll 1
