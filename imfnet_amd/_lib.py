@@ -50,7 +50,7 @@ class HeadArgs(C.Structure):
         ("w2_packed", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
         ("l2norm", C.c_int32), ("c_out", C.c_int32),
         ("n", C.c_int64), ("n_dev", C.c_void_p), ("out", C.c_void_p), ("flags", C.c_void_p),
-        ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p), ("a_split", C.c_int32),
+        ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p), ("a_split", C.c_int32), ("variant", C.c_int32),
     ]
 
 

@@ -241,6 +241,171 @@ k_pointwise_head(const HeadParams p) {
   if (p.err && __ballot(bad) != 0ull && lane == 0) atomicOr(p.err, 32);
 }
 
+// bf16x3 (variant 3, round 5): the same head on fp32-exact operands.  fp32 rows in, the conv1_tr image of
+// imf_pack_weights_bf16x3 (12 KiB per 32 input channels) once per workgroup in LDS, `final`'s image (12 fragments) in 48
+// VGPRs, rows and the hidden block split into three bf16 parts in registers, six MFMAs per 32 channels in k_spconv_g's
+// order (IMF_B3_TERMS per chunk, chunks ascending) -- bit-identical to the two k_spconv_g launches it replaces.  The image is
+// 1.5x the split-f16 one, so the workgroup is EIGHT wavefronts sharing it (36 + 96 KiB of LDS for 96 input channels, one
+// workgroup per CU, two wavefronts per SIMD); a workgroup step covers 128 rows.  No range guard (nothing to guard).
+template <int NCC>
+__global__ void __launch_bounds__(512, 1)
+k_pointwise_head_b3(const HeadParams p) {
+  constexpr int NW = 8;
+  constexpr int W1_F4 = NCC * 768;                   // conv1_tr image: NCC sub-stages of 12 KiB
+  constexpr int AW_F4 = NCC * 128;                   // one wavefront's 16 rows x NCC x 128 B
+  __shared__ float4 smem[W1_F4 + 2 * NW * AW_F4];
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  long long n = p.n;
+  if (p.n_dev) {
+    const long long nd = *p.n_dev;
+    n = nd < n ? nd : n;
+  }
+  constexpr int STEP_ROWS = 16 * NW;
+  const long long n_steps = (n + STEP_ROWS - 1) / STEP_ROWS;
+  long long step = blockIdx.x;
+  if (step >= n_steps) return;
+  const int ncc_a = p.c_a >> 5;
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w1), (short)0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.in_a), (short)0, (int)(n * p.c_a * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.in_b ? p.in_b : p.in_a), (short)0, (int)(n * (p.in_b ? p.c_b : p.c_a) * 4), 0x00020000);
+  const unsigned stride_a = (unsigned)p.c_a * 4u, stride_b = (unsigned)p.c_b * 4u;
+  const int row_w = lane >> 2;
+  const unsigned wr_byte = 16u * (unsigned)((lane & 3) ^ ((4 - (row_w >> 2)) & 3));
+  const int rd_slot = 4 * r16 + (q4 ^ ((4 - (r16 >> 2)) & 3));
+  float4 *const abase = smem + W1_F4 + wave * (2 * AW_F4);   // the wavefront's two row buffers
+
+#define IMF_HB_DMA(t, buf)                                                                                          \
+  {                                                                                                                 \
+    const unsigned row_ = (unsigned)((t) * STEP_ROWS + wave * 16 + row_w);                                          \
+    float4 *const ab_ = abase + (buf) * AW_F4;                                                                      \
+    _Pragma("unroll") for (int cc_ = 0; cc_ < NCC; ++cc_) {                                                         \
+      const bool second_ = cc_ >= ncc_a;                                                                            \
+      const unsigned voff_ = row_ * (second_ ? stride_b : stride_a) + wr_byte;                                      \
+      const unsigned soff_ = (unsigned)(second_ ? cc_ - ncc_a : cc_) << 7;                                          \
+      const __amdgpu_buffer_rsrc_t rs_ = second_ ? rs_b : rs_a;                                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(ab_ + 128 * cc_), 16, voff_, soff_, 0, 0);         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(ab_ + 128 * cc_ + 64), 16, voff_ + 64u, soff_, 0, 0); \
+    }                                                                                                               \
+  }
+
+  IMF_HB_DMA(step, 0)
+  // the conv1_tr image, verbatim: NCC x 12 one-KiB pieces over the 8 wavefronts (piece j of the image at float4 64 j)
+  for (int j = wave; j < 12 * NCC; j += NW)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(smem + j * 64), 16, (unsigned)lane * 16u, (unsigned)j * 1024u, 0, 0);
+  bf16x8 w2[2][2][3];                                 // `final`: [chunk][column block][part]
+  {
+    const float4 *const w2g = reinterpret_cast<const float4 *>(p.w2);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int h = 0; h < 3; ++h) w2[cc][cb][h] = __builtin_bit_cast(bf16x8, w2g[cc * 384 + (3 * cb + h) * 64 + lane]);
+  }
+  float sc1[4], sh1[4], sc2[2], sh2[2];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    sc1[cb] = p.scale1 ? p.scale1[cb * 16 + r16] : 1.f;
+    sh1[cb] = p.shift1 ? p.shift1[cb * 16 + r16] : 0.f;
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    sc2[cb] = p.scale2 ? p.scale2[cb * 16 + r16] : 1.f;
+    sh2[cb] = p.shift2 ? p.shift2[cb * 16 + r16] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                    // the weight image is complete for every wavefront
+
+  int cur = 0;
+#pragma unroll 1
+  for (; step < n_steps; step += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's rows have landed (and the previous step's stores)
+    const long long next = step + gridDim.x;
+    if (next < n_steps) IMF_HB_DMA(next, cur ^ 1)     // lands under this step's arithmetic
+    float4 *const abuf = abase + cur * AW_F4;
+    cur ^= 1;
+
+    // ---- conv1_tr: [16, 32 NCC] x [32 NCC, 64] ----
+    f32x4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+      bf16x8 ap[3], bp[4][3];
+      split_b3(hd_lds16(&abuf[128 * cc + rd_slot]), hd_lds16(&abuf[128 * cc + 64 + rd_slot]), ap[0], ap[1], ap[2]);
+      const float4 *const wbuf = smem + cc * 768;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, hd_lds16(&wbuf[(3 * cb + h) * 64 + lane]));
+#define IMF_HB_TERM(I, J)                                                                              \
+  _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                     \
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[I], bp[cb][J], acc[cb], 0, 0, 0);
+      IMF_B3_TERMS(IMF_HB_TERM)
+#undef IMF_HB_TERM
+    }
+    // ---- epilogue 1 (conv_epilogue's expressions) -> the hidden block in A-fragment layout, in the free row buffer ----
+    const long long row0 = step * STEP_ROWS + wave * 16 + q4 * 4;
+    float *const hbuf = reinterpret_cast<float *>(abuf);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int col32 = (cb & 1) * 16 + r16, piece = col32 >> 2;
+      const int chunk = cb >> 1, half = piece >> 2, q = piece & 3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = (acc[cb][r] * 1.f) * sc1[cb] + sh1[cb];
+        if (p.relu1) x = fmaxf(x, 0.f);
+        const int row = q4 * 4 + r;
+        hbuf[(128 * chunk + 64 * half + 4 * row + (q ^ ((4 - (row >> 2)) & 3))) * 4 + (col32 & 3)] = x;
+      }
+    }
+    // ---- final: [16, 64] x [64, 32] ----
+    f32x4 acc2[2];
+    acc2[0] = acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      bf16x8 ap[3];
+      split_b3(hd_lds16(&abuf[128 * cc + rd_slot]), hd_lds16(&abuf[128 * cc + 64 + rd_slot]), ap[0], ap[1], ap[2]);
+#define IMF_HB_TERM(I, J)                                                                              \
+  _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                     \
+      acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[I], w2[cc][cb][J], acc2[cb], 0, 0, 0);
+      IMF_B3_TERMS(IMF_HB_TERM)
+#undef IMF_HB_TERM
+    }
+    // ---- epilogue 2: bias, L2 norm over the row's 32 columns (16 lanes x 2 blocks), store ----
+    float v[2][4];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[cb][r] = (acc2[cb][r] * 1.f) * sc2[cb] + sh2[cb];
+    if (p.l2norm) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float ss = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) ss += v[cb][r] * v[cb][r];
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+        ss += __shfl_xor(ss, 8, 64);
+        const float nrm = sqrtf(ss);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) v[cb][r] = v[cb][r] / nrm;   // no eps: resunet.py:230
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (row0 + r < n) p.out[(row0 + r) * 32 + cb * 16 + r16] = v[cb][r];
+  }
+#undef IMF_HB_DMA
+}
+
 }  // namespace imf
 
 using namespace imf;
@@ -260,6 +425,19 @@ int imf_pointwise_head(const imf_head_args *a, void *stream) {
               "imf_pointwise_head: n=%lld (inputs must stay below 2 GiB each: raw-buffer addressing)", (long long)a->n);
   HeadParams p{a->in_a, a->in_b, a->c_a, a->c_b, a->w1_packed, a->scale1, a->shift1, a->relu1,
                a->w2_packed, a->scale2, a->shift2, a->l2norm, (long long)a->n, a->n_dev, a->out, a->flags};
+  hipStream_t st3 = (hipStream_t)stream;
+  if (a->variant == 3) {   // bf16x3 images, fp32 rows
+    IMF_REQUIRE(!a->a_split && ncc <= 3, "imf_pointwise_head: variant 3 takes fp32 rows and 64 or 96 input channels (%d, a_split %d)",
+                32 * ncc, a->a_split);
+    const long long steps = div_up(a->n, 128);
+    const unsigned grid3 = (unsigned)(steps < 256 ? steps : 256);   // one resident 8-wavefront workgroup per CU
+    if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st3));
+    if (ncc == 2) k_pointwise_head_b3<2><<<grid3, 512, 0, st3>>>(p); else k_pointwise_head_b3<3><<<grid3, 512, 0, st3>>>(p);
+    IMF_CHECK_LAUNCH("k_pointwise_head_b3");
+    if (a->ev_end) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_end, st3));
+    return IMF_OK;
+  }
+  IMF_REQUIRE(a->variant == 0 || a->variant == 6, "imf_pointwise_head: variant %d (6 = split-f16 images, 3 = bf16x3 images)", a->variant);
   const long long tiles = div_up(a->n, IMF_TILE_ROWS);
   const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);   // two resident workgroups per CU walk the tiles
   hipStream_t st = (hipStream_t)stream;

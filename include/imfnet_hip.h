@@ -361,6 +361,8 @@ typedef struct imf_head_args {
   int32_t *flags;          /* optional device word: IMF_FLAG_RANGE when a hidden value cannot be a split-f16 operand */
   void *ev_begin, *ev_end; /* optional hipEvent_t pair recorded around the kernel */
   int32_t a_split;         /* in_a / in_b are split-f16 operand images (imf_conv_args.operand_format) */
+  int32_t variant;         /* 0 or 6: split16 weight images (above).  3: imf_pack_weights_bf16x3 images, fp32 rows, c_a + c_b
+                              <= 96, no range flag -- bit-identical to two imf_spconv_fwd calls with variant 3 */
 } imf_head_args;
 int imf_pointwise_head(const imf_head_args *args /* [host] */, void *stream);
 

@@ -286,7 +286,9 @@ def test_spconv_bf16x3_is_fp32_class(ops, clouds):
                                                  (64, 64, 64, cm.transpose_rulebook(2, 3, 2), n1, None, 1.0),
                                                  (64, 32, 64, cm.conv_rulebook(1, 1, 1), n0, None, 1.0),
                                                  (64, 0, 128, cm.conv_rulebook(2, 3, 1), n1, "wave4", 1e6),
-                                                 (64, 64, 128, cm.conv_rulebook(2, 3, 1), n1, "wave8", 1.0)):
+                                                 (64, 64, 128, cm.conv_rulebook(2, 3, 1), n1, "wave8", 1.0),
+                                                 (64, 64, 128, cm.conv_rulebook(2, 3, 1), n1, "wave4h", 1.0),
+                                                 (64, 0, 64, cm.conv_rulebook(1, 3, 1), n0, "wave4h", 1e6)):
         fa, fb = _rand((n_in, ca), 90).to(DEV) * amp, (_rand((n_in, cb), 91).to(DEV) * amp if cb else None)
         w = _rand((rb.kvol, ca + cb, cout), 92, 0.05).to(DEV) / amp
         b3 = ops.spconv(fa, ops.pack_weights(w, variant=3), cout, rb, in_b=fb, variant=3, split_k=1, staging=staging)
@@ -304,6 +306,15 @@ def test_spconv_bf16x3_is_fp32_class(ops, clouds):
         scale = ref.abs().max().item()
         assert e3 <= 1.5 * e0 + 1e-7 * scale, (ca, cb, cout, staging, e3, e0, scale)
         assert e0 <= 2e-6 * scale * 8, (ca, cb, cout, staging, e0, scale)                        # (the reference itself is sane)
+        if staging == "wave4h":
+            # half-tile workgroups walk their tile's offset list with the same four wavefront ranges: the SAME sums as the
+            # whole-tile launch, bit for bit -- plain and through the fused epilogue (scale / shift / residual / ReLU)
+            w3 = ops.pack_weights(w, variant=3)
+            assert torch.equal(b3, ops.spconv(fa, w3, cout, rb, in_b=fb, variant=3, split_k=1, staging="wave4"))
+            sc, sh = (_rand((cout,), 93).abs() + 0.5).to(DEV), _rand((cout,), 94).to(DEV)
+            res = _rand((rb.n_out, cout), 95).to(DEV) * amp
+            kw = dict(in_b=fb, variant=3, split_k=1, scale=sc, shift=sh, residual=res, relu=True)
+            assert torch.equal(ops.spconv(fa, w3, cout, rb, staging="wave4h", **kw), ops.spconv(fa, w3, cout, rb, staging="wave4", **kw))
 
 
 def test_spconv_operand_images(ops, clouds):
