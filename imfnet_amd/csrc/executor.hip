@@ -521,9 +521,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   // ones imf_pointwise_head serves; bit-identical to the two convolution launches.
   const imf_net_conv &h1 = net->conv[21], &h2 = net->conv[22];
   const int head_cin = s.tr[2] + s.ch[1];
-  const bool fused_head = h1.w_packed && h2.w_packed && h1.variant == 6 && h2.variant == 6 && h1.kvol == 1 &&
+  const bool head_b3 = h1.variant == 3 && h2.variant == 3;           // bf16x3 images: 64 or 96 input channels (head.hip)
+  const bool fused_head = h1.w_packed && h2.w_packed && ((h1.variant == 6 && h2.variant == 6) || head_b3) && h1.kvol == 1 &&
                           h2.kvol == 1 && h1.cout == 64 && h2.cin == 64 && h2.cout == 32 && h1.cin == head_cin &&
-                          s.tr[2] % 32 == 0 && s.ch[1] % 32 == 0 && head_cin >= 64 && head_cin <= 128 && !h1.l2norm &&
+                          s.tr[2] % 32 == 0 && s.ch[1] % 32 == 0 && head_cin >= 64 && head_cin <= (head_b3 ? 96 : 128) && !h1.l2norm &&
                           (size_t)s.n[0] * (size_t)(s.tr[2] > s.ch[1] ? s.tr[2] : s.ch[1]) * 4 < (1ull << 31);
   const int n_tail = fused_head ? n_steps - 2 : n_steps;
   for (int i = n_enc; i < n_tail; ++i)
@@ -535,6 +536,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     a.in_b = buf[ebuf(0, 2)]; a.c_b = s.ch[1];
     IMF_REQUIRE(is_split[dbuf(0, 2)] == is_split[ebuf(0, 2)], "imf_resunet_forward: the head's two sources differ in format");
     a.a_split = is_split[dbuf(0, 2)] ? 1 : 0;
+    a.variant = head_b3 ? 3 : 6;
     a.w1_packed = h1.w_packed; a.scale1 = h1.scale; a.shift1 = h1.shift; a.relu1 = h1.relu; a.c_mid = 64;
     a.w2_packed = h2.w_packed; a.scale2 = h2.scale; a.shift2 = h2.shift; a.l2norm = h2.l2norm; a.c_out = 32;
     a.n = s.n[0];

@@ -415,7 +415,7 @@ def conv_kernel_name(variant, cin, cout, staging=None, kernel_tag=0):
     kernels too since round 5 (AR = kArF32, csrc/spconv_g.hip / spconv_w.hip): same family names with an `/f32` suffix;
     kernel_tag bit 1 / staging="regs" selects round 1's register-staged k_spconv_mfma."""
     if kernel_tag & 16:
-        return "k_pointwise_head"
+        return "k_pointwise_head_b3" if variant == 3 else "k_pointwise_head"
     suffix = {0: "/f32", 3: "/b3"}.get(variant, "")
     regs0 = variant == 0 and (kernel_tag & 2 or staging == "regs")
     if variant in (0, 3, 6) and not regs0 and (kernel_tag & 12 or staging in ("wave8", "wave4", "wave4h")):
@@ -518,10 +518,12 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
 
 
 def pointwise_head(in_a, in_b, w1_packed, w2_packed, scale1=None, shift1=None, relu1=True, scale2=None, shift2=None,
-                   l2norm=True, out=None, flags=None, n_dev=None, a_split=False):
+                   l2norm=True, out=None, flags=None, n_dev=None, a_split=False, variant=6):
     """imf_pointwise_head: conv1_tr + norm1_tr + ReLU + final + L2 normalisation (model/resunet.py:219-233) in one
     launch.  a_split: in_a / in_b are split-f16 operand images (`to_operand_image`).  in_a [n, c_a], in_b [n, c_b] or None; weight images from pack_weights_split16 (kvol 1); hidden width 64,
-    output [n, 32].  Bit-identical to two `spconv(..., variant=6)` calls."""
+    output [n, 32].  Bit-identical to two `spconv(..., variant=6)` calls.  variant=3: bf16x3 weight images
+    (`pack_weights(..., variant=3)`), fp32 rows, at most 96 input channels, no range flag -- bit-identical to two
+    `spconv(..., variant=3)` calls."""
     _req(in_a, torch.float32, "in_a", 2)
     if in_b is not None:
         _req(in_b, torch.float32, "in_b", 2)
@@ -534,13 +536,16 @@ def pointwise_head(in_a, in_b, w1_packed, w2_packed, scale1=None, shift1=None, r
     a.in_a, a.in_b = in_a.data_ptr(), _ptr(in_b)
     a.c_a, a.c_b = in_a.shape[1], (0 if in_b is None else in_b.shape[1])
     L = _lib.lib()
-    if w1_packed.numel() != L.imf_packed_weight_floats_split16(1, a.c_a + a.c_b, 64) or \
-            w2_packed.numel() != L.imf_packed_weight_floats_split16(1, 64, 32):
-        raise ImfError("pointwise_head: packed weight images do not match [c_a + c_b, 64] / [64, 32] (split16)")
+    if variant not in (3, 6):
+        raise ImfError(f"pointwise_head: variant={variant} (6 = split-f16 images, 3 = bf16x3 images)")
+    floats = L.imf_packed_weight_floats_bf16x3 if variant == 3 else L.imf_packed_weight_floats_split16
+    if w1_packed.numel() != floats(1, a.c_a + a.c_b, 64) or w2_packed.numel() != floats(1, 64, 32):
+        raise ImfError("pointwise_head: packed weight images do not match [c_a + c_b, 64] / [64, 32] of this variant")
     a.w1_packed, a.scale1, a.shift1, a.relu1, a.c_mid = w1_packed.data_ptr(), _ptr(scale1), _ptr(shift1), int(bool(relu1)), 64
     a.w2_packed, a.scale2, a.shift2, a.l2norm, a.c_out = w2_packed.data_ptr(), _ptr(scale2), _ptr(shift2), int(bool(l2norm)), 32
     a.n, a.n_dev, a.out = n, _ptr(n_dev), out.data_ptr()
     a.a_split = int(bool(a_split))
+    a.variant = int(variant)
     a.flags = None if flags is None else flags.data_ptr()
     check(L.imf_pointwise_head(C.byref(a), _stream()), "imf_pointwise_head")
     return out

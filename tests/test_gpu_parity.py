@@ -477,6 +477,46 @@ def test_pointwise_head(ops, ca, cb, n):
         ops.pointwise_head(a[:, :32].contiguous(), None, w1p, w2p)
 
 
+@pytest.mark.parametrize("ca,cb,n", [(64, 32, 5182), (64, 32, 128 * 300 + 17), (64, 0, 1000), (32, 32, 333), (96, 0, 63)])
+def test_pointwise_head_bf16x3(ops, ca, cb, n):
+    """imf_pointwise_head with variant 3 (bf16x3 images, fp32 rows): against fp64 (fp32-class error on unit rows), bit-identical
+    to the two variant-3 convolution launches it replaces, the device-side row count of the capacity mode, no range flag for
+    hidden values far outside the f16 range, and 128 input channels refused (the image would not fit beside the row buffers)."""
+    from imfnet_amd.ops import Rulebook
+    fa, fb = _rand((n, ca), 80), (_rand((n, cb), 81) if cb else None)
+    w1, w2 = _rand((1, ca + cb, 64), 82, 1.0 / np.sqrt(ca + cb)), _rand((1, 64, 32), 83, 0.125)
+    sc, sh, bias = _rand((64,), 84).abs() + 0.5, _rand((64,), 85), _rand((32,), 86)
+    w1p, w2p = ops.pack_weights(w1.to(DEV), variant=3), ops.pack_weights(w2.to(DEV), variant=3)
+    a, b = fa.to(DEV), (None if fb is None else fb.to(DEV))
+    kw = dict(scale1=sc.to(DEV), shift1=sh.to(DEV), relu1=True, shift2=bias.to(DEV), l2norm=True, variant=3)
+    got = ops.pointwise_head(a, b, w1p, w2p, **kw)
+    fin = (fa if fb is None else torch.cat([fa, fb], 1)).double()
+    hid = torch.relu(fin @ w1[0].double() * sc.double() + sh.double())
+    ref = hid @ w2[0].double() + bias.double()
+    ref = ref / ref.norm(dim=1, keepdim=True)
+    assert got.shape == (n, 32)
+    assert (got.cpu().double() - ref).abs().max() < 1e-6
+    rb = Rulebook(None, None, None, (n + 63) // 64 * 64, n, 1)
+    h = ops.spconv(a, w1p, 64, rb, in_b=b, scale=sc.to(DEV), shift=sh.to(DEV), relu=True, variant=3)
+    two = ops.spconv(h, w2p, 32, rb, shift=bias.to(DEV), l2norm=True, variant=3)
+    assert torch.equal(got, two)
+    m = max(1, n - 37)
+    n_dev = torch.tensor([m], dtype=torch.int32, device=DEV)
+    out = torch.full((n, 32), 7.0, device=DEV)
+    ops.pointwise_head(a, b, w1p, w2p, out=out, n_dev=n_dev, **kw)
+    assert torch.equal(out[:m], got[:m]) and bool((out[m:] == 7.0).all())
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    big = ops.pointwise_head(a * 1e3, b, w1p, w2p, scale1=torch.full((64,), 1e3, device=DEV), relu1=False, l2norm=False,
+                             flags=flags, variant=3).cpu().double()                            # hidden ~ 1e6: fine here
+    assert int(flags.item()) == 0
+    fin_big = (fa * 1e3 if fb is None else torch.cat([fa * 1e3, fb], 1)).double()
+    want = (fin_big @ w1[0].double() * 1e3) @ w2[0].double()
+    assert (big - want).abs().max() <= 2e-6 * want.abs().max()
+    with pytest.raises(Exception):
+        ops.pointwise_head(torch.zeros((64, 128), device=DEV), None, ops.pack_weights(_rand((1, 128, 64), 87).to(DEV), variant=3),
+                           w2p, variant=3)
+
+
 def test_spconv_split16_variant(ops, geom_s5):
     """Variant 6 (split-f16 MFMA): the packed image decodes to hi + lo == w within 2^-21, epilogues and
     determinism as the fp32 kernels, and fp32-class error on inputs spanning seven decades."""
@@ -776,7 +816,8 @@ def model6(model, fast_mode):
 
 def test_native_executor_equals_python_plan_bf16x3(model, clouds, images, monkeypatch):
     """The default arithmetic (variant 3): imf_resunet_forward issues exactly the launches of the op-by-op Python executor on
-    fp32 buffers -- bit-identical descriptors; 23 convolution launches traced (no fused head in this arithmetic)."""
+    fp32 buffers -- bit-identical descriptors; 20 convolution launches traced + the fused head (conv1_tr + final, which the
+    op-by-op executor runs as two launches with the same sums)."""
     from imfnet_amd import ops as O_
     from imfnet_amd.extract import sparse_tensor_from_points
     assert O_.CONV_VARIANT == 3
@@ -795,7 +836,8 @@ def test_native_executor_equals_python_plan_bf16x3(model, clouds, images, monkey
             trace, O_.TRACE = O_.TRACE, None
         assert model._native_plan is not None
         assert torch.equal(a, b)
-        assert len(trace) == 22 and all(r["kernel"].endswith("/b3") for r in trace)
+        assert len(trace) == 21 and all(r["kernel"].endswith("/b3") for r in trace[:-1])
+        assert trace[-1]["kernel"] == "k_pointwise_head_b3"          # conv1_tr + final: one launch (csrc/head.hip)
 
 
 def test_native_executor_equals_python_plan(model6, clouds, images, monkeypatch):
