@@ -178,6 +178,12 @@ int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int vari
   // n_items is static in every mode (the batch of a forward), so exact mode, capacity mode and a replay still agree bit
   // for bit.
   if (variant == 3 && n_items == 1) return 8 | 64;
+  // A pair's (or triple's) stride-8 level: 34 tiles x 4 slabs = 136 workgroups for 256 CUs, and every tile-aligned way of
+  // cutting them finer gives 17 x 2^n units.  48-row UNITS that ignore the tile boundaries (kernel_tag 4 | 128, spconv_w.hip
+  // RB 3; a unit walks the union of its two tiles' offset lists) are 46 x 4 = 184 workgroups of 3 / 4 of the work: the
+  // 256 -> 256 layer 67.7 -> 52.2 us, 128 -> 256 38.1 -> 29.5, pair step 1.246 -> 1.215 ms (A/B/A/B on one box).  The stride-4
+  // level (120 tiles x 2 slabs = 240 workgroups already) loses with them (41 -> 58 us).
+  if (variant == 3 && level == 3 && (n_items == 2 || n_items == 3)) return 4 | 128;
   // measured on the S50k pair (profiles/r03_conv_isolated.txt, r05_conv_isolated_*.txt): level 1 (438 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
   return level == 1 ? 8 : 4;

@@ -90,15 +90,18 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 // 272 half-tile workgroups of 4 wavefronts (40 KiB of LDS: up to three per CU) every CU works.  The rulebook is untouched --
 // a half tile walks its tile's offset list (the tile's mask is a superset of the half's) -- and a row's sums depend on
 // (W, the tile's offset list) only, as before.
+// RB 3 = 48-row UNITS that ignore the tile boundaries (unit u = slots 48 u .. 48 u + 47; it walks the union of the offset
+// lists of the one or two tiles it touches): 2 176 rows are 46 units instead of 34 tiles, x 4 slabs = 184 workgroups with
+// 3 / 4 of a tile's work each.
 template <bool CAT, int W, int AR = kArF16x2, int USE = 0, int RB = 4>
 __global__ void __launch_bounds__(64 * W, RB == 2 ? 3 : 2)
 k_spconv_w(const ConvParams p) {
-  static_assert(RB == 4 || (RB == 2 && AR == kArBf16x3), "half tiles: bf16x3 only (its weights need no LDS region)");
-  constexpr int HPT = 4 / RB;                        // workgroups (units) per 64-row tile
+  static_assert(RB == 4 || ((RB == 2 || RB == 3) && AR == kArBf16x3), "part tiles: bf16x3 only (its weights need no LDS region)");
+  constexpr int UR = 16 * RB;                        // rows (slots) per workgroup: the UNIT
   constexpr bool PRE = AR == kArF16x2Pre;
   constexpr unsigned SUB_BYTES = AR == kArBf16x3 ? 12288u : 8192u;   // weight image bytes per (offset, 32-channel) sub-stage
   constexpr int NT = 64 * W;
-  constexpr int REG_F4 = RB == 2 ? 512 : 1024;       // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512 (half tile, bf16x3: rows 256; the partial tile 512)
+  constexpr int REG_F4 = RB == 4 ? 1024 : 256 * RB;  // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512 (part tiles, bf16x3: rows 128 RB; the partial tile 256 RB)
   constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
   constexpr int TAB_F4 = (kSubTab + 3) / 4;
   constexpr int KL_F4 = (kKCache + 3) / 4;
@@ -120,7 +123,7 @@ k_spconv_w(const ConvParams p) {
     // from the ACTUAL tiles; the launcher pads gridDim.x to a multiple of 8 so that every XCD has enough workgroups.
     const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
     const unsigned xcd = lin & 7u, j = lin >> 3;
-    const unsigned groups = 8u / ns, t_act = (unsigned)(slots_act / IMF_TILE_ROWS) * HPT;   // (units)
+    const unsigned groups = 8u / ns, t_act = (unsigned)((slots_act + UR - 1) / UR);   // (units)
     const unsigned chunk = (t_act + groups - 1) / groups;
     y = (int)(xcd % ns);
     if (j >= chunk) return;
@@ -131,16 +134,19 @@ k_spconv_w(const ConvParams p) {
     y = (int)(xcd % ns);
     tile = (int)(j * (8u / ns) + xcd / ns);
   }
-  const int r_off = (tile % HPT) * (16 * RB);        // first row of this workgroup inside its tile
-  tile /= HPT;
-  if ((long long)tile * IMF_TILE_ROWS >= slots_act) return;
+  const long long row0 = (long long)tile * UR;       // (`tile` is the UNIT index up to here) first slot of this workgroup
+  if (row0 >= slots_act) return;
+  const long long last = row0 + UR - 1 < slots_act - 1 ? row0 + UR - 1 : slots_act - 1;
+  tile = (int)(row0 / IMF_TILE_ROWS);
+  const int tile_b = (int)(last / IMF_TILE_ROWS);    // != tile only for units that ignore the tile boundaries (RB 3)
   if (IMF_W_ABL & 8) return;
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cin = p.c_a + (CAT ? p.c_b : 0);
   const int ncc = cin / 32;
 
-  const uint32_t m = p.tile_mask ? p.tile_mask[tile * IMF_MASK_WORDS] : 1u;      // kvol == 1: offset 0, every tile
+  uint32_t m = p.tile_mask ? p.tile_mask[tile * IMF_MASK_WORDS] : 1u;            // kvol == 1: offset 0, every tile
+  if (RB == 3 && p.tile_mask && tile_b != tile) m |= p.tile_mask[tile_b * IMF_MASK_WORDS];
   const int nk = __builtin_popcount(m);
   if (nk == 0) return;                               // padding tile
   if (tid < 32 && ((m >> tid) & 1u)) klist[__builtin_popcount(m & ((1u << tid) - 1u))] = tid;
@@ -150,7 +156,8 @@ k_spconv_w(const ConvParams p) {
     constexpr int JSTEP = NT / IMF_TILE_ROWS;        // offsets covered per pass of the workgroup: 8 / 4
     constexpr int kPer = (kKCache + JSTEP - 1) / JSTEP;
     const int srow = tid & 63, j0 = tid >> 6;
-    const long long slot = (long long)tile * IMF_TILE_ROWS + srow;
+    const bool in_unit = srow < UR && row0 + srow < slots_act;      // (table rows beyond the unit: "no input")
+    const long long slot = in_unit ? row0 + srow : row0;
     int v[kPer];
     if (p.nbr) {
       const int32_t *const src = p.nbr + slot;
@@ -178,7 +185,7 @@ k_spconv_w(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       const int j = j0 + JSTEP * i;
-      if (j < nk) nbr_lds[j * IMF_TILE_ROWS + srow] = v[i] >= 0 ? (unsigned)v[i] : kNoRowW;
+      if (j < nk) nbr_lds[j * IMF_TILE_ROWS + srow] = (v[i] >= 0 && in_unit) ? (unsigned)v[i] : kNoRowW;
       else if (j == kDummyJkW) nbr_lds[j * IMF_TILE_ROWS + srow] = kNoRowW;
     }
   }
@@ -210,7 +217,7 @@ k_spconv_w(const ConvParams p) {
   struct Rows { unsigned r[4]; };
 #define IMF_W_ROWS(dst, e)                                                                                         \
   {                                                                                                                \
-    const unsigned *const base_ = nbr_lds + ((((unsigned)(e)) >> 9) & 31u) * IMF_TILE_ROWS + r_off + row_w;        \
+    const unsigned *const base_ = nbr_lds + ((((unsigned)(e)) >> 9) & 31u) * IMF_TILE_ROWS + row_w;                \
     _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) (dst).r[b_] = w_lds_u32(base_ + 16 * b_);                    \
   }
   // LDS-DMA of one sub-stage into the wavefront's region: 8 KiB of weights verbatim, 64 rows x 128 B as 8 images
@@ -441,11 +448,12 @@ k_spconv_w(const ConvParams p) {
         }
   }
   __syncthreads();
-  constexpr int PT = 256 * RB / NT;                  // float4 per thread: 2 (W 8) / 4 (W 4)
+  constexpr int PT = (256 * RB + NT - 1) / NT;       // float4 per thread: 2 (W 8) / 4 (W 4)
   const float un = p.w_unscale ? *p.w_unscale : 1.f;
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int idx = i * NT + tid, row = idx >> 4, c4 = idx & 15;
+    if ((256 * RB) % NT != 0 && idx >= 256 * RB) break;
     const int col = y * 64 + 4 * c4;
     const int phys = row * 16 + (c4 ^ (((row >> 2) & 1) << 2));
     float4 s = w_lds16(&smem[phys]);
@@ -454,7 +462,7 @@ k_spconv_w(const ConvParams p) {
       const float4 v = w_lds16(&smem[w * REG_F4 + phys]);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    const int orow = row_of_slot(p, (long long)tile * IMF_TILE_ROWS + r_off + row);
+    const int orow = row0 + row < slots_act ? row_of_slot(p, row0 + row) : -1;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + col);
     if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + col);
@@ -489,10 +497,12 @@ k_spconv_w(const ConvParams p) {
 
 // grid = (tiles, cout / 64); `waves` = 8 (512 threads, one workgroup per CU) or 4 (256 threads, two per CU)
 void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st, int use) {
-  // use bit 1: half-tile workgroups (RB 2; bf16x3 with 4 wavefronts only)
+  // use bit 1: half-tile workgroups (RB 2; bf16x3 with 4 wavefronts only); bit 2: 48-row units (RB 3; bf16x3, 8 wavefronts)
   const bool half = (use & 2) != 0 && waves == 4 && p_in.arith == kArBf16x3;
+  const bool u48 = (use & 4) != 0 && waves == 8 && p_in.arith == kArBf16x3 && !half;
   use &= 1;
   if (half) tiles *= 2;
+  if (u48) tiles = (tiles * 4u + 2u) / 3u;
   // w_xcd 1 = slab by XCD, tiles interleaved (pair step 1.092 -> 1.074 ms, round 3); 2 = slab by XCD AND one range of
   // consecutive tiles per XCD (0.953 -> 0.940 ms on top: the XCD's L2 serves a fraction of the input rows)
   const int xcd_env = 2;
@@ -520,6 +530,10 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
   else if (half) {
     if (cat) k_spconv_w<true, 4, kArBf16x3, 0, 2><<<grid, 256, 0, st>>>(p);
     else     k_spconv_w<false, 4, kArBf16x3, 0, 2><<<grid, 256, 0, st>>>(p);
+  }
+  else if (u48) {
+    if (cat) k_spconv_w<true, 8, kArBf16x3, 0, 3><<<grid, 512, 0, st>>>(p);
+    else     k_spconv_w<false, 8, kArBf16x3, 0, 3><<<grid, 512, 0, st>>>(p);
   }
   else if (ar == kArBf16x3) IMF_W_LAUNCH(kArBf16x3);
   else if (ar == kArF16x2Pre) IMF_W_LAUNCH(kArF16x2Pre);
