@@ -183,7 +183,8 @@ int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int vari
   // RB 3; a unit walks the union of its two tiles' offset lists) are 46 x 4 = 184 workgroups of 3 / 4 of the work: the
   // 256 -> 256 layer 67.7 -> 52.2 us, 128 -> 256 38.1 -> 29.5, pair step 1.246 -> 1.215 ms (A/B/A/B on one box).  The stride-4
   // level (120 tiles x 2 slabs = 240 workgroups already) loses with them (41 -> 58 us).
-  if (variant == 3 && level == 3 && (n_items == 2 || n_items == 3)) return 4 | 128;
+  // (the same on fp32 MFMA: 115.7 -> 91.2 us, step 2.00 -> 1.92 ms; split-f16: 38.6 -> 33.7 us, 0.940 -> 0.933 ms)
+  if (level == 3 && (n_items == 2 || n_items == 3)) return 4 | 128;
   // measured on the S50k pair (profiles/r03_conv_isolated.txt, r05_conv_isolated_*.txt): level 1 (438 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
   return level == 1 ? 8 : 4;

@@ -90,18 +90,18 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 // 272 half-tile workgroups of 4 wavefronts (40 KiB of LDS: up to three per CU) every CU works.  The rulebook is untouched --
 // a half tile walks its tile's offset list (the tile's mask is a superset of the half's) -- and a row's sums depend on
 // (W, the tile's offset list) only, as before.
-// RB 3 = 48-row UNITS that ignore the tile boundaries (unit u = slots 48 u .. 48 u + 47; it walks the union of the offset
+// RB 3 (every arithmetic) = 48-row UNITS that ignore the tile boundaries (unit u = slots 48 u .. 48 u + 47; it walks the union of the offset
 // lists of the one or two tiles it touches): 2 176 rows are 46 units instead of 34 tiles, x 4 slabs = 184 workgroups with
 // 3 / 4 of a tile's work each.
 template <bool CAT, int W, int AR = kArF16x2, int USE = 0, int RB = 4>
 __global__ void __launch_bounds__(64 * W, RB == 2 ? 3 : 2)
 k_spconv_w(const ConvParams p) {
-  static_assert(RB == 4 || ((RB == 2 || RB == 3) && AR == kArBf16x3), "part tiles: bf16x3 only (its weights need no LDS region)");
+  static_assert(RB == 4 || RB == 3 || (RB == 2 && AR == kArBf16x3), "half tiles: bf16x3 only (its weights need no LDS region)");
   constexpr int UR = 16 * RB;                        // rows (slots) per workgroup: the UNIT
   constexpr bool PRE = AR == kArF16x2Pre;
   constexpr unsigned SUB_BYTES = AR == kArBf16x3 ? 12288u : 8192u;   // weight image bytes per (offset, 32-channel) sub-stage
   constexpr int NT = 64 * W;
-  constexpr int REG_F4 = RB == 4 ? 1024 : 256 * RB;  // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512 (part tiles, bf16x3: rows 128 RB; the partial tile 256 RB)
+  constexpr int REG_F4 = (RB == 4 || AR != kArBf16x3) ? 1024 : 256 * RB;  // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512 (part tiles, bf16x3: rows 128 RB; the partial tile 256 RB)
   constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
   constexpr int TAB_F4 = (kSubTab + 3) / 4;
   constexpr int KL_F4 = (kKCache + 3) / 4;
@@ -499,7 +499,7 @@ k_spconv_w(const ConvParams p) {
 void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st, int use) {
   // use bit 1: half-tile workgroups (RB 2; bf16x3 with 4 wavefronts only); bit 2: 48-row units (RB 3; bf16x3, 8 wavefronts)
   const bool half = (use & 2) != 0 && waves == 4 && p_in.arith == kArBf16x3;
-  const bool u48 = (use & 4) != 0 && waves == 8 && p_in.arith == kArBf16x3 && !half;
+  const bool u48 = (use & 4) != 0 && waves == 8 && !half;
   use &= 1;
   if (half) tiles *= 2;
   if (u48) tiles = (tiles * 4u + 2u) / 3u;
@@ -526,14 +526,22 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
       else     k_spconv_w<false, 4, AR><<<grid, 256, 0, st>>>(p);           \
     }                                                                       \
   } while (0)
-  if (ar == kArF32) IMF_W_LAUNCH(kArF32);
+  if (ar == kArF32 && !u48) IMF_W_LAUNCH(kArF32);
   else if (half) {
     if (cat) k_spconv_w<true, 4, kArBf16x3, 0, 2><<<grid, 256, 0, st>>>(p);
     else     k_spconv_w<false, 4, kArBf16x3, 0, 2><<<grid, 256, 0, st>>>(p);
   }
   else if (u48) {
-    if (cat) k_spconv_w<true, 8, kArBf16x3, 0, 3><<<grid, 512, 0, st>>>(p);
-    else     k_spconv_w<false, 8, kArBf16x3, 0, 3><<<grid, 512, 0, st>>>(p);
+#define IMF_W_LAUNCH_U(AR)                                                  \
+  do {                                                                      \
+    if (cat) k_spconv_w<true, 8, AR, 0, 3><<<grid, 512, 0, st>>>(p);        \
+    else     k_spconv_w<false, 8, AR, 0, 3><<<grid, 512, 0, st>>>(p);       \
+  } while (0)
+    if (ar == kArF32) IMF_W_LAUNCH_U(kArF32);
+    else if (ar == kArBf16x3) IMF_W_LAUNCH_U(kArBf16x3);
+    else if (ar == kArF16x2Pre) IMF_W_LAUNCH_U(kArF16x2Pre);
+    else IMF_W_LAUNCH_U(kArF16x2);
+#undef IMF_W_LAUNCH_U
   }
   else if (ar == kArBf16x3) IMF_W_LAUNCH(kArBf16x3);
   else if (ar == kArF16x2Pre) IMF_W_LAUNCH(kArF16x2Pre);

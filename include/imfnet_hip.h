@@ -282,7 +282,7 @@ typedef struct imf_conv_args {
                              bit 6 (64), with bit 3 and variant 3 only: HALF-TILE workgroups -- each 4-wavefront workgroup
                              owns 32 of a tile's 64 rows (same offset list, same per-row sums as bit 3 alone): twice the
                              workgroups for levels that leave CUs idle (one fragment per forward).
-                             bit 7 (128), with bit 2 and variant 3 only: 48-ROW UNITS -- each 8-wavefront workgroup owns
+                             bit 7 (128), with bit 2: 48-ROW UNITS -- each 8-wavefront workgroup owns
                              slots 48 u .. 48 u + 47 whatever the tile boundaries and walks the union of the offset lists
                              of the tiles it touches (a pair's stride-8 level: 184 workgroups instead of 136) */
   int32_t *dyn_err;       /* optional device flag word (any mode): IMF_FLAG_SPLIT_COVER when the rule asks for more
@@ -550,8 +550,8 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
  * the value for imf_conv_args.kernel_tag.  Level 0 (thousands of 64-row tiles): k_spconv_g, unsplit (variant 3: the
  * wave-split kernel with 4 wavefronts and half-tile workgroups, kernel_tag 8 | 64, for the 64 -> 64 layers).  Level 1: the
  * wave-split kernel with 4 wavefronts per workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4); variant 3 with
- * ONE fragment in the forward (n_items == 1): half-tile workgroups of 4 wavefronts (8 | 64) on levels 1-3; with two or
- * three fragments: 48-row units (4 | 128) on level 3.  The choice is
+ * ONE fragment in the forward (n_items == 1): half-tile workgroups of 4 wavefronts (8 | 64) on levels 1-3; every variant
+ * with two or three fragments: 48-row units (4 | 128) on level 3.  The choice is
  * a function of the LEVEL, the layer's channel counts and the batch size only -- never of the row count -- so exact mode,
  * capacity mode and a graph replay form every sum in the
  * same order (bit-identical descriptors) without a device-side split rule; no executor launch uses split-K partitions
