@@ -184,7 +184,11 @@ int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int vari
   // 256 -> 256 layer 67.7 -> 52.2 us, 128 -> 256 38.1 -> 29.5, pair step 1.246 -> 1.215 ms (A/B/A/B on one box).  The stride-4
   // level (120 tiles x 2 slabs = 240 workgroups already) loses with them (41 -> 58 us).
   // (the same on fp32 MFMA: 115.7 -> 91.2 us, step 2.00 -> 1.92 ms; split-f16: 38.6 -> 33.7 us, 0.940 -> 0.933 ms)
-  if (level == 3 && (n_items == 2 || n_items == 3)) return 4 | 128;
+  // Larger batches too (units are 3 / 4 of a tile: shorter tails): four fragments per forward 2.197 -> 2.128 ms, eight
+  // 3.978 -> 3.858 ms; and from three fragments on the stride-4 level (>= 180 tiles x 2 slabs: more than one round of
+  // 8-wavefront workgroups) runs on 4-wavefront workgroups, two per CU: 2.128 -> 2.089 ms and 3.858 -> 3.828 ms.
+  if (level == 3 && n_items >= 2) return 4 | 128;
+  if (level == 2 && n_items >= 3) return 8;
   // measured on the S50k pair (profiles/r03_conv_isolated.txt, r05_conv_isolated_*.txt): level 1 (438 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
   return level == 1 ? 8 : 4;

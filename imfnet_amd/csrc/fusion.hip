@@ -350,7 +350,7 @@ static int run_feed_forward(const imf_fusion_weights *w, long long n, const int3
     memset(&a, 0, sizeof(a));
     a.in_a = g; a.c_a = kFH; a.w_packed = w->w2_f32; a.kvol = 1; a.cout = kFD;
     a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = 0;
-    a.kernel_tag = (n_items == 2 || n_items == 3) ? (4 | 128) : 4;   // wave-split like the launch below (AR = kArF32)
+    a.kernel_tag = n_items >= 2 ? (4 | 128) : 4;   // wave-split like the launch below (AR = kArF32)
     a.n_out_dev = n_dev; a.dyn_err = err;
     return imf_spconv_fwd(&a, st);
   }
@@ -370,7 +370,7 @@ static int run_feed_forward(const imf_fusion_weights *w, long long n, const int3
   a.n_slots = slots; a.n_out = n; a.shift = w->b2; a.residual = y; a.out = out; a.split_k = 1; a.variant = variant;
   // wave-split, 8 wavefronts: K = 1024 is 32 sub-stages per tile; one fragment per forward on bf16x3 (17 tiles x 4 slabs):
   // half-tile workgroups of 4 wavefronts, a pair: 48-row units (imf_resunet_conv_kernel_tag's rules for the stride-8 level)
-  a.kernel_tag = (b3 && n_items == 1) ? (8 | 64) : (n_items == 2 || n_items == 3) ? (4 | 128) : 4;
+  a.kernel_tag = (b3 && n_items == 1) ? (8 | 64) : n_items >= 2 ? (4 | 128) : 4;
   a.n_out_dev = n_dev; a.dyn_err = err;              // z feeds conv4_tr (split-f16): range guard
   a.operand_format = b3 ? 0 : (IMF_FMT_A_SPLIT | (out_split ? IMF_FMT_OUT_SPLIT : 0));
   return imf_spconv_fwd(&a, st);

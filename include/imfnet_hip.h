@@ -551,7 +551,7 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
  * wave-split kernel with 4 wavefronts and half-tile workgroups, kernel_tag 8 | 64, for the 64 -> 64 layers).  Level 1: the
  * wave-split kernel with 4 wavefronts per workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4); variant 3 with
  * ONE fragment in the forward (n_items == 1): half-tile workgroups of 4 wavefronts (8 | 64) on levels 1-3; every variant
- * with two or three fragments: 48-row units (4 | 128) on level 3.  The choice is
+ * with two or more fragments: 48-row units (4 | 128) on level 3, and from three fragments on 4 wavefronts on level 2.  The choice is
  * a function of the LEVEL, the layer's channel counts and the batch size only -- never of the row count -- so exact mode,
  * capacity mode and a graph replay form every sum in the
  * same order (bit-identical descriptors) without a device-side split rule; no executor launch uses split-K partitions
