@@ -90,6 +90,9 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 // 272 half-tile workgroups of 4 wavefronts (40 KiB of LDS: up to three per CU) every CU works.  The rulebook is untouched --
 // a half tile walks its tile's offset list (the tile's mask is a superset of the half's) -- and a row's sums depend on
 // (W, the tile's offset list) only, as before.
+// (RB 1, quarter tiles of 4 wavefronts -- 94 VGPRs, 24 KiB -- was built and measured too: slower than half tiles for a single
+// fragment on every level (sum of the wave-split shapes 304 -> 379 us, forward 0.867 -> 0.912 ms) and than 48-row units
+// for a pair's stride-8 level (52 -> 84 us): each workgroup streams its slab's whole weight image for 16 rows.)
 // RB 3 (every arithmetic) = 48-row UNITS that ignore the tile boundaries (unit u = slots 48 u .. 48 u + 47; it walks the union of the offset
 // lists of the one or two tiles it touches): 2 176 rows are 46 units instead of 34 tiles, x 4 slabs = 184 workgroups with
 // 3 / 4 of a tile's work each.
