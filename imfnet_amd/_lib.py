@@ -160,6 +160,8 @@ SIGNATURES = {
     "imf_ply_read_points": (_L, [C.c_char_p, _P, _L]),
     "imf_png_info": (_I, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "imf_png_read_f32": (_I, [C.c_char_p, _P, _L, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "imf_jpeg_info": (_I, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "imf_jpeg_read_u8": (_I, [C.c_char_p, _P, _L, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "imf_resize_bilinear_f32": (_I, [_P, _I, _I, _I, _P, _I, _I, _I]),
     "imf_npz_write": (_I, [C.c_char_p, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
                            C.POINTER(C.c_int64), C.POINTER(C.c_void_p), _I]),

@@ -89,6 +89,16 @@ def read_image(path):
             rc = L.imf_png_read_f32(p, out.ctypes.data_as(C.c_void_p), out.size, C.byref(h), C.byref(w), C.byref(c))
             if rc == 0:
                 return out[:, :, 0] if c.value == 1 else out          # matplotlib returns [H,W] for grey images
+    elif os.path.splitext(path)[1].lower() in (".jpg", ".jpeg"):
+        # the native decoder (csrc/jpeg.hip): baseline YCbCr files, bit-identical to PIL; anything else -> PIL below
+        import ctypes as C
+        L = _native()
+        p = os.fsencode(path)
+        h, w, c = C.c_int(), C.c_int(), C.c_int()
+        if L.imf_jpeg_info(p, C.byref(h), C.byref(w), C.byref(c)) == 0:
+            out = np.empty((h.value, w.value, 3), dtype=np.uint8)
+            if L.imf_jpeg_read_u8(p, out.ctypes.data_as(C.c_void_p), out.size, C.byref(h), C.byref(w), C.byref(c)) == 0:
+                return out
     return read_image_pil(path)
 
 

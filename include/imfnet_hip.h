@@ -795,6 +795,14 @@ int imf_png_info(const char *path, int *h, int *w, int *channels);
 /* matplotlib.image.imread of a .png: float32 [H,W,C] in [0,1] (8-bit / 255, 16-bit / 65535, palette -> RGB).
  * IMF_EUNSUPPORTED for interlaced or sub-byte files (callers fall back to a generic decoder). */
 int imf_png_read_f32(const char *path, float *out, int64_t capacity_floats, int *h, int *w, int *channels);
+
+/* matplotlib.image.imread of a .jpg (scripts/generate_desc.py:88-92: PIL = libjpeg's defaults, integer "islow" inverse DCT
+ * and fancy chroma upsampling): uint8 [H, W, 3].  Baseline / extended sequential Huffman files with three YCbCr components in
+ * one scan, 4:4:4 / 4:2:2 / 4:2:0, restart intervals: bit-identical to PIL (tests/test_cabi_and_host.py).  IMF_EUNSUPPORTED
+ * for everything else a JPEG file may hold (progressive, arithmetic, 12-bit, grey, CMYK, other sampling factors): callers
+ * fall back to a generic decoder.  [host] */
+int imf_jpeg_info(const char *path, int *h, int *w, int *channels);
+int imf_jpeg_read_u8(const char *path, uint8_t *out, int64_t capacity_bytes, int *h, int *w, int *channels);
 /* cv2.resize(INTER_LINEAR) for float images [H,W,C]; chw != 0 writes [C,H_out,W_out] (generate_desc.py:96-97). */
 int imf_resize_bilinear_f32(const float *in, int H, int W, int C, float *out, int H_out, int W_out, int chw);
 /* np.savez (level 0) / np.savez_compressed (level 1..9, raw deflate) of n_arrays C-ordered arrays: names[i] (member

@@ -332,6 +332,75 @@ def test_native_ply_reader(tmp_path, clouds, fmt, dtype):
         dataio.read_ply_points(str(tmp_path / "missing.ply"))
 
 
+def test_native_jpeg_decoder_equals_pil(tmp_path):
+    """The `.jpg` branch (scripts/generate_desc.py:88-92: matplotlib.image.imread = PIL = libjpeg's defaults): the native
+    baseline decoder (csrc/jpeg.hip: integer islow inverse DCT, fancy chroma upsampling, fixed-point YCbCr -> RGB) returns PIL's
+    bytes exactly -- 4:4:4 / 4:2:2 / 4:2:0, qualities 5-100, odd and degenerate sizes (components one or two samples wide are
+    replicated, not filtered), restart intervals, optimised tables, saturating noise; what it does not cover (progressive)
+    answers IMF_EUNSUPPORTED and read_image falls back to PIL; truncated / corrupt files are errors, not crashes."""
+    import ctypes as C
+    from PIL import Image
+    from imfnet_amd import _lib, dataio
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    path = str(tmp_path / "t.jpg")
+
+    def picture(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 100 * np.sin(x / 17.0 + y / 23.0), 127 + 90 * np.cos(x / 9.0) * np.sin(y / 31.0), (x * 3 + y * 5) % 256], -1)
+        return np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+
+    def native(p):
+        h, w, c = C.c_int(), C.c_int(), C.c_int()
+        rc = L.imf_jpeg_info(os.fsencode(p), C.byref(h), C.byref(w), C.byref(c))
+        if rc:
+            return rc, None
+        out = np.empty((h.value, w.value, 3), np.uint8)
+        rc = L.imf_jpeg_read_u8(os.fsencode(p), out.ctypes.data_as(C.c_void_p), out.size, C.byref(h), C.byref(w), C.byref(c))
+        return rc, out
+
+    n = 0
+    for h, w in ((480, 640), (37, 53), (1, 1), (33, 2), (33, 3), (33, 5), (2, 33), (5, 6), (64, 48)):
+        img = picture(h, w)
+        for q in (5, 30, 75, 95, 100):
+            for ss in (0, 1, 2):
+                for kw in ({}, {"restart_marker_blocks": 2}, {"optimize": True}):
+                    try:
+                        Image.fromarray(img).save(path, quality=q, subsampling=ss, **kw)
+                    except OSError:                      # (PIL's encoder buffer on a few tiny / quality-100 cases)
+                        continue
+                    rc, got = native(path)
+                    assert rc == 0, (h, w, q, ss, kw, L.imf_last_error())
+                    assert np.array_equal(got, np.asarray(Image.open(path))), (h, w, q, ss, kw)
+                    n += 1
+    assert n > 300
+    noise = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    for q in (10, 50, 100):
+        for ss in (0, 1, 2):
+            Image.fromarray(noise).save(path, quality=q, subsampling=ss)
+            rc, got = native(path)
+            assert rc == 0 and np.array_equal(got, np.asarray(Image.open(path)))
+    assert np.array_equal(dataio.read_image(path), np.asarray(Image.open(path)))           # the harness entry: uint8 HWC
+    # not covered natively -> IMF_EUNSUPPORTED, read_image decodes with PIL
+    Image.fromarray(picture(64, 64)).save(path, quality=80, progressive=True)
+    assert native(path)[0] == -3 and b"progressive" in L.imf_last_error()
+    assert np.array_equal(dataio.read_image(path), np.asarray(Image.open(path)))
+    Image.fromarray(picture(64, 64)[:, :, 0]).save(path, quality=80)                          # grey: one component
+    assert native(path)[0] == -3
+    # truncated and corrupted streams: an error code (or a decoded picture), never a crash
+    Image.fromarray(picture(120, 160)).save(path, quality=75)
+    data = open(path, "rb").read()
+    for cut in (1, 3, 20, 200, len(data) // 2):
+        open(path, "wb").write(data[:cut])
+        assert native(path)[0] != 0 or cut > 200
+    for k in range(40):
+        b = bytearray(data)
+        for pos in rng.integers(2, len(b), 8):
+            b[pos] = int(rng.integers(0, 256))
+        open(path, "wb").write(bytes(b))
+        native(path)
+
+
 def test_native_png_reader_and_resize(tmp_path):
     """imf_png_read_f32 == matplotlib's imread semantics as PIL decodes them (8/16-bit, RGB / RGBA / grey / palette, every
     scan-line filter via real image content), interlaced files fall back; imf_resize_bilinear_f32 == the torch bilinear."""
