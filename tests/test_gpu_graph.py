@@ -107,6 +107,22 @@ def test_graph_batched_pair_equals_exact(model, clouds, images):
     assert res.flags == 0 and res.counts == counts and torch.equal(res.F, F)
 
 
+@pytest.mark.parametrize("nb", [3, 4])
+def test_graph_batches_of_three_and_four_equal_exact(model, clouds, images, nb):
+    """The executors' kernel policy depends on the batch size (imf_resunet_conv_kernel_tag: 48-row units on the stride-8 level
+    from two fragments on, 4-wavefront workgroups on the stride-4 level from three on): capacity mode must still equal the exact
+    path bit for bit, because the batch size is static in both."""
+    pts = [clouds[k % 2].astype(np.float64) * (1.0 + 0.07 * k) for k in range(nb)]
+    imgs = np.concatenate([images[k % 2] for k in range(nb)], 0)
+    F, inds, counts, bbox, items, coords = _exact(model, pts, imgs, 0.025)
+    r = _runner(model)
+    r.observe(sum(len(p) for p in pts), counts, bbox)
+    xyz, starts = _cat(pts)
+    res = r.run(xyz, starts, torch.as_tensor(imgs).to(DEV), 0.025, stream=torch.cuda.Stream())
+    assert res.flags == 0 and res.counts == counts and res.items(0) == [tuple(i) for i in items]
+    assert torch.equal(res.F, F) and torch.equal(res.first_idx, inds)
+
+
 def test_capacity_overflow_is_flagged(model, clouds, images):
     """Rows beyond a level's capacity: count clamped, flag 2 raised (never a silent wrong result or a fault)."""
     pts = [clouds[0].astype(np.float64)]
