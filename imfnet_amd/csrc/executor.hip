@@ -189,6 +189,10 @@ int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int vari
   // 8-wavefront workgroups) runs on 4-wavefront workgroups, two per CU: 2.128 -> 2.089 ms and 3.858 -> 3.828 ms.
   if (level == 3 && n_items >= 2) return 4 | 128;
   if (level == 2 && n_items >= 3) return 8;
+  // the decoder's up-convolutions (cin > cout: conv3_tr 256 -> 64, conv4_tr 256 -> 128): their tiles are grouped by parity
+  // class and walk 1-8 offsets -- short loops, so twice the workgroups help: half tiles 36.1 -> 31.7 us and 24.4 -> 21.8 us
+  // in isolation, pair step -0.8 % (A/B/A/B on one box)
+  if (variant == 3 && cin > cout) return 8 | 64;
   // measured on the S50k pair (profiles/r03_conv_isolated.txt, r05_conv_isolated_*.txt): level 1 (438 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
   return level == 1 ? 8 : 4;
