@@ -396,6 +396,7 @@ class Workload:
         self.runner = self.bucket = None
         self.stream = torch.cuda.Stream(device=dev)
         self.replicas, self._turn = [], 0
+        self.buckets, self._done, self.pipelined = [], [], False
 
     def exact_step(self):
         """Round 1's path: geometry stream + one count readback + native executor."""
@@ -405,9 +406,12 @@ class Workload:
             self.last_st = st
             return self.model(st, self.img).F
 
-    def prepare_graph(self, replicate=False):
+    def prepare_graph(self, replicate=False, pipelined=False):
         """Capacity bucket from one exact step's counts; inputs staged in the bucket's static buffers.  replicate: the
-        points additionally as enough device copies to exceed the Infinity Cache; every step reads the next one."""
+        points additionally as enough device copies to exceed the Infinity Cache; every step reads the next one.
+        pipelined: TWO buckets of the same capacities, steps alternate between them and step k + 1's head (table reset,
+        level-0 pyramid, image fork: ~60 us) is issued on the side stream, under step k's decoder -- what the streaming
+        pipeline does with consecutive forwards (imf_fragment_io.head_on_side); same kernels, same results."""
         F = self.exact_step()
         torch.cuda.synchronize()
         cm = self.last_st.coordinate_manager
@@ -423,19 +427,40 @@ class Workload:
         self.stream = r.main_stream(self.dev)            # capacity-mode forwards run on the runner's own main stream
         b = self.bucket = r.bucket(key, self.dev, self.stream)
         self.n_points = r.stage(b, self.xyz, self.starts, self.img, self.stream)
+        self.buckets, self._done, self.pipelined = [b], [None], bool(pipelined)
+        if pipelined:
+            b1 = r.bucket(key, self.dev, self.stream, lane=1)
+            assert r.stage(b1, self.xyz, self.starts, self.img, self.stream) == self.n_points
+            self.buckets.append(b1)
+            self._done.append(None)
         if replicate:
             nbytes = self.xyz.numel() * self.xyz.element_size()
             self.replicas = [self.xyz.clone() for _ in range(max(2, -(-self.MALL_BYTES // nbytes)))]
             self._home = b.io.xyz
+            self._homes = [bb.io.xyz for bb in self.buckets]
         return F
 
     def graph_step(self, trace_list=None):
+        pipe = self.pipelined and not self.runner.use_graph and trace_list is None
+        k = self._turn % len(self.buckets) if pipe else 0
+        b = self.buckets[k] if self.buckets else self.bucket
         if self.replicas and not self.runner.use_graph:  # (a captured graph has the bucket's own buffer baked in)
-            self.bucket.io.xyz = self.replicas[self._turn % len(self.replicas)].data_ptr()
-            self._turn += 1
+            b.io.xyz = self.replicas[self._turn % len(self.replicas)].data_ptr()
         elif self.replicas:
-            self.bucket.io.xyz = self._home
-        res = self.runner.launch(self.bucket, self.n_points, len(self.starts), self.stream, trace_list=trace_list)
+            b.io.xyz = self._homes[k]
+        self._turn += 1
+        reuse = None
+        if pipe:
+            # the end of this bucket's previous forward (two steps ago): nothing else reads its buffers in the bench
+            reuse = self._done[k]
+            if reuse is None:
+                reuse = torch.cuda.Event()
+                reuse.record(self.stream)
+        res = self.runner.launch(b, self.n_points, len(self.starts), self.stream, trace_list=trace_list, reuse_event=reuse)
+        if pipe:
+            e = torch.cuda.Event()
+            e.record(self.stream)
+            self._done[k] = e
         self.last_res = res
         return res
 
@@ -646,11 +671,14 @@ def main():
                     help="fragments per forward: 2 = the in-tree fragment PAIR (cloud_bin_0 + cloud_bin_1, one image "
                          "each) as ONE batched sparse tensor, the batched call of model/resunet.py:241-250; 4 / 8: the pair "
                          "repeated (IMF_MAX_BATCH = 8)")
-    ap.add_argument("--mode", default="auto", choices=("auto", "capacity", "graph", "exact"),
-                    help="capacity: imf_fragment_forward per step (device-side counts, no host readback); graph: the same "
-                         "as one hipGraph replay; auto (default): both are timed after the clocks have settled and the faster "
-                         "one runs the timed region (config.capacity_mode.picked says which); exact: count readback + native "
-                         "executor")
+    ap.add_argument("--mode", default="auto", choices=("auto", "capacity", "pipelined", "graph", "exact"),
+                    help="capacity: imf_fragment_forward per step (device-side counts, no host readback), one bucket: every step "
+                         "queues behind the previous one; pipelined: the same launches over TWO buckets, step k + 1's head "
+                         "(table reset, level-0 pyramid, image fork) on the side stream under step k's decoder, as the streaming "
+                         "pipeline issues consecutive forwards; graph: one hipGraph replay per step; auto (default): all three "
+                         "are timed after the clocks have settled and the fastest runs the timed region "
+                         "(config.capacity_mode.picked says which, probe_ms_per_step has all of them); exact: count readback + "
+                         "native executor")
     ap.add_argument("--repeats", type=int, default=9,
                     help="the timed region (exactly --steps steps between barrier + synchronize) is repeated this many times; "
                          "ms_per_step / value are the MEDIAN repeat, min and max are reported beside it")
@@ -708,10 +736,11 @@ def main():
     graph_info = None
     with torch.no_grad():
         dyn = args.mode != "exact"
-        F_exact = wl.prepare_graph(replicate=True).clone() if dyn else None
+        F_exact = wl.prepare_graph(replicate=True, pipelined=True).clone() if dyn else None
         step = (lambda tl=None: wl.graph_step(tl)) if dyn else (lambda tl=None: wl.exact_step())
         if dyn:
             wl.runner.use_graph = args.mode == "graph"
+            wl.pipelined = args.mode == "pipelined"
         for _ in range(args.warmup):
             out = step()
         sync()
@@ -726,16 +755,17 @@ def main():
             settle_steps += 10
 
         picked = {"mode": args.mode}
-        if args.mode == "auto":                           # eager capacity-mode launches vs ONE hipGraph replay: measure, pick
-            probe = {}
+        if args.mode == "auto":                           # eager capacity-mode launches (one bucket / two, pipelined) vs ONE
+            probe = {}                                    # hipGraph replay: measure, pick
             for rnd in range(2):                          # interleaved rounds; the capture happens in round 0's warm-up
-                for name, ug in (("capacity", False), ("graph", True)):
-                    wl.runner.use_graph = ug
-                    for _ in range(3):
+                for name, ug, pl in (("capacity", False, False), ("pipelined", False, True), ("graph", True, False)):
+                    wl.runner.use_graph, wl.pipelined = ug, pl
+                    for _ in range(4):
                         step()
+                    sync()
                     probe.setdefault(name, []).append(timed(step, max(10, args.steps), sync) * 1e3)
             best = min(probe, key=lambda k: min(probe[k]))
-            wl.runner.use_graph = best == "graph"
+            wl.runner.use_graph, wl.pipelined = best == "graph", best == "pipelined"
             picked = {"mode": "auto", "picked": best,
                       "probe_ms_per_step": {k: [round(v, 4) for v in vs] for k, vs in probe.items()}}
             for _ in range(3):
@@ -751,7 +781,8 @@ def main():
             F_ref = out.F.clone()
             same = bool(torch.equal(F_ref, F_exact))
             assert float((F_ref - F_exact).abs().max()) < 1e-5, "graph path differs from the exact path"
-            graph_info = {"hipgraph_replay": bool(wl.runner.use_graph), "graph_nodes": wl.bucket.n_nodes,
+            graph_info = {"hipgraph_replay": bool(wl.runner.use_graph), "pipelined_over_two_buckets": bool(wl.pipelined),
+                          "graph_nodes": wl.bucket.n_nodes,
                           "equals_exact_path_bitwise": same, "host_readbacks_per_step": 0,
                           "capacities": {"points": wl.bucket.caps.n_points, "rows": list(wl.bucket.caps.rows)},
                           "input_replicas": len(wl.replicas), **picked}
@@ -843,7 +874,7 @@ def main():
             roofline = build_roofline(groups, args.arith, traced_steps, elapsed / args.steps * 1e3, iso_groups)
             if world == 1 and not args.no_extras:
                 extras = extra_legs(model, dev, args, sync)
-                arithmetics = other_arithmetics(dev, args, sync, F_ref)
+                arithmetics = other_arithmetics(dev, args, sync, F_ref, pipelined=bool(wl.pipelined))
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(xyz1, img1, voxel, sd)
@@ -886,6 +917,13 @@ def main():
                        "fragments_per_step": world * args.batch,
                        "execution": {"capacity": "one imf_fragment_forward call per step in capacity mode: device-side row counts, "
                                                  "no host readback, launches issued natively on three streams",
+                                     "pipelined": "one imf_fragment_forward call per step in capacity mode (device-side row counts, no "
+                                                  "host readback, launches issued natively on three streams); consecutive steps "
+                                                  "alternate between TWO capacity buckets and a step's head (table reset, level-0 "
+                                                  "pyramid, image fork: ~60 us) is issued on the side stream, under the previous "
+                                                  "step's decoder -- the order in which the streaming pipeline issues consecutive "
+                                                  "forwards (imf_fragment_io.head_on_side); every step is complete when the timed "
+                                                  "region ends; the one-bucket step time is capacity_mode.probe_ms_per_step.capacity",
                                      "graph": "one hipGraph replay per step of imf_fragment_forward in capacity mode",
                                      "exact": "exact mode: row-count readback + native executor (imf_resunet_forward)"}[run_mode],
                        "capacity_mode": graph_info,
@@ -1013,7 +1051,7 @@ def extra_legs(model, dev, args, sync):
     return out
 
 
-def other_arithmetics(dev, args, sync, F_headline):
+def other_arithmetics(dev, args, sync, F_headline, pipelined=False):
     """The same pair step on the arithmetics the headline does NOT run, each measured like the headline: capacity mode
     (imf_fragment_forward, no readback), exactly --steps steps between synchronize per repeat, median of 5 repeats after a
     settle, input replicas beyond the Infinity Cache; then three traced steps -> its own `roofline` (dominant kernel, useful
@@ -1031,7 +1069,7 @@ def other_arithmetics(dev, args, sync, F_headline):
             m, _ = build_model(dev, variant=A["variant"])
             wl = Workload(m, dev, pts2 * (args.batch // 2) if args.batch >= 2 else pts2[:1],
                           np.concatenate([imgs2] * (args.batch // 2), 0) if args.batch >= 2 else imgs2[:1], args.voxel)
-            F_exact = wl.prepare_graph(replicate=True).clone()
+            F_exact = wl.prepare_graph(replicate=True, pipelined=pipelined).clone()
             assert wl.runner.variant == A["variant"]
             wl.runner.use_graph = False
             t_s = time.perf_counter()

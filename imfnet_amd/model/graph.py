@@ -211,13 +211,19 @@ class _Bucket:
             self._first_view = self.pyr[off:off + 4 * self.caps.rows[0]].view(torch.int32)
         return self._first_view
 
-    def enqueue(self, runner, stream, trace=None):
-        """All launches of one fragment on `stream` (+ the bucket's side / image streams), eagerly."""
+    def enqueue(self, runner, stream, trace=None, reuse_event=None):
+        """All launches of one fragment on `stream` (+ the bucket's side / image streams), eagerly.
+        reuse_event (a recorded torch.cuda.Event, or None): the forwards of SEVERAL buckets are issued back to back on one
+        main stream and this one's head (table reset, level-0 pyramid, image fork) goes to the side stream, under the
+        previous forward's decoder (imf_fragment_io.head_on_side) -- the event marks the end of everything that still
+        touches THIS bucket's buffers (its own previous forward and whatever read its outputs); inputs are in place."""
         self.io.main_stream = stream.cuda_stream
         self.io.trace = trace
-        # (the streaming pipeline shares these buckets and sets head_on_side per job: a direct launch inherits the main
-        # stream's order instead -- the bucket's previous forward may still be running on it)
+        # (the streaming pipeline shares these buckets and sets head_on_side per job: a plain direct launch inherits the
+        # main stream's order instead -- the bucket's previous forward may still be running on it)
         self.io.head_on_side, self.io.inputs_event, self.io.reuse_event = 0, None, None
+        if reuse_event is not None:
+            self.io.head_on_side, self.io.reuse_event = 1, C.c_void_p(reuse_event.cuda_event)
         check(self.L.imf_fragment_forward(C.byref(runner.net_desc), C.byref(runner.img_plan.desc), C.byref(self.caps),
                                           C.byref(self.io)), "imf_fragment_forward")
 
@@ -420,9 +426,10 @@ class FragmentRunner:
                 b.dyn_values = vals
         return n
 
-    def launch(self, b, n_points, n_items, stream, trace_list=None, meta_to=None):
+    def launch(self, b, n_points, n_items, stream, trace_list=None, meta_to=None, reuse_event=None):
         """One fragment on `stream`: graph replay (captured on first use) or eager capacity-mode launches (always
-        when `trace_list` is given: per-convolution HIP events are appended to it as ops.TRACE records)."""
+        when `trace_list` is given: per-convolution HIP events are appended to it as ops.TRACE records).
+        reuse_event: eager launches only -- this forward's head on the side stream (_Bucket.enqueue)."""
         from .. import ops
         from .plan import NativePlan, _RB
         fp32_buffers = 1 if os.environ.get("IMFNET_FP32_BUFFERS") == "1" else 0
@@ -437,7 +444,7 @@ class FragmentRunner:
                     evs = [ops._Ev() for _ in range(23)]
                     for i, e in enumerate(evs):
                         trace[i].ev_begin, trace[i].ev_end, trace[i].launched = e.begin, e.end, 0
-                b.enqueue(self, stream, trace)
+                b.enqueue(self, stream, trace, reuse_event=reuse_event)
                 self.stats["eager"] += 1
             else:
                 if not b.graph:

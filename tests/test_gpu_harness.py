@@ -161,6 +161,36 @@ def test_bench_workload_pair_capacity_mode_vs_oracle(seeded_sd):
     assert row0 == F.shape[0] == res.counts[0] and row0 > 100_000
 
 
+def test_bench_pipelined_steps_equal_the_one_bucket_steps():
+    """bench.py's pipelined mode (two capacity buckets, a step's head on the side stream under the previous step's decoder --
+    imf_fragment_io.head_on_side with a reuse event, the order the streaming pipeline uses): every step of a back-to-back
+    run returns the exact path's descriptors bit for bit, from both buckets, with a different replica of the points each
+    step, and traced / one-bucket steps can follow pipelined ones on the same workload."""
+    import bench
+    dev = torch.device("cuda:0")
+    model, sd = bench.build_model(dev)
+    pts, imgs = bench.load_pair(1.0)
+    wl = bench.Workload(model, dev, pts, imgs, 0.025)
+    with torch.no_grad():
+        F_exact = wl.prepare_graph(replicate=True, pipelined=True).clone()
+        wl.runner.use_graph = False
+        assert len(wl.buckets) == 2 and wl.buckets[0] is not wl.buckets[1]
+        wl.pipelined = True
+        outs = [wl.graph_step() for _ in range(9)]
+        torch.cuda.synchronize()
+        assert {id(r.bucket) for r in outs[-2:]} == {id(b) for b in wl.buckets}       # both buckets took steps
+        for r in outs[-2:]:
+            assert r.flags == 0 and torch.equal(r.F, F_exact)
+        tr = []
+        r = wl.graph_step(tr)                                   # a traced step (bucket 0, head on the main stream) right behind
+        torch.cuda.synchronize()
+        assert len(tr) > 15 and torch.equal(r.F, F_exact)
+        wl.pipelined = False
+        r = wl.graph_step()
+        torch.cuda.synchronize()
+        assert torch.equal(r.F, F_exact)
+
+
 def test_extract_features_stream_equals_extract_features(clouds, images, seeded_sd):
     """extract_features_stream (pinned staging, several forwards in flight through the capacity buckets) returns, in order,
     what extract_features returns fragment by fragment -- for fragments of different sizes (different buckets), float32 and
