@@ -429,7 +429,8 @@ class Workload:
         self.n_points = r.stage(b, self.xyz, self.starts, self.img, self.stream)
         self.buckets, self._done, self.pipelined = [b], [None], bool(pipelined)
         if pipelined:
-            b1 = r.bucket(key, self.dev, self.stream, lane=1)
+            # (a lane of its own: lanes 1..n of a key belong to the runner's FragmentStreamer, which the host-span leg uses)
+            b1 = r.bucket(key, self.dev, self.stream, lane="bench")
             assert r.stage(b1, self.xyz, self.starts, self.img, self.stream) == self.n_points
             self.buckets.append(b1)
             self._done.append(None)
