@@ -46,6 +46,26 @@ def test_library_exports_every_declared_symbol():
     assert L.imf_spconv_workspace_bytes(1088, 256, 1) == 0
 
 
+def test_kernel_policy_is_static_per_layer_and_batch():
+    """imf_resunet_conv_kernel_tag (include/imfnet_hip.h): the executors' kernel choice is a function of (level, kvol, cin,
+    cout, variant, n_items) ONLY -- never of a row count -- and encodes the measured rules: bit 2 / 3 = 8 / 4 wavefronts, bit 6
+    = half tiles, bit 7 = 48-row units; pointwise layers and cout % 64 != 0 go to k_spconv_g (0)."""
+    from imfnet_amd import _lib
+    tag = _lib.lib().imf_resunet_conv_kernel_tag
+    for v in (0, 3, 6):
+        assert tag(0, 1, 96, 64, v, 2) == 0 and tag(2, 27, 64, 32, v, 2) == 0           # pointwise / 32 output channels
+        assert tag(1, 27, 64, 64, v, 2) == 8 and tag(2, 27, 128, 128, v, 2) == 4        # a pair: level 1 on 4, level 2 on 8 wavefronts
+        assert tag(3, 27, 256, 256, v, 2) == (4 | 128) == tag(3, 27, 128, 256, v, 8)    # 48-row units on level 3 from two fragments on
+        assert tag(2, 27, 128, 128, v, 3) == 8 == tag(2, 27, 128, 128, v, 8)            # level 2 on 4 wavefronts from three on
+        assert tag(0, 27, 32, 32, v, 2) == 0 and tag(0, 27, 128, 64, v, 2) == 0         # stride 1: k_spconv_g
+    assert tag(0, 27, 64, 64, 3, 2) == (8 | 64) and tag(0, 27, 64, 64, 6, 2) == 0       # bf16x3: block1_tr on half tiles
+    assert tag(1, 27, 256, 64, 3, 2) == (8 | 64) == tag(2, 27, 256, 128, 3, 2)          # bf16x3: the up-convolutions too
+    for level in (1, 2, 3):                                                             # one fragment per forward: half tiles
+        assert tag(level, 27, 128, 128, 3, 1) == (8 | 64)
+        assert tag(level, 27, 128, 128, 6, 1) == (8 if level == 1 else 4) == tag(level, 27, 128, 128, 0, 1)
+    assert tag(2, 27, 64, 64, 1, 2) == 0                                                 # other variants: no wave-split kernel
+
+
 def test_conv_args_struct_matches_header_layout():
     """ctypes mirror of struct imf_conv_args: field order / count tracks the header."""
     from imfnet_amd._lib import ConvArgs
