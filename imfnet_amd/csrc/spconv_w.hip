@@ -358,6 +358,10 @@ k_spconv_w(const ConvParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the trailing requests (see above)
   } else {
+  // (fp32 / split-f16 keep BOTH operands as LDS-DMA images.  Their 8 KiB weight block as eight register loads a sub-stage
+  // ahead -- the bf16x3 scheme above, 179-192 VGPRs -- was built and measured: fp32 MFMA pair step 1.917 -> 1.98 ms, the
+  // wave-split shapes in isolation +3 % (fp32) / +3-5 % (split-f16), split-f16 step +-0.  With 8 instead of 12 pieces per
+  // sub-stage and one register set more to copy there is nothing to win.)
 #pragma unroll 1
   for (int t = t0; t < t1; ++t) {
     // sub-stage t has landed: the region is private, the wavefront's own counter is the only wait
