@@ -344,6 +344,21 @@ def rulebook_conv(in_level, out_level, ksize):
     return Rulebook(tile_rows, nbr, mask, n_slots, n_out, kvol)
 
 
+def rulebook_sorted(rb):
+    """imf_rulebook_sort_by_occupancy: the occupancy-sorted twin of a stride-1 map in identity slot order (same rows, same
+    inputs, tiles of rows with similar neighbour masks: fewer active (tile, offset) pairs for imf_spconv_fwd to walk)."""
+    L = _lib.lib()
+    dev = rb.nbr.device
+    tile_rows = torch.empty(rb.n_slots, dtype=torch.int32, device=dev)
+    nbr = torch.empty(rb.kvol * rb.n_slots, dtype=torch.int32, device=dev)
+    mask = torch.empty(rb.n_slots // TILE_ROWS * MASK_WORDS, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.imf_rulebook_sorted_workspace_bytes(rb.n_slots), dtype=torch.uint8, device=dev)
+    check(L.imf_rulebook_sort_by_occupancy(rb.nbr.data_ptr(), rb.kvol, rb.n_slots, rb.n_out, None, tile_rows.data_ptr(),
+                                           nbr.data_ptr(), mask.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "imf_rulebook_sort_by_occupancy")
+    return Rulebook(tile_rows, nbr, mask, rb.n_slots, rb.n_out, rb.kvol, rb.max_active)
+
+
 def rulebook_transpose(coarse_level, fine_level, ksize=3):
     """Kernel map of ME.MinkowskiConvolutionTranspose(kernel_size=3, stride=2): coarse -> fine."""
     L = _lib.lib()

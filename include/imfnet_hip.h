@@ -165,6 +165,20 @@ int imf_rulebook_conv(const imf_slot *in_table, int64_t in_capacity,
                       const int32_t *out_coords, int64_t n_out, int ts_in, int ksize,
                       int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream);
 
+/* Occupancy-sorted twin of a stride-1 map (csrc/rulebook_sort.hip): the same rows and inputs, the SLOTS re-ordered so that
+ * the 64 rows of a tile have similar neighbour-occupancy masks -- stable sort by key = (slot >> 14) << 27 | mask (mask bit k
+ * <=> nbr_in[k][slot] >= 0), i.e. inside windows of 16 384 consecutive rows; slots >= the row count sort last.  nbr_in: a map
+ * in identity slot order (imf_rulebook_conv(_dyn), ksize 3: kvol <= 27); outputs: tile_rows[slot] = the row now in that slot
+ * (-1: padding), nbr_out[k][slot] = nbr_in[k][row], tile_mask recomputed.  Tiles then walk ~78 % of the 27 offsets instead of
+ * ~100 % (stride-1 level of a 3DMatch fragment), with no change to imf_spconv_fwd.  n_out_dev: optional device-side row count
+ * (capacity mode; n_out is then the capacity).  Replaces: nothing in the reference (MinkowskiEngine's kernel maps have no
+ * tile structure); used by the executors for the decoder's stride-1 block (model/resunet.py:136-146).
+ * workspace: imf_rulebook_sorted_workspace_bytes(n_slots) bytes of device memory. */
+size_t imf_rulebook_sorted_workspace_bytes(int64_t n_slots);
+int imf_rulebook_sort_by_occupancy(const int32_t *nbr_in, int kvol, int64_t n_slots, int64_t n_out, const int32_t *n_out_dev,
+                                   int32_t *tile_rows, int32_t *nbr_out, uint32_t *tile_mask, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+
 /* Capacity mode: tables sized for n_out_cap rows, the actual count read from *n_out_dev; tiles without rows keep
  * mask 0 and their neighbour slices are left unwritten (imf_spconv_fwd never looks at them). */
 int imf_rulebook_conv_dyn(const imf_slot *in_table, int64_t in_capacity,

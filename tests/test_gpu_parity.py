@@ -254,6 +254,43 @@ def test_spconv_chip_filling_launches_match_fp32_mfma(ops, clouds):
         assert ((c - b).abs() <= bound * sc + 1e-6).all(), (ca, cb, cout, float((c - b).abs().max()))
 
 
+def test_rulebook_sorted_by_occupancy(ops, clouds):
+    """imf_rulebook_sort_by_occupancy against its numpy restatement (stable sort of the slots by (slot >> 14) << 27 | mask,
+    padding last): tile_rows, the gathered neighbour table and the recomputed tile masks integer-exact on a map of several
+    sort windows; a convolution over the sorted map returns the rows of the plain one (same terms, other partition: fp32
+    round-off), and walks fewer (tile, offset) pairs."""
+    xyz = clouds[0].astype(np.float64) * 1.7
+    cm = _build_levels(ops, ops.voxelize(torch.as_tensor(xyz).to(DEV), 0.025))
+    for ts in (1, 2):
+        rb = cm.conv_rulebook(ts, 3, 1)
+        rs = ops.rulebook_sorted(rb)
+        K, S, n = rb.kvol, rb.n_slots, rb.n_out
+        nbr = rb.nbr.view(K, S).cpu().numpy()
+        occ = nbr >= 0
+        slot = np.arange(S)
+        mask = (occ.astype(np.uint64) << np.arange(K, dtype=np.uint64)[:, None]).sum(0)
+        key = np.where(slot < n, ((slot >> 14).astype(np.uint64) << np.uint64(27)) | mask, np.uint64(0xFFFFFFFF))
+        perm = np.argsort(key, kind="stable")
+        valid = perm < n
+        want_rows = np.where(valid, perm, -1).astype(np.int32)
+        want_nbr = np.where(valid[None, :], nbr[:, perm], -1)
+        want_mask = np.zeros((S // 64, 4), dtype=np.uint32)
+        want_mask[:, 0] = ((want_nbr >= 0).reshape(K, S // 64, 64).any(2).astype(np.uint32) << np.arange(K, dtype=np.uint32)[:, None]).sum(0)
+        assert np.array_equal(rs.tile_rows.cpu().numpy(), want_rows)
+        assert np.array_equal(rs.nbr.view(K, S).cpu().numpy(), want_nbr)
+        assert np.array_equal(rs.tile_mask.cpu().numpy().view(np.uint32).reshape(-1, 4), want_mask)
+        active = lambda m: np.unpackbits(m.cpu().numpy().view(np.uint8)).sum() / (K * S // 64)
+        if ts == 1:
+            assert n > 3 * 16384 and active(rs.tile_mask) < 0.9 * active(rb.tile_mask)
+        fa = _rand((n, 64), 40).to(DEV)
+        w = _rand((K, 64, 64), 41, 0.05).to(DEV)
+        for variant, staging in ((3, None), (3, "wave4h"), (0, "wave8"), (6, "wave4")):
+            wp = ops.pack_weights(w, variant=variant)
+            a = ops.spconv(fa, wp, 64, rb, variant=variant, split_k=1, staging=staging)
+            b = ops.spconv(fa, wp, 64, rs, variant=variant, split_k=1, staging=staging)
+            assert float((a - b).abs().max()) < (2e-5 if variant != 6 else 5e-5) * float(a.abs().max())
+
+
 def test_pack_weights_bf16x3_is_an_exact_split(ops):
     """imf_pack_weights_bf16x3: every weight as three bf16 parts whose sum IS the fp32 value (three 8-bit significands carry
     fp32's 24 bits; bf16 has fp32's exponent range, so magnitudes from 1e-30 to 1e30 survive), in the split-f16 image's lane
