@@ -73,13 +73,19 @@ size_t rb_words(int64_t n_slots, int kvol) {
   return (size_t)n_slots + (size_t)kvol * n_slots + (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS;
 }
 
+// the occupancy-sorted twin of the stride-1 3x3x3 map (csrc/rulebook_sort.hip) + the sort's workspace, behind the other maps
+size_t sorted_map_words(const Sizes &s) {
+  if (!s.small_first) return 0;
+  return rb_words(s.slots[0], 27) + 64 /* alignment slack */ + imf_rulebook_sorted_workspace_bytes(s.slots[0]) / 4;
+}
+
 size_t int_words(const Sizes &s) {
   size_t w = 0;
   if (!s.small_first) w += rb_words(s.slots[0], s.first_kvol);
   for (int i = 0; i < 4; ++i) w += rb_words(s.slots[i], 27);
   for (int i = 0; i < 3; ++i) w += rb_words(s.slots[i + 1], 27);
   for (int i = 0; i < 3; ++i) w += rb_words(s.up_slots[i], 27);
-  return w + 16 * 3;
+  return w + sorted_map_words(s) + 16 * 3;
 }
 
 // feature buffers: e{i}{a,b,c} (encoder level i: conv out, block mid, block out), d{i}{a,b,c}, head, fused
@@ -259,14 +265,15 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
                 imf_resunet_float_arena_bytes(net, io->n));
   }
   hipStream_t main = (hipStream_t)io->main_stream, side = (hipStream_t)io->side_stream;
-  const int n_events = pyr ? 9 : 7;
+  const int n_events = pyr ? 9 : (s.small_first ? 8 : 7);   // (the occupancy-sorted stride-1 map has its own join)
   for (int i = 0; i < n_events; ++i) IMF_REQUIRE(io->events[i], "imf_resunet_forward: events[%d] missing", i);
   // flag word: capacity mode collects every flag in the level-0 error word; exact mode takes the caller's (optional)
   int32_t *err = dyn ? const_cast<int32_t *>(meta) + 1 : io->flags;
 
   // ---- rulebooks in the int arena --------------------------------------------------------------
-  Rb rb_first, rb_k3[4], rb_dn[3], rb_up[3], rb_id;
-  int32_t *p = (int32_t *)(((uintptr_t)io->int_arena + 255) & ~(uintptr_t)255);
+  Rb rb_first, rb_k3[4], rb_dn[3], rb_up[3], rb_id, rb_k3s;
+  int32_t *const ibase = (int32_t *)(((uintptr_t)io->int_arena + 255) & ~(uintptr_t)255);
+  int32_t *p = ibase;
   if (!s.small_first) {
     rb_first.n_slots = s.slots[0]; rb_first.n_out = s.n[0]; rb_first.kvol = rb_first.max_active = s.first_kvol;
     p = rb_first.place(p);
@@ -287,9 +294,23 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     rb_up[i].slots_extra = 8 * IMF_TILE_ROWS;
     p = rb_up[i].place(p);
   }
+  // The decoder's stride-1 block (block1_tr: the two largest launches of a step) walks the OCCUPANCY-SORTED twin of the
+  // stride-1 map: tiles of rows with similar neighbour masks, ~78 % of the (tile, offset) pairs instead of ~100 % -- 142 ->
+  // 113 us per 64 -> 64 layer with the same kernel (csrc/rulebook_sort.hip).  Built on the side stream, under the encoder.
+  const bool use_sorted = s.small_first;
+  int32_t *sort_ws = nullptr;
+  const size_t sort_ws_bytes = use_sorted ? imf_rulebook_sorted_workspace_bytes(s.slots[0]) : 0;
+  if (use_sorted) {
+    rb_k3s.n_slots = s.slots[0]; rb_k3s.n_out = s.n[0]; rb_k3s.kvol = rb_k3s.max_active = 27;
+    rb_k3s.level = 0;
+    p = rb_k3s.place(p);
+    sort_ws = (int32_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    p += 64 + sort_ws_bytes / 4;
+  }
   int32_t *counters = p;
   p += 16 * 3;
   uint32_t *bitgrid = (uint32_t *)p;
+  IMF_REQUIRE(p == ibase + int_words(s), "imf_resunet_forward: int arena layout");
   rb_id.n_slots = s.slots[0]; rb_id.n_out = s.n[0]; rb_id.kvol = rb_id.max_active = 1;   // no tables: identity
   rb_id.level = 0;
 
@@ -397,8 +418,9 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     const int src = i == 2 ? FUSED : dbuf(i + 1, 2), c_src = i == 2 ? s.ch[4] : s.dec[i + 1];
     const int skip = i == 2 ? -1 : ebuf(i + 1, 2), c_skip = i == 2 ? 0 : s.ch[i + 2];
     sched[n_steps++] = Step{conv0, &rb_up[i], src, c_src, dbuf(i, 0), skip, c_skip, -1};
-    sched[n_steps++] = Step{conv0 + 1, &rb_k3[i], dbuf(i, 0), t, dbuf(i, 1), -1, 0, -1};
-    sched[n_steps++] = Step{conv0 + 2, &rb_k3[i], dbuf(i, 1), t, dbuf(i, 2), -1, 0, dbuf(i, 0)};
+    Rb *const rbk = (i == 0 && use_sorted) ? &rb_k3s : &rb_k3[i];
+    sched[n_steps++] = Step{conv0 + 1, rbk, dbuf(i, 0), t, dbuf(i, 1), -1, 0, -1};
+    sched[n_steps++] = Step{conv0 + 2, rbk, dbuf(i, 1), t, dbuf(i, 2), -1, 0, dbuf(i, 0)};
   }
   sched[n_steps++] = Step{21, &rb_id, dbuf(0, 2), s.tr[2], HEAD, ebuf(0, 2), s.ch[1], -1};
   sched[n_steps++] = Step{22, &rb_id, HEAD, s.tr[1], -3, -1, 0, -1};
@@ -456,6 +478,19 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     }
     if (rc) return rc;
     is_split[ebuf(0, 0)] = wrote_split;
+  }
+
+  // ---- the occupancy-sorted twin of the stride-1 map, on the side stream (behind the coarse levels' chain: the decoder's
+  // last block needs it ~0.9 ms from here) ----
+  if (use_sorted) {
+    if (first_and_map) {   // the stride-1 map came out of the first convolution's launch on the MAIN stream
+      IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[6], main));
+      IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->events[6], 0));
+    }
+    if ((rc = imf_rulebook_sort_by_occupancy(rb_k3[0].nbr, 27, rb_k3[0].n_slots, s.n[0], dyn ? meta : nullptr, rb_k3s.tile_rows,
+                                             rb_k3s.nbr, rb_k3s.tile_mask, sort_ws, sort_ws_bytes, side)))
+      return rc;
+    if (side != main && (rc = mark(rb_k3s))) return rc;
   }
 
   auto launch = [&](const Step &st) -> int {

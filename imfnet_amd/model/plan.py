@@ -161,8 +161,12 @@ class FusedPlan:
         rb_dn = [_RB(slots[i + 1], n[i + 1], 27, 27, level=i + 1) for i in range(3)]
         rb_up = [_RB(L.imf_rulebook_transpose_slots(n[i]), n[i], 27, 8, level=i) for i in range(3)]
         rb_id = _RB(slots[0], n[0], 1, 1)
-        all_rb = ([] if self.small_first else [rb_first]) + rb_k3 + rb_dn + rb_up
-        words = sum(r.words() for r in all_rb) + 16 * 3
+        # the occupancy-sorted twin of the stride-1 map, for the decoder's stride-1 block (csrc/rulebook_sort.hip; the native
+        # executors build and use it the same way: bit-identical descriptors)
+        rb_k3s = _RB(slots[0], n[0], 27, 27, level=0) if self.small_first else None
+        sort_ws_bytes = L.imf_rulebook_sorted_workspace_bytes(slots[0]) if rb_k3s is not None else 0
+        all_rb = ([] if self.small_first else [rb_first]) + rb_k3 + rb_dn + rb_up + ([rb_k3s] if rb_k3s is not None else [])
+        words = sum(r.words() for r in all_rb) + 16 * 3 + 64 + sort_ws_bytes // 4
         main = torch.cuda.current_stream(dev)
         side = ops.aux_streams(dev)[1][1]        # born with the geometry / image streams: distinct hardware queues
         with torch.cuda.stream(side):           # side-stream pool: no need to wait for the main stream
@@ -172,6 +176,7 @@ class FusedPlan:
         for r in all_rb:
             p = r.place(p)
         counters = [p + 64 * i for i in range(3)]
+        sort_ws = (p + 64 * 3 + 255) // 256 * 256
         # rb_first and k3@1 are needed at once: main stream.  Everything else is built on a side
         # stream while conv1 / block1 (MFMA-bound, whole GPU) run; each group is joined by an event
         # right before its first use.
@@ -207,6 +212,13 @@ class FusedPlan:
             e = torch.cuda.Event()
             e.record(side)
             ready[id(rb_up[i])] = e
+        if rb_k3s is not None:                  # (small_first: the stride-1 map was built on the side stream, above)
+            check(L.imf_rulebook_sort_by_occupancy(rb_k3[0].nbr, 27, rb_k3[0].n_slots, n[0], None, rb_k3s.tile_rows,
+                                                   rb_k3s.nbr, rb_k3s.tile_mask, sort_ws, sort_ws_bytes, ss),
+                  "imf_rulebook_sort_by_occupancy")
+            e = torch.cuda.Event()
+            e.record(side)
+            ready[id(rb_k3s)] = e
         self._ready, self._main = ready, main
         self._flags = m.flag_word(dev).data_ptr()
 
@@ -227,8 +239,9 @@ class FusedPlan:
             src, c_src = ("fused", Ch[4]) if i == 2 else (f"d{i + 1}c", dec_ch[i + 1])
             skip, c_skip = (None, 0) if i == 2 else (f"e{i + 1}c", Ch[i + 2])
             sched.append((f"conv{i + 2}_tr", rb_up[i], src, c_src, f"d{i}a", skip, c_skip, None))
-            sched.append((f"block{i + 2}_tr.conv1", rb_k3[i], f"d{i}a", t, f"d{i}b", None, 0, None))
-            sched.append((f"block{i + 2}_tr.conv2", rb_k3[i], f"d{i}b", t, f"d{i}c", None, 0, f"d{i}a"))
+            rbk = rb_k3s if (i == 0 and rb_k3s is not None) else rb_k3[i]
+            sched.append((f"block{i + 2}_tr.conv1", rbk, f"d{i}a", t, f"d{i}b", None, 0, None))
+            sched.append((f"block{i + 2}_tr.conv2", rbk, f"d{i}b", t, f"d{i}c", None, 0, f"d{i}a"))
         sched.append(("conv1_tr", rb_id, "d0c", T[2], "head", "e0c", Ch[1], None))
         sched.append(("final", rb_id, "head", T[1], "F", None, 0, None))
 
