@@ -12,7 +12,7 @@
 // so features, skip connections and the descriptors' order are untouched; a row's sum is formed over its tile's offset
 // list, so the partition (not the set) of its terms changes with the map, as between any two tile layouts.
 //
-//   key[s]  = s < n ? (s >> 14) << 27 | mask(s) : 0xFFFFFFFF          mask bit k <=> nbr[k][s] >= 0
+//   key[s]  = s < n ? (s >> 14) << 27 | mask(s) : ~0 (64 bits)        mask bit k <=> nbr[k][s] >= 0
 //   perm    = stable sort of the slots by key (rocPRIM LSD radix sort: deterministic)
 //   out: tile_rows[s] = perm[s] (or -1), nbr[k][s] = nbr_in[k][perm[s]], tile_mask = OR over each tile's 64 slots
 // The input map is in identity slot order (imf_rulebook_conv, stride 1); in capacity mode the row count is read from the
@@ -31,16 +31,16 @@ constexpr int kWindowShift = 14;   // 16 384 rows per sort window
 
 __global__ void __launch_bounds__(256)
 k_rbs_keys(const int32_t *__restrict__ nbr, int kvol, long long n_slots, long long n_out, const int32_t *__restrict__ n_dev,
-           uint32_t *__restrict__ keys, int32_t *__restrict__ vals) {
+           uint64_t *__restrict__ keys, int32_t *__restrict__ vals) {
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
   long long n = n_out;
   if (n_dev) n = *n_dev < n ? *n_dev : n;
-  uint32_t key = 0xFFFFFFFFu;
+  uint64_t key = ~0ull;
   if (s < n) {
     uint32_t m = 0u;
     for (int k = 0; k < kvol; ++k) m |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << k;
-    key = ((uint32_t)(s >> kWindowShift) << 27) | m;
+    key = ((uint64_t)(s >> kWindowShift) << 27) | m;
   }
   keys[s] = key;
   vals[s] = (int32_t)s;
@@ -73,8 +73,8 @@ k_rbs_gather(const int32_t *__restrict__ nbr, int kvol, long long n_slots, long 
 
 size_t sort_temp_bytes(long long n_slots) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)nullptr,
-                                  (int32_t *)nullptr, (size_t)n_slots, 0u, 32u, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const int32_t *)nullptr,
+                                  (int32_t *)nullptr, (size_t)n_slots, 0u, 64u, (hipStream_t)0);
   return (bytes + 255) / 256 * 256;
 }
 
@@ -87,31 +87,30 @@ extern "C" {
 
 size_t imf_rulebook_sorted_workspace_bytes(int64_t n_slots) {
   if (n_slots <= 0) return 0;
-  return 4 * (((size_t)n_slots * 4 + 255) / 256 * 256) + sort_temp_bytes(n_slots);
+  return 6 * (((size_t)n_slots * 4 + 255) / 256 * 256) + sort_temp_bytes(n_slots);   // keys (8 B) and slots (4 B), in and out
 }
 
 int imf_rulebook_sort_by_occupancy(const int32_t *nbr_in, int kvol, int64_t n_slots, int64_t n_out, const int32_t *n_out_dev,
                                    int32_t *tile_rows, int32_t *nbr_out, uint32_t *tile_mask, void *workspace,
                                    size_t workspace_bytes, void *stream) {
   IMF_REQUIRE(nbr_in && tile_rows && nbr_out && tile_mask && workspace, "imf_rulebook_sort_by_occupancy: null pointer");
-  IMF_REQUIRE(kvol >= 1 && kvol <= 27, "imf_rulebook_sort_by_occupancy: kvol=%d (1 .. 27: the mask shares a 32-bit key with the window)", kvol);
-  IMF_REQUIRE(n_slots > 0 && n_slots % IMF_TILE_ROWS == 0 && n_out > 0 && n_out <= n_slots && (n_slots >> kWindowShift) < 31,
-              "imf_rulebook_sort_by_occupancy: n_slots=%lld n_out=%lld (whole tiles, at most 31 windows of %d rows)",
-              (long long)n_slots, (long long)n_out, 1 << kWindowShift);
+  IMF_REQUIRE(kvol >= 1 && kvol <= 27, "imf_rulebook_sort_by_occupancy: kvol=%d (1 .. 27: the mask takes the key's low 27 bits)", kvol);
+  IMF_REQUIRE(n_slots > 0 && n_slots % IMF_TILE_ROWS == 0 && n_out > 0 && n_out <= n_slots && n_slots < (1ll << 31),
+              "imf_rulebook_sort_by_occupancy: n_slots=%lld n_out=%lld (whole tiles)", (long long)n_slots, (long long)n_out);
   IMF_REQUIRE(workspace_bytes >= imf_rulebook_sorted_workspace_bytes(n_slots), "imf_rulebook_sort_by_occupancy: workspace %zu < %zu bytes",
               workspace_bytes, imf_rulebook_sorted_workspace_bytes(n_slots));
   IMF_REQUIRE(nbr_in != nbr_out, "imf_rulebook_sort_by_occupancy: in place");
   hipStream_t st = (hipStream_t)stream;
   const size_t arr = ((size_t)n_slots * 4 + 255) / 256 * 256;
   char *w = (char *)workspace;
-  uint32_t *k_in = (uint32_t *)w, *k_out = (uint32_t *)(w + arr);
-  int32_t *v_in = (int32_t *)(w + 2 * arr), *v_out = (int32_t *)(w + 3 * arr);
-  void *tmp = w + 4 * arr;
-  size_t tmp_bytes = workspace_bytes - 4 * arr;
+  uint64_t *k_in = (uint64_t *)w, *k_out = (uint64_t *)(w + 2 * arr);
+  int32_t *v_in = (int32_t *)(w + 4 * arr), *v_out = (int32_t *)(w + 5 * arr);
+  void *tmp = w + 6 * arr;
+  size_t tmp_bytes = workspace_bytes - 6 * arr;
   const unsigned blocks = (unsigned)((n_slots + 255) / 256);
   k_rbs_keys<<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, k_in, v_in);
   IMF_CHECK_LAUNCH("k_rbs_keys");
-  IMF_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n_slots, 0u, 32u, st));
+  IMF_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n_slots, 0u, 48u, st));   // 27 mask bits + 17 window bits (2^31 slots); ~0 keys agree in them
   k_rbs_gather<<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, v_out, tile_rows, nbr_out, tile_mask);
   IMF_CHECK_LAUNCH("k_rbs_gather");
   return IMF_OK;

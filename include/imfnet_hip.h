@@ -166,7 +166,7 @@ int imf_rulebook_conv(const imf_slot *in_table, int64_t in_capacity,
                       int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream);
 
 /* Occupancy-sorted twin of a stride-1 map (csrc/rulebook_sort.hip): the same rows and inputs, the SLOTS re-ordered so that
- * the 64 rows of a tile have similar neighbour-occupancy masks -- stable sort by key = (slot >> 14) << 27 | mask (mask bit k
+ * the 64 rows of a tile have similar neighbour-occupancy masks -- stable sort by the 64-bit key = (slot >> 14) << 27 | mask (mask bit k
  * <=> nbr_in[k][slot] >= 0), i.e. inside windows of 16 384 consecutive rows; slots >= the row count sort last.  nbr_in: a map
  * in identity slot order (imf_rulebook_conv(_dyn), ksize 3: kvol <= 27); outputs: tile_rows[slot] = the row now in that slot
  * (-1: padding), nbr_out[k][slot] = nbr_in[k][row], tile_mask recomputed.  Tiles then walk ~78 % of the 27 offsets instead of

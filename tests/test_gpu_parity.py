@@ -255,7 +255,7 @@ def test_spconv_chip_filling_launches_match_fp32_mfma(ops, clouds):
 
 
 def test_rulebook_sorted_by_occupancy(ops, clouds):
-    """imf_rulebook_sort_by_occupancy against its numpy restatement (stable sort of the slots by (slot >> 14) << 27 | mask,
+    """imf_rulebook_sort_by_occupancy against its numpy restatement (stable sort of the slots by the 64-bit key (slot >> 14) << 27 | mask,
     padding last): tile_rows, the gathered neighbour table and the recomputed tile masks integer-exact on a map of several
     sort windows; a convolution over the sorted map returns the rows of the plain one (same terms, other partition: fp32
     round-off), and walks fewer (tile, offset) pairs."""
@@ -269,7 +269,7 @@ def test_rulebook_sorted_by_occupancy(ops, clouds):
         occ = nbr >= 0
         slot = np.arange(S)
         mask = (occ.astype(np.uint64) << np.arange(K, dtype=np.uint64)[:, None]).sum(0)
-        key = np.where(slot < n, ((slot >> 14).astype(np.uint64) << np.uint64(27)) | mask, np.uint64(0xFFFFFFFF))
+        key = np.where(slot < n, ((slot >> 14).astype(np.uint64) << np.uint64(27)) | mask, np.uint64(0xFFFFFFFFFFFFFFFF))
         perm = np.argsort(key, kind="stable")
         valid = perm < n
         want_rows = np.where(valid, perm, -1).astype(np.int32)
