@@ -294,10 +294,16 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     rb_up[i].slots_extra = 8 * IMF_TILE_ROWS;
     p = rb_up[i].place(p);
   }
-  // The decoder's stride-1 block (block1_tr: the two largest launches of a step) walks the OCCUPANCY-SORTED twin of the
+  // The decoder's stride-1 block (the two largest launches of a step) CAN walk the OCCUPANCY-SORTED twin of the
   // stride-1 map: tiles of rows with similar neighbour masks, ~78 % of the (tile, offset) pairs instead of ~100 % -- 142 ->
   // 113 us per 64 -> 64 layer with the same kernel (csrc/rulebook_sort.hip).  Built on the side stream, under the encoder.
-  const bool use_sorted = s.small_first;
+  // OPT-IN (IMF_SORTED_MAP=1, bf16x3): measured at the end of round 5, the two layers are ~20 us faster each in the step's
+  // own trace, yet the pair step does not move (1.2495 / 1.2501 with, 1.2470 / 1.2581 ms without, A/B/A/B on one box) and on
+  // fp32 MFMA the sort's launches on the side stream cost the encoder's 8-wavefront workgroups more than the map returns
+  // (1.91 -> 2.01 ms).  Where the saved time goes is the next thing to find out (tools/sorted_rulebook_probe.py has the
+  // isolated numbers); until then the executors walk the plain map.
+  static const int sorted_env = getenv("IMF_SORTED_MAP") ? atoi(getenv("IMF_SORTED_MAP")) : 0;
+  const bool use_sorted = s.small_first && net->conv[19].variant == 3 && sorted_env != 0;
   int32_t *sort_ws = nullptr;
   const size_t sort_ws_bytes = use_sorted ? imf_rulebook_sorted_workspace_bytes(s.slots[0]) : 0;
   if (use_sorted) {
@@ -306,6 +312,8 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     p = rb_k3s.place(p);
     sort_ws = (int32_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     p += 64 + sort_ws_bytes / 4;
+  } else {
+    p += sorted_map_words(s);
   }
   int32_t *counters = p;
   p += 16 * 3;

@@ -110,7 +110,11 @@ int imf_rulebook_sort_by_occupancy(const int32_t *nbr_in, int kvol, int64_t n_sl
   const unsigned blocks = (unsigned)((n_slots + 255) / 256);
   k_rbs_keys<<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, k_in, v_in);
   IMF_CHECK_LAUNCH("k_rbs_keys");
-  IMF_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n_slots, 0u, 48u, st));   // 27 mask bits + 17 window bits (2^31 slots); ~0 keys agree in them
+  // only the bits that can differ are sorted: 27 mask bits + the window index's (+ 1, so that the all-ones key of the
+  // padding slots stays above every window index): 32 bits = four radix passes for the pair's 10 windows
+  unsigned wbits = 1;
+  while ((n_slots >> kWindowShift) >> wbits) ++wbits;
+  IMF_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n_slots, 0u, 27u + wbits + 1u, st));
   k_rbs_gather<<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, v_out, tile_rows, nbr_out, tile_mask);
   IMF_CHECK_LAUNCH("k_rbs_gather");
   return IMF_OK;

@@ -163,7 +163,8 @@ class FusedPlan:
         rb_id = _RB(slots[0], n[0], 1, 1)
         # the occupancy-sorted twin of the stride-1 map, for the decoder's stride-1 block (csrc/rulebook_sort.hip; the native
         # executors build and use it the same way: bit-identical descriptors)
-        rb_k3s = _RB(slots[0], n[0], 27, 27, level=0) if self.small_first else None
+        rb_k3s = _RB(slots[0], n[0], 27, 27, level=0) if (self.small_first and self.convs["block2_tr.conv1"][0].variant == 3 and
+                                                        os.environ.get("IMF_SORTED_MAP", "0") not in ("", "0")) else None   # opt-in, as in csrc/executor.hip
         sort_ws_bytes = L.imf_rulebook_sorted_workspace_bytes(slots[0]) if rb_k3s is not None else 0
         all_rb = ([] if self.small_first else [rb_first]) + rb_k3 + rb_dn + rb_up + ([rb_k3s] if rb_k3s is not None else [])
         words = sum(r.words() for r in all_rb) + 16 * 3 + 64 + sort_ws_bytes // 4

@@ -2,9 +2,13 @@
 the device-side-count path must reproduce the exact (host-count) path BIT FOR BIT -- descriptors, voxel order,
 first-point indices, counts -- eagerly and as a replayed graph, for single fragments and batches, across
 fragments of different size sharing one capacity bucket; overflow must be flagged, never silent."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -121,6 +125,51 @@ def test_graph_batches_of_three_and_four_equal_exact(model, clouds, images, nb):
     res = r.run(xyz, starts, torch.as_tensor(imgs).to(DEV), 0.025, stream=torch.cuda.Stream())
     assert res.flags == 0 and res.counts == counts and res.items(0) == [tuple(i) for i in items]
     assert torch.equal(res.F, F) and torch.equal(res.first_idx, inds)
+
+
+def test_opt_in_sorted_map_keeps_the_modes_bit_identical():
+    """IMF_SORTED_MAP=1 (csrc/executor.hip: the decoder's stride-1 block walks the occupancy-sorted twin of the stride-1 map,
+    csrc/rulebook_sort.hip): in a process of its own (the switch is read once) the native executor still equals the op-by-op
+    Python plan bit for bit, capacity mode equals the exact path for one fragment and for the pair, and the descriptors stay
+    within round-off of the default map's (same terms, other partition)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, os.path.join(%r, "oracle"))
+        import bench
+        from imfnet_amd.extract import sparse_tensor_from_points
+        dev = torch.device("cuda:0")
+        model, sd = bench.build_model(dev)
+        pts, imgs = bench.load_pair(1.0)
+        with torch.no_grad():
+            for k in (0, 1):
+                img = torch.as_tensor(imgs[k:k + 1]).to(dev)
+                os.environ["IMFNET_PYTHON_EXECUTOR"] = "1"
+                st, _ = sparse_tensor_from_points(pts[k], 0.025, dev)
+                a = model(st, img).F.clone()
+                del os.environ["IMFNET_PYTHON_EXECUTOR"]
+                st, _ = sparse_tensor_from_points(pts[k], 0.025, dev)
+                b = model(st, img).F.clone()
+                assert torch.equal(a, b), "native executor != python plan"
+            for sel in ([0], [0, 1]):
+                wl = bench.Workload(model, dev, [pts[i] for i in sel], imgs[sel], 0.025)
+                F = wl.prepare_graph().clone()
+                wl.runner.use_graph = False
+                r = wl.graph_step(); torch.cuda.synchronize()
+                assert r.flags == 0 and torch.equal(r.F, F), "capacity mode != exact path"
+                w = (torch.arange(F.numel(), device=dev, dtype=torch.float64) %% 7 + 1).view_as(F)
+                print("F", len(sel), repr(float((F.double() * w).sum())), flush=True)
+        print("OK")
+    """) % (ROOT, ROOT, ROOT)
+    outs = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, IMF_SORTED_MAP=flag)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+        outs[flag] = [float(l.split()[2]) for l in p.stdout.splitlines() if l.startswith("F ")]
+    for a, b in zip(outs["1"], outs["0"]):
+        assert abs(a - b) <= 1e-6 * abs(b) + 1e-3                # the same descriptors to round-off ...
+    assert outs["1"] != outs["0"]                                # ... formed over another partition: the switch took effect
 
 
 def test_capacity_overflow_is_flagged(model, clouds, images):
