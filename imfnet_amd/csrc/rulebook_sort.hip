@@ -27,7 +27,10 @@
 namespace imf {
 namespace {
 
-constexpr int kWindowShift = 14;   // 16 384 rows per sort window
+#ifndef IMF_RBS_WINDOW_SHIFT
+#define IMF_RBS_WINDOW_SHIFT 14
+#endif
+constexpr int kWindowShift = IMF_RBS_WINDOW_SHIFT;   // 16 384 rows per sort window
 
 __global__ void __launch_bounds__(256)
 k_rbs_keys(const int32_t *__restrict__ nbr, int kvol, long long n_slots, long long n_out, const int32_t *__restrict__ n_dev,
