@@ -184,6 +184,63 @@ int imf_cpu_rulebook_transpose(const imf_slot *coarse_table, int64_t coarse_capa
   return IMF_OK;
 }
 
+/* imf_rulebook_sort_by_occupancy (csrc/rulebook_sort.hip): the slots of a stride-1 map in identity order, stably sorted by the
+ * 64-bit key (slot >> 14) << 27 | mask (mask bit k <=> nbr_in[k][slot] >= 0); slots >= the row count last.  A plain stable
+ * merge sort here -- the HIP side's LSD radix sort must produce the same permutation. */
+static void tw_merge_sort(uint64_t *key, int32_t *val, uint64_t *tk, int32_t *tv, int64_t lo, int64_t hi) {
+  if (hi - lo < 2) return;
+  const int64_t mid = lo + (hi - lo) / 2;
+  tw_merge_sort(key, val, tk, tv, lo, mid);
+  tw_merge_sort(key, val, tk, tv, mid, hi);
+  int64_t i = lo, j = mid, o = lo;
+  while (i < mid && j < hi) {
+    if (key[j] < key[i]) { tk[o] = key[j]; tv[o++] = val[j++]; }
+    else { tk[o] = key[i]; tv[o++] = val[i++]; }
+  }
+  while (i < mid) { tk[o] = key[i]; tv[o++] = val[i++]; }
+  while (j < hi) { tk[o] = key[j]; tv[o++] = val[j++]; }
+  for (int64_t q = lo; q < hi; ++q) { key[q] = tk[q]; val[q] = tv[q]; }
+}
+
+size_t imf_cpu_rulebook_sorted_workspace_bytes(int64_t n_slots) { return n_slots > 0 ? (size_t)n_slots * 24 : 0; }
+
+int imf_cpu_rulebook_sort_by_occupancy(const int32_t *nbr_in, int kvol, int64_t n_slots, int64_t n_out, const int32_t *n_out_dev,
+                                       int32_t *tile_rows, int32_t *nbr_out, uint32_t *tile_mask, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+  (void)stream;
+  if (!nbr_in || !tile_rows || !nbr_out || !tile_mask || !workspace || kvol < 1 || kvol > 27 || n_slots <= 0 ||
+      n_slots % IMF_TILE_ROWS || n_out <= 0 || n_out > n_slots || workspace_bytes < (size_t)n_slots * 24 || nbr_in == nbr_out)
+    return IMF_EINVAL;
+  int64_t n = n_out;
+  if (n_out_dev && *n_out_dev < n) n = *n_out_dev;
+  uint64_t *key = (uint64_t *)workspace, *tk = key + n_slots;
+  int32_t *val = (int32_t *)(tk + n_slots), *tv = val + n_slots;
+  for (int64_t s = 0; s < n_slots; ++s) {
+    uint64_t k = ~(uint64_t)0;
+    if (s < n) {
+      uint32_t m = 0;
+      for (int q = 0; q < kvol; ++q) m |= (uint32_t)(nbr_in[(int64_t)q * n_slots + s] >= 0) << q;
+      k = ((uint64_t)(s >> 14) << 27) | m;
+    }
+    key[s] = k;
+    val[s] = (int32_t)s;
+  }
+  tw_merge_sort(key, val, tk, tv, 0, n_slots);
+  for (int64_t t = 0; t < n_slots / IMF_TILE_ROWS; ++t)
+    for (int w = 0; w < IMF_MASK_WORDS; ++w) tile_mask[t * IMF_MASK_WORDS + w] = 0u;
+  for (int64_t s = 0; s < n_slots; ++s) {
+    const int32_t r = val[s];
+    const int valid = r < n;
+    tile_rows[s] = valid ? r : -1;
+    for (int q = 0; q < kvol; ++q) {
+      const int32_t v = valid ? nbr_in[(int64_t)q * n_slots + r] : -1;
+      nbr_out[(int64_t)q * n_slots + s] = v;
+      if (v >= 0) tile_mask[(s / IMF_TILE_ROWS) * IMF_MASK_WORDS] |= 1u << q;
+    }
+  }
+  return IMF_OK;
+}
+
 /* imf_spconv_fwd for args->variant == 0 (w_packed = the imf_pack_weights fp32 image): out[o] = epilogue(sum_k in[nbr[k][o]] W[k]),
  * two sources (cat), scale / shift, residual, ReLU, L2 norm; offsets ascending, channels ascending, fp32 FMA chain */
 int imf_cpu_spconv_fwd_abi(const imf_conv_args *a, void *stream) {

@@ -21,6 +21,9 @@ def _lib():
         L.imf_cpu_rulebook_transpose.restype = I
         L.imf_cpu_rulebook_transpose.argtypes = [P, L64, P, L64, I, I, P, P, P, L64, P, P]
         L.imf_cpu_spconv_fwd_abi.restype, L.imf_cpu_spconv_fwd_abi.argtypes = I, [P, P]
+        L.imf_cpu_rulebook_sorted_workspace_bytes.restype, L.imf_cpu_rulebook_sorted_workspace_bytes.argtypes = C.c_size_t, [L64]
+        L.imf_cpu_rulebook_sort_by_occupancy.restype = I
+        L.imf_cpu_rulebook_sort_by_occupancy.argtypes = [P, I, L64, L64, P, P, P, P, P, C.c_size_t, P]
         L._twins_bound = True
     return L
 
@@ -74,6 +77,21 @@ def rulebook_conv(in_level, out_level, ts_in, ksize):
                                       ts_in, ksize, rows.ctypes.data, nbr.ctypes.data, mask.ctypes.data, None)
     assert rc == 0
     return rows, nbr, mask
+
+
+def rulebook_sort_by_occupancy(nbr, n_out):
+    """imf_rulebook_sort_by_occupancy on a host map in identity slot order (nbr [kvol, n_slots]): the permuted (tile_rows, nbr,
+    tile_mask)."""
+    kvol, n_slots = nbr.shape
+    nbr = np.ascontiguousarray(nbr, np.int32)
+    rows, out = np.empty(n_slots, np.int32), np.empty((kvol, n_slots), np.int32)
+    mask = np.empty((n_slots // TILE, 4), np.uint32)
+    L = _lib()
+    ws = np.empty(L.imf_cpu_rulebook_sorted_workspace_bytes(n_slots), np.uint8)
+    rc = L.imf_cpu_rulebook_sort_by_occupancy(nbr.ctypes.data, kvol, n_slots, n_out, None, rows.ctypes.data, out.ctypes.data,
+                                              mask.ctypes.data, ws.ctypes.data, ws.size, None)
+    assert rc == 0
+    return rows, out, mask
 
 
 def rulebook_transpose(coarse_level, fine_level, ts_fine, ksize=3):

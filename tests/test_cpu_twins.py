@@ -57,6 +57,27 @@ def test_geometry_twins_match_the_oracle(clouds):
         assert pop.max() <= 8                               # parity-class grouping: at most 8 offsets per tile
 
 
+def test_sorted_map_twin_matches_its_numpy_restatement(clouds):
+    """imf_cpu_rulebook_sort_by_occupancy (the twin of csrc/rulebook_sort.hip) against numpy's stable argsort of the same key,
+    on a map spanning several 16 k-row windows: same permutation, gathered table and tile masks; every row appears once."""
+    xyz = np.concatenate([clouds[0], clouds[1] + 3.0]).astype(np.float64)
+    lv0, err = T.voxelize(xyz, 0.02)
+    rows, nbr, mask = T.rulebook_conv(lv0, lv0, 1, 3)
+    n, S, K = lv0.n, len(rows), 27
+    assert err == 0 and n > 2 * 16384
+    srows, snbr, smask = T.rulebook_sort_by_occupancy(nbr, n)
+    slot = np.arange(S)
+    m = ((nbr >= 0).astype(np.uint64) << np.arange(K, dtype=np.uint64)[:, None]).sum(0)
+    key = np.where(slot < n, ((slot >> 14).astype(np.uint64) << np.uint64(27)) | m, np.uint64(0xFFFFFFFFFFFFFFFF))
+    perm = np.argsort(key, kind="stable")
+    valid = perm < n
+    assert (srows == np.where(valid, perm, -1)).all() and sorted(srows[:n].tolist()) == list(range(n))
+    assert (snbr == np.where(valid[None, :], nbr[:, perm], -1)).all()
+    act = (snbr.reshape(K, -1, 64) >= 0).any(2)
+    assert (smask[:, 0] == (act.astype(np.uint32) << np.arange(K, dtype=np.uint32)[:, None]).sum(0)).all() and not smask[:, 1:].any()
+    assert act.mean() < 0.9 * (nbr.reshape(K, -1, 64) >= 0).any(2).mean()        # fewer active (tile, offset) pairs
+
+
 def test_convolution_twin_matches_the_oracle(clouds):
     from imfnet_amd._lib import ConvArgs
     xyz = clouds[0][::3].astype(np.float64)

@@ -52,6 +52,14 @@ def test_geometry_equals_the_cpu_twins(both):
         _same_map(cm.transpose_rulebook(2 << i, 3, 2), T.rulebook_transpose(levels[i + 1], levels[i], 1 << i))
 
 
+def test_sorted_map_equals_the_cpu_twin(both):
+    """imf_rulebook_sort_by_occupancy (rocPRIM radix sort) against its twin (a stable merge sort): the same permutation."""
+    ops, cm, levels = both
+    for i in (0, 1):
+        rb = cm.conv_rulebook(1 << i, 3, 1)
+        _same_map(ops.rulebook_sorted(rb), T.rulebook_sort_by_occupancy(rb.nbr.cpu().numpy().reshape(27, rb.n_slots), rb.n_out))
+
+
 @pytest.mark.parametrize("variant", [0, 3])
 def test_fused_convolution_equals_the_cpu_twin(both, variant):
     from imfnet_amd._lib import ConvArgs
