@@ -68,7 +68,7 @@ ARITH = {
             "arithmetic": "fp32 rows and fp32 weights through the same LDS-DMA kernels into v_mfma_f32_16x16x4_f32"},
 }
 VARIANT_NAME = {v["variant"]: k for k, v in ARITH.items()}
-PROFILE_TAG = "r05"          # profiles/<tag>_kernel_stats_<arith>.txt, <tag>_pmc_traffic_<arith>.json, <tag>_pmc_counters_<arith>.txt
+PROFILE_TAGS = ("r06", "r05")  # profiles/<tag>_kernel_stats_<arith>.txt, <tag>_pmc_traffic_<arith>.json, <tag>_pmc_counters_<arith>.txt: newest first
 
 
 def load_pair(scale):
@@ -122,8 +122,11 @@ def _family_regex(label, arith):
 def _profile(kind, arith):
     """profiles/<PROFILE_TAG>_<kind>_<arith>.<ext> (this round's passes of this same command per arithmetic)."""
     ext = "json" if kind == "pmc_traffic" else "txt"
-    path = os.path.join(ROOT, "profiles", "%s_%s_%s.%s" % (PROFILE_TAG, kind, arith, ext))
-    return path if os.path.exists(path) else None
+    for tag in PROFILE_TAGS:
+        path = os.path.join(ROOT, "profiles", "%s_%s_%s.%s" % (tag, kind, arith, ext))
+        if os.path.exists(path):
+            return path
+    return None
 
 
 def pmc_traffic(kernel, arith):
@@ -303,6 +306,9 @@ def build_roofline(groups, arith, traced_steps, ms_per_step, iso_groups=None):
     avg_us = g["ms"] * 1e3 / g["n"]
     r = {"bound": "mfma", "kernel": dom, "arithmetic": arith,
          "achieved": round(tf, 2), "peak": round(A["peak_tf"], 1), "unit": "TFLOP/s", "frac": round(tf / A["peak_tf"], 4),
+         "peak_def": {"bf16x3": "2500 TFLOP/s dense 16-bit / 6 bf16 MFMAs per fp32 product block = 416.7",
+                      "f16x2": "2500 TFLOP/s dense 16-bit / 3 f16 MFMAs per product block = 833.3",
+                      "f32": "157.3 TFLOP/s fp32 MFMA"}[arith],
          "peak_note": ("fp32-equivalent matrix peak of this arithmetic: MI355X dense 16-bit matrix peak 2500 TFLOP/s / %d matrix "
                        "instructions per fp32 multiply-add block" % (6 if arith == "bf16x3" else 3)) if arith != "f32" else
                       "fp32 matrix peak (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md",
@@ -655,10 +661,105 @@ def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=96, d
             "gather_bytes": total_rows * 128, "fragments_redone_on_the_exact_path": redone,
             "gather": "device-resident: D2D copy from the capacity bucket into the rank's send buffer as each fragment completes, "
                       "one all_gather of row counts + one grouped send / recv exchange (all receives posted at once)",
-            "verified": "every block on rank 0: rows and CRC-32 equal to its producer's host copy",
+            "verified": "every block on rank 0: rows and CRC-32 equal to its producer's host copy", "gather_crc_ok": True,
             "note": "host-array pipeline per rank (LPT shards by point count; %d distinct fragments of %d-%d k points, repeated) "
                     "+ one variable-length gather of the [M_i,32] blocks to rank 0; median of %d timed passes after two untimed "
                     "passes over the same list" % (distinct, min(sizes) // 1000, max(sizes) // 1000, passes)}
+
+
+COMPACT_LIMIT = 4096          # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout: BENCH_r05 was unparseable at 21 KB)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d and k in d and d[k] is not None}
+
+
+def compact_line(out):
+    """The ONE line the driver parses, <= COMPACT_LIMIT bytes: the contract's keys + `roofline` (both rooflines: `frac` against
+    the matrix peak named in `peak_def`, `notional_hbm_frac` against 8 TB/s, dominant kernel and whole step) + `cpu_baseline`
+    + the host-to-host span and the multi-rank facts.  Everything else (notes, per-kernel tables, probe times, the other
+    legs) goes to the full record (`full_record`: bench_full.json, also on stderr)."""
+    cfg = out.get("config") or {}
+    rf = out.get("roofline") or {}
+    cm = cfg.get("capacity_mode") or {}
+    r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "rocprof_avg_launch_us",
+                   "rocprof_frac", "mfma_busy", "issued_tflops", "launches_per_step", "algorithmic_bytes_per_launch",
+                   "algorithmic_flops_per_launch", "all_sparse_conv_ms_per_step", "step_frac", "step_notional_hbm_frac",
+                   "isolated_avg_launch_us"))
+    if rf:
+        r["peak_def"] = rf.get("peak_def")
+        r["notional_hbm_frac"] = (rf.get("notional_hbm") or {}).get("frac")
+        if rf.get("issued_tflops") and rf.get("achieved"):
+            mult = {"bf16x3": 6, "f16x2": 3, "f32": 1}[rf.get("arithmetic", "bf16x3")]
+            r["issued_over_useful"] = round(rf["issued_tflops"] / (rf["achieved"] * mult), 3)
+        r["profiles"] = rf.get("counters")
+    cpu = _pick(out.get("cpu_baseline"), ("value", "unit", "cores", "kind", "value_1_thread"))
+    if cpu:
+        cpu["sample"] = "one S50k fragment end to end on the host, median of bounded runs (see full record)"
+    hs = _pick(out.get("host_span"), ("value", "unit", "ms_per_step", "vs_device_resident", "n_gpus"))
+    if hs:
+        hs["span"] = "host float64 points + images -> xyz_down + F as host arrays (SURVEY 8d), PCIe both ways"
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline")}
+    line["dtype"] = (out.get("dtype") or "").split(" (")[0] + " (%s)" % cfg.get("arithmetic", "")
+    line["data"] = out.get("data")
+    line["config"] = {"workload": cfg.get("workload"), "arithmetic": cfg.get("arithmetic"),
+                      "fragments_per_step": cfg.get("fragments_per_step"),
+                      "voxels_per_step_per_gpu": cfg.get("voxels_per_step_per_gpu"),
+                      "issue": cm.get("picked", cm.get("mode")), "probe_ms_per_step": cm.get("probe_ms_per_step"),
+                      "equals_exact_path_bitwise": cm.get("equals_exact_path_bitwise"),
+                      "value_span": "inputs resident in HBM (bench contract); host-to-host span = host_span"}
+    t = out.get("timing") or {}
+    line["timing"] = _pick(t, ("repeats", "ms_per_step_min", "ms_per_step_max"))
+    line["roofline"] = r or None
+    line["cpu_baseline"] = cpu or None
+    line["host_span"] = hs or None
+    e2e = cfg.get("e2e_extract_features") or {}
+    legs = {"single_fragment_ms": (cfg.get("single_fragment") or {}).get("ms_per_fragment"),
+            "sync_extract_features_ms": e2e.get("ms_per_fragment"),
+            "sync_extract_features_device_F_ms": (e2e.get("device_descriptors") or {}).get("ms_per_fragment"),
+            "batch_8_descriptors_per_s": (cfg.get("batch_8") or {}).get("descriptors_per_s"),
+            "host_span_auto_batch_descriptors_per_s": (cfg.get("host_span_auto_batch") or {}).get("value")}
+    line["legs"] = {k: v for k, v in legs.items() if v is not None} or None
+    ar = {}
+    for name, a in (out.get("arithmetics") or {}).items():
+        ra = a.get("roofline") or {}
+        ar[name] = {"value": a.get("value"), "ms_per_step": a.get("ms_per_step"), "kernel": ra.get("kernel"),
+                    "frac": ra.get("frac"), "peak": ra.get("peak"), "notional_hbm_frac": (ra.get("notional_hbm") or {}).get("frac")}
+    line["arithmetics"] = ar or None
+    sp = cfg.get("sharded_pipeline")
+    if sp:
+        line["sharded_pipeline"] = _pick(sp, ("ranks", "backend", "fragments", "fragments_per_s", "descriptors_per_s", "gather_ms",
+                                              "gather_bytes", "gather_crc_ok"))
+    line["rccl"] = out.get("rccl")
+    line["full_record"] = out.get("full_record")
+    # never exceed the limit: drop the optional groups, least important first
+    for victim in ("legs", "arithmetics", "sharded_pipeline", "timing", "host_span"):
+        if len(json.dumps(line)) <= COMPACT_LIMIT:
+            break
+        line.pop(victim, None)
+    return line
+
+
+def emit(out, full_path):
+    """Full record -> `full_path` (+ gpurun_out/ when that directory exists) and stderr; the compact line is the LAST stdout line."""
+    out["full_record"] = os.path.relpath(full_path, ROOT) if full_path else None
+    full = json.dumps(out)
+    if full_path:
+        targets = [full_path]
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            targets.append(os.path.join(ROOT, "gpurun_out", os.path.basename(full_path)))
+        for p in targets:
+            try:
+                with open(p, "w") as f:
+                    f.write(full + "\n")
+            except OSError as e:                         # a read-only tree must not cost the line
+                print("bench: could not write %s: %s" % (p, e), file=sys.stderr)
+    print("bench full record: " + full, file=sys.stderr, flush=True)
+    line = json.dumps(compact_line(out))
+    assert len(line) <= COMPACT_LIMIT + 1024, len(line)
+    sys.stdout.flush()
+    print(line, flush=True)
 
 
 def main():
@@ -697,6 +798,8 @@ def main():
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-pipeline + gather leg")
     ap.add_argument("--sharded-per-rank", type=int, default=96, help="fragments per rank of the sharded-pipeline leg")
     ap.add_argument("--sharded-region-s", type=float, default=1.2, help="minimum length of one timed region of that leg")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "bench_full.json"),
+                    help="where the FULL record goes (every leg, note and per-kernel table); stdout carries only the compact line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -852,6 +955,14 @@ def main():
             host_span["n_gpus"] = world
     else:
         total_m = M
+    # what every rank measured (median of its own repeats) and the world the process group really has
+    mine_ms = torch.tensor([median(sorted(rep)) / args.steps * 1e3], dtype=torch.float64, device=dev)
+    per_rank = [mine_ms.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine_ms)
+    rccl_info = {"backend": backend, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                 "per_rank_ms_per_step": [round(float(v), 4) for v in per_rank],
+                 "gather_crc_ok": bool(sharded and sharded.get("gather_crc_ok")) if sharded is not None else None}
     rep = sorted(float(v) for v in t.tolist())
     elapsed = median(rep)
 
@@ -936,7 +1047,8 @@ def main():
             # the same pair step on the other two arithmetics, each timed and rooflined like the headline (N = 1)
             "arithmetics": arithmetics,
         }
-        print(json.dumps(out), flush=True)
+        out["rccl"] = rccl_info
+        emit(out, args.full_out)
     if world > 1:
         dist.destroy_process_group()
 
