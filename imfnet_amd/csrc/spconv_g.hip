@@ -329,15 +329,25 @@ k_spconv_g(const ConvParams p) {
   // sub-stage t + D + 2 and the input rows of t + D + 1 are read in iteration t, the DMA of t + D is issued in it.
   // Waits are counted by hand (the compiler does not order ds_reads after LDS-DMAs, and __syncthreads() would
   // drain the whole queue): vmcnt(PER (D - 1)) leaves the D - 1 younger sub-stages in flight across the barrier.
+  // Empty 16-row blocks are skipped (round 6): a wavefront whose RB blocks have NO input at a sub-stage's offset takes part in
+  // the barriers and the weight copy but leaves out its fragment reads, its split and its MFMAs (they would add exact zeros:
+  // the sums are the same bit for bit).  In slot = row order 96 % of the (block, offset) pairs are active; on the
+  // occupancy-sorted maps (csrc/rulebook_sort.hip) ~68 %.  actq[i] = "sub-stage t + i has an input row for this wavefront".
+#define IMF_ROWS_ACTIVE(rows) ([&]() { bool a_ = false; _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) a_ |= (rows).r[b_] != kNoRow; \
+                                      return __ballot(a_) != 0ull; }())
   unsigned e_b, e_c = IMF_READ_E(D), e_d = IMF_READ_E(D + 1);
   Rows irow_b, irow_c;
+  bool actq[D + 1];
   IMF_READ_ROWS(irow_c, e_c)
+  actq[D] = IMF_ROWS_ACTIVE(irow_c);
 #pragma unroll
   for (int d = 0; d < D; ++d) {
+    actq[d] = false;
     if (d < n_sub) {
       const unsigned e0 = IMF_READ_E(d);
       Rows irow0;
       IMF_READ_ROWS(irow0, e0)
+      actq[d] = IMF_ROWS_ACTIVE(irow0);
       if (!WS1 || d == 0) IMF_DMA_W(e0, d)          // (WS1: one weight block in flight, row sub-stages 0 .. D - 1)
       IMF_DMA_R(e0, irow0, d)
     }
@@ -364,6 +374,10 @@ k_spconv_g(const ConvParams p) {
     if (!WS1 && t + D < n_sub) IMF_DMA(e_b, irow_b, slot_wr)   // (WS1: after the fragment reads, below)
     IMF_READ_ROWS(irow_c, e_c)
     e_d = IMF_READ_E(t + D + 2);
+    const bool act = actq[0] || (ABL != 0);             // this wavefront has work in sub-stage t
+#pragma unroll
+    for (int i = 0; i < D; ++i) actq[i] = actq[i + 1];
+    actq[D] = IMF_ROWS_ACTIVE(irow_c);                  // rows of sub-stage t + D + 1
     IMF_GSTAMP(10 + 4 * t);
     const float4 *const wbuf = IMF_WBUF(slot_rd);
     const float4 *const abuf = IMF_ABUF(slot_rd);
@@ -387,17 +401,20 @@ k_spconv_g(const ConvParams p) {
     }
     if constexpr (AR == kArF32) {
       float4 a0[RB], a1[RB], b0[CO_BLK], b1[CO_BLK];
+      if (act) {
 #pragma unroll
-      for (int b = 0; b < RB; ++b) {
-        a0[b] = lds_read16(&abuf[128 * b + rd_slot]);
-        a1[b] = lds_read16(&abuf[128 * b + 64 + rd_slot]);
-      }
+        for (int b = 0; b < RB; ++b) {
+          a0[b] = lds_read16(&abuf[128 * b + rd_slot]);
+          a1[b] = lds_read16(&abuf[128 * b + 64 + rd_slot]);
+        }
 #pragma unroll
-      for (int cb = 0; cb < CO_BLK; ++cb) {      // quad (j, cb) of the fp32 image: W[16 j + 4 q4 + t][16 cb + r16]
-        b0[cb] = lds_read16(&wbuf[cb * 64 + lane]);
-        b1[cb] = lds_read16(&wbuf[(CO_BLK + cb) * 64 + lane]);
+        for (int cb = 0; cb < CO_BLK; ++cb) {    // quad (j, cb) of the fp32 image: W[16 j + 4 q4 + t][16 cb + r16]
+          b0[cb] = lds_read16(&wbuf[cb * 64 + lane]);
+          b1[cb] = lds_read16(&wbuf[(CO_BLK + cb) * 64 + lane]);
+        }
       }
       IMF_WS_MID
+      if (!act) continue;
 #define IMF_G_STEP(AV, BV, C)                                                                          \
   _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                       \
       _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                            \
@@ -409,6 +426,10 @@ k_spconv_g(const ConvParams p) {
     }
     if constexpr (AR == kArBf16x3) {
       // fp32 rows -> three bf16 parts in registers; the image's quads (3 cb + part) are the matching B parts
+      if (!act) {
+        IMF_WS_MID
+        continue;
+      }
       bf16x8 ap[RB][3], bp[CO_BLK][3];
 #pragma unroll
       for (int b = 0; b < RB; ++b)
@@ -427,22 +448,25 @@ k_spconv_g(const ConvParams p) {
       continue;
     }
     f16x8 ah[RB], al[RB];
+    f16x8 bh[CO_BLK], bl[CO_BLK];
+    if (act) {
 #pragma unroll
-    for (int b = 0; b < RB; ++b) {
-      if ((ABL & 2) || PRE) {
-        ah[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + rd_slot]));
-        al[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + 64 + rd_slot]));
-      } else {
-        split8(lds_read16(&abuf[128 * b + rd_slot]), lds_read16(&abuf[128 * b + 64 + rd_slot]), ah[b], al[b]);
+      for (int b = 0; b < RB; ++b) {
+        if ((ABL & 2) || PRE) {
+          ah[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + rd_slot]));
+          al[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + 64 + rd_slot]));
+        } else {
+          split8(lds_read16(&abuf[128 * b + rd_slot]), lds_read16(&abuf[128 * b + 64 + rd_slot]), ah[b], al[b]);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) {
+        bh[cb] = lds_read_f16x8(&wbuf[(2 * cb) * 64 + lane]);
+        bl[cb] = lds_read_f16x8(&wbuf[(2 * cb + 1) * 64 + lane]);
       }
     }
-    f16x8 bh[CO_BLK], bl[CO_BLK];
-#pragma unroll
-    for (int cb = 0; cb < CO_BLK; ++cb) {
-      bh[cb] = lds_read_f16x8(&wbuf[(2 * cb) * 64 + lane]);
-      bl[cb] = lds_read_f16x8(&wbuf[(2 * cb + 1) * 64 + lane]);
-    }
     IMF_WS_MID
+    if (!act) continue;
 #ifdef IMF_G_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers (perturbs the schedule a little)
     IMF_GSTAMP(11 + 4 * t);
@@ -477,6 +501,7 @@ k_spconv_g(const ConvParams p) {
 #undef IMF_DMA_W
 #undef IMF_DMA_R
 #undef IMF_READ_ROWS
+#undef IMF_ROWS_ACTIVE
 #undef IMF_READ_E
 #undef IMF_WBUF
 #undef IMF_ABUF
