@@ -1,52 +1,171 @@
-// Occupancy-sorted rulebooks (round 5): the SLOTS of a stride-1 kernel map re-ordered so that the rows of a tile have
-// similar neighbour-occupancy patterns.
+// Occupancy-sorted rulebooks: the SLOTS of a kernel map re-ordered so that the rows of a 16-row block have similar
+// neighbour-occupancy patterns (round 5: tiles; round 6: blocks, every map, one launch per sort).
 //
-// Why.  The convolution kernels walk, per 64-row tile, every kernel offset at which ANY of its rows has an input.  In
-// slot = row order 99.7 % of the (tile, offset) pairs of the stride-1 level are active although only 52 % of its
-// (row, offset) pairs exist (a surface: every voxel misses the offsets off its sheet, but neighbours in first-occurrence
-// order miss different ones).  Rows sorted by their 27-bit occupancy mask share their missing offsets: 78 % of the
-// (tile, offset) pairs stay active when the sort runs inside windows of 16 384 consecutive rows (the window keeps a tile's
-// gathers inside ~4 MB of the feature matrix: a global sort reaches 70-74 % but spreads a tile over the whole level), and
-// the two 64 -> 64 layers of the stride-1 decoder block take 142 -> 113 us each on the S50k pair with NO change to a kernel
-// (tools/sorted_rulebook_probe.py).  Rows keep their numbers -- tile_rows[slot] = row, nbr[k][slot] = that row's input --
-// so features, skip connections and the descriptors' order are untouched; a row's sum is formed over its tile's offset
-// list, so the partition (not the set) of its terms changes with the map, as between any two tile layouts.
+// Why.  The convolution kernels walk, per unit of rows, every kernel offset at which ANY of its rows has an input, and
+// since round 6 leave out the 16-row blocks of a sub-stage that have none.  In slot = row order 96 % of the (block, offset)
+// pairs of a stride-1 level are active although only 52 % of its (row, offset) pairs exist (a surface: every voxel misses
+// the offsets off its sheet, but neighbours in first-occurrence order miss different ones): 1.86 issued multiply-adds per
+// useful one.  Rows sorted by their occupancy pattern share their missing offsets: 1.32 (strided maps: 2.5 -> 1.5).
+// Rows keep their numbers -- tile_rows[slot] = row, nbr[k][slot] = that row's input -- so features, skip connections and
+// the descriptors' order are untouched; a row's sum is formed over its unit's offset list, so the partition (not the set) of
+// its terms changes with the map, as between any two tile layouts.
 //
-//   key[s]  = s < n ? (s >> 14) << 27 | mask(s) : ~0 (64 bits)        mask bit k <=> nbr[k][s] >= 0
-//   perm    = stable sort of the slots by key (rocPRIM LSD radix sort: deterministic)
+// The order.  Inside windows of 16 384 consecutive slots (a window keeps a unit's gathers inside ~4 MB of the feature
+// matrix; a global sort is 5 % better on paper and spreads a tile over the whole level), stable, by the 21-bit key
+//   r    = the 12 edge offsets (two coordinates differ) in bits 19 .. 8, the 6 face offsets in bits 7 .. 2, the corner
+//          offsets 0 and 26 in bits 1, 0        -- the most evenly split offsets decide first
+//   key  = gray^-1(r) = r ^ r >> 1 ^ r >> 2 ^ ...   -- neighbours in the order differ in ONE of the deciding offsets
+//          (numeric order of r: 1.35; this order: 1.32; all 27 bits, four passes: 1.30), slots >= the row count: 1 << 20.
+// Measured on the S50k fragment (tools: LAB_NOTES round 6): issued / useful multiply-adds with 16-row blocks, identity
+// order -> this order: stride-1 maps of the four levels 1.86 / 1.87 / 1.92 / 1.97 -> 1.32 / 1.33 / 1.48 / 1.67, strided maps
+// 2.48 / 2.53 / 2.66 -> 1.46 / 1.58 / 1.88.
+//
+// The sort.  One 1024-thread workgroup per window, everything in LDS: keys (64 KiB), two index arrays (2 x 32 KiB), one
+// histogram per wavefront.  Three LSD passes of 7 bits; a wavefront owns 1024 consecutive positions and ranks 64 of them
+// at a time with seven ballots (lanes with the same digit), so equal digits keep their order: deterministic, and equal to a
+// stable comparison sort (the CPU twin, oracle/imf_cpu_twins.c).  Round 5 used rocPRIM's device radix sort of 64-bit keys
+// (eight launches per map); this is one launch per map plus the gather.
 //   out: tile_rows[s] = perm[s] (or -1), nbr[k][s] = nbr_in[k][perm[s]], tile_mask = OR over each tile's 64 slots
-// The input map is in identity slot order (imf_rulebook_conv, stride 1); in capacity mode the row count is read from the
-// device and every slot beyond it sorts last (its input slice is never read).
+// The input map is in identity slot order (imf_rulebook_conv); in capacity mode the row count is read from the device and
+// every slot beyond it sorts last (its input slice is never read).
 #include <hip/hip_runtime.h>
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 
 namespace imf {
 namespace {
 
-#ifndef IMF_RBS_WINDOW_SHIFT
-#define IMF_RBS_WINDOW_SHIFT 14
-#endif
-constexpr int kWindowShift = IMF_RBS_WINDOW_SHIFT;   // 16 384 rows per sort window
+constexpr int kWindowShift = 14;                     // 16 384 slots per sort window
+constexpr int kWindow = 1 << kWindowShift;
+constexpr int kSortThreads = 1024, kSortWaves = kSortThreads / 64, kPerThread = kWindow / kSortThreads;   // 16, 16
+constexpr int kDigitBits = 7, kDigits = 1 << kDigitBits, kPasses = 3;
+constexpr unsigned kInvalidKey = 1u << 20;
 
-__global__ void __launch_bounds__(256)
-k_rbs_keys(const int32_t *__restrict__ nbr, int kvol, long long n_slots, long long n_out, const int32_t *__restrict__ n_dev,
-           uint64_t *__restrict__ keys, int32_t *__restrict__ vals) {
-  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_slots) return;
+// bit of the 27-bit occupancy mask -> bit of r (-1: not part of the key)
+__device__ __forceinline__ constexpr int key_bit_of_offset(int k) {
+  constexpr int edges[12] = {1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25};
+  constexpr int faces[6] = {4, 10, 12, 14, 16, 22};
+  for (int i = 0; i < 12; ++i)
+    if (edges[i] == k) return 19 - i;
+  for (int i = 0; i < 6; ++i)
+    if (faces[i] == k) return 7 - i;
+  return k == 0 ? 1 : (k == 26 ? 0 : -1);
+}
+
+__device__ __forceinline__ unsigned gray_inverse20(unsigned r) {
+  r ^= r >> 1;
+  r ^= r >> 2;
+  r ^= r >> 4;
+  r ^= r >> 8;
+  r ^= r >> 16;
+  return r & 0xFFFFFu;
+}
+
+template <int KVOL>
+__global__ void __launch_bounds__(kSortThreads)
+k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slots, long long n_out,
+                  const int32_t *__restrict__ n_dev, int32_t *__restrict__ perm) {
+  __shared__ unsigned keys[kWindow];                 // 64 KiB
+  __shared__ unsigned short idx0[kWindow], idx1[kWindow];   // 2 x 32 KiB
+  __shared__ unsigned hist[kSortWaves * kDigits], dtot[kDigits], doff[kDigits];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long wbase = (long long)blockIdx.x * kWindow;
   long long n = n_out;
   if (n_dev) n = *n_dev < n ? *n_dev : n;
-  uint64_t key = ~0ull;
-  if (s < n) {
-    uint32_t m = 0u;
-    for (int k = 0; k < kvol; ++k) m |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << k;
-    key = ((uint64_t)(s >> kWindowShift) << 27) | m;
+  const int kvol = KVOL ? KVOL : kvol_rt;
+
+  // ---- keys: thread t takes the slots wbase + t + 1024 i (every load of a wavefront is one line of one offset)
+#pragma unroll 4
+  for (int i = 0; i < kPerThread; ++i) {
+    const int loc = tid + kSortThreads * i;
+    const long long s = wbase + loc;
+    unsigned key = kInvalidKey;
+    if (s < n) {
+      unsigned r = 0u;
+      if (KVOL == 27) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+          const int bit = key_bit_of_offset(k);
+          if (bit >= 0) r |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << bit;
+        }
+      } else {
+        for (int k = 0; k < kvol && k < 20; ++k) r |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << k;
+      }
+      key = gray_inverse20(r);
+    }
+    keys[loc] = key;
   }
-  keys[s] = key;
-  vals[s] = (int32_t)s;
+  __syncthreads();
+
+  // ---- three stable LSD passes over the window-local index
+  unsigned short *src = idx0, *dst = idx1;
+#pragma unroll 1
+  for (int pass = 0; pass < kPasses; ++pass) {
+    const int shift = kDigitBits * pass;
+    for (int d = tid; d < kSortWaves * kDigits; d += kSortThreads) hist[d] = 0u;
+    __syncthreads();
+    unsigned *const myhist = hist + wave * kDigits;
+    const int chunk = wave * (kWindow / kSortWaves);
+    // count (order is irrelevant here)
+#pragma unroll 4
+    for (int it = 0; it < kWindow / kSortWaves / 64; ++it) {
+      const int pos = chunk + 64 * it + lane;
+      const unsigned id = pass == 0 ? (unsigned)pos : (unsigned)src[pos];
+      atomicAdd(&myhist[(keys[id] >> shift) & (kDigits - 1)], 1u);
+    }
+    __syncthreads();
+    // digit-major, wavefront-minor exclusive offsets
+    if (tid < kDigits) {
+      unsigned run = 0u;
+#pragma unroll
+      for (int w = 0; w < kSortWaves; ++w) {
+        const unsigned c = hist[w * kDigits + tid];
+        hist[w * kDigits + tid] = run;
+        run += c;
+      }
+      dtot[tid] = run;
+    }
+    __syncthreads();
+    if (tid < kDigits) {
+      unsigned off = 0u;
+      for (int d = 0; d < tid; ++d) off += dtot[d];
+      doff[tid] = off;
+    }
+    __syncthreads();
+    // rank and scatter, 64 positions at a time in order: lanes with the same digit keep their order
+#pragma unroll 2
+    for (int it = 0; it < kWindow / kSortWaves / 64; ++it) {
+      const int pos = chunk + 64 * it + lane;
+      const unsigned id = pass == 0 ? (unsigned)pos : (unsigned)src[pos];
+      const unsigned d = (keys[id] >> shift) & (kDigits - 1);
+      unsigned long long same = ~0ull;
+#pragma unroll
+      for (int b = 0; b < kDigitBits; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        same &= bit ? bal : ~bal;
+      }
+      const int rank = __builtin_popcountll(same & ((1ull << lane) - 1ull));
+      const int cnt = __builtin_popcountll(same);
+      const unsigned base = myhist[d];
+      if (rank == cnt - 1) myhist[d] = base + (unsigned)cnt;      // (LDS operations of a wavefront execute in order)
+      dst[base + doff[d] + (unsigned)rank] = (unsigned short)id;
+    }
+    __syncthreads();
+    unsigned short *const t = src;
+    src = dst;
+    dst = t;
+  }
+
+  // ---- new slot wbase + p takes old slot wbase + src[p]; slots beyond the rows: -1
+#pragma unroll 4
+  for (int i = 0; i < kPerThread; ++i) {
+    const int loc = tid + kSortThreads * i;
+    if (wbase + loc >= n_slots) break;
+    const unsigned id = src[loc];
+    perm[wbase + loc] = keys[id] == kInvalidKey ? -1 : (int32_t)(wbase + id);
+  }
 }
 
 // one wavefront = one tile of the OUTPUT map: 64 consecutive new slots
@@ -74,13 +193,6 @@ k_rbs_gather(const int32_t *__restrict__ nbr, int kvol, long long n_slots, long 
   }
 }
 
-size_t sort_temp_bytes(long long n_slots) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const int32_t *)nullptr,
-                                  (int32_t *)nullptr, (size_t)n_slots, 0u, 64u, (hipStream_t)0);
-  return (bytes + 255) / 256 * 256;
-}
-
 }  // namespace
 }  // namespace imf
 
@@ -90,35 +202,27 @@ extern "C" {
 
 size_t imf_rulebook_sorted_workspace_bytes(int64_t n_slots) {
   if (n_slots <= 0) return 0;
-  return 6 * (((size_t)n_slots * 4 + 255) / 256 * 256) + sort_temp_bytes(n_slots);   // keys (8 B) and slots (4 B), in and out
+  return ((size_t)n_slots * 4 + 255) / 256 * 256;           // the permutation
 }
 
 int imf_rulebook_sort_by_occupancy(const int32_t *nbr_in, int kvol, int64_t n_slots, int64_t n_out, const int32_t *n_out_dev,
                                    int32_t *tile_rows, int32_t *nbr_out, uint32_t *tile_mask, void *workspace,
                                    size_t workspace_bytes, void *stream) {
   IMF_REQUIRE(nbr_in && tile_rows && nbr_out && tile_mask && workspace, "imf_rulebook_sort_by_occupancy: null pointer");
-  IMF_REQUIRE(kvol >= 1 && kvol <= 27, "imf_rulebook_sort_by_occupancy: kvol=%d (1 .. 27: the mask takes the key's low 27 bits)", kvol);
+  IMF_REQUIRE(kvol >= 1 && kvol <= 27, "imf_rulebook_sort_by_occupancy: kvol=%d (1 .. 27)", kvol);
   IMF_REQUIRE(n_slots > 0 && n_slots % IMF_TILE_ROWS == 0 && n_out > 0 && n_out <= n_slots && n_slots < (1ll << 31),
               "imf_rulebook_sort_by_occupancy: n_slots=%lld n_out=%lld (whole tiles)", (long long)n_slots, (long long)n_out);
   IMF_REQUIRE(workspace_bytes >= imf_rulebook_sorted_workspace_bytes(n_slots), "imf_rulebook_sort_by_occupancy: workspace %zu < %zu bytes",
               workspace_bytes, imf_rulebook_sorted_workspace_bytes(n_slots));
   IMF_REQUIRE(nbr_in != nbr_out, "imf_rulebook_sort_by_occupancy: in place");
   hipStream_t st = (hipStream_t)stream;
-  const size_t arr = ((size_t)n_slots * 4 + 255) / 256 * 256;
-  char *w = (char *)workspace;
-  uint64_t *k_in = (uint64_t *)w, *k_out = (uint64_t *)(w + 2 * arr);
-  int32_t *v_in = (int32_t *)(w + 4 * arr), *v_out = (int32_t *)(w + 5 * arr);
-  void *tmp = w + 6 * arr;
-  size_t tmp_bytes = workspace_bytes - 6 * arr;
+  int32_t *perm = (int32_t *)workspace;
+  const unsigned windows = (unsigned)((n_slots + kWindow - 1) / kWindow);
+  if (kvol == 27) k_rbs_window_sort<27><<<windows, kSortThreads, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, perm);
+  else            k_rbs_window_sort<0><<<windows, kSortThreads, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, perm);
+  IMF_CHECK_LAUNCH("k_rbs_window_sort");
   const unsigned blocks = (unsigned)((n_slots + 255) / 256);
-  k_rbs_keys<<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, k_in, v_in);
-  IMF_CHECK_LAUNCH("k_rbs_keys");
-  // only the bits that can differ are sorted: 27 mask bits + the window index's (+ 1, so that the all-ones key of the
-  // padding slots stays above every window index): 32 bits = four radix passes for the pair's 10 windows
-  unsigned wbits = 1;
-  while ((n_slots >> kWindowShift) >> wbits) ++wbits;
-  IMF_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n_slots, 0u, 27u + wbits + 1u, st));
-  k_rbs_gather<<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, v_out, tile_rows, nbr_out, tile_mask);
+  k_rbs_gather<<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, perm, tile_rows, nbr_out, tile_mask);
   IMF_CHECK_LAUNCH("k_rbs_gather");
   return IMF_OK;
 }

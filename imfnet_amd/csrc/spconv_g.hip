@@ -142,7 +142,10 @@ k_spconv_g(const ConvParams p) {
   __shared__ float4 smem[LDS_BUFS + NBR_F4 + TAB_F4 + KL_F4];
   unsigned *const nbr_lds = reinterpret_cast<unsigned *>(smem + LDS_BUFS);               // [kKCache][ROWS]
   unsigned *const stab = reinterpret_cast<unsigned *>(smem + LDS_BUFS + NBR_F4);          // [kSubTab]
-  int *const klist = reinterpret_cast<int *>(smem + LDS_BUFS + NBR_F4 + TAB_F4);          // [kKCache]
+  // [kKCache] bits 0-7: the j-th offset of the list; bits 8-11 (round 6): 16-row block i of the tile has an input at it.  (No
+  // array of its own: the NB 2 kernels sit exactly at four workgroups per CU.)  Entry j is written, and read in full, by the
+  // wavefront that loads offset j only; everybody else masks the low bits.
+  int *const klist = reinterpret_cast<int *>(smem + LDS_BUFS + NBR_F4 + TAB_F4);
   // weight block / this wavefront's row images of ring slot b
 #define IMF_WBUF(b) (WS1 ? smem : smem + (b) * BUF_F4)
 #define IMF_ABUF(b) (WS1 ? smem + SUB_F4 + (b) * (4 * AW_F4) + wave * AW_F4 : smem + (b) * BUF_F4 + SUB_F4 + wave * AW_F4)
@@ -228,7 +231,7 @@ k_spconv_g(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
           const int j = j0 + JSTEP * i;
-          kk[i] = klist[j < nk ? j : 0];
+          kk[i] = klist[j < nk ? j : 0] & 31;
           if (IMF_G_ABL & 128) { v[i] = lane + j; continue; }
           v[i] = src[(long long)kk[i] * p.n_slots];
         }
@@ -239,23 +242,39 @@ k_spconv_g(const ConvParams p) {
     } else if (tid < ROWS && nk > 0 && vb) {         // kvol == 1: the slot's own row
       v[0] = row_of_slot(p, slot);
     }
-    if (tid < kSubTab) {
-      unsigned e = (unsigned)kDummyJk << 9;
-      if (tid < n_sub) {
-        const int jk = tid / ncc, cc = tid - jk * ncc;
-        const int ch0 = cc * 32;
-        const bool second = CAT && ch0 >= p.c_a;
-        const int cch = second ? (ch0 - p.c_a) >> 5 : cc;
-        e = (unsigned)(klist[jk] * ncc + cc) | ((unsigned)jk << 9) | ((second ? 1u : 0u) << 14) | ((unsigned)cch << 15);
-      }
-      stab[tid] = e;
-    }
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       const int j = j0 + JSTEP * i;
       if (j < nk) nbr_lds[j * ROWS + srow] = v[i] >= 0 ? (unsigned)v[i] : kNoRow;
       else if (j == kDummyJk) nbr_lds[j * ROWS + srow] = kNoRow;
+      // which 16-row blocks have an input at this offset (the 64 lanes of the wavefront = 64 consecutive rows of one offset)
+      const unsigned long long bal = __ballot(v[i] >= 0);
+      static_assert(RB == 1, "block bits: one wavefront = the 64 rows of one offset");
+      if (lane == 0 && j < kKCache) {
+        const unsigned bits = ((bal & 0xFFFFull) ? 1u : 0u) | ((bal & 0xFFFF0000ull) ? 2u : 0u) |
+                              ((bal & 0xFFFF00000000ull) ? 4u : 0u) | ((bal & 0xFFFF000000000000ull) ? 8u : 0u);
+        if (j < nk) klist[j] = (klist[j] & 31) | (int)(bits << 8);
+      }
     }
+  }
+  __syncthreads();
+  // Sub-stage table.  Bits 20 .. 27 of an entry: the 16-row blocks of the workgroup's rows that have an input at the
+  // sub-stage's offset (round 6).  A wavefront whose RB blocks have none takes part in the barriers and the weight copy of the
+  // sub-stage but leaves out its fragment reads, its split and its MFMAs -- they would add exact zeros, the sums are the same
+  // bit for bit.  In slot = row order 96 % of the (block, offset) pairs are active; on the occupancy-sorted maps
+  // (csrc/rulebook_sort.hip) ~68 %.
+  if (tid < kSubTab) {
+    unsigned e = (unsigned)kDummyJk << 9;
+    if (tid < n_sub) {
+      const int jk = tid / ncc, cc = tid - jk * ncc;
+      const int ch0 = cc * 32;
+      const bool second = CAT && ch0 >= p.c_a;
+      const int cch = second ? (ch0 - p.c_a) >> 5 : cc;
+      const int kl = klist[jk];
+      e = (unsigned)((kl & 31) * ncc + cc) | ((unsigned)jk << 9) | ((second ? 1u : 0u) << 14) | ((unsigned)cch << 15) |
+          ((p.nbr ? (unsigned)(kl >> 8) & 15u : 15u) << 20);
+    }
+    stab[tid] = e;
   }
   __syncthreads();
 
@@ -311,7 +330,7 @@ k_spconv_g(const ConvParams p) {
   {                                                                                                              \
     const unsigned ee = (unsigned)__builtin_amdgcn_readfirstlane((int)(e));                                      \
     const bool second = CAT && ((ee >> 14) & 1u);                                                                \
-    const unsigned soff = (ee >> 15) << 7;                                                                       \
+    const unsigned soff = ((ee >> 15) & 31u) << 7;                                                                       \
     const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                      \
     float4 *const ab = IMF_ABUF(b);                                                                              \
     if (!(ABL & 4)) {                                                                                            \
@@ -329,25 +348,22 @@ k_spconv_g(const ConvParams p) {
   // sub-stage t + D + 2 and the input rows of t + D + 1 are read in iteration t, the DMA of t + D is issued in it.
   // Waits are counted by hand (the compiler does not order ds_reads after LDS-DMAs, and __syncthreads() would
   // drain the whole queue): vmcnt(PER (D - 1)) leaves the D - 1 younger sub-stages in flight across the barrier.
-  // Empty 16-row blocks are skipped (round 6): a wavefront whose RB blocks have NO input at a sub-stage's offset takes part in
-  // the barriers and the weight copy but leaves out its fragment reads, its split and its MFMAs (they would add exact zeros:
-  // the sums are the same bit for bit).  In slot = row order 96 % of the (block, offset) pairs are active; on the
-  // occupancy-sorted maps (csrc/rulebook_sort.hip) ~68 %.  actq[i] = "sub-stage t + i has an input row for this wavefront".
-#define IMF_ROWS_ACTIVE(rows) ([&]() { bool a_ = false; _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) a_ |= (rows).r[b_] != kNoRow; \
-                                      return __ballot(a_) != 0ull; }())
+  // actq[i]: this wavefront's block has an input in sub-stage t + i (bit 20 + wave of its table entry; scalar)
+#define IMF_E_ACTIVE(e) (((((unsigned)__builtin_amdgcn_readfirstlane((int)(e))) >> (20 + wave)) & 1u) != 0u)
   unsigned e_b, e_c = IMF_READ_E(D), e_d = IMF_READ_E(D + 1);
   Rows irow_b, irow_c;
-  bool actq[D + 1];
+  bool actq[D + 2];
+#pragma unroll
+  for (int d = 0; d < D; ++d) actq[d] = IMF_E_ACTIVE(IMF_READ_E(d));
+  actq[D] = IMF_E_ACTIVE(e_c);
+  actq[D + 1] = IMF_E_ACTIVE(e_d);
   IMF_READ_ROWS(irow_c, e_c)
-  actq[D] = IMF_ROWS_ACTIVE(irow_c);
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    actq[d] = false;
     if (d < n_sub) {
       const unsigned e0 = IMF_READ_E(d);
       Rows irow0;
       IMF_READ_ROWS(irow0, e0)
-      actq[d] = IMF_ROWS_ACTIVE(irow0);
       if (!WS1 || d == 0) IMF_DMA_W(e0, d)          // (WS1: one weight block in flight, row sub-stages 0 .. D - 1)
       IMF_DMA_R(e0, irow0, d)
     }
@@ -374,10 +390,14 @@ k_spconv_g(const ConvParams p) {
     if (!WS1 && t + D < n_sub) IMF_DMA(e_b, irow_b, slot_wr)   // (WS1: after the fragment reads, below)
     IMF_READ_ROWS(irow_c, e_c)
     e_d = IMF_READ_E(t + D + 2);
-    const bool act = actq[0] || (ABL != 0);             // this wavefront has work in sub-stage t
+    // (not in the 64-column bf16x3 kernel with single buffers: at its 96 VGPRs -- five workgroups per CU -- the branches cost
+    // 13 spilled registers; its launches are the transposed maps', whose tiles are grouped by parity class and have no empty
+    // blocks to speak of)
+    constexpr bool SKIP = ABL == 0 && !(WS1 && CO_BLK == 4 && AR == kArBf16x3);
+    const bool act = SKIP ? actq[0] : true;             // this wavefront has work in sub-stage t
 #pragma unroll
-    for (int i = 0; i < D; ++i) actq[i] = actq[i + 1];
-    actq[D] = IMF_ROWS_ACTIVE(irow_c);                  // rows of sub-stage t + D + 1
+    for (int i = 0; i <= D; ++i) actq[i] = actq[i + 1];
+    actq[D + 1] = IMF_E_ACTIVE(e_d);
     IMF_GSTAMP(10 + 4 * t);
     const float4 *const wbuf = IMF_WBUF(slot_rd);
     const float4 *const abuf = IMF_ABUF(slot_rd);
@@ -426,38 +446,41 @@ k_spconv_g(const ConvParams p) {
     }
     if constexpr (AR == kArBf16x3) {
       // fp32 rows -> three bf16 parts in registers; the image's quads (3 cb + part) are the matching B parts
-      if (!act) {
-        IMF_WS_MID
-        continue;
+      // (the fragments are READ before the mid-iteration barrier and SPLIT after it: the requests of sub-stage t + 1 go out as
+      // early as possible and land under the split and the MFMAs)
+      float4 ar0[RB], ar1[RB], bp[CO_BLK][3];
+      if (act) {
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          ar0[b] = lds_read16(&abuf[128 * b + rd_slot]);
+          ar1[b] = lds_read16(&abuf[128 * b + 64 + rd_slot]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CO_BLK; ++cb)
+#pragma unroll
+          for (int h = 0; h < 3; ++h) bp[cb][h] = lds_read16(&wbuf[(3 * cb + h) * 64 + lane]);
       }
-      bf16x8 ap[RB][3], bp[CO_BLK][3];
-#pragma unroll
-      for (int b = 0; b < RB; ++b)
-        split_b3(lds_read16(&abuf[128 * b + rd_slot]), lds_read16(&abuf[128 * b + 64 + rd_slot]), ap[b][0], ap[b][1], ap[b][2]);
-#pragma unroll
-      for (int cb = 0; cb < CO_BLK; ++cb)
-#pragma unroll
-        for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, lds_read16(&wbuf[(3 * cb + h) * 64 + lane]));
       IMF_WS_MID
+      if (act) {
+        bf16x8 ap[RB][3];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) split_b3(ar0[b], ar1[b], ap[b][0], ap[b][1], ap[b][2]);
 #define IMF_G_TERM(I, J)                                                                               \
   _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                       \
       _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                            \
-          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], bp[cb][J], acc[b][cb], 0, 0, 0);
-      IMF_B3_TERMS(IMF_G_TERM)
+          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], __builtin_bit_cast(bf16x8, bp[cb][J]), acc[b][cb], 0, 0, 0);
+        IMF_B3_TERMS(IMF_G_TERM)
 #undef IMF_G_TERM
+      }
       continue;
     }
-    f16x8 ah[RB], al[RB];
+    float4 ar0[RB], ar1[RB];
     f16x8 bh[CO_BLK], bl[CO_BLK];
     if (act) {
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
-        if ((ABL & 2) || PRE) {
-          ah[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + rd_slot]));
-          al[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + 64 + rd_slot]));
-        } else {
-          split8(lds_read16(&abuf[128 * b + rd_slot]), lds_read16(&abuf[128 * b + 64 + rd_slot]), ah[b], al[b]);
-        }
+        ar0[b] = lds_read16(&abuf[128 * b + rd_slot]);
+        ar1[b] = lds_read16(&abuf[128 * b + 64 + rd_slot]);
       }
 #pragma unroll
       for (int cb = 0; cb < CO_BLK; ++cb) {
@@ -467,6 +490,16 @@ k_spconv_g(const ConvParams p) {
     }
     IMF_WS_MID
     if (!act) continue;
+    f16x8 ah[RB], al[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      if ((ABL & 2) || PRE) {
+        ah[b] = __builtin_bit_cast(f16x8, ar0[b]);
+        al[b] = __builtin_bit_cast(f16x8, ar1[b]);
+      } else {
+        split8(ar0[b], ar1[b], ah[b], al[b]);
+      }
+    }
 #ifdef IMF_G_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers (perturbs the schedule a little)
     IMF_GSTAMP(11 + 4 * t);
@@ -501,7 +534,7 @@ k_spconv_g(const ConvParams p) {
 #undef IMF_DMA_W
 #undef IMF_DMA_R
 #undef IMF_READ_ROWS
-#undef IMF_ROWS_ACTIVE
+#undef IMF_E_ACTIVE
 #undef IMF_READ_E
 #undef IMF_WBUF
 #undef IMF_ABUF

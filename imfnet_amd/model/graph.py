@@ -387,6 +387,12 @@ class FragmentRunner:
         b.last_use = self._use_tick
         return b
 
+    def touch(self, b):
+        """Bucket b is being used without going through bucket() (a streamer re-issuing one of its idle lanes): it is the most
+        recently used one for the eviction below."""
+        self._use_tick = getattr(self, "_use_tick", 0) + 1
+        b.last_use = self._use_tick
+
     def drop_bucket(self, bk):
         """Forget bucket `bk` (= key, or (key, lane)): its device blocks are released once the last holder lets go (the
         streamers drop theirs in `FragmentStreamer._evict`; pinned slots only hold weak references)."""

@@ -91,7 +91,8 @@ class FragmentStreamer:
             raise ImfError("imf_pipeline_create failed: " + self.L.imf_last_error().decode())
         self.main = main
         self._free = {}              # capacity key -> lanes not in flight
-        self._made = {}              # capacity key -> lanes created so far
+        self._made = {}              # capacity key -> SET of the live lane numbers (a dropped lane's number is free again:
+                                     # ADVICE r5 -- a count would re-issue the number of a lane that still exists)
         self._used = {}              # capacity key -> submit counter at its last use (eviction is LRU over keys)
         self._tick = 0
         self._inflight = []          # StreamJobs not yet completed, in submit order
@@ -125,19 +126,28 @@ class FragmentStreamer:
                 if free:
                     b = free.pop()
                     b.in_flight = True
+                    self.runner.touch(b)              # (the runner's eviction is LRU: a lane in use is not the oldest)
                     return b
-                if self._made.get(key, 0) < self.n_buckets:
+                if len(self._made.get(key, ())) < self.n_buckets:
                     if key not in self._made:
                         self._evict_lru(keep=key)
-                    lane = self._made.get(key, 0) + 1            # lanes 1 ..: lane 0 belongs to the direct launches
-                    self._made[key] = lane
-                    b = self.runner.bucket(key, self.device, self.main, lane=lane)
+                    b = self._new_lane(key)
                     b.in_flight = True
                     return b
                 old = next((j for j in self._inflight if j.bucket.key == key), None)
             if old is None:
                 raise ImfError("streamer: no bucket of this capacity is free and none is in flight")
             self._complete(old)                       # (outside the lock: it blocks on the GPU)
+
+    def _new_lane(self, key):
+        """A further bucket of `key` under the smallest lane number this streamer does not hold (lanes 1 ..: lane 0 belongs to
+        the direct launches).  Called under the lock."""
+        lanes = self._made.setdefault(key, set())
+        lane = next(i for i in range(1, len(lanes) + 2) if i not in lanes)
+        lanes.add(lane)
+        b = self.runner.bucket(key, self.device, self.main, lane=lane)
+        b.lane = lane
+        return b
 
     def _release(self, b):
         b.in_flight = False
@@ -148,14 +158,14 @@ class FragmentStreamer:
     def _evict_lru(self, keep=None):
         """Drop least-recently-used keys with nothing in flight until fewer than MAX_KEYS remain (called under the lock)."""
         while len(self._made) >= self.MAX_KEYS:
-            idle = [k for k in self._made if k != keep and len(self._free.get(k, ())) == self._made[k]]
+            idle = [k for k in self._made if k != keep and len(self._free.get(k, ())) == len(self._made[k])]
             if not idle:
                 return
             victim = min(idle, key=lambda k: self._used.get(k, 0))
             lanes = self._made.pop(victim)
             self._free.pop(victim, None)
             self._used.pop(victim, None)
-            for lane in range(1, lanes + 1):           # every job of these lanes has been waited for: nothing is queued on them
+            for lane in sorted(lanes):                 # every job of these lanes has been waited for: nothing is queued on them
                 self.runner.drop_bucket((victim, lane))
 
     def forget(self, b):
@@ -164,21 +174,21 @@ class FragmentStreamer:
             lanes = self._free.get(b.key)
             if lanes and b in lanes:
                 lanes.remove(b)
-                self._made[b.key] -= 1
-                if self._made[b.key] <= 0 and not any(j.bucket.key == b.key for j in self._inflight):
-                    self._made.pop(b.key, None)
-                    self._free.pop(b.key, None)
-                    self._used.pop(b.key, None)
+                live = self._made.get(b.key)
+                if live is not None:
+                    live.discard(getattr(b, "lane", None))
+                    if not live and not any(j.bucket.key == b.key for j in self._inflight):
+                        self._made.pop(b.key, None)
+                        self._free.pop(b.key, None)
+                        self._used.pop(b.key, None)
 
     def fill_lanes(self):
         """Create every lane still missing for the capacity keys seen so far (lanes are otherwise created on demand -- when
         all existing ones of a key are in flight -- which depends on timing; a measurement wants them all to exist)."""
         with self._lock:
             for key in list(self._made):
-                while self._made[key] < self.n_buckets:
-                    lane = self._made[key] + 1
-                    self._made[key] = lane
-                    self._free.setdefault(key, []).append(self.runner.bucket(key, self.device, self.main, lane=lane))
+                while len(self._made[key]) < self.n_buckets:
+                    self._free.setdefault(key, []).append(self._new_lane(key))
 
     # -- submit / wait ------------------------------------------------------------------------------------------------
     def submit(self, items, voxel_size, slot, more_follow=False, skip_descriptors=False):

@@ -66,11 +66,7 @@ def test_sorted_map_twin_matches_its_numpy_restatement(clouds):
     n, S, K = lv0.n, len(rows), 27
     assert err == 0 and n > 2 * 16384
     srows, snbr, smask = T.rulebook_sort_by_occupancy(nbr, n)
-    slot = np.arange(S)
-    m = ((nbr >= 0).astype(np.uint64) << np.arange(K, dtype=np.uint64)[:, None]).sum(0)
-    key = np.where(slot < n, ((slot >> 14).astype(np.uint64) << np.uint64(27)) | m, np.uint64(0xFFFFFFFFFFFFFFFF))
-    perm = np.argsort(key, kind="stable")
-    valid = perm < n
+    perm, valid = O.occupancy_sorted_slots(nbr, n)
     assert (srows == np.where(valid, perm, -1)).all() and sorted(srows[:n].tolist()) == list(range(n))
     assert (snbr == np.where(valid[None, :], nbr[:, perm], -1)).all()
     act = (snbr.reshape(K, -1, 64) >= 0).any(2)
