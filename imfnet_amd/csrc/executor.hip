@@ -73,10 +73,12 @@ size_t rb_words(int64_t n_slots, int kvol) {
   return (size_t)n_slots + (size_t)kvol * n_slots + (size_t)(n_slots / IMF_TILE_ROWS) * IMF_MASK_WORDS;
 }
 
-// the occupancy-sorted twin of the stride-1 3x3x3 map (csrc/rulebook_sort.hip) + the sort's workspace, behind the other maps
+// the occupancy-sorted twins of the stride-1 maps of levels 0-2 for the decoder's blocks (csrc/rulebook_sort.hip) + the sorts'
+// workspace (one: the side stream runs them one after the other), behind the other maps
 size_t sorted_map_words(const Sizes &s) {
-  if (!s.small_first) return 0;
-  return rb_words(s.slots[0], 27) + 64 /* alignment slack */ + imf_rulebook_sorted_workspace_bytes(s.slots[0]) / 4;
+  size_t w = 64 /* alignment slack */ + imf_rulebook_sorted_workspace_bytes(s.slots[0]) / 4;
+  for (int i = 0; i < 3; ++i) w += rb_words(s.slots[i], 27);
+  return w;
 }
 
 size_t int_words(const Sizes &s) {
@@ -157,6 +159,9 @@ int fork_image_branch(const FragmentCtx &c, hipStream_t main) {
   return IMF_OK;
 }
 
+#ifndef IMF_SORTED_MAPS_DEFAULT
+#define IMF_SORTED_MAPS_DEFAULT 0x07               // sorted twins of the stride-1 maps of levels 0, 1, 2 for the decoder (measured: LAB_NOTES round 6)
+#endif
 constexpr int kMetaBBox = 8;                        // meta[2 * n_levels + 0..7] with n_levels = 4
 constexpr int kMetaStarts = 16;                     // meta[16 + IMF_MAX_BATCH * level + item]
 
@@ -202,6 +207,17 @@ int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int vari
   // measured on the S50k pair (profiles/r03_conv_isolated.txt, r05_conv_isolated_*.txt): level 1 (438 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
   return level == 1 ? 8 : 4;
+}
+
+int imf_resunet_sorted_maps(int variant) {
+  // bit i (0 .. 2): the decoder's block on level i walks an occupancy-sorted twin of the level's stride-1 map.  Default: all
+  // three on bf16x3, none on fp32 MFMA / split-f16 -- measured on the S50k pair, A/B/A/B on one box (round 6, LAB_NOTES):
+  // bf16x3 1.1919 / 1.1886 -> 1.1735 / 1.1733 ms (level 0 alone: 1.1787), fp32 1.914 -> 1.973, split-f16 0.914 -> 0.958: their
+  // coarse-level kernels hold a CU's whole LDS, as the sort's workgroups do, and lose more to the sorts running beside them
+  // than the decoder gains.  IMF_SORTED_MAP overrides for every arithmetic (A/B; 0 = none).
+  static const int env = getenv("IMF_SORTED_MAP") ? (int)strtol(getenv("IMF_SORTED_MAP"), nullptr, 0) & 0x07 : -1;
+  if (env >= 0) return env;
+  return variant == 3 ? IMF_SORTED_MAPS_DEFAULT : 0;
 }
 
 size_t imf_resunet_int_arena_bytes(const imf_resunet_desc *net, const int64_t *n, const int32_t *bbox) {
@@ -265,13 +281,13 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
                 imf_resunet_float_arena_bytes(net, io->n));
   }
   hipStream_t main = (hipStream_t)io->main_stream, side = (hipStream_t)io->side_stream;
-  const int n_events = pyr ? 9 : (s.small_first ? 8 : 7);   // (the occupancy-sorted stride-1 map has its own join)
+  const int n_events = pyr ? 9 : 10;   // (the occupancy-sorted twins have their own joins: up to three)
   for (int i = 0; i < n_events; ++i) IMF_REQUIRE(io->events[i], "imf_resunet_forward: events[%d] missing", i);
   // flag word: capacity mode collects every flag in the level-0 error word; exact mode takes the caller's (optional)
   int32_t *err = dyn ? const_cast<int32_t *>(meta) + 1 : io->flags;
 
   // ---- rulebooks in the int arena --------------------------------------------------------------
-  Rb rb_first, rb_k3[4], rb_dn[3], rb_up[3], rb_id, rb_k3s;
+  Rb rb_first, rb_k3[4], rb_dn[3], rb_up[3], rb_id, rb_k3s[3];
   int32_t *const ibase = (int32_t *)(((uintptr_t)io->int_arena + 255) & ~(uintptr_t)255);
   int32_t *p = ibase;
   if (!s.small_first) {
@@ -294,27 +310,22 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     rb_up[i].slots_extra = 8 * IMF_TILE_ROWS;
     p = rb_up[i].place(p);
   }
-  // The decoder's stride-1 block (the two largest launches of a step) CAN walk the OCCUPANCY-SORTED twin of the
-  // stride-1 map: tiles of rows with similar neighbour masks, ~78 % of the (tile, offset) pairs instead of ~100 % -- 142 ->
-  // 113 us per 64 -> 64 layer with the same kernel (csrc/rulebook_sort.hip).  Built on the side stream, under the encoder.
-  // OPT-IN (IMF_SORTED_MAP=1, bf16x3): measured at the end of round 5, the two layers are ~20 us faster each in the step's
-  // own trace, yet the pair step does not move (1.2495 / 1.2501 with, 1.2470 / 1.2581 ms without, A/B/A/B on one box) and on
-  // fp32 MFMA the sort's launches on the side stream cost the encoder's 8-wavefront workgroups more than the map returns
-  // (1.91 -> 2.01 ms).  Where the saved time goes is the next thing to find out (tools/sorted_rulebook_probe.py has the
-  // isolated numbers); until then the executors walk the plain map.
-  static const int sorted_env = getenv("IMF_SORTED_MAP") ? atoi(getenv("IMF_SORTED_MAP")) : 0;
-  const bool use_sorted = s.small_first && net->conv[19].variant == 3 && sorted_env != 0;
-  int32_t *sort_ws = nullptr;
-  const size_t sort_ws_bytes = use_sorted ? imf_rulebook_sorted_workspace_bytes(s.slots[0]) : 0;
-  if (use_sorted) {
-    rb_k3s.n_slots = s.slots[0]; rb_k3s.n_out = s.n[0]; rb_k3s.kvol = rb_k3s.max_active = 27;
-    rb_k3s.level = 0;
-    p = rb_k3s.place(p);
-    sort_ws = (int32_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-    p += 64 + sort_ws_bytes / 4;
-  } else {
-    p += sorted_map_words(s);
+  // Occupancy-sorted TWINS of the stride-1 maps (csrc/rulebook_sort.hip; imf_resunet_sorted_maps() says which levels): the
+  // slots re-ordered so that the rows of a tile share their missing offsets -- tiles walk ~78 % of the 27 offsets instead of
+  // ~100 %.  The ENCODER's blocks walk the maps as built (a sort in front of them sits on the step's critical path: measured
+  // +65 us per sorted level, round 6); the DECODER's blocks (block4_tr on level 2, block3_tr on level 1, block2_tr on level 0)
+  // walk the twins, which are sorted at the END of the side stream's chain, under the encoder and the fusion.
+  const int sorted_maps = imf_resunet_sorted_maps(net->conv[19].variant);
+  bool twin[3];
+  for (int i = 0; i < 3; ++i) {
+    twin[i] = ((sorted_maps >> i) & 1) != 0 && (i > 0 || s.small_first);
+    rb_k3s[i].n_slots = s.slots[i]; rb_k3s[i].n_out = s.n[i]; rb_k3s[i].kvol = rb_k3s[i].max_active = 27;
+    rb_k3s[i].level = i;
+    p = rb_k3s[i].place(p);
   }
+  int32_t *const sort_ws = (int32_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+  const size_t sort_ws_bytes = imf_rulebook_sorted_workspace_bytes(s.slots[0]);
+  p += 64 + sort_ws_bytes / 4;
   int32_t *counters = p;
   p += 16 * 3;
   uint32_t *bitgrid = (uint32_t *)p;
@@ -426,7 +437,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     const int src = i == 2 ? FUSED : dbuf(i + 1, 2), c_src = i == 2 ? s.ch[4] : s.dec[i + 1];
     const int skip = i == 2 ? -1 : ebuf(i + 1, 2), c_skip = i == 2 ? 0 : s.ch[i + 2];
     sched[n_steps++] = Step{conv0, &rb_up[i], src, c_src, dbuf(i, 0), skip, c_skip, -1};
-    Rb *const rbk = (i == 0 && use_sorted) ? &rb_k3s : &rb_k3[i];
+    Rb *const rbk = twin[i] ? &rb_k3s[i] : &rb_k3[i];
     sched[n_steps++] = Step{conv0 + 1, rbk, dbuf(i, 0), t, dbuf(i, 1), -1, 0, -1};
     sched[n_steps++] = Step{conv0 + 2, rbk, dbuf(i, 1), t, dbuf(i, 2), -1, 0, dbuf(i, 0)};
   }
@@ -488,17 +499,17 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     is_split[ebuf(0, 0)] = wrote_split;
   }
 
-  // ---- the occupancy-sorted twin of the stride-1 map, on the side stream (behind the coarse levels' chain: the decoder's
-  // last block needs it ~0.9 ms from here) ----
-  if (use_sorted) {
-    if (first_and_map) {   // the stride-1 map came out of the first convolution's launch on the MAIN stream
-      IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[6], main));
-      IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->events[6], 0));
-    }
-    if ((rc = imf_rulebook_sort_by_occupancy(rb_k3[0].nbr, 27, rb_k3[0].n_slots, s.n[0], dyn ? meta : nullptr, rb_k3s.tile_rows,
-                                             rb_k3s.nbr, rb_k3s.tile_mask, sort_ws, sort_ws_bytes, side)))
+  // ---- the occupancy-sorted twins, at the end of the side stream's chain (level 2 first: the decoder reaches it first) ----
+  if (twin[0] && first_and_map) {   // the level-0 map came out of the first convolution's launch on the MAIN stream
+    IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[6], main));
+    IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->events[6], 0));
+  }
+  for (int i = 2; i >= 0; --i) {
+    if (!twin[i]) continue;
+    if ((rc = imf_rulebook_sort_by_occupancy(rb_k3[i].nbr, 27, rb_k3[i].n_slots, s.n[i], dyn ? meta + 2 * i : nullptr,
+                                             rb_k3s[i].tile_rows, rb_k3s[i].nbr, rb_k3s[i].tile_mask, sort_ws, sort_ws_bytes, side)))
       return rc;
-    if (side != main && (rc = mark(rb_k3s))) return rc;
+    if (side != main && (rc = mark(rb_k3s[i]))) return rc;
   }
 
   auto launch = [&](const Step &st) -> int {

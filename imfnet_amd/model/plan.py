@@ -161,12 +161,13 @@ class FusedPlan:
         rb_dn = [_RB(slots[i + 1], n[i + 1], 27, 27, level=i + 1) for i in range(3)]
         rb_up = [_RB(L.imf_rulebook_transpose_slots(n[i]), n[i], 27, 8, level=i) for i in range(3)]
         rb_id = _RB(slots[0], n[0], 1, 1)
-        # the occupancy-sorted twin of the stride-1 map, for the decoder's stride-1 block (csrc/rulebook_sort.hip; the native
-        # executors build and use it the same way: bit-identical descriptors)
-        rb_k3s = _RB(slots[0], n[0], 27, 27, level=0) if (self.small_first and self.convs["block2_tr.conv1"][0].variant == 3 and
-                                                        os.environ.get("IMF_SORTED_MAP", "0") not in ("", "0")) else None   # opt-in, as in csrc/executor.hip
-        sort_ws_bytes = L.imf_rulebook_sorted_workspace_bytes(slots[0]) if rb_k3s is not None else 0
-        all_rb = ([] if self.small_first else [rb_first]) + rb_k3 + rb_dn + rb_up + ([rb_k3s] if rb_k3s is not None else [])
+        # occupancy-sorted twins of the stride-1 maps of levels 0-2 for the decoder's blocks (csrc/rulebook_sort.hip), exactly
+        # as the native executors build and use them (imf_resunet_sorted_maps says which levels): bit-identical descriptors
+        sorted_maps = L.imf_resunet_sorted_maps(int(self.convs["block2_tr.conv1"][0].variant))
+        rb_k3s = [_RB(slots[i], n[i], 27, 27, level=i) if ((sorted_maps >> i) & 1 and (i > 0 or self.small_first)) else None
+                  for i in range(3)]
+        sort_ws_bytes = L.imf_rulebook_sorted_workspace_bytes(slots[0])
+        all_rb = ([] if self.small_first else [rb_first]) + rb_k3 + rb_dn + rb_up + [r for r in rb_k3s if r is not None]
         words = sum(r.words() for r in all_rb) + 16 * 3 + 64 + sort_ws_bytes // 4
         main = torch.cuda.current_stream(dev)
         side = ops.aux_streams(dev)[1][1]        # born with the geometry / image streams: distinct hardware queues
@@ -213,13 +214,15 @@ class FusedPlan:
             e = torch.cuda.Event()
             e.record(side)
             ready[id(rb_up[i])] = e
-        if rb_k3s is not None:                  # (small_first: the stride-1 map was built on the side stream, above)
-            check(L.imf_rulebook_sort_by_occupancy(rb_k3[0].nbr, 27, rb_k3[0].n_slots, n[0], None, rb_k3s.tile_rows,
-                                                   rb_k3s.nbr, rb_k3s.tile_mask, sort_ws, sort_ws_bytes, ss),
+        for i in (2, 1, 0):                     # (small_first: the level-0 map was built on the side stream too, above)
+            if rb_k3s[i] is None:
+                continue
+            check(L.imf_rulebook_sort_by_occupancy(rb_k3[i].nbr, 27, rb_k3[i].n_slots, n[i], None, rb_k3s[i].tile_rows,
+                                                   rb_k3s[i].nbr, rb_k3s[i].tile_mask, sort_ws, sort_ws_bytes, ss),
                   "imf_rulebook_sort_by_occupancy")
             e = torch.cuda.Event()
             e.record(side)
-            ready[id(rb_k3s)] = e
+            ready[id(rb_k3s[i])] = e
         self._ready, self._main = ready, main
         self._flags = m.flag_word(dev).data_ptr()
 
@@ -240,7 +243,7 @@ class FusedPlan:
             src, c_src = ("fused", Ch[4]) if i == 2 else (f"d{i + 1}c", dec_ch[i + 1])
             skip, c_skip = (None, 0) if i == 2 else (f"e{i + 1}c", Ch[i + 2])
             sched.append((f"conv{i + 2}_tr", rb_up[i], src, c_src, f"d{i}a", skip, c_skip, None))
-            rbk = rb_k3s if (i == 0 and rb_k3s is not None) else rb_k3[i]
+            rbk = rb_k3s[i] if rb_k3s[i] is not None else rb_k3[i]
             sched.append((f"block{i + 2}_tr.conv1", rbk, f"d{i}a", t, f"d{i}b", None, 0, None))
             sched.append((f"block{i + 2}_tr.conv2", rbk, f"d{i}b", t, f"d{i}c", None, 0, f"d{i}a"))
         sched.append(("conv1_tr", rb_id, "d0c", T[2], "head", "e0c", Ch[1], None))
@@ -349,7 +352,7 @@ class NativePlan:
         self.fw = fw                                  # keeps the packed tensors alive
         d.fusion, d.fusion_scale = fw.c, fw.scale
         self.io = ResunetIO()
-        self._events = [self.L.imf_event_create() for _ in range(8)]
+        self._events = [self.L.imf_event_create() for _ in range(10)]
         for i, e in enumerate(self._events):
             self.io.events[i] = e
         self._side = {}

@@ -165,15 +165,19 @@ int imf_rulebook_conv(const imf_slot *in_table, int64_t in_capacity,
                       const int32_t *out_coords, int64_t n_out, int ts_in, int ksize,
                       int32_t *tile_rows, int32_t *nbr, uint32_t *tile_mask, void *stream);
 
-/* Occupancy-sorted twin of a stride-1 map (csrc/rulebook_sort.hip): the same rows and inputs, the SLOTS re-ordered so that
- * the 64 rows of a tile have similar neighbour-occupancy masks -- stable sort by the 64-bit key = (slot >> 14) << 27 | mask (mask bit k
- * <=> nbr_in[k][slot] >= 0), i.e. inside windows of 16 384 consecutive rows; slots >= the row count sort last.  nbr_in: a map
- * in identity slot order (imf_rulebook_conv(_dyn), ksize 3: kvol <= 27); outputs: tile_rows[slot] = the row now in that slot
- * (-1: padding), nbr_out[k][slot] = nbr_in[k][row], tile_mask recomputed.  Tiles then walk ~78 % of the 27 offsets instead of
- * ~100 % (stride-1 level of a 3DMatch fragment), with no change to imf_spconv_fwd.  n_out_dev: optional device-side row count
- * (capacity mode; n_out is then the capacity).  Replaces: nothing in the reference (MinkowskiEngine's kernel maps have no
- * tile structure); used by the executors for the decoder's stride-1 block (model/resunet.py:136-146).
- * workspace: imf_rulebook_sorted_workspace_bytes(n_slots) bytes of device memory. */
+/* Occupancy-sorted twin of a kernel map (csrc/rulebook_sort.hip): the same rows and inputs, the SLOTS re-ordered so that the
+ * rows of a tile / of a 16-row block have similar neighbour-occupancy patterns -- stable sort inside windows of 16 384
+ * consecutive slots by key = gray^-1(r), r = the occupancy bits (nbr_in[k][slot] >= 0) of the 12 edge offsets of the 3x3x3
+ * kernel in bits 19 .. 8 (k = 1, 3, .. 25 without 13, in that order from bit 19 down), of the 6 face offsets (4, 10, 12, 14,
+ * 16, 22) in bits 7 .. 2 and of the corner offsets 0 and 26 in bits 1, 0; slots >= the row count sort last in their window
+ * (kvol != 27: r = the bits of the first 20 offsets).  nbr_in: a map in identity slot order (imf_rulebook_conv(_dyn), kvol
+ * <= 27); outputs: tile_rows[slot] = the row now in that slot (-1: padding), nbr_out[k][slot] = nbr_in[k][row], tile_mask
+ * recomputed.  A 64-row tile then walks ~78 % of the 27 offsets instead of ~100 % (stride-1 level of a 3DMatch fragment; 1.47
+ * issued multiply-adds per useful one instead of 1.91), with no change to imf_spconv_fwd.  n_out_dev: optional
+ * device-side row count (capacity mode; n_out is then the capacity).  One launch per window + one gather launch.  Replaces:
+ * nothing in the reference (MinkowskiEngine's kernel maps have no tile structure); used by the executors for the decoder's
+ * stride-1 blocks (model/resunet.py:136-146, imf_resunet_sorted_maps).
+ * workspace: imf_rulebook_sorted_workspace_bytes(n_slots) bytes of device memory (the permutation). */
 size_t imf_rulebook_sorted_workspace_bytes(int64_t n_slots);
 int imf_rulebook_sort_by_occupancy(const int32_t *nbr_in, int kvol, int64_t n_slots, int64_t n_out, const int32_t *n_out_dev,
                                    int32_t *tile_rows, int32_t *nbr_out, uint32_t *tile_mask, void *workspace,
@@ -573,6 +577,14 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
  * a variant other than 6 / 3 / 0).  Replaces: the implicit per-layer algorithm choice inside
  * ME.MinkowskiConvolution (model/resunet.py:168-226). */
 int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int variant, int n_items);
+/* For which pyramid levels (bit i = level i, 0 .. 2) the executors (imf_resunet_forward, imf_fragment_forward, the Python plan)
+ * build an occupancy-sorted TWIN of the stride-1 map (imf_rulebook_sort_by_occupancy) that the DECODER's block of the level
+ * walks -- block2_tr / block3_tr / block4_tr of model/resunet.py:136-146; the encoder's blocks walk the map as built (a sort in
+ * front of them would sit on the critical path).  A function of the arithmetic (imf_conv_args.variant of the layers: 7 for
+ * bf16x3, 0 for fp32 MFMA and split-f16, where the sorts cost more than the twins return) and of the process environment
+ * (IMF_SORTED_MAP overrides) only, so every execution mode walks the same maps and forms the same sums.  Replaces: nothing in
+ * the reference. */
+int imf_resunet_sorted_maps(int variant);
 
 typedef struct imf_resunet_io {        /* per fragment */
   imf_level level[4];                  /* tensor strides 1, 2, 4, 8 (imf_pyramid_build) */

@@ -127,9 +127,10 @@ def test_graph_batches_of_three_and_four_equal_exact(model, clouds, images, nb):
     assert torch.equal(res.F, F) and torch.equal(res.first_idx, inds)
 
 
-def test_opt_in_sorted_map_keeps_the_modes_bit_identical():
-    """IMF_SORTED_MAP=1 (csrc/executor.hip: the decoder's stride-1 block walks the occupancy-sorted twin of the stride-1 map,
-    csrc/rulebook_sort.hip): in a process of its own (the switch is read once) the native executor still equals the op-by-op
+def test_sorted_twins_keep_the_modes_bit_identical():
+    """The decoder's blocks walk occupancy-sorted twins of the stride-1 maps of levels 0-2 (csrc/executor.hip,
+    csrc/rulebook_sort.hip; default IMF_SORTED_MAP=7, 0 = the maps as built): in a process of its own for each setting (the
+    switch is read once) the native executor equals the op-by-op
     Python plan bit for bit, capacity mode equals the exact path for one fragment and for the pair, and the descriptors stay
     within round-off of the default map's (same terms, other partition)."""
     import subprocess, sys, textwrap
@@ -162,14 +163,16 @@ def test_opt_in_sorted_map_keeps_the_modes_bit_identical():
         print("OK")
     """) % (ROOT, ROOT, ROOT)
     outs = {}
-    for flag in ("1", "0"):
+    for flag in ("7", "1", "0"):
         env = dict(os.environ, IMF_SORTED_MAP=flag)
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
         outs[flag] = [float(l.split()[2]) for l in p.stdout.splitlines() if l.startswith("F ")]
-    for a, b in zip(outs["1"], outs["0"]):
-        assert abs(a - b) <= 1e-6 * abs(b) + 1e-3                # the same descriptors to round-off ...
-    assert outs["1"] != outs["0"]                                # ... formed over another partition: the switch took effect
+    for flag in ("7", "1"):
+        for a, b in zip(outs[flag], outs["0"]):
+            assert abs(a - b) <= 1e-6 * abs(b) + 1e-3            # the same descriptors to round-off ...
+        assert outs[flag] != outs["0"]                           # ... formed over another partition: the switch took effect
+    assert outs["7"] != outs["1"]
 
 
 def test_capacity_overflow_is_flagged(model, clouds, images):

@@ -142,7 +142,10 @@ k_spconv_g(const ConvParams p) {
   __shared__ float4 smem[LDS_BUFS + NBR_F4 + TAB_F4 + KL_F4];
   unsigned *const nbr_lds = reinterpret_cast<unsigned *>(smem + LDS_BUFS);               // [kKCache][ROWS]
   unsigned *const stab = reinterpret_cast<unsigned *>(smem + LDS_BUFS + NBR_F4);          // [kSubTab]
-  int *const klist = reinterpret_cast<int *>(smem + LDS_BUFS + NBR_F4 + TAB_F4);          // [kKCache]
+  // [kKCache] bits 0-7: the j-th offset of the list; bits 8-11 (round 6): 16-row block i of the tile has an input at it.  (No
+  // array of its own: the NB 2 kernels sit exactly at four workgroups per CU.)  Entry j is written, and read in full, by the
+  // wavefront that loads offset j only; everybody else masks the low bits.
+  int *const klist = reinterpret_cast<int *>(smem + LDS_BUFS + NBR_F4 + TAB_F4);
   // weight block / this wavefront's row images of ring slot b
 #define IMF_WBUF(b) (WS1 ? smem : smem + (b) * BUF_F4)
 #define IMF_ABUF(b) (WS1 ? smem + SUB_F4 + (b) * (4 * AW_F4) + wave * AW_F4 : smem + (b) * BUF_F4 + SUB_F4 + wave * AW_F4)
@@ -228,7 +231,7 @@ k_spconv_g(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
           const int j = j0 + JSTEP * i;
-          kk[i] = klist[j < nk ? j : 0];
+          kk[i] = klist[j < nk ? j : 0] & 31;
           if (IMF_G_ABL & 128) { v[i] = lane + j; continue; }
           v[i] = src[(long long)kk[i] * p.n_slots];
         }
@@ -239,25 +242,42 @@ k_spconv_g(const ConvParams p) {
     } else if (tid < ROWS && nk > 0 && vb) {         // kvol == 1: the slot's own row
       v[0] = row_of_slot(p, slot);
     }
-    if (tid < kSubTab) {
-      unsigned e = (unsigned)kDummyJk << 9;
-      if (tid < n_sub) {
-        const int jk = tid / ncc, cc = tid - jk * ncc;
-        const int ch0 = cc * 32;
-        const bool second = CAT && ch0 >= p.c_a;
-        const int cch = second ? (ch0 - p.c_a) >> 5 : cc;
-        e = (unsigned)(klist[jk] * ncc + cc) | ((unsigned)jk << 9) | ((second ? 1u : 0u) << 14) | ((unsigned)cch << 15);
-      }
-      stab[tid] = e;
-    }
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       const int j = j0 + JSTEP * i;
       if (j < nk) nbr_lds[j * ROWS + srow] = v[i] >= 0 ? (unsigned)v[i] : kNoRow;
       else if (j == kDummyJk) nbr_lds[j * ROWS + srow] = kNoRow;
+      // which 16-row blocks have an input at this offset (the 64 lanes of the wavefront = 64 consecutive rows of one offset)
+      const unsigned long long bal = __ballot(v[i] >= 0);
+      static_assert(RB == 1, "block bits: one wavefront = the 64 rows of one offset");
+      if (lane == 0 && j < kKCache) {
+        const unsigned bits = ((bal & 0xFFFFull) ? 1u : 0u) | ((bal & 0xFFFF0000ull) ? 2u : 0u) |
+                              ((bal & 0xFFFF00000000ull) ? 4u : 0u) | ((bal & 0xFFFF000000000000ull) ? 8u : 0u);
+        if (j < nk) klist[j] = (klist[j] & 31) | (int)(bits << 8);
+      }
     }
   }
   __syncthreads();
+  // Sub-stage table.  Bits 20 .. 23 of an entry: the 16-row blocks of the tile that have an input at the sub-stage's offset
+  // (round 6).  A wavefront whose block has none takes part in the barriers and the weight copy of the sub-stage but leaves
+  // out its fragment reads, its split and its MFMAs -- they would add exact zeros, the sums are the same bit for bit.  In
+  // slot = row order 96 % of the (block, offset) pairs are active; on the occupancy-sorted maps (csrc/rulebook_sort.hip) ~70 %.
+  // Every wavefront writes the WHOLE table (lane = offset of the list): all four store the same words, so nobody needs a
+  // barrier before reading it.
+  if (lane < 32) {
+    const bool on = lane < nk && n_sub > 0;
+    const int kl = klist[on ? lane : 0];
+    for (int cc = 0; cc < ncc; ++cc) {
+      if (on) {
+        const int ch0 = cc * 32;
+        const bool second = CAT && ch0 >= p.c_a;
+        const int cch = second ? (ch0 - p.c_a) >> 5 : cc;
+        stab[lane * ncc + cc] = (unsigned)((kl & 31) * ncc + cc) | ((unsigned)lane << 9) | ((second ? 1u : 0u) << 14) | ((unsigned)cch << 15) |
+                                ((p.nbr ? (unsigned)(kl >> 8) & 15u : 15u) << 20);
+      }
+    }
+    if (lane < 8) stab[lane < 7 && n_sub + lane < kSubTab - 1 ? n_sub + lane : kSubTab - 1] = (unsigned)kDummyJk << 9;   // look-ahead entries
+  }
 
   f32x4 acc[RB][CO_BLK];
 #pragma unroll
@@ -311,7 +331,7 @@ k_spconv_g(const ConvParams p) {
   {                                                                                                              \
     const unsigned ee = (unsigned)__builtin_amdgcn_readfirstlane((int)(e));                                      \
     const bool second = CAT && ((ee >> 14) & 1u);                                                                \
-    const unsigned soff = (ee >> 15) << 7;                                                                       \
+    const unsigned soff = ((ee >> 15) & 31u) << 7;                                                                       \
     const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                      \
     float4 *const ab = IMF_ABUF(b);                                                                              \
     if (!(ABL & 4)) {                                                                                            \
@@ -329,8 +349,15 @@ k_spconv_g(const ConvParams p) {
   // sub-stage t + D + 2 and the input rows of t + D + 1 are read in iteration t, the DMA of t + D is issued in it.
   // Waits are counted by hand (the compiler does not order ds_reads after LDS-DMAs, and __syncthreads() would
   // drain the whole queue): vmcnt(PER (D - 1)) leaves the D - 1 younger sub-stages in flight across the barrier.
+  // actq[i]: this wavefront's block has an input in sub-stage t + i (bit 20 + wave of its table entry; scalar)
+#define IMF_E_ACTIVE(e) (((((unsigned)__builtin_amdgcn_readfirstlane((int)(e))) >> (20 + wave)) & 1u) != 0u)
   unsigned e_b, e_c = IMF_READ_E(D), e_d = IMF_READ_E(D + 1);
   Rows irow_b, irow_c;
+  bool actq[D + 2];
+#pragma unroll
+  for (int d = 0; d < D; ++d) actq[d] = IMF_E_ACTIVE(IMF_READ_E(d));
+  actq[D] = IMF_E_ACTIVE(e_c);
+  actq[D + 1] = IMF_E_ACTIVE(e_d);
   IMF_READ_ROWS(irow_c, e_c)
 #pragma unroll
   for (int d = 0; d < D; ++d) {
@@ -364,6 +391,14 @@ k_spconv_g(const ConvParams p) {
     if (!WS1 && t + D < n_sub) IMF_DMA(e_b, irow_b, slot_wr)   // (WS1: after the fragment reads, below)
     IMF_READ_ROWS(irow_c, e_c)
     e_d = IMF_READ_E(t + D + 2);
+    // (not in the 64-column bf16x3 kernel with single buffers: at its 96 VGPRs -- five workgroups per CU -- the branches cost
+    // 13 spilled registers; its launches are the transposed maps', whose tiles are grouped by parity class and have no empty
+    // blocks to speak of)
+    constexpr bool SKIP = ABL == 0 && !(WS1 && CO_BLK == 4 && AR == kArBf16x3);
+    const bool act = SKIP ? actq[0] : true;             // this wavefront has work in sub-stage t
+#pragma unroll
+    for (int i = 0; i <= D; ++i) actq[i] = actq[i + 1];
+    actq[D + 1] = IMF_E_ACTIVE(e_d);
     IMF_GSTAMP(10 + 4 * t);
     const float4 *const wbuf = IMF_WBUF(slot_rd);
     const float4 *const abuf = IMF_ABUF(slot_rd);
@@ -387,17 +422,20 @@ k_spconv_g(const ConvParams p) {
     }
     if constexpr (AR == kArF32) {
       float4 a0[RB], a1[RB], b0[CO_BLK], b1[CO_BLK];
+      if (act) {
 #pragma unroll
-      for (int b = 0; b < RB; ++b) {
-        a0[b] = lds_read16(&abuf[128 * b + rd_slot]);
-        a1[b] = lds_read16(&abuf[128 * b + 64 + rd_slot]);
-      }
+        for (int b = 0; b < RB; ++b) {
+          a0[b] = lds_read16(&abuf[128 * b + rd_slot]);
+          a1[b] = lds_read16(&abuf[128 * b + 64 + rd_slot]);
+        }
 #pragma unroll
-      for (int cb = 0; cb < CO_BLK; ++cb) {      // quad (j, cb) of the fp32 image: W[16 j + 4 q4 + t][16 cb + r16]
-        b0[cb] = lds_read16(&wbuf[cb * 64 + lane]);
-        b1[cb] = lds_read16(&wbuf[(CO_BLK + cb) * 64 + lane]);
+        for (int cb = 0; cb < CO_BLK; ++cb) {    // quad (j, cb) of the fp32 image: W[16 j + 4 q4 + t][16 cb + r16]
+          b0[cb] = lds_read16(&wbuf[cb * 64 + lane]);
+          b1[cb] = lds_read16(&wbuf[(CO_BLK + cb) * 64 + lane]);
+        }
       }
       IMF_WS_MID
+      if (!act) continue;
 #define IMF_G_STEP(AV, BV, C)                                                                          \
   _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                       \
       _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                            \
@@ -409,40 +447,60 @@ k_spconv_g(const ConvParams p) {
     }
     if constexpr (AR == kArBf16x3) {
       // fp32 rows -> three bf16 parts in registers; the image's quads (3 cb + part) are the matching B parts
-      bf16x8 ap[RB][3], bp[CO_BLK][3];
+      // (the fragments are READ before the mid-iteration barrier and SPLIT after it: the requests of sub-stage t + 1 go out as
+      // early as possible and land under the split and the MFMAs)
+      float4 ar0[RB], ar1[RB], bp[CO_BLK][3];
+      if (act) {
 #pragma unroll
-      for (int b = 0; b < RB; ++b)
-        split_b3(lds_read16(&abuf[128 * b + rd_slot]), lds_read16(&abuf[128 * b + 64 + rd_slot]), ap[b][0], ap[b][1], ap[b][2]);
+        for (int b = 0; b < RB; ++b) {
+          ar0[b] = lds_read16(&abuf[128 * b + rd_slot]);
+          ar1[b] = lds_read16(&abuf[128 * b + 64 + rd_slot]);
+        }
 #pragma unroll
-      for (int cb = 0; cb < CO_BLK; ++cb)
+        for (int cb = 0; cb < CO_BLK; ++cb)
 #pragma unroll
-        for (int h = 0; h < 3; ++h) bp[cb][h] = __builtin_bit_cast(bf16x8, lds_read16(&wbuf[(3 * cb + h) * 64 + lane]));
+          for (int h = 0; h < 3; ++h) bp[cb][h] = lds_read16(&wbuf[(3 * cb + h) * 64 + lane]);
+      }
       IMF_WS_MID
+      if (act) {
+        bf16x8 ap[RB][3];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) split_b3(ar0[b], ar1[b], ap[b][0], ap[b][1], ap[b][2]);
 #define IMF_G_TERM(I, J)                                                                               \
   _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                       \
       _Pragma("unroll") for (int cb = 0; cb < CO_BLK; ++cb)                                            \
-          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], bp[cb][J], acc[b][cb], 0, 0, 0);
-      IMF_B3_TERMS(IMF_G_TERM)
+          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], __builtin_bit_cast(bf16x8, bp[cb][J]), acc[b][cb], 0, 0, 0);
+        IMF_B3_TERMS(IMF_G_TERM)
 #undef IMF_G_TERM
+      }
       continue;
     }
+    float4 ar0[RB], ar1[RB];
+    f16x8 bh[CO_BLK], bl[CO_BLK];
+    if (act) {
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        ar0[b] = lds_read16(&abuf[128 * b + rd_slot]);
+        ar1[b] = lds_read16(&abuf[128 * b + 64 + rd_slot]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CO_BLK; ++cb) {
+        bh[cb] = lds_read_f16x8(&wbuf[(2 * cb) * 64 + lane]);
+        bl[cb] = lds_read_f16x8(&wbuf[(2 * cb + 1) * 64 + lane]);
+      }
+    }
+    IMF_WS_MID
+    if (!act) continue;
     f16x8 ah[RB], al[RB];
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
       if ((ABL & 2) || PRE) {
-        ah[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + rd_slot]));
-        al[b] = __builtin_bit_cast(f16x8, lds_read16(&abuf[128 * b + 64 + rd_slot]));
+        ah[b] = __builtin_bit_cast(f16x8, ar0[b]);
+        al[b] = __builtin_bit_cast(f16x8, ar1[b]);
       } else {
-        split8(lds_read16(&abuf[128 * b + rd_slot]), lds_read16(&abuf[128 * b + 64 + rd_slot]), ah[b], al[b]);
+        split8(ar0[b], ar1[b], ah[b], al[b]);
       }
     }
-    f16x8 bh[CO_BLK], bl[CO_BLK];
-#pragma unroll
-    for (int cb = 0; cb < CO_BLK; ++cb) {
-      bh[cb] = lds_read_f16x8(&wbuf[(2 * cb) * 64 + lane]);
-      bl[cb] = lds_read_f16x8(&wbuf[(2 * cb + 1) * 64 + lane]);
-    }
-    IMF_WS_MID
 #ifdef IMF_G_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers (perturbs the schedule a little)
     IMF_GSTAMP(11 + 4 * t);
@@ -477,6 +535,7 @@ k_spconv_g(const ConvParams p) {
 #undef IMF_DMA_W
 #undef IMF_DMA_R
 #undef IMF_READ_ROWS
+#undef IMF_E_ACTIVE
 #undef IMF_READ_E
 #undef IMF_WBUF
 #undef IMF_ABUF

@@ -108,10 +108,13 @@ k_spconv_w(const ConvParams p) {
   constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
   constexpr int TAB_F4 = (kSubTab + 3) / 4;
   constexpr int KL_F4 = (kKCache + 3) / 4;
-  __shared__ float4 smem[W * REG_F4 + NBR_F4 + TAB_F4 + KL_F4];
+  constexpr int EX_F4 = 2 * KL_F4;                  // block bits, the unit's own offset list
+  __shared__ float4 smem[W * REG_F4 + NBR_F4 + TAB_F4 + KL_F4 + EX_F4];
   unsigned *const nbr_lds = reinterpret_cast<unsigned *>(smem + W * REG_F4);              // [kKCache][64]
   unsigned *const stab = reinterpret_cast<unsigned *>(smem + W * REG_F4 + NBR_F4);        // [kSubTab]
   int *const klist = reinterpret_cast<int *>(smem + W * REG_F4 + NBR_F4 + TAB_F4);        // [kKCache]
+  unsigned *const bact = reinterpret_cast<unsigned *>(smem + W * REG_F4 + NBR_F4 + TAB_F4 + KL_F4);   // [kKCache] bit b: block b of the unit has an input at cached offset j
+  unsigned *const jact = bact + 4 * KL_F4;           // [kKCache] q-th offset of the UNIT's list: j | bits << 8 | preceding cost << 12
 
   // XCD-aware (tile, slab) order (p.w_xcd): workgroups go to the 8 XCDs round-robin in launch order, so with the plain
   // (x = tile, y = slab) order every XCD's 4 MiB L2 sees every slab of the weight image (7 MB for 256 -> 256).  Here the
@@ -154,8 +157,7 @@ k_spconv_w(const ConvParams p) {
   if (nk == 0) return;                               // padding tile
   if (tid < 32 && ((m >> tid) & 1u)) klist[__builtin_popcount(m & ((1u << tid) - 1u))] = tid;
   __syncthreads();
-  const int n_sub = nk * ncc;
-  {   // the tile's slice of the neighbour table (24-bit row indices) and the sub-stage table; unconditional loads
+  {   // the tile's slice of the neighbour table (24-bit row indices); unconditional loads
     constexpr int JSTEP = NT / IMF_TILE_ROWS;        // offsets covered per pass of the workgroup: 8 / 4
     constexpr int kPer = (kKCache + JSTEP - 1) / JSTEP;
     const int srow = tid & 63, j0 = tid >> 6;
@@ -174,25 +176,72 @@ k_spconv_w(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < kPer; ++i) v[i] = row_of_slot(p, slot);
     }
-    if (tid < kSubTab) {
-      unsigned e = (unsigned)kDummyJkW << 9;
-      if (tid < n_sub) {
-        const int jk = tid / ncc, cc = tid - jk * ncc;
-        const int ch0 = cc * 32;
-        const bool second = CAT && ch0 >= p.c_a;
-        const int cch = second ? (ch0 - p.c_a) >> 5 : cc;
-        e = (unsigned)(klist[jk] * ncc + cc) | ((unsigned)jk << 9) | ((second ? 1u : 0u) << 14) | ((unsigned)cch << 15);
-      }
-      stab[tid] = e;
-    }
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       const int j = j0 + JSTEP * i;
-      if (j < nk) nbr_lds[j * IMF_TILE_ROWS + srow] = (v[i] >= 0 && in_unit) ? (unsigned)v[i] : kNoRowW;
+      const bool have = v[i] >= 0 && in_unit && j < nk;
+      if (j < nk) nbr_lds[j * IMF_TILE_ROWS + srow] = have ? (unsigned)v[i] : kNoRowW;
       else if (j == kDummyJkW) nbr_lds[j * IMF_TILE_ROWS + srow] = kNoRowW;
+      // which 16-row blocks of the unit have an input at this offset (the wavefront's lanes = the 64 slots of one offset)
+      const unsigned long long bal = __ballot(have);
+      if (lane == 0 && j < kKCache)
+        bact[j] = ((bal & 0xFFFFull) ? 1u : 0u) | ((bal & 0xFFFF0000ull) ? 2u : 0u) | ((bal & 0xFFFF00000000ull) ? 4u : 0u) |
+                  ((bal & 0xFFFF000000000000ull) ? 8u : 0u);
     }
   }
   __syncthreads();
+  // Round 6: the UNIT's own offset list and its 16-row blocks.  The tile mask says where ANY of the tile's 64 rows has an
+  // input; a half tile / 48-row unit walks only the offsets at which one of ITS rows has one, and inside a sub-stage a row
+  // block without inputs is left out (no split, no MFMAs: they would add exact zeros).  In slot = row order that is 4 % of
+  // the (block, offset) pairs, on the occupancy-sorted maps (csrc/rulebook_sort.hip) ~30 %.  The wavefronts' ranges are cut
+  // by COST (active blocks + 1 per sub-stage) instead of by count.  Everything is a function of the unit's own rows and of
+  // W: the sums of a row are the same in every launch that contains it (exact == capacity).
+  // Every wavefront derives the list, the table and its own range BY ITSELF from the block bits (lane = offset; ballots and
+  // popcounts, one LDS bounce inside the wavefront) and writes the whole table: all wavefronts store the same words, nobody
+  // waits for anybody -- no barrier beyond the one above (a first version built the table with one wavefront between two
+  // more barriers: +0.9 us per workgroup, 3-5 % of the launches).
+  int n_sub, t0, t1;
+  {
+    const unsigned bits = (p.nbr == nullptr) ? (lane == 0 ? (1u << RB) - 1u : 0u) : (lane < nk ? bact[lane] : 0u);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long bal = __ballot(bits != 0u);
+    const int nact = __builtin_popcountll(bal);
+    const int c = bits ? __builtin_popcount(bits) + 1 : 0;              // cost of the offset's sub-stages: 0, 2 .. 5
+    int cx = 0, tot = 0;                                                // cost of the offsets before this one / of all
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const unsigned long long pb = __ballot(((c >> bb) & 1) != 0);
+      cx += __builtin_popcountll(pb & below) << bb;
+      tot += __builtin_popcountll(pb) << bb;
+    }
+    if (bits) jact[__builtin_popcountll(bal & below)] = (unsigned)lane | (bits << 8) | ((unsigned)cx << 12);
+    n_sub = nact * ncc;
+    // lane q: the q-th offset of the unit's list (this wavefront's own store above: LDS operations execute in order)
+    const bool on = lane < nact;
+    const unsigned ja = on ? jact[lane] : 0u;
+    const int jk = (int)(ja & 31u), qcx = (int)(ja >> 12);
+    const unsigned qbits = (ja >> 8) & 15u;
+    const int qc = __builtin_popcount(qbits) + 1;
+    const int kl = klist[jk];
+    const int total = tot * ncc;
+    const int b0 = wave * total / W, b1 = (wave + 1) * total / W;      // this wavefront starts where the preceding cost reaches wave / W
+    t0 = t1 = 0;
+    for (int cc = 0; cc < ncc; ++cc) {
+      const int c0 = ncc * qcx + cc * qc;
+      t0 += __builtin_popcountll(__ballot(on && c0 < b0));
+      t1 += __builtin_popcountll(__ballot(on && c0 < b1));
+      if (on) {
+        const int ch0 = cc * 32;
+        const bool second = CAT && ch0 >= p.c_a;
+        const int cch = second ? (ch0 - p.c_a) >> 5 : cc;
+        stab[lane * ncc + cc] = (unsigned)(kl * ncc + cc) | ((unsigned)jk << 9) | ((second ? 1u : 0u) << 14) | ((unsigned)cch << 15) | (qbits << 20);
+      }
+    }
+    if (lane < 4) stab[lane < 3 && n_sub + lane < kSubTab - 1 ? n_sub + lane : kSubTab - 1] = (unsigned)kDummyJkW << 9;   // look-ahead entries
+    t0 = __builtin_amdgcn_readfirstlane(t0);
+    t1 = __builtin_amdgcn_readfirstlane(t1);
+    if (IMF_W_ABL & 1) t1 = t0;
+  }
 
   f32x4 acc[RB][4];
 #pragma unroll
@@ -231,7 +280,7 @@ k_spconv_w(const ConvParams p) {
     _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(wreg + 64 * j), 16, woff + 1024u * j, wso, 0, 0); \
     const bool second = CAT && ((ee >> 14) & 1u);                                                                  \
-    const unsigned soff = (ee >> 15) << 7;                                                                         \
+    const unsigned soff = ((ee >> 15) & 31u) << 7;                                                                         \
     const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                        \
     _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) {                                                               \
       const unsigned voff = __umul24((rows).r[b_], second ? stride_b : stride_a) + wr_byte;                        \
@@ -245,7 +294,7 @@ k_spconv_w(const ConvParams p) {
   {                                                                                                                \
     const unsigned ee = (unsigned)(e);                                                                             \
     const bool second = CAT && ((ee >> 14) & 1u);                                                                  \
-    const unsigned soff = (ee >> 15) << 7;                                                                         \
+    const unsigned soff = ((ee >> 15) & 31u) << 7;                                                                         \
     const __amdgpu_buffer_rsrc_t rs = second ? rs_b : rs_a;                                                        \
     _Pragma("unroll") for (int b_ = 0; b_ < RB; ++b_) {                                                               \
       const unsigned voff = __umul24((rows).r[b_], second ? stride_b : stride_a) + wr_byte;                        \
@@ -267,7 +316,6 @@ k_spconv_w(const ConvParams p) {
   }
 
   // this wavefront's range of the tile's sub-stages
-  const int t0 = (int)((long long)wave * n_sub / W), t1 = (IMF_W_ABL & 1) ? t0 : (int)((long long)(wave + 1) * n_sub / W);
   unsigned e_cur = 0, e_nxt = 0;
   Rows rows_nxt;
   if (t0 < t1) {
@@ -314,6 +362,7 @@ k_spconv_w(const ConvParams p) {
 #pragma unroll 1
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
+      const unsigned act = (e_cur >> 20) & 15u;                   // (scalar) the unit's row blocks with an input at this offset
       IMF_W_LD_WHALF(bB, e_cur, 1)                                // half B of t: lands under the first 48 MFMAs
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");           // rows of t have landed (the two weight halves may be in flight)
       float4 a0[RB], a1[RB];
@@ -329,17 +378,27 @@ k_spconv_w(const ConvParams p) {
       }
       IMF_W_DMA_ROWS(e_nxt, rows_nxt)                             // rows of t + 1: a whole sub-stage to land
       __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks the requests below ~40 MFMAs)
-      bf16x8 ap[RB][3];
-#pragma unroll
-      for (int b = 0; b < RB; ++b) split_b3(a0[b], a1[b], ap[b][0], ap[b][1], ap[b][2]);
+      // (the parts live in 128-bit registers across the two conditional regions of a block: as bf16 vectors hipcc merges them
+      // element by element at the joins -- 72 v_perm + 48 shifts per sub-stage)
+      f32x4 ap[RB][3];
+      // Per accumulator the six terms in IMF_B3_TERMS order, as before; a block's two accumulators of this half alternate (one
+      // MFMA between two on the same accumulator covers the dependency); a block without inputs is left out.  (Blocks in
+      // pairs with a three-way branch -- term-major over four accumulators when both are active -- costs ~130 accumulator
+      // copies at the joins per sub-stage.)
 #define IMF_W_TERM(I, J)                                                                                 \
-  _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                          \
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                   \
-          acc[b][CB0 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], BP[cb][J], acc[b][CB0 + cb], 0, 0, 0);
+          acc[b][CB0 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[b][I]), BP[cb][J], acc[b][CB0 + cb], 0, 0, 0);
       {
         constexpr int CB0 = 0;
 #define BP bA
-        IMF_B3_TERMS(IMF_W_TERM)
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+          if ((act >> b) & 1u) {
+            bf16x8 s0, s1, s2;
+            split_b3(a0[b], a1[b], s0, s1, s2);
+            ap[b][0] = __builtin_bit_cast(f32x4, s0); ap[b][1] = __builtin_bit_cast(f32x4, s1); ap[b][2] = __builtin_bit_cast(f32x4, s2);
+            IMF_B3_TERMS(IMF_W_TERM)
+          }
 #undef BP
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -351,7 +410,11 @@ k_spconv_w(const ConvParams p) {
       {
         constexpr int CB0 = 2;
 #define BP bB
-        IMF_B3_TERMS(IMF_W_TERM)
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+          if ((act >> b) & 1u) {
+            IMF_B3_TERMS(IMF_W_TERM)
+          }
 #undef BP
       }
 #undef IMF_W_TERM
@@ -366,6 +429,8 @@ k_spconv_w(const ConvParams p) {
   for (int t = t0; t < t1; ++t) {
     // sub-stage t has landed: the region is private, the wavefront's own counter is the only wait
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned act = (e_cur >> 20) & 15u;         // (scalar) the unit's row blocks with an input at this offset
+    e_cur = e_nxt;
     float4 a0[RB], a1[RB];
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
@@ -388,11 +453,14 @@ k_spconv_w(const ConvParams p) {
       }
       // k-step (j, t): channel 16 j + 4 q4 + t; sixteen independent accumulators between two MFMAs of one accumulator
 #define IMF_W_STEP(AV, BV, C)                                                                            \
-  _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                          \
       _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                   \
           acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[b].C, BV[cb].C, acc[b][cb], 0, 0, 0);
-      IMF_W_STEP(a0, b0, x) IMF_W_STEP(a0, b0, y) IMF_W_STEP(a0, b0, z) IMF_W_STEP(a0, b0, w)
-      IMF_W_STEP(a1, b1, x) IMF_W_STEP(a1, b1, y) IMF_W_STEP(a1, b1, z) IMF_W_STEP(a1, b1, w)
+#pragma unroll
+      for (int b = 0; b < RB; ++b)
+        if ((act >> b) & 1u) {
+          IMF_W_STEP(a0, b0, x) IMF_W_STEP(a0, b0, y) IMF_W_STEP(a0, b0, z) IMF_W_STEP(a0, b0, w)
+          IMF_W_STEP(a1, b1, x) IMF_W_STEP(a1, b1, y) IMF_W_STEP(a1, b1, z) IMF_W_STEP(a1, b1, w)
+        }
 #undef IMF_W_STEP
     } else {
     f16x8 bh[4], bl[4];
@@ -408,28 +476,23 @@ k_spconv_w(const ConvParams p) {
       e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 2 < kSubTab ? t + 2 : kSubTab - 1]));
       IMF_W_ROWS(rows_nxt, e_nxt)
     }
-    f16x8 ah[RB], al[RB];
-#pragma unroll
-    for (int b = 0; b < RB; ++b) {
-      if (PRE) { ah[b] = __builtin_bit_cast(f16x8, a0[b]); al[b] = __builtin_bit_cast(f16x8, a1[b]); }
-      else w_split8(a0[b], a1[b], ah[b], al[b]);
-    }
     // per accumulator: lo*hi, hi*lo, hi*hi (k_spconv_g's order); consecutive MFMAs on different accumulators
 #pragma unroll
     for (int b = 0; b < RB; ++b)
+      if ((act >> b) & 1u) {
+        f16x8 ah, al;
+        if (PRE) { ah = __builtin_bit_cast(f16x8, a0[b]); al = __builtin_bit_cast(f16x8, a1[b]); }
+        else w_split8(a0[b], a1[b], ah, al);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-        acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b], bh[cb], acc[b][cb], 0, 0, 0);
+        for (int cb = 0; cb < 4; ++cb)
+          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[cb], acc[b][cb], 0, 0, 0);
 #pragma unroll
-    for (int b = 0; b < RB; ++b)
+        for (int cb = 0; cb < 4; ++cb)
+          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[cb], acc[b][cb], 0, 0, 0);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-        acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bl[cb], acc[b][cb], 0, 0, 0);
-#pragma unroll
-    for (int b = 0; b < RB; ++b)
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-        acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], bh[cb], acc[b][cb], 0, 0, 0);
+        for (int cb = 0; cb < 4; ++cb)
+          acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[cb], acc[b][cb], 0, 0, 0);
+      }
     }
   }
   }
