@@ -509,12 +509,16 @@ def host_span_leg(model, dev, args, barrier, sync, pts, imgs, voxel, f32_valued=
     for k in [k for k in st if k.startswith("stream_")]:
         st.pop(k)
     st["stream_trace"] = []
+    # A timed region of a STREAM pays the pipeline's fill and drain once (the first job's upload, the last job's download:
+    # ~1.5 ms together): regions of >= 100 pair-steps, so that the edges weigh 1 % instead of the 4-6 % they were in
+    # --steps-long regions (rounds 4-5 reported those; `region_steps` says what was timed).
+    region = max(args.steps, 100)
     rep, m = [], 0
     for _ in range(max(3, min(args.repeats, 5))):
         barrier()
         sync()
         t0 = time.perf_counter()
-        m = run(args.steps)
+        m = run(region)
         sync()
         barrier()
         rep.append(time.perf_counter() - t0)
@@ -522,9 +526,9 @@ def host_span_leg(model, dev, args, barrier, sync, pts, imgs, voxel, f32_valued=
     jobs = max(1, st.get("stream_jobs", 1))
     t = median(rep)
     streamer = model.fragment_runner().streamer(dev)
-    out = {"value": round(m / t, 1), "unit": "descriptors/s", "ms_per_step": round(t / args.steps * 1e3, 4),
-           "ms_per_fragment": round(t / args.steps / len(pts) * 1e3, 4),
-           "ms_per_step_all": [round(v / args.steps * 1e3, 4) for v in sorted(rep)],
+    out = {"value": round(m / t, 1), "unit": "descriptors/s", "ms_per_step": round(t / region * 1e3, 4),
+           "ms_per_fragment": round(t / region / len(pts) * 1e3, 4), "region_steps": region,
+           "ms_per_step_all": [round(v / region * 1e3, 4) for v in sorted(rep)],
            "span": "host float64 point arrays + host images -> (voxelise, pyramid, rulebooks, image branch, 23 convolutions, "
                    "fusion) -> xyz_down float64 and descriptors float32 as host arrays (views of the pinned block), "
                    "PCIe both ways; extract_features_stream(batch=%s, depth=3, copy=False)" % (batch or len(pts)),
@@ -611,14 +615,14 @@ def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=96, d
         torch.cuda.synchronize()
         # a timed region = `reps` passes over the shard, >= min_region_s long on the slowest rank's probe (same on all ranks)
         reps = torch.tensor([max(1, int(np.ceil(min_region_s / max(time.perf_counter() - t0, 1e-3))))], device=coll)
-        if world > 1:
+        if dist.is_initialized():
             dist.all_reduce(reps, op=dist.ReduceOp.MAX)
         reps = int(reps.item())
         st = model.fragment_runner().stats
         redone0 = st.get("redone", 0)
         t_pass = []
         for _ in range(passes):
-            if world > 1:
+            if dist.is_initialized():
                 (barrier or dist.barrier)()
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -629,7 +633,7 @@ def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=96, d
         packed = (rows, send_buf if coll.type == "cuda" else send_buf.cpu())   # (gloo test hook: the collective is on the host)
         t_gather = []
         for _ in range(passes):
-            if world > 1:
+            if dist.is_initialized():
                 (barrier or dist.barrier)()
             t1 = time.perf_counter()
             gathered = idist.gather_fragment_descriptors(None, n_frag, shards, dst=0, device=coll, packed=packed)
@@ -638,7 +642,7 @@ def sharded_pipeline_leg(model, dev, voxel, rank, world, backend, per_rank=96, d
             t_gather.append(time.perf_counter() - t1)
     tt = torch.tensor([t_pass, t_gather], dtype=torch.float64, device=coll)
     crcs = crcs.to(coll)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)        # per pass: the slowest rank
         dist.all_reduce(crcs, op=dist.ReduceOp.MAX)      # every entry is written by exactly one rank, zero elsewhere
     if rank != 0:
@@ -833,7 +837,7 @@ def main():
     wl = Workload(model, dev, pts, imgs, voxel)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():                         # (also ONE rank with a process group: IMF_DIST_FORCE_INIT=1, the RCCL test)
             dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
 
     sync = torch.cuda.synchronize
@@ -942,7 +946,7 @@ def main():
 
     t = torch.tensor(rep, dtype=torch.float64, device=dev)
     hs = torch.tensor([host_span["ms_per_step"] if host_span else 0.0, float(M)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per repeat: the slowest rank
         m = torch.tensor([M], dtype=torch.int64, device=dev)
         dist.all_reduce(m, op=dist.ReduceOp.SUM)
@@ -958,9 +962,10 @@ def main():
     # what every rank measured (median of its own repeats) and the world the process group really has
     mine_ms = torch.tensor([median(sorted(rep)) / args.steps * 1e3], dtype=torch.float64, device=dev)
     per_rank = [mine_ms.clone() for _ in range(world)]
-    if world > 1:
+    if dist.is_initialized():
         dist.all_gather(per_rank, mine_ms)
-    rccl_info = {"backend": backend, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+    rccl_info = {"backend": backend if dist.is_initialized() else None, "process_group": dist.is_initialized(),
+                 "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                  "per_rank_ms_per_step": [round(float(v), 4) for v in per_rank],
                  "gather_crc_ok": bool(sharded and sharded.get("gather_crc_ok")) if sharded is not None else None}
     rep = sorted(float(v) for v in t.tolist())
@@ -1049,7 +1054,7 @@ def main():
         }
         out["rccl"] = rccl_info
         emit(out, args.full_out)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

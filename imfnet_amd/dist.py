@@ -22,7 +22,8 @@ def init_from_env(backend=None):
     # IMF_FORCE_DEVICE=0 runs N ranks on one device
     backend = os.environ.get("IMF_DIST_BACKEND", backend)
     forced = os.environ.get("IMF_FORCE_DEVICE")
-    if world > 1 and not dist.is_initialized():
+    # IMF_DIST_FORCE_INIT=1: a process group also for ONE rank (tests: the RCCL code paths on a single-GPU box)
+    if (world > 1 or os.environ.get("IMF_DIST_FORCE_INIT") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl" and forced is None:
@@ -123,8 +124,10 @@ def gather_fragment_descriptors(results, n_fragments, shards, dst=0, device=None
         assert len(out) == n_fragments
         return out
 
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return split([rows], [feats])
+    # (one rank WITH a process group takes the collective path too: the table's all_gather runs under the backend -- RCCL on
+    # the rank's GPU -- and the exchange below has no peers)
     L = max(len(s) for s in shards)
     t = torch.zeros(L + 1, dtype=torch.int64)
     t[0] = D

@@ -651,7 +651,7 @@ typedef struct imf_fragment_caps {     /* [host] one capacity bucket */
   int64_t n_points;                    /* points (all items together) */
   int64_t rows[4];                     /* voxels at tensor strides 1, 2, 4, 8 */
   int32_t n_items, img_h, img_w;
-  size_t bitgrid_words;                /* conv1 occupancy grid: >= imf_bitgrid_words of the largest bounding box */
+  size_t bitgrid_words;                /* conv1 occupancy grid: >= imf_bitgrid_words of the largest bounding box, a multiple of 4 */
 } imf_fragment_caps;
 
 typedef struct imf_fragment_io {       /* [host]; all buffers device memory owned by the caller */

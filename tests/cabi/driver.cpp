@@ -305,7 +305,7 @@ int main() {
     caps.n_points = n + 512; caps.rows[0] = 1536; caps.rows[1] = 320; caps.rows[2] = 64; caps.rows[3] = 64;
     caps.n_items = 1; caps.img_h = H; caps.img_w = W;
     const int32_t box[8] = {0, -16, -16, -4, 0, 16, 16, 8};
-    caps.bitgrid_words = imf_bitgrid_words(box, 5);
+    caps.bitgrid_words = (imf_bitgrid_words(box, 5) + 3) / 4 * 4;      // (a multiple of 4 words: the grid is cleared 16 bytes at a time)
     if (!caps.bitgrid_words) { printf("fragment forward: bit grid size query failed\n"); return 21; }
     imf_fragment_io io;
     memset(&io, 0, sizeof(io));
