@@ -745,7 +745,7 @@ def compact_line(out):
     return line
 
 
-def emit(out, full_path):
+def emit(out, full_path, seal_stdout=False):
     """Full record -> `full_path` (+ gpurun_out/ when that directory exists) and stderr; the compact line is the LAST stdout line."""
     out["full_record"] = os.path.relpath(full_path, ROOT) if full_path else None
     full = json.dumps(out)
@@ -763,7 +763,18 @@ def emit(out, full_path):
     line = json.dumps(compact_line(out))
     assert len(line) <= COMPACT_LIMIT + 1024, len(line)
     sys.stdout.flush()
+    try:                                                 # native libraries' buffered stdout (RCCL's banner) goes out BEFORE the line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                    # noqa: BLE001
+        pass
     print(line, flush=True)
+    # ... and nothing may follow it: whatever a native library still prints to stdout (at exit, from a destructor) is dropped
+    if seal_stdout:
+        try:
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+        except OSError:
+            pass
 
 
 def main():
@@ -822,6 +833,12 @@ def main():
         torch.cuda.set_device(int(os.environ["IMF_FORCE_DEVICE"]))
     rank, world, local = idist.init_from_env(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if rank != 0:                                        # only rank 0 owns stdout (one JSON line, last): the others' native
+        try:                                             # libraries (RCCL's banner) must not write behind it
+            sys.stdout.flush()
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+        except OSError:
+            pass
     if "IMF_FORCE_DEVICE" in os.environ:
         local = int(os.environ["IMF_FORCE_DEVICE"])
     torch.cuda.set_device(local)
@@ -971,6 +988,7 @@ def main():
     rep = sorted(float(v) for v in t.tolist())
     elapsed = median(rep)
 
+    final = None
     if rank == 0:
         # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
         groups = group_trace(trace)
@@ -1053,9 +1071,13 @@ def main():
             "arithmetics": arithmetics,
         }
         out["rccl"] = rccl_info
-        emit(out, args.full_out)
+        final = out
+    # the process group goes FIRST: whatever RCCL has to say (its version banner sits in the C library's stdout buffer until
+    # the process ends -- found in round 6: it came out AFTER the JSON line) is out before the line that must be last
     if dist.is_initialized():
         dist.destroy_process_group()
+    if final is not None:
+        emit(final, args.full_out, seal_stdout=True)
 
 
 def extra_legs(model, dev, args, sync):

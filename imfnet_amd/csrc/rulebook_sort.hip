@@ -74,6 +74,11 @@ k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slot
   long long n = n_out;
   if (n_dev) n = *n_dev < n ? *n_dev : n;
   const int kvol = KVOL ? KVOL : kvol_rt;
+  // slots of this window (a level smaller than a window sorts what it has: positions beyond are never produced), in whole
+  // wavefront groups per wavefront: every wavefront owns `per_wave` consecutive positions, a multiple of 64
+  const int n_win = (int)((n_slots - wbase) < kWindow ? (n_slots - wbase) : kWindow);
+  const int per_wave = ((n_win + kSortWaves - 1) / kSortWaves + 63) / 64 * 64;
+  const int n_pos = per_wave * kSortWaves;            // <= kWindow, >= n_win
 
   // ---- keys: thread t takes the slots wbase + t + 1024 i (every load of a wavefront is one line of one offset)
 #pragma unroll 4
@@ -81,7 +86,7 @@ k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slot
     const int loc = tid + kSortThreads * i;
     const long long s = wbase + loc;
     unsigned key = kInvalidKey;
-    if (s < n) {
+    if (s < n && loc < n_pos) {
       unsigned r = 0u;
       if (KVOL == 27) {
 #pragma unroll
@@ -106,10 +111,9 @@ k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slot
     for (int d = tid; d < kSortWaves * kDigits; d += kSortThreads) hist[d] = 0u;
     __syncthreads();
     unsigned *const myhist = hist + wave * kDigits;
-    const int chunk = wave * (kWindow / kSortWaves);
+    const int chunk = wave * per_wave;
     // count (order is irrelevant here)
-#pragma unroll 4
-    for (int it = 0; it < kWindow / kSortWaves / 64; ++it) {
+    for (int it = 0; it < per_wave / 64; ++it) {
       const int pos = chunk + 64 * it + lane;
       const unsigned id = pass == 0 ? (unsigned)pos : (unsigned)src[pos];
       atomicAdd(&myhist[(keys[id] >> shift) & (kDigits - 1)], 1u);
@@ -127,15 +131,20 @@ k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slot
       dtot[tid] = run;
     }
     __syncthreads();
-    if (tid < kDigits) {
-      unsigned off = 0u;
-      for (int d = 0; d < tid; ++d) off += dtot[d];
-      doff[tid] = off;
+    if (tid < 64) {   // exclusive scan of the 128 digit totals by one wavefront: two per lane + a shuffle scan
+      const unsigned a = dtot[2 * tid], b = dtot[2 * tid + 1];
+      unsigned incl = a + b;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += up;
+      }
+      doff[2 * tid] = incl - a - b;
+      doff[2 * tid + 1] = incl - b;
     }
     __syncthreads();
     // rank and scatter, 64 positions at a time in order: lanes with the same digit keep their order
-#pragma unroll 2
-    for (int it = 0; it < kWindow / kSortWaves / 64; ++it) {
+    for (int it = 0; it < per_wave / 64; ++it) {
       const int pos = chunk + 64 * it + lane;
       const unsigned id = pass == 0 ? (unsigned)pos : (unsigned)src[pos];
       const unsigned d = (keys[id] >> shift) & (kDigits - 1);
@@ -159,10 +168,9 @@ k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slot
   }
 
   // ---- new slot wbase + p takes old slot wbase + src[p]; slots beyond the rows: -1
-#pragma unroll 4
-  for (int i = 0; i < kPerThread; ++i) {
+  for (int i = 0; i < n_pos / kSortThreads; ++i) {
     const int loc = tid + kSortThreads * i;
-    if (wbase + loc >= n_slots) break;
+    if (loc >= n_win) break;
     const unsigned id = src[loc];
     perm[wbase + loc] = keys[id] == kInvalidKey ? -1 : (int32_t)(wbase + id);
   }
