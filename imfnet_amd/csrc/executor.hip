@@ -499,18 +499,39 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     is_split[ebuf(0, 0)] = wrote_split;
   }
 
-  // ---- the occupancy-sorted twins, at the end of the side stream's chain (level 2 first: the decoder reaches it first) ----
-  if (twin[0] && first_and_map) {   // the level-0 map came out of the first convolution's launch on the MAIN stream
-    IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[6], main));
-    IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->events[6], 0));
-  }
-  for (int i = 2; i >= 0; --i) {
-    if (!twin[i]) continue;
-    if ((rc = imf_rulebook_sort_by_occupancy(rb_k3[i].nbr, 27, rb_k3[i].n_slots, s.n[i], dyn ? meta + 2 * i : nullptr,
-                                             rb_k3s[i].tile_rows, rb_k3s[i].nbr, rb_k3s[i].tile_mask, sort_ws, sort_ws_bytes, side)))
-      return rc;
-    if (side != main && (rc = mark(rb_k3s[i]))) return rc;
-  }
+  // ---- the occupancy-sorted twins (level 2 first: the decoder reaches it first).  Fragment forward: on the IMAGE stream,
+  // behind the image trunk -- that stream is idle from ~0.45 ms on, whereas the side stream must be free for the next
+  // forward's head (streaming pipeline, bench's pipelined mode: with the sorts at the end of the SIDE chain the head of step
+  // k + 1 queued behind 240 us of sorts and the steps lost what the twins gain).  Otherwise: at the end of the side chain.
+  hipStream_t sort_stream = side;
+  if (fctx && fctx->imgs && fctx->imgs != side && fctx->imgs != main && items_event >= 0) sort_stream = fctx->imgs;
+  auto issue_sorts = [&]() -> int {
+    if (!(twin[0] || twin[1] || twin[2])) return IMF_OK;
+    if (sort_stream != side) {
+      // Image stream: ONE dependency, on the MAIN stream at the point of the call (behind conv3's launch: the main stream
+      // has waited for the side chain's level-1 and level-2 maps by then, and the level-0 map is its own).  Not on the side
+      // stream's events: the side stream may have waited for the image branch (image_joined_side), and two captured streams
+      // that wait for each other send hipStreamEndCapture into an endless recursion (ROCm 7.2, found with rocgdb).
+      IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[6], main));
+      IMF_CHECK_HIP(hipStreamWaitEvent(sort_stream, (hipEvent_t)io->events[6], 0));
+    } else if (twin[0] && first_and_map) {   // the level-0 map came out of the first convolution's launch on the MAIN stream
+      IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[6], main));
+      IMF_CHECK_HIP(hipStreamWaitEvent(sort_stream, (hipEvent_t)io->events[6], 0));
+    }
+    for (int i = 2; i >= 0; --i) {
+      if (!twin[i]) continue;
+      int rc2 = imf_rulebook_sort_by_occupancy(rb_k3[i].nbr, 27, rb_k3[i].n_slots, s.n[i], dyn ? meta + 2 * i : nullptr,
+                                               rb_k3s[i].tile_rows, rb_k3s[i].nbr, rb_k3s[i].tile_mask, sort_ws, sort_ws_bytes,
+                                               sort_stream);
+      if (rc2) return rc2;
+      if (sort_stream != main) {
+        IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[ev], sort_stream));
+        rb_k3s[i].ready_event = ev++;
+      }
+    }
+    return IMF_OK;
+  };
+  if (sort_stream == side && (rc = issue_sorts())) return rc;
 
   auto launch = [&](const Step &st) -> int {
     const imf_net_conv &c = net->conv[st.conv];
@@ -558,9 +579,17 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     return imf_spconv_fwd(&a, main);
   };
 
+  bool sorts_issued = false, saw_conv3 = false;
   for (int i = 0; i < n_enc; ++i) {
     if ((rc = launch(sched[i]))) return rc;
     if (fctx && fctx->fork_after == i && (rc = fork_image_branch(*fctx, main))) return rc;
+    // the sorts on the image stream: behind the image branch's fork and behind the launch that made the main stream wait for
+    // the level-2 map (conv3, the consumer of rb_dn[1]) -- see issue_sorts
+    if (sched[i].rb == &rb_dn[1]) saw_conv3 = true;
+    if (sort_stream != side && !sorts_issued && saw_conv3 && i >= fctx->fork_after) {
+      if ((rc = issue_sorts())) return rc;
+      sorts_issued = true;
+    }
   }
 
   // ---- bottleneck fusion (model/resunet.py:237-273) ----------------------------------------------------

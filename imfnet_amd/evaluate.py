@@ -134,7 +134,8 @@ def run_scene_matching(scene_name, seq_name, desc_root, benchmark_root, out_root
     # is ~20 ms of zlib inflate: the cache holds the whole scene when it fits the budget (IMFNET_EVAL_CACHE_MB, default 6 GB:
     # a 3DMatch scene is <= 66 fragments x ~14 MB), least recently used first out.  Round 4 kept 8 files and re-read one
     # per pair at full size (profiled: 70 % of the evaluator's time).
-    budget = int(float(os.environ.get("IMFNET_EVAL_CACHE_MB", "6144")) * (1 << 20))
+    # (per PROCESS: the default is divided by the ranks that share the host -- N ranks x 6 GB was the old behaviour)
+    budget = int(float(os.environ.get("IMFNET_EVAL_CACHE_MB", str(6144 // max(1, int(world))))) * (1 << 20))
     held = [0]
 
     def load(name):

@@ -179,6 +179,9 @@ def _extract_with_runner(runner, xyz, voxel_size, device, image, host_descriptor
 POINT_BUDGET = 1_100_000          # batch="auto": points per forward (four S50k fragments)
 
 
+FragmentStreamerLanes = 3          # FragmentStreamer's default n_buckets (stream.py): forwards of one capacity key in flight
+
+
 def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, copy=True, batch=2, point_budget=None,
                             device_sink=None):
     """`extract_features` over a STREAM of host fragments (SURVEY 8d's span -- host arrays in, descriptors back on the
@@ -207,6 +210,11 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
         model.eval()
     runner = model.fragment_runner() if hasattr(model, "fragment_runner") else None
     depth = max(1, int(depth))
+    if device_sink is not None:
+        # the sink reads a job's rows from its capacity BUCKET after job.wait(): with more jobs of one key in flight than the
+        # streamer has lanes, the streamer completes the oldest job itself and hands its bucket to the new submit -- whose
+        # forward could overwrite the rows before finish() reaches the sink.  The pinned host copy is not affected.
+        depth = min(depth, FragmentStreamerLanes)
     n_slots = depth + 2                               # in flight + the one the consumer holds (copy=False) + one being staged
     auto = isinstance(batch, str)
     if auto and batch != "auto":

@@ -122,14 +122,19 @@ class ResUNet2(ME.MinkowskiNetwork):
     def _refresh(self):
         # (packed weights, plans and runners are built for ONE arithmetic: a changed ops.CONV_VARIANT rebuilds them too)
         # (`pinned_variant`: a model built for one arithmetic beside the process default -- bench.build_model(variant=...))
-        want = self.pinned_variant if self.pinned_variant is not None else ops.CONV_VARIANT
+        want = self.effective_variant()
         if self._stale() or getattr(self, "_built_variant", want) != want:
             self._invalidate()
 
     pinned_variant = None
 
+    def effective_variant(self):
+        """The arithmetic THIS model's packed weights, plans and flag semantics belong to: its pinned one, else the process
+        default (the flag mask and the fusion images followed the global even for a pinned model)."""
+        return self.pinned_variant if self.pinned_variant is not None else ops.CONV_VARIANT
+
     def _invalidate(self):
-        self._built_variant = self.pinned_variant if self.pinned_variant is not None else ops.CONV_VARIANT
+        self._built_variant = self.effective_variant()
         self._plan = None
         self._native_plan = None
         self._folded = None
@@ -251,7 +256,7 @@ class ResUNet2(ME.MinkowskiNetwork):
         v = int(w.item())
         if v:
             w.zero_()
-        if ops.CONV_VARIANT != 6:
+        if self.effective_variant() != 6:
             v &= ~32                                   # IMF_FLAG_RANGE (_lib.FLAG_RANGE)
         return v
 
@@ -372,8 +377,10 @@ class ResUNet2(ME.MinkowskiNetwork):
             if packed is not None:                         # one HIP kernel: attention + GEGLU feed-forward
                 for t in packed[0] + packed[1]:
                     t.record_stream(cur)
+                ev_ = self.effective_variant()
                 out = ops.fusion_attention_batched(f8, items, packed[0], packed[1], packed[2], packed[3],
-                                                   self._fusion_weights(), flags=self.flag_word(f8.device))
+                                                   self._fusion_weights(), flags=self.flag_word(f8.device),
+                                                   variant=ev_ if ev_ in (6, 3) else 0)
             elif kv is not None and image_feat.shape[0] == 1:
                 kv.record_stream(cur)
                 out = self._fusion_fast(f8, kv[0])
@@ -430,7 +437,7 @@ class ResUNet2(ME.MinkowskiNetwork):
     def _fusion_weights(self):
         self._refresh()
         if self._fw is None:
-            self._fw = ops.FusionKernelWeights(self.attention_fusion)
+            self._fw = ops.FusionKernelWeights(self.attention_fusion, variant=self.effective_variant())
         return self._fw
 
     def _fusion_fast(self, x, kv):

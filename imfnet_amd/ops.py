@@ -623,8 +623,11 @@ def conv_first_bitgrid(level, kernel, ksize, scale=None, shift=None, relu=False)
 class FusionKernelWeights:
     """Packed weights of the bottleneck fusion block for imf_fusion_attention (built once per model)."""
 
-    def __init__(self, attention_fusion):
+    def __init__(self, attention_fusion, variant=None):
+        """variant: the arithmetic of the owning model's convolutions (None: the process default) -- picks the 16-bit image of
+        the two feed-forward matrices (bf16x3 for 3, split-f16 otherwise)."""
         from ._lib import FusionWeights
+        variant = CONV_VARIANT if variant is None else int(variant)
         blk0, blk1 = attention_fusion.cross_attend_blocks
         att, ff = blk0.fn, blk1.fn.net
         self.dim, self.inner, self.hidden = att.to_q.in_features, att.to_q.out_features, ff[2].in_features
@@ -644,9 +647,9 @@ class FusionKernelWeights:
         self.t = dict(ln1_g=f(blk0.norm.weight), ln1_b=f(blk0.norm.bias), wq_p=pack_weights(f(att.to_q.weight).t()),
                       wo_p=pack_weights(f(att.to_out.weight).t()), bo=f(att.to_out.bias), ln2_g=f(blk1.norm.weight),
                       # (w1_p / w2_p: the image of the 16-bit variant the process runs -- split-f16 for 6, three bf16 parts for 3)
-                      ln2_b=f(blk1.norm.bias), w1_p=pack_weights(w1t, variant=3 if CONV_VARIANT == 3 else 6),
+                      ln2_b=f(blk1.norm.bias), w1_p=pack_weights(w1t, variant=3 if variant == 3 else 6),
                       b1=f(ff[0].bias)[perm].contiguous(),
-                      w2_p=pack_weights(f(ff[2].weight).t(), variant=3 if CONV_VARIANT == 3 else 6), b2=f(ff[2].bias),
+                      w2_p=pack_weights(f(ff[2].weight).t(), variant=3 if variant == 3 else 6), b2=f(ff[2].bias),
                       # the same two matrices as fp32 images: the feed-forward of the variant-0 (fp32 MFMA) recompute
                       w1_f32=pack_weights(w1t), w2_f32=pack_weights(f(ff[2].weight).t()))
         self.c = FusionWeights(**{k: v.data_ptr() for k, v in self.t.items()})

@@ -1,5 +1,9 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_graph.py tests/test_gpu_cpu_twins.py -q -x 2>&1 | tail -3
-run() { echo "== v$1 sorted=$2"; IMF_SORTED_MAP=$2 IMF_CONV_VARIANT=$1 timeout 300 python tools/step_pair.py 2>&1 | grep -v amdgpu.ids | head -${3:-5}; }
-run 3 0; run 3 7; run 3 1; run 3 0; run 3 7; run 3 3; run 3 4
-run 0 0 2; run 0 7 2; run 6 0 2; run 6 7 2
+python -m pytest tests/test_gpu_graph.py tests/test_gpu_harness.py -q -x 2>&1 | tail -3
+for rep in 1 2; do for sm in 0 7; do
+  echo "== IMF_SORTED_MAP=$sm"
+  IMF_SORTED_MAP=$sm python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-sharded --full-out /tmp/f.json 2>/dev/null | python -c "
+import sys, json
+c = json.loads(sys.stdin.read().splitlines()[-1])
+print('  value ms/step', c['ms_per_step'], 'issue', c['config']['issue'], c['config']['probe_ms_per_step'], 'host_span', c['host_span']['ms_per_step'], c['host_span']['vs_device_resident'])"
+done; done
