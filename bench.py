@@ -101,6 +101,35 @@ def algorithmic_bytes(rec):
     return pairs * (rec["cin"] + rec["cout"]) * 4 + pairs * 8 + rec["kvol"] * rec["cin"] * rec["cout"] * 4, pairs
 
 
+def delivered_bytes(rec, arith, pairs):
+    """Bytes that enter the CUs through their vector-memory path (L2 -> L1 / LDS / registers: 64 B per clock and CU, 34.5 TB/s
+    chip-wide, MI355X_MICROARCH.md) for one launch of the LDS-DMA convolution kernels -- the resource that binds them:
+    every unit of rows (64-row tile; half tile: kernel_tag 64; 48-row unit: 128) fetches the weight block of each active (offset,
+    32-channel) sub-stage of its tile once per 64-column slab (12 KiB bf16x3, 8 KiB split-f16 / fp32), plus the gathered input
+    rows of the occupied pairs, once per slab (a missing neighbour is a zero fill without traffic).  None for 1x1x1 layers."""
+    rb = rec["rb"]
+    if rec["kvol"] <= 1 or "arena" not in rec or not rb.nbr:
+        return None
+    arena = rec["arena"]
+    start = (rb.nbr - arena.data_ptr()) // 4 + rb.kvol * rb.n_slots      # the tile masks sit behind the neighbour table
+    n_tiles = rb.n_slots // 64
+    if "res" in rec:
+        rows = rec["res"].counts[rec["level"]]
+        n_tiles = min(n_tiles, ((rows + 63) // 64 * 64 + rec["slots_extra"]) // 64)
+    words = arena[start:start + 4 * n_tiles].view(n_tiles, 4)[:, 0]
+    m = words.to(torch.int64) & 0x7FFFFFF
+    active = 0
+    for k in range(27):
+        active += int(((m >> k) & 1).sum().item())
+    tag = rec.get("kernel_tag", 0)
+    units = 2.0 if tag & 64 else (4.0 / 3.0 if tag & 128 else 1.0)
+    cin, cout = rec["cin"], rec["cout"]
+    wide = cout % 64 == 0
+    slabs = cout // 64 if wide else cout // 32
+    sub = (12288 if arith == "bf16x3" else 8192) // (1 if wide else 2)
+    return int(active * units * (cin // 32) * slabs * sub + pairs * cin * 4 * slabs)
+
+
 def _family_regex(label, arith):
     """Regex over demangled kernel symbols (without the imf:: prefix and the argument list) for a bench label.  Labels come
     from ops.conv_kernel_name: `k_spconv_w<W>` / `k_spconv_g<CB, 0>` (+ `/b3`, `/f32`) name a template FAMILY -- every
@@ -246,21 +275,28 @@ def cpu_baseline(xyz, img, voxel, sd, seconds_budget=12.0):
                       f"convolutions as {names[impl]} + torch-CPU image encoder and attention"}
 
 
-def group_trace(records):
+def group_trace(records, arith=None):
     """Traced launches (HIP events recorded by the library right around each convolution kernel on its launch stream) grouped
     by kernel family: total ms, algorithmic bytes and useful flops."""
-    groups, cache = {}, {}
+    groups, cache, dcache = {}, {}, {}
     for rec in records:
         ms = rec["ev"].elapsed_ms()
         assert ms >= 0.0
         key = id(rec["rb"]) if "arena" not in rec else (rec["rb"].nbr, rec["rb"].n_slots), rec["cin"], rec["cout"]
         if key not in cache:
             cache[key] = algorithmic_bytes(rec)
-        g = groups.setdefault(rec["kernel"], {"ms": 0.0, "bytes": 0, "n": 0, "flops": 0})
+        g = groups.setdefault(rec["kernel"], {"ms": 0.0, "bytes": 0, "n": 0, "flops": 0, "delivered": 0, "delivered_ms": 0.0})
         g["ms"] += ms
         g["bytes"] += cache[key][0]
         g["flops"] += 2 * cache[key][1] * rec["cin"] * rec["cout"]
         g["n"] += 1
+        if arith is not None:
+            dkey = key + (rec.get("kernel_tag", 0),)
+            if dkey not in dcache:
+                dcache[dkey] = delivered_bytes(rec, arith, cache[key][1])
+            if dcache[dkey] is not None:
+                g["delivered"] += dcache[dkey]
+                g["delivered_ms"] += ms
     return groups
 
 
@@ -297,6 +333,9 @@ def build_roofline(groups, arith, traced_steps, ms_per_step, iso_groups=None):
              "useful_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
              "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / A["peak_tf"], 4),
              "notional_hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        cp = cu_path(v)
+        if cp:
+            e["cu_vmem_frac"] = cp["frac"]
         e.update(counters(k, avg_us))
         rp = rocprof_avg_us(k, arith)
         if rp:
@@ -304,6 +343,16 @@ def build_roofline(groups, arith, traced_steps, ms_per_step, iso_groups=None):
         return e
 
     avg_us = g["ms"] * 1e3 / g["n"]
+
+    def cu_path(v):
+        """The CU vector-memory path: bytes delivered into the CUs (delivered_bytes) / launch time against 34.5 TB/s."""
+        if not v.get("delivered_ms"):
+            return None
+        gbs = v["delivered"] / (v["delivered_ms"] * 1e-3) / 1e9
+        return {"achieved": round(gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / L2_PEAK_GBS, 4)}
+
+    conv_delivered = sum(v["delivered"] for v in groups.values()) / traced_steps
+    conv_delivered_ms = sum(v["delivered_ms"] for v in groups.values()) / traced_steps
     r = {"bound": "mfma", "kernel": dom, "arithmetic": arith,
          "achieved": round(tf, 2), "peak": round(A["peak_tf"], 1), "unit": "TFLOP/s", "frac": round(tf / A["peak_tf"], 4),
          "peak_def": {"bf16x3": "2500 TFLOP/s dense 16-bit / 6 bf16 MFMAs per fp32 product block = 416.7",
@@ -319,6 +368,11 @@ def build_roofline(groups, arith, traced_steps, ms_per_step, iso_groups=None):
                           "note": "SURVEY 8(d)'s algorithmic bytes per launch / launch time / 8 TB/s: the contract's HBM roofline. "
                                   "Notional -- the counter traffic above is a fraction of these bytes (rows are re-gathered "
                                   "from L2 / Infinity Cache), so HBM is not the binding resource"},
+         "cu_vmem_path": dict(cu_path(g) or {}, note="what BINDS these kernels (DESIGN 3): bytes that enter the CUs through their "
+                              "vector-memory path (L2 -> L1 / LDS / registers, 64 B per clock and CU = 34.5 TB/s): every unit of rows "
+                              "re-fetches the weight block of each of its active sub-stages (12 KiB bf16x3) + the gathered rows; "
+                              "the L2s serve them (hit 0.91-0.93), HBM sees a sixth"),
+         "step_cu_vmem_frac": round(conv_delivered / (conv_delivered_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4) if conv_delivered_ms else None,
          "launches_per_step": g["n"] // traced_steps,
          "avg_launch_us": round(avg_us, 2),
          "algorithmic_bytes_per_launch": g["bytes"] // g["n"],
@@ -693,6 +747,8 @@ def compact_line(out):
     if rf:
         r["peak_def"] = rf.get("peak_def")
         r["notional_hbm_frac"] = (rf.get("notional_hbm") or {}).get("frac")
+        r["cu_vmem_frac"] = (rf.get("cu_vmem_path") or {}).get("frac")
+        r["step_cu_vmem_frac"] = rf.get("step_cu_vmem_frac")
         if rf.get("issued_tflops") and rf.get("achieved"):
             mult = {"bf16x3": 6, "f16x2": 3, "f32": 1}[rf.get("arithmetic", "bf16x3")]
             r["issued_over_useful"] = round(rf["issued_tflops"] / (rf["achieved"] * mult), 3)
@@ -991,7 +1047,7 @@ def main():
     final = None
     if rank == 0:
         # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
-        groups = group_trace(trace)
+        groups = group_trace(trace, args.arith)
         extras, arithmetics = {}, None
         with torch.no_grad():
             iso_groups = None
@@ -1230,7 +1286,7 @@ def other_arithmetics(dev, args, sync, F_headline, pipelined=False):
                          "dtype": A["dtype"], "conv_arithmetic": A["arithmetic"],
                          "equals_exact_mode_bitwise": True,
                          "max_abs_diff_vs_headline_descriptors": float((r.F - F_headline).abs().max()),
-                         "roofline": build_roofline(group_trace(tr), name, 3, dt * 1e3)}
+                         "roofline": build_roofline(group_trace(tr, name), name, 3, dt * 1e3)}
             del m, wl
         finally:
             ops.CONV_VARIANT = prev

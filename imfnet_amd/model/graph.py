@@ -484,7 +484,7 @@ class FragmentRunner:
                                                                    kernel_tag=t.kernel_tag),
                                        kvol=t.kvol, cin=t.cin, cout=t.cout, rb=rb, split=t.split, ev=e,
                                        name=NativePlan.ORDER[i], arena=arena, res=res, level=t.level,
-                                       slots_extra=t.slots_extra))
+                                       slots_extra=t.slots_extra, kernel_tag=t.kernel_tag))
         return res
 
     def run(self, xyz, item_starts, image, voxel, stream=None):

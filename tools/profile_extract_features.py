@@ -1,5 +1,5 @@
 import sys, time, cProfile, pstats
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle")
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "oracle"))
 import numpy as np, torch
 import imf_oracle as O
 from imfnet_amd.extract import extract_features
