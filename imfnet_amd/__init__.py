@@ -23,9 +23,12 @@ def _runtime_untouched():
 # SIDE EFFECT of importing this package: ROC_CPU_WAIT_FOR_SIGNAL=0 in the process environment (unless already set).  The
 # variable only DECLARES the mode; stream.py measures the effective one when it creates a pipeline (a runtime started by
 # something else before this import ignores it).
+# OPT-OUT: IMFNET_LEAVE_ENV=1 -- the import leaves the environment alone; the pipeline then uses the copy engines
+# only if the embedding process set ROC_CPU_WAIT_FOR_SIGNAL=0 itself, and copy kernels otherwise (correct either way).
 if _runtime_untouched():
-    _os.environ.setdefault("ROC_CPU_WAIT_FOR_SIGNAL", "0")
-    SDMA_ASYNC = _os.environ["ROC_CPU_WAIT_FOR_SIGNAL"] == "0"
+    if _os.environ.get("IMFNET_LEAVE_ENV") != "1":
+        _os.environ.setdefault("ROC_CPU_WAIT_FOR_SIGNAL", "0")
+    SDMA_ASYNC = _os.environ.get("ROC_CPU_WAIT_FOR_SIGNAL") == "0"
 else:
     SDMA_ASYNC = False
 

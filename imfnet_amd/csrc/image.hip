@@ -321,7 +321,9 @@ int imf_image_branch(const imf_image_desc *net, const float *image, int B, int H
     // 10 tiles): branch alone 229 -> 182 us, pair step 1.030 -> 1.018 ms on the same box (14 launches fewer on a chain that
     // reaches the fusion's join last).  Always the 8-wavefront instance: the wavefront count is part of the arithmetic (it
     // cuts the sub-stage ranges, csrc/spconv_w.hip), so it is a static choice per layer -- never a function of the batch or
-    // image size, or an image's features would differ in the last bits between batch sizes.
+    // image size, or an image's features would differ in the last bits between batch sizes.  (This holds for the
+    // IMAGE trunk only: the ResUNet's own layers choose their workgroup shape by batch size since round 5,
+    // imf_resunet_conv_kernel_tag -- a fragment's descriptors agree between batch sizes to round-off, not bit for bit.)
     const int waves = c.kvol == 9 && (c.variant == 6 || c.variant == 0 || c.variant == 3) && c.cout % 64 == 0 ? 8 : 0;
     if (waves == 8) a.kernel_tag = 4 | 1;
     else if (waves == 4) a.kernel_tag = 8 | 1;

@@ -572,7 +572,10 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
  * with two or more fragments: 48-row units (4 | 128) on level 3, and from three fragments on 4 wavefronts on level 2.  The choice is
  * a function of the LEVEL, the layer's channel counts and the batch size only -- never of the row count -- so exact mode,
  * capacity mode and a graph replay form every sum in the
- * same order (bit-identical descriptors) without a device-side split rule; no executor launch uses split-K partitions
+ * same order (bit-identical descriptors) without a device-side split rule.  What DOES depend on n_items is the partition of a
+ * row's sum (wavefront count, unit shape): the descriptors of a fragment computed alone and computed inside a batch of two
+ * or more agree to fp32 round-off (~1e-7), not bit for bit, and the same holds between batch sizes 2 and >= 3; set
+ * n_items consistently where reproducibility across batch sizes matters.  No executor launch uses split-K partitions
  * or the k_spconv_reduce pass any more.  0 for shapes the wave-split kernel does not serve (kvol == 1, cout % 64 != 0,
  * a variant other than 6 / 3 / 0).  Replaces: the implicit per-layer algorithm choice inside
  * ME.MinkowskiConvolution (model/resunet.py:168-226). */

@@ -133,6 +133,12 @@ def test_package_import_prepares_the_runtime_for_async_copies():
     assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split() == ["0", "True"]
     env["ROC_CPU_WAIT_FOR_SIGNAL"] = "1"
     assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split() == ["1", "False"]
+    # the opt-out: IMFNET_LEAVE_ENV=1 -- the import does not touch the environment; copy engines only if the host set the mode
+    del env["ROC_CPU_WAIT_FOR_SIGNAL"]
+    env["IMFNET_LEAVE_ENV"] = "1"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split() == ["None", "False"]
+    env["ROC_CPU_WAIT_FOR_SIGNAL"] = "0"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split() == ["0", "True"]
 
 
 def test_errors_are_loud_without_gpu():
