@@ -11,20 +11,21 @@
 // its terms changes with the map, as between any two tile layouts.
 //
 // The order.  Inside windows of 16 384 consecutive slots (a window keeps a unit's gathers inside ~4 MB of the feature
-// matrix; a global sort is 5 % better on paper and spreads a tile over the whole level), stable, by the 21-bit key
-//   r    = the 12 edge offsets (two coordinates differ) in bits 19 .. 8, the 6 face offsets in bits 7 .. 2, the corner
-//          offsets 0 and 26 in bits 1, 0        -- the most evenly split offsets decide first
+// matrix; a global sort is 5 % better on paper and spreads a tile over the whole level), stable, by the 18-bit key
+//   r    = the 12 edge offsets (two coordinates differ) in bits 17 .. 6, the 6 face offsets in bits 5 .. 0
+//                                              -- the most evenly split offsets decide first
 //   key  = gray^-1(r) = r ^ r >> 1 ^ r >> 2 ^ ...   -- neighbours in the order differ in ONE of the deciding offsets
-//          (numeric order of r: 1.35; this order: 1.32; all 27 bits, four passes: 1.30), slots >= the row count: 1 << 20.
+//          (numeric order of r: 1.35; this order: 1.32; all 27 bits, four passes: 1.30); slots >= the row count keep their
+//          place at the window's end.
 // Measured on the S50k fragment (tools: LAB_NOTES round 6): issued / useful multiply-adds with 16-row blocks, identity
 // order -> this order: stride-1 maps of the four levels 1.86 / 1.87 / 1.92 / 1.97 -> 1.32 / 1.33 / 1.48 / 1.67, strided maps
 // 2.48 / 2.53 / 2.66 -> 1.46 / 1.58 / 1.88.
 //
-// The sort.  One 1024-thread workgroup per window, everything in LDS: keys (64 KiB), two index arrays (2 x 32 KiB), one
-// histogram per wavefront.  Three LSD passes of 7 bits; a wavefront owns 1024 consecutive positions and ranks 64 of them
-// at a time with seven ballots (lanes with the same digit), so equal digits keep their order: deterministic, and equal to a
-// stable comparison sort (the CPU twin, oracle/imf_cpu_twins.c).  Round 5 used rocPRIM's device radix sort of 64-bit keys
-// (eight launches per map); this is one launch per map plus the gather.
+// The sort.  One 1024-thread workgroup per window, everything in LDS and registers (k_rbs_window_sort below): three stable
+// LSD passes of 6 bits over 32-bit words key << 14 | slot; deterministic, and equal to a stable comparison sort (the CPU
+// twin, oracle/imf_cpu_twins.c).  Round 5 used rocPRIM's device radix sort of 64-bit keys (eight launches per map); this is
+// one launch per map plus the gather (first version of this round: keys and indices in separate arrays, two dependent LDS
+// reads per element and sweep, 76-90 us per map; this one: ~25 us).
 //   out: tile_rows[s] = perm[s] (or -1), nbr[k][s] = nbr_in[k][perm[s]], tile_mask = OR over each tile's 64 slots
 // The input map is in identity slot order (imf_rulebook_conv); in capacity mode the row count is read from the device and
 // every slot beyond it sorts last (its input slice is never read).
@@ -39,54 +40,62 @@ namespace {
 constexpr int kWindowShift = 14;                     // 16 384 slots per sort window
 constexpr int kWindow = 1 << kWindowShift;
 constexpr int kSortThreads = 1024, kSortWaves = kSortThreads / 64, kPerThread = kWindow / kSortThreads;   // 16, 16
-constexpr int kDigitBits = 7, kDigits = 1 << kDigitBits, kPasses = 3;
-constexpr unsigned kInvalidKey = 1u << 20;
+constexpr int kDigitBits = 6, kDigits = 1 << kDigitBits, kPasses = 3, kKeyBits = kDigitBits * kPasses;    // 18-bit key
+constexpr int kMaxGroups = kWindow / kSortWaves / 64;                                                      // 16 per wavefront
 
 // bit of the 27-bit occupancy mask -> bit of r (-1: not part of the key)
 __device__ __forceinline__ constexpr int key_bit_of_offset(int k) {
   constexpr int edges[12] = {1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25};
   constexpr int faces[6] = {4, 10, 12, 14, 16, 22};
   for (int i = 0; i < 12; ++i)
-    if (edges[i] == k) return 19 - i;
+    if (edges[i] == k) return 17 - i;
   for (int i = 0; i < 6; ++i)
-    if (faces[i] == k) return 7 - i;
-  return k == 0 ? 1 : (k == 26 ? 0 : -1);
+    if (faces[i] == k) return 5 - i;
+  return -1;
 }
 
-__device__ __forceinline__ unsigned gray_inverse20(unsigned r) {
+__device__ __forceinline__ unsigned gray_inverse18(unsigned r) {
   r ^= r >> 1;
   r ^= r >> 2;
   r ^= r >> 4;
   r ^= r >> 8;
   r ^= r >> 16;
-  return r & 0xFFFFFu;
+  return r & 0x3FFFFu;
 }
 
+// One workgroup = one window.  An element travels as ONE 32-bit word, key << 14 | window-local slot, through two LDS
+// arrays (2 x 64 KiB); a pass is two sweeps of the wavefront's own <= 16 groups of 64 consecutive positions:
+//   A  digit of every element, the lanes of the group with the same digit (6 ballots) -> rank inside the group and count;
+//      the first lane of each digit adds the count to the wavefront's histogram; word, digit, rank, count stay in registers
+//   -- digit-major, wavefront-minor exclusive scan of the 16 x 64 counters --
+//   B  position = wavefront's running base of the digit + rank; the last lane of each digit advances the base
+// so equal digits keep their order (stable, deterministic).  The valid slots of a window are a prefix of it (slots >= the row
+// count sit at the level's tail), so only ceil(valid / 1024) groups per wavefront are sorted; the padding of the last group
+// carries the largest key and, being behind every valid element, stays behind (stability) -- the first `valid` outputs are
+// exactly the valid slots.
 template <int KVOL>
 __global__ void __launch_bounds__(kSortThreads)
 k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slots, long long n_out,
                   const int32_t *__restrict__ n_dev, int32_t *__restrict__ perm) {
-  __shared__ unsigned keys[kWindow];                 // 64 KiB
-  __shared__ unsigned short idx0[kWindow], idx1[kWindow];   // 2 x 32 KiB
+  __shared__ unsigned val0[kWindow], val1[kWindow];  // 2 x 64 KiB
   __shared__ unsigned hist[kSortWaves * kDigits], dtot[kDigits], doff[kDigits];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long wbase = (long long)blockIdx.x * kWindow;
   long long n = n_out;
   if (n_dev) n = *n_dev < n ? *n_dev : n;
   const int kvol = KVOL ? KVOL : kvol_rt;
-  // slots of this window (a level smaller than a window sorts what it has: positions beyond are never produced), in whole
-  // wavefront groups per wavefront: every wavefront owns `per_wave` consecutive positions, a multiple of 64
-  const int n_win = (int)((n_slots - wbase) < kWindow ? (n_slots - wbase) : kWindow);
-  const int per_wave = ((n_win + kSortWaves - 1) / kSortWaves + 63) / 64 * 64;
-  const int n_pos = per_wave * kSortWaves;            // <= kWindow, >= n_win
+  const int n_win = (int)((n_slots - wbase) < kWindow ? (n_slots - wbase) : kWindow);            // slots of this window
+  const int n_valid = (int)(n - wbase < 0 ? 0 : (n - wbase < n_win ? n - wbase : n_win));         // ... that hold a row
+  const int groups = ((n_valid + kSortWaves - 1) / kSortWaves + 63) / 64;                         // per wavefront, <= 16
+  const int per_wave = groups * 64, n_pos = per_wave * kSortWaves;
 
   // ---- keys: thread t takes the slots wbase + t + 1024 i (every load of a wavefront is one line of one offset)
 #pragma unroll 4
   for (int i = 0; i < kPerThread; ++i) {
     const int loc = tid + kSortThreads * i;
     const long long s = wbase + loc;
-    unsigned key = kInvalidKey;
-    if (s < n && loc < n_pos) {
+    unsigned key = (1u << kKeyBits) - 1u;            // padding of the last group
+    if (loc < n_valid) {
       unsigned r = 0u;
       if (KVOL == 27) {
 #pragma unroll
@@ -95,32 +104,44 @@ k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slot
           if (bit >= 0) r |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << bit;
         }
       } else {
-        for (int k = 0; k < kvol && k < 20; ++k) r |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << k;
+        for (int k = 0; k < kvol && k < kKeyBits; ++k) r |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << k;
       }
-      key = gray_inverse20(r);
+      key = gray_inverse18(r);
     }
-    keys[loc] = key;
+    if (loc < n_pos) val0[loc] = (key << kWindowShift) | (unsigned)loc;
   }
   __syncthreads();
 
-  // ---- three stable LSD passes over the window-local index
-  unsigned short *src = idx0, *dst = idx1;
+  unsigned *src = val0, *dst = val1;
+  unsigned *const myhist = hist + wave * kDigits;
+  const int chunk = wave * per_wave;
+  const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll 1
   for (int pass = 0; pass < kPasses; ++pass) {
-    const int shift = kDigitBits * pass;
+    const int shift = kWindowShift + kDigitBits * pass;
     for (int d = tid; d < kSortWaves * kDigits; d += kSortThreads) hist[d] = 0u;
     __syncthreads();
-    unsigned *const myhist = hist + wave * kDigits;
-    const int chunk = wave * per_wave;
-    // count (order is irrelevant here)
-    for (int it = 0; it < per_wave / 64; ++it) {
-      const int pos = chunk + 64 * it + lane;
-      const unsigned id = pass == 0 ? (unsigned)pos : (unsigned)src[pos];
-      atomicAdd(&myhist[(keys[id] >> shift) & (kDigits - 1)], 1u);
+    unsigned word[kMaxGroups], info[kMaxGroups];      // info = digit | rank << 6 | (count - 1) << 12
+#pragma unroll
+    for (int g = 0; g < kMaxGroups; ++g) {
+      if (g < groups) {                                // (uniform)
+        const unsigned v = src[chunk + 64 * g + lane];
+        const unsigned d = (v >> shift) & (kDigits - 1);
+        unsigned long long same = ~0ull;
+#pragma unroll
+        for (int b = 0; b < kDigitBits; ++b) {
+          const bool bit = (d >> b) & 1u;
+          const unsigned long long bal = __ballot(bit);
+          same &= bit ? bal : ~bal;
+        }
+        const unsigned rank = (unsigned)__builtin_popcountll(same & below), cnt = (unsigned)__builtin_popcountll(same);
+        if (rank == 0) atomicAdd(&myhist[d], cnt);     // one lane per digit of the group: no two lanes share an address
+        word[g] = v;
+        info[g] = d | (rank << 6) | ((cnt - 1u) << 12);
+      }
     }
     __syncthreads();
-    // digit-major, wavefront-minor exclusive offsets
-    if (tid < kDigits) {
+    if (tid < kDigits) {                               // digit-major, wavefront-minor exclusive offsets
       unsigned run = 0u;
 #pragma unroll
       for (int w = 0; w < kSortWaves; ++w) {
@@ -128,52 +149,34 @@ k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slot
         hist[w * kDigits + tid] = run;
         run += c;
       }
-      dtot[tid] = run;
-    }
-    __syncthreads();
-    if (tid < 64) {   // exclusive scan of the 128 digit totals by one wavefront: two per lane + a shuffle scan
-      const unsigned a = dtot[2 * tid], b = dtot[2 * tid + 1];
-      unsigned incl = a + b;
+      unsigned incl = run;                             // exclusive scan of the 64 digit totals: this IS wavefront 0
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const unsigned up = __shfl_up(incl, o, 64);
         if (tid >= o) incl += up;
       }
-      doff[2 * tid] = incl - a - b;
-      doff[2 * tid + 1] = incl - b;
+      doff[tid] = incl - run;
     }
     __syncthreads();
-    // rank and scatter, 64 positions at a time in order: lanes with the same digit keep their order
-    for (int it = 0; it < per_wave / 64; ++it) {
-      const int pos = chunk + 64 * it + lane;
-      const unsigned id = pass == 0 ? (unsigned)pos : (unsigned)src[pos];
-      const unsigned d = (keys[id] >> shift) & (kDigits - 1);
-      unsigned long long same = ~0ull;
 #pragma unroll
-      for (int b = 0; b < kDigitBits; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long bal = __ballot(bit);
-        same &= bit ? bal : ~bal;
+    for (int g = 0; g < kMaxGroups; ++g) {
+      if (g < groups) {
+        const unsigned d = info[g] & 63u, rank = (info[g] >> 6) & 63u, last = info[g] >> 12;
+        const unsigned base = myhist[d];
+        if (rank == last) myhist[d] = base + last + 1u;               // (LDS operations of a wavefront execute in order)
+        dst[base + doff[d] + rank] = word[g];
       }
-      const int rank = __builtin_popcountll(same & ((1ull << lane) - 1ull));
-      const int cnt = __builtin_popcountll(same);
-      const unsigned base = myhist[d];
-      if (rank == cnt - 1) myhist[d] = base + (unsigned)cnt;      // (LDS operations of a wavefront execute in order)
-      dst[base + doff[d] + (unsigned)rank] = (unsigned short)id;
     }
     __syncthreads();
-    unsigned short *const t = src;
+    unsigned *const t = src;
     src = dst;
     dst = t;
   }
 
-  // ---- new slot wbase + p takes old slot wbase + src[p]; slots beyond the rows: -1
-  for (int i = 0; i < n_pos / kSortThreads; ++i) {
-    const int loc = tid + kSortThreads * i;
-    if (loc >= n_win) break;
-    const unsigned id = src[loc];
-    perm[wbase + loc] = keys[id] == kInvalidKey ? -1 : (int32_t)(wbase + id);
-  }
+  // ---- new slot wbase + p takes old slot wbase + (src[p] & 16383); slots beyond the rows: -1
+  for (int loc = tid; loc < n_win; loc += kSortThreads)
+    perm[wbase + loc] = loc < n_valid ? (int32_t)(wbase + (src[loc] & (kWindow - 1))) : -1;
+  (void)dtot;
 }
 
 // one wavefront = one tile of the OUTPUT map: 64 consecutive new slots

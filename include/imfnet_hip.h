@@ -168,9 +168,9 @@ int imf_rulebook_conv(const imf_slot *in_table, int64_t in_capacity,
 /* Occupancy-sorted twin of a kernel map (csrc/rulebook_sort.hip): the same rows and inputs, the SLOTS re-ordered so that the
  * rows of a tile / of a 16-row block have similar neighbour-occupancy patterns -- stable sort inside windows of 16 384
  * consecutive slots by key = gray^-1(r), r = the occupancy bits (nbr_in[k][slot] >= 0) of the 12 edge offsets of the 3x3x3
- * kernel in bits 19 .. 8 (k = 1, 3, .. 25 without 13, in that order from bit 19 down), of the 6 face offsets (4, 10, 12, 14,
- * 16, 22) in bits 7 .. 2 and of the corner offsets 0 and 26 in bits 1, 0; slots >= the row count sort last in their window
- * (kvol != 27: r = the bits of the first 20 offsets).  nbr_in: a map in identity slot order (imf_rulebook_conv(_dyn), kvol
+ * kernel in bits 17 .. 6 (k = 1, 3, .. 25 without 13, in that order from bit 17 down) and of the 6 face offsets (4, 10, 12,
+ * 14, 16, 22) in bits 5 .. 0; slots >= the row count stay last in their window (kvol != 27: r = the bits of the first 18
+ * offsets).  nbr_in: a map in identity slot order (imf_rulebook_conv(_dyn), kvol
  * <= 27); outputs: tile_rows[slot] = the row now in that slot (-1: padding), nbr_out[k][slot] = nbr_in[k][row], tile_mask
  * recomputed.  A 64-row tile then walks ~78 % of the 27 offsets instead of ~100 % (stride-1 level of a 3DMatch fragment; 1.47
  * issued multiply-adds per useful one instead of 1.91), with no change to imf_spconv_fwd.  n_out_dev: optional

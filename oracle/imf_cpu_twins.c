@@ -185,23 +185,21 @@ int imf_cpu_rulebook_transpose(const imf_slot *coarse_table, int64_t coarse_capa
 }
 
 /* imf_rulebook_sort_by_occupancy (csrc/rulebook_sort.hip): the slots of a map in identity order, stably sorted inside windows of
- * 16 384 slots by key = gray^-1(r), r = the occupancy bits (nbr_in[k][slot] >= 0) of the 12 edge offsets in bits 19 .. 8, of the 6
- * face offsets in bits 7 .. 2 and of the corner offsets 0 and 26 in bits 1, 0 (kvol != 27: the first 20 offsets in bits 0 .. 19);
- * slots >= the row count last.  A plain stable merge sort here -- the HIP side's LDS radix sort must produce the same permutation. */
+ * 16 384 slots by key = gray^-1(r), r = the occupancy bits (nbr_in[k][slot] >= 0) of the 12 edge offsets in bits 17 .. 6 and of
+ * the 6 face offsets in bits 5 .. 0 (kvol != 27: the first 18 offsets in bits 0 .. 17); slots >= the row count last in their
+ * window.  A plain stable merge sort here -- the HIP side's LDS radix sort must produce the same permutation. */
 static uint32_t tw_occupancy_key(const int32_t *nbr_in, int kvol, int64_t n_slots, int64_t s) {
   static const int edges[12] = {1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25}, faces[6] = {4, 10, 12, 14, 16, 22};
   uint32_t r = 0;
   if (kvol == 27) {
-    for (int i = 0; i < 12; ++i) r |= (uint32_t)(nbr_in[(int64_t)edges[i] * n_slots + s] >= 0) << (19 - i);
-    for (int i = 0; i < 6; ++i) r |= (uint32_t)(nbr_in[(int64_t)faces[i] * n_slots + s] >= 0) << (7 - i);
-    r |= (uint32_t)(nbr_in[s] >= 0) << 1;
-    r |= (uint32_t)(nbr_in[(int64_t)26 * n_slots + s] >= 0);
+    for (int i = 0; i < 12; ++i) r |= (uint32_t)(nbr_in[(int64_t)edges[i] * n_slots + s] >= 0) << (17 - i);
+    for (int i = 0; i < 6; ++i) r |= (uint32_t)(nbr_in[(int64_t)faces[i] * n_slots + s] >= 0) << (5 - i);
   } else {
-    for (int q = 0; q < kvol && q < 20; ++q) r |= (uint32_t)(nbr_in[(int64_t)q * n_slots + s] >= 0) << q;
+    for (int q = 0; q < kvol && q < 18; ++q) r |= (uint32_t)(nbr_in[(int64_t)q * n_slots + s] >= 0) << q;
   }
   uint32_t b = 0;
   for (; r; r >>= 1) b ^= r;                       /* gray^-1: b = r ^ r >> 1 ^ r >> 2 ^ ... */
-  return b & 0xFFFFFu;
+  return b & 0x3FFFFu;
 }
 static void tw_merge_sort(uint64_t *key, int32_t *val, uint64_t *tk, int32_t *tv, int64_t lo, int64_t hi) {
   if (hi - lo < 2) return;
@@ -232,8 +230,8 @@ int imf_cpu_rulebook_sort_by_occupancy(const int32_t *nbr_in, int kvol, int64_t 
   uint64_t *key = (uint64_t *)workspace, *tk = key + n_slots;
   int32_t *val = (int32_t *)(tk + n_slots), *tv = val + n_slots;
   for (int64_t s = 0; s < n_slots; ++s) {
-    uint64_t k = ((uint64_t)(s >> 14) << 21) | (1u << 20);          /* padding: last inside its window */
-    if (s < n) k = ((uint64_t)(s >> 14) << 21) | tw_occupancy_key(nbr_in, kvol, n_slots, s);
+    uint64_t k = ((uint64_t)(s >> 14) << 19) | (1u << 18);          /* padding: last inside its window */
+    if (s < n) k = ((uint64_t)(s >> 14) << 19) | tw_occupancy_key(nbr_in, kvol, n_slots, s);
     key[s] = k;
     val[s] = (int32_t)s;
   }

@@ -136,9 +136,9 @@ def occupancy_sorted_slots(nbr, n_out, window=16384):
     """The slot order of csrc/rulebook_sort.hip (no reference counterpart: MinkowskiEngine's kernel maps have no tile
     structure; an ordering of the OUTPUT slots, the rows keep their numbers).  nbr [kvol, n_slots] in identity slot order.
     Stable sort inside windows of `window` slots by key = gray^-1(r): r = occupancy bits of the 12 edge offsets of the 3x3x3
-    kernel (exactly two non-zero coordinates... offsets 1, 3, .., 25 without 13) in bits 19..8, of the 6 face offsets in bits
-    7..2, of the corners 0 and 26 in bits 1, 0; slots >= n_out last in their window.  Returns perm (new slot s takes old slot
-    perm[s]) and the boolean `valid` of the new slots."""
+    kernel (exactly two non-zero coordinates: offsets 1, 3, .., 25 without 13) in bits 17..6 and of the 6 face offsets in
+    bits 5..0; slots >= n_out last in their window.  Returns perm (new slot s takes old slot perm[s]) and the boolean
+    `valid` of the new slots."""
     nbr = np.asarray(nbr)
     kvol, n_slots = nbr.shape
     occ = (nbr >= 0).astype(np.uint64)
@@ -146,21 +146,20 @@ def occupancy_sorted_slots(nbr, n_out, window=16384):
     if kvol == 27:
         edges, faces = [1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25], [4, 10, 12, 14, 16, 22]
         for i, k in enumerate(edges):
-            r |= occ[k] << np.uint64(19 - i)
+            r |= occ[k] << np.uint64(17 - i)
         for i, k in enumerate(faces):
-            r |= occ[k] << np.uint64(7 - i)
-        r |= (occ[0] << np.uint64(1)) | occ[26]
+            r |= occ[k] << np.uint64(5 - i)
     else:
-        for k in range(min(kvol, 20)):
+        for k in range(min(kvol, 18)):
             r |= occ[k] << np.uint64(k)
     key = r.copy()
     sh = 1
     while sh < 32:                                    # gray^-1: key = r ^ r >> 1 ^ r >> 2 ^ ...
         key ^= key >> np.uint64(sh)
         sh *= 2
-    key &= np.uint64(0xFFFFF)
+    key &= np.uint64(0x3FFFF)
     slot = np.arange(n_slots)
-    key = np.where(slot < n_out, key, np.uint64(1 << 20)) | ((slot // window).astype(np.uint64) << np.uint64(21))
+    key = np.where(slot < n_out, key, np.uint64(1 << 18)) | ((slot // window).astype(np.uint64) << np.uint64(19))
     perm = np.argsort(key, kind="stable")
     return perm, perm < n_out
 
