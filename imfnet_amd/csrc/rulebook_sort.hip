@@ -24,7 +24,7 @@
 // The sort.  One 1024-thread workgroup per window, everything in LDS and registers (k_rbs_window_sort below): three stable
 // LSD passes of 6 bits over 32-bit words key << 14 | slot; deterministic, and equal to a stable comparison sort (the CPU
 // twin, oracle/imf_cpu_twins.c).  Round 5 used rocPRIM's device radix sort of 64-bit keys (eight launches per map); this is
-// one launch per map plus the gather (first version of this round: keys and indices in separate arrays, two dependent LDS
+// a key launch, one sort launch per map and the gather (first version of this round: keys and indices in separate arrays, two dependent LDS
 // reads per element and sweep, 76-90 us per map; this one: ~25 us).
 //   out: tile_rows[s] = perm[s] (or -1), nbr[k][s] = nbr_in[k][perm[s]], tile_mask = OR over each tile's 64 slots
 // The input map is in identity slot order (imf_rulebook_conv); in capacity mode the row count is read from the device and
@@ -63,6 +63,30 @@ __device__ __forceinline__ unsigned gray_inverse18(unsigned r) {
   return r & 0x3FFFFu;
 }
 
+// Keys of all slots, by the whole chip: one CU reading 18 offsets x 16 k slots (1.2 MB) through its own L1 path took ~15 us of the
+// window sort; 400 workgroups do the level-0 map's 7.4 MB in 3-4 us.  keys[s] = gray^-1(r) for s < n (rows), undefined beyond.
+template <int KVOL>
+__global__ void __launch_bounds__(256)
+k_rbs_keys(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slots, long long n_out, const int32_t *__restrict__ n_dev,
+           unsigned *__restrict__ keys) {
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = n_out;
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
+  if (s >= n || s >= n_slots) return;
+  const int kvol = KVOL ? KVOL : kvol_rt;
+  unsigned r = 0u;
+  if (KVOL == 27) {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const int bit = key_bit_of_offset(k);
+      if (bit >= 0) r |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << bit;
+    }
+  } else {
+    for (int k = 0; k < kvol && k < kKeyBits; ++k) r |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << k;
+  }
+  keys[s] = gray_inverse18(r);
+}
+
 // One workgroup = one window.  An element travels as ONE 32-bit word, key << 14 | window-local slot, through two LDS
 // arrays (2 x 64 KiB); a pass is two sweeps of the wavefront's own <= 16 groups of 64 consecutive positions:
 //   A  digit of every element, the lanes of the group with the same digit (6 ballots) -> rank inside the group and count;
@@ -73,9 +97,8 @@ __device__ __forceinline__ unsigned gray_inverse18(unsigned r) {
 // count sit at the level's tail), so only ceil(valid / 1024) groups per wavefront are sorted; the padding of the last group
 // carries the largest key and, being behind every valid element, stays behind (stability) -- the first `valid` outputs are
 // exactly the valid slots.
-template <int KVOL>
 __global__ void __launch_bounds__(kSortThreads)
-k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slots, long long n_out,
+k_rbs_window_sort(const unsigned *__restrict__ keys, long long n_slots, long long n_out,
                   const int32_t *__restrict__ n_dev, int32_t *__restrict__ perm) {
   __shared__ unsigned val0[kWindow], val1[kWindow];  // 2 x 64 KiB
   __shared__ unsigned hist[kSortWaves * kDigits], dtot[kDigits], doff[kDigits];
@@ -83,32 +106,16 @@ k_rbs_window_sort(const int32_t *__restrict__ nbr, int kvol_rt, long long n_slot
   const long long wbase = (long long)blockIdx.x * kWindow;
   long long n = n_out;
   if (n_dev) n = *n_dev < n ? *n_dev : n;
-  const int kvol = KVOL ? KVOL : kvol_rt;
   const int n_win = (int)((n_slots - wbase) < kWindow ? (n_slots - wbase) : kWindow);            // slots of this window
   const int n_valid = (int)(n - wbase < 0 ? 0 : (n - wbase < n_win ? n - wbase : n_win));         // ... that hold a row
   const int groups = ((n_valid + kSortWaves - 1) / kSortWaves + 63) / 64;                         // per wavefront, <= 16
   const int per_wave = groups * 64, n_pos = per_wave * kSortWaves;
 
-  // ---- keys: thread t takes the slots wbase + t + 1024 i (every load of a wavefront is one line of one offset)
+  // ---- the window's words: key << 14 | slot (k_rbs_keys computed the keys); the padding of the last group: the largest key
 #pragma unroll 4
   for (int i = 0; i < kPerThread; ++i) {
     const int loc = tid + kSortThreads * i;
-    const long long s = wbase + loc;
-    unsigned key = (1u << kKeyBits) - 1u;            // padding of the last group
-    if (loc < n_valid) {
-      unsigned r = 0u;
-      if (KVOL == 27) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-          const int bit = key_bit_of_offset(k);
-          if (bit >= 0) r |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << bit;
-        }
-      } else {
-        for (int k = 0; k < kvol && k < kKeyBits; ++k) r |= (nbr[(long long)k * n_slots + s] >= 0 ? 1u : 0u) << k;
-      }
-      key = gray_inverse18(r);
-    }
-    if (loc < n_pos) val0[loc] = (key << kWindowShift) | (unsigned)loc;
+    if (loc < n_pos) val0[loc] = ((loc < n_valid ? keys[wbase + loc] : (1u << kKeyBits) - 1u) << kWindowShift) | (unsigned)loc;
   }
   __syncthreads();
 
@@ -213,7 +220,7 @@ extern "C" {
 
 size_t imf_rulebook_sorted_workspace_bytes(int64_t n_slots) {
   if (n_slots <= 0) return 0;
-  return ((size_t)n_slots * 4 + 255) / 256 * 256;           // the permutation
+  return 2 * ((((size_t)n_slots + 63) / 64 * 64) * 4 + 255) / 256 * 256;   // the permutation, the keys
 }
 
 int imf_rulebook_sort_by_occupancy(const int32_t *nbr_in, int kvol, int64_t n_slots, int64_t n_out, const int32_t *n_out_dev,
@@ -229,10 +236,13 @@ int imf_rulebook_sort_by_occupancy(const int32_t *nbr_in, int kvol, int64_t n_sl
   hipStream_t st = (hipStream_t)stream;
   int32_t *perm = (int32_t *)workspace;
   const unsigned windows = (unsigned)((n_slots + kWindow - 1) / kWindow);
-  if (kvol == 27) k_rbs_window_sort<27><<<windows, kSortThreads, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, perm);
-  else            k_rbs_window_sort<0><<<windows, kSortThreads, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, perm);
-  IMF_CHECK_LAUNCH("k_rbs_window_sort");
   const unsigned blocks = (unsigned)((n_slots + 255) / 256);
+  unsigned *keys = (unsigned *)(perm + (((size_t)n_slots + 63) / 64 * 64));
+  if (kvol == 27) k_rbs_keys<27><<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, keys);
+  else            k_rbs_keys<0><<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, keys);
+  IMF_CHECK_LAUNCH("k_rbs_keys");
+  k_rbs_window_sort<<<windows, kSortThreads, 0, st>>>(keys, n_slots, n_out, n_out_dev, perm);
+  IMF_CHECK_LAUNCH("k_rbs_window_sort");
   k_rbs_gather<<<blocks, 256, 0, st>>>(nbr_in, kvol, n_slots, n_out, n_out_dev, perm, tile_rows, nbr_out, tile_mask);
   IMF_CHECK_LAUNCH("k_rbs_gather");
   return IMF_OK;

@@ -174,7 +174,7 @@ int imf_rulebook_conv(const imf_slot *in_table, int64_t in_capacity,
  * <= 27); outputs: tile_rows[slot] = the row now in that slot (-1: padding), nbr_out[k][slot] = nbr_in[k][row], tile_mask
  * recomputed.  A 64-row tile then walks ~78 % of the 27 offsets instead of ~100 % (stride-1 level of a 3DMatch fragment; 1.47
  * issued multiply-adds per useful one instead of 1.91), with no change to imf_spconv_fwd.  n_out_dev: optional
- * device-side row count (capacity mode; n_out is then the capacity).  One launch per window + one gather launch.  Replaces:
+ * device-side row count (capacity mode; n_out is then the capacity).  Three launches: keys, the window sort, the gather.  Replaces:
  * nothing in the reference (MinkowskiEngine's kernel maps have no tile structure); used by the executors for the decoder's
  * stride-1 blocks (model/resunet.py:136-146, imf_resunet_sorted_maps).
  * workspace: imf_rulebook_sorted_workspace_bytes(n_slots) bytes of device memory (the permutation). */
