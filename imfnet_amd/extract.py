@@ -214,7 +214,8 @@ def extract_features_stream(model, fragments, voxel_size, device=None, depth=3, 
         # the sink reads a job's rows from its capacity BUCKET after job.wait(): with more jobs of one key in flight than the
         # streamer has lanes, the streamer completes the oldest job itself and hands its bucket to the new submit -- whose
         # forward could overwrite the rows before finish() reaches the sink.  The pinned host copy is not affected.
-        depth = min(depth, FragmentStreamerLanes)
+        lanes = runner.streamer(device).n_buckets if runner is not None else FragmentStreamerLanes
+        depth = min(depth, lanes)
     n_slots = depth + 2                               # in flight + the one the consumer holds (copy=False) + one being staged
     auto = isinstance(batch, str)
     if auto and batch != "auto":
