@@ -53,11 +53,38 @@ def test_geometry_equals_the_cpu_twins(both):
 
 
 def test_sorted_map_equals_the_cpu_twin(both):
-    """imf_rulebook_sort_by_occupancy (rocPRIM radix sort) against its twin (a stable merge sort): the same permutation."""
+    """imf_rulebook_sort_by_occupancy (three launches: keys, one LDS radix sort per 16 k-slot window, gather) against its twin (a
+    stable merge sort): the same permutation -- stride-1 maps of all four levels (several windows, two, and less than one:
+    only a window's valid prefix is sorted) and the three strided maps."""
     ops, cm, levels = both
-    for i in (0, 1):
+    for i in range(4):
         rb = cm.conv_rulebook(1 << i, 3, 1)
         _same_map(ops.rulebook_sorted(rb), T.rulebook_sort_by_occupancy(rb.nbr.cpu().numpy().reshape(27, rb.n_slots), rb.n_out))
+    for i in range(3):
+        rb = cm.conv_rulebook(1 << i, 3, 2)
+        _same_map(ops.rulebook_sorted(rb), T.rulebook_sort_by_occupancy(rb.nbr.cpu().numpy().reshape(27, rb.n_slots), rb.n_out))
+
+
+def test_sorted_map_of_tiny_and_window_edge_sizes(both):
+    """Row counts around the sort's internal sizes: fewer rows than one 64-lane group, exactly one wavefront's share, one row
+    short of / exactly / one row beyond a 16 384-slot window: against the numpy restatement, run twice (same bits)."""
+    import imf_oracle as O
+    ops, cm, levels = both
+    rb0 = cm.conv_rulebook(1, 3, 1)
+    K, S0 = 27, rb0.n_slots
+    full = rb0.nbr.view(K, S0)
+    for n in (1, 50, 64, 1024, 16383, 16384, 16385, 20000):
+        S = (n + 63) // 64 * 64
+        nbr = torch.where(full[:, :S] < n, full[:, :S], torch.full_like(full[:, :S], -1)).contiguous()   # a map of the first n rows
+        nbr[:, n:] = -1
+        mask = torch.zeros(S // 64 * 4, dtype=torch.int32, device=nbr.device)
+        rb = ops.Rulebook(None, nbr.view(-1), mask, S, n, K, K)
+        a, b = ops.rulebook_sorted(rb), ops.rulebook_sorted(rb)
+        perm, valid = O.occupancy_sorted_slots(nbr.cpu().numpy(), n)
+        want_rows = np.where(valid, perm, -1).astype(np.int32)
+        assert np.array_equal(a.tile_rows.cpu().numpy(), want_rows), n
+        assert np.array_equal(a.nbr.view(K, S).cpu().numpy(), np.where(valid[None, :], nbr.cpu().numpy()[:, perm], -1)), n
+        assert torch.equal(a.tile_rows, b.tile_rows) and torch.equal(a.nbr, b.nbr) and torch.equal(a.tile_mask, b.tile_mask)
 
 
 @pytest.mark.parametrize("variant", [0, 3])
