@@ -606,8 +606,8 @@ typedef struct imf_resunet_io {        /* per fragment */
   void *int_arena;  size_t int_arena_bytes;     /* >= imf_resunet_int_arena_bytes   */
   void *float_arena; size_t float_arena_bytes;  /* >= imf_resunet_float_arena_bytes */
   float *out;                          /* [n0, out_channels] descriptors */
-  void *events[16];                    /* caller-owned hipEvent_t (imf_event_create): side-stream joins (7 used; 9 with
-                                          `pyramid`) */
+  void *events[16];                    /* caller-owned hipEvent_t (imf_event_create): side-stream joins (10 used: seven
+                                          maps + up to three sorted twins; 9 with `pyramid`) */
   void *side_stream, *main_stream;
   imf_net_trace *trace;                /* [host] 23 records or NULL */
   /* Capacity mode (dyn != 0): n[] are CAPACITIES (arenas: the *_cap size queries), the row counts, the level-0
