@@ -110,3 +110,33 @@ def test_single_process_gather_is_identity():
     assert gather_blocks(x)[0] is x
     out = gather_fragment_descriptors({0: x, 1: x * 2}, 2, [[0, 1]])
     assert torch.equal(out[1], x * 2)
+
+
+def _worker_one_rank_group(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      IMF_DIST_FORCE_INIT="1")
+    from imfnet_amd import dist as idist
+    r, w, _ = idist.init_from_env("gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+    rows = [3, 0, 7]
+    shards = idist.shard_fragments([4, 1, 8], 1)
+    feats = torch.arange(sum(rows) * 4, dtype=torch.float32).view(-1, 4)
+    got = idist.gather_fragment_descriptors(None, 3, shards, dst=0, packed=([rows[i] for i in shards[0]], feats))
+    at = 0
+    for i in shards[0]:
+        assert torch.equal(got[i], feats[at:at + rows[i]])
+        at += rows[i]
+    res = {i: torch.full((rows[i], 4), float(i)) for i in range(3)}
+    got = idist.gather_fragment_descriptors(res, 3, shards, dst=0)
+    assert all(torch.equal(got[i], res[i]) for i in range(3))
+    assert torch.equal(idist.gather_blocks(feats, dst=0)[0], feats)
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, "ok"), "w").write("1")
+
+
+def test_one_rank_with_a_process_group_takes_the_collective_path(tmp_path):
+    """IMF_DIST_FORCE_INIT=1 (round 6): a process group of ONE rank -- what lets the RCCL half run on a single-GPU box
+    (tests/test_gpu_dist_rccl.py) -- goes through the table's all_gather and the (peer-less) exchange, not the early return."""
+    mp.spawn(_worker_one_rank_group, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok")
