@@ -311,11 +311,71 @@ k_spconv_w(const ConvParams p) {
     // 525-530 -> 542 us in sum, the 4-wavefront ones 512-518 -> 504 us, pair step 1.231-1.242 vs 1.237-1.243 ms: a wash.)
     // (Also dropped: both weight halves of t + 1 requested during sub-stage t -- four register sets, 206 VGPRs, one register
     // copy of 48 VGPRs per sub-stage: the wave-split shapes +4-5 % in sum, pair step 1.283-1.292 -> 1.335 ms.)
-    // (Round 6, measured and dropped again, this time WITHOUT register copies: the whole weight block of t + 1 requested at the
-    // head of t into a second register pair, loop unrolled by two, pairs alternating by code -- 226 VGPRs, bit-identical; whole
-    // tiles 64 -> 64 at 103 k rows 147 -> 151 us, 8 wavefronts 151 -> 172, 48-row units 147 -> 178, pair step 1.204 -> 1.257 ms:
-    // more requests in flight delay the row pieces more than the earlier weights help.  tools/experiments/
-    // spconv_w_full_stage_prefetch.hip)
+    // Round 6, units of >= 48 rows (RB 3, 4): the WHOLE weight block of sub-stage t + 1 is requested at the head of t, into a
+    // second register pair -- the loop is unrolled by two and the two pairs alternate BY CODE (no register copies: what sank
+    // round 5's attempt).  Why: timing-only ablations of this loop (tools/r06_ab.sh, LAB_NOTES 4g-7: whole tiles, 64 -> 64 at
+    // 103 k rows 152 us; without MFMAs and split 72; without weights, rows, MFMAs and split 31) show data movement and compute
+    // almost ADDING UP at two wavefronts per SIMD -- a half requested while the other half's 48 MFMAs run (~770 cycles) arrives
+    // after them.  Half tiles (RB 2, three wavefronts per SIMD at 140 VGPRs) keep the loop below: the second pair would cost
+    // them a wavefront per SIMD.  An odd number of sub-stages ends on a dummy one (no rows -> zeros, the weights of the slab's
+    // first block: 96 MFMAs that add exact zeros; the loop stays branch-free).
+    constexpr bool PF2 = RB >= 3 && !(IMF_W_ABL & 0x1F0);
+    if constexpr (PF2) {
+      constexpr unsigned kDummyE = (unsigned)kDummyJkW << 9;
+      bf16x8 wA0[2][3], wB0[2][3], wA1[2][3], wB1[2][3];
+      if (t0 < t1) {
+        IMF_W_LD_WHALF(wA0, e_cur, 0)
+        IMF_W_LD_WHALF(wB0, e_cur, 1)
+      }
+#define IMF_W_TERM(I, J)                                                                                 \
+  _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                          \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                   \
+          acc[b][CB0 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][I], BP[cb][J], acc[b][CB0 + cb], 0, 0, 0);
+      // one sub-stage: request the next block into (NA, NB), wait for this one's rows (and block), fragments, next rows, compute
+#define IMF_W_HALFSTEP(CA, CBW, NA, NB, E_NEXT, ROWS_NEXT)                                               \
+      {                                                                                                  \
+        IMF_W_LD_WHALF(NA, E_NEXT, 0)                                                                    \
+        IMF_W_LD_WHALF(NB, E_NEXT, 1)                                                                    \
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   /* everything older than the 12 requests above has landed */ \
+        float4 a0[RB], a1[RB];                                                                           \
+        _Pragma("unroll") for (int b = 0; b < RB; ++b) {                                                  \
+          a0[b] = w_lds16(&areg[128 * b + rd_slot]);                                                     \
+          a1[b] = w_lds16(&areg[128 * b + 64 + rd_slot]);                                                \
+        }                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the row region is free */                \
+        IMF_W_DMA_ROWS(E_NEXT, ROWS_NEXT)                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        bf16x8 ap[RB][3];                                                                                \
+        _Pragma("unroll") for (int b = 0; b < RB; ++b) split_b3(a0[b], a1[b], ap[b][0], ap[b][1], ap[b][2]); \
+        { constexpr int CB0 = 0; IMF_W_PF_TERMS(CA) }                                                    \
+        { constexpr int CB0 = 2; IMF_W_PF_TERMS(CBW) }                                                   \
+      }
+#define IMF_W_PF_TERMS(SET)                                                                              \
+  _Pragma("unroll") for (int tm = 0; tm < 6; ++tm) {                                                     \
+    constexpr int ti_[6] = {0, 1, 2, 0, 1, 0}, tj_[6] = {2, 1, 0, 1, 0, 0};   /* IMF_B3_TERMS order */    \
+    _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                        \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                   \
+        acc[b][CB0 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[b][ti_[tm]], SET[cb][tj_[tm]], acc[b][CB0 + cb], 0, 0, 0); \
+  }
+#pragma unroll 1
+      for (int t = t0; t < t1; t += 2) {
+        // sub-stage t on pair 0; the next one (t + 1, or the dummy) goes into pair 1
+        const unsigned e1 = t + 1 < t1 ? e_nxt : kDummyE;
+        Rows rows1;
+        IMF_W_ROWS(rows1, e1)
+        IMF_W_HALFSTEP(wA0, wB0, wA1, wB1, e1, rows1)
+        // sub-stage t + 1 on pair 1; t + 2 (or the dummy) into pair 0
+        const unsigned e2 = t + 2 < t1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 2])) : kDummyE;
+        Rows rows2;
+        IMF_W_ROWS(rows2, e2)
+        IMF_W_HALFSTEP(wA1, wB1, wA0, wB0, e2, rows2)
+        e_nxt = t + 3 < t1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 3])) : kDummyE;
+      }
+#undef IMF_W_HALFSTEP
+#undef IMF_W_PF_TERMS
+#undef IMF_W_TERM
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the trailing requests
+    } else {
     bf16x8 bA[2][3], bB[2][3];
     if (t0 < t1) IMF_W_LD_WHALF(bA, e_cur, 0)
 #pragma unroll 1
@@ -373,6 +433,7 @@ k_spconv_w(const ConvParams p) {
 #undef IMF_W_TERM
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the trailing requests (see above)
+    }
   } else {
   // (fp32 / split-f16 keep BOTH operands as LDS-DMA images.  Their 8 KiB weight block as eight register loads a sub-stage
   // ahead -- the bf16x3 scheme above, 179-192 VGPRs -- was built and measured: fp32 MFMA pair step 1.917 -> 1.98 ms, the

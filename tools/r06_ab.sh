@@ -1,9 +1,7 @@
 #!/bin/bash
-# sorted decoder twins for the other arithmetics, with the sorts on the image stream (bench value = pipelined steps)
-for v in 6 0; do for sm in 0 7 0 7; do
-  echo "== variant $v IMF_SORTED_MAP=$sm"
-  IMF_CONV_VARIANT=$v IMF_SORTED_MAP=$sm python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-sharded --no-host-span --full-out /tmp/f.json 2>/dev/null | python -c "
-import sys, json
-c = json.loads(sys.stdin.read().splitlines()[-1])
-print('  value ms/step', c['ms_per_step'], c['config']['issue'], c['config']['probe_ms_per_step'])"
-done; done
+# Round 6: timing-only ablations of k_spconv_w's bf16x3 main loop (wrong results): what does a sub-stage wait for?
+# build here:  tools/w_ablations.sh build "0 16 32 48 64 128 192 240 256"      then on the GPU box:  tools/r06_ab.sh
+# masks: 16 no weight loads, 32 no row pieces, 48 neither, 64 no MFMAs, 128 no split, 192 neither, 240 none of the four, 256 no LDS fragment reads
+for m in ${MASKS:-0 16 32 48 64 128 192 240 256 0}; do
+  echo "== mask $m"; IMF_LIB=$PWD/imfnet_amd/_abl/libw_$m.so BATCH=2 VARIANT=3 timeout 300 python tools/conv_iso.py wave4h wave4 wave8 2>&1 | grep -v amdgpu.ids | grep -E "block2_tr|block2 |block3|block4 |conv2 |sum" | cut -c1-150
+done
