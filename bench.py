@@ -141,7 +141,7 @@ def _family_regex(label, arith):
         ar = "1"                                          # the ResUNet's launches read operand images; 0 = the image trunk's
     m = re.match(r"k_spconv_w<(\d)>$", base)
     if m:
-        return r"k_spconv_w<(true|false), %s, %s, 0(, \d)?>$" % (m.group(1), ar)   # (label 0; 1 = the image trunk's launches; RB)
+        return r"k_spconv_w<(true|false), %s, %s, 0(, \d)*>$" % (m.group(1), ar)   # (label 0; 1 = the image trunk's launches; RB, OCC)
     m = re.match(r"k_spconv_g<(\d), (\d)>$", base)
     if m:
         return r"k_spconv_g<%s, %s, (true|false), \d, \d, %s(, (true|false))?>$" % (m.group(1), m.group(2), ar)

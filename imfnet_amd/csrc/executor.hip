@@ -181,7 +181,14 @@ int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int vari
   // side streams are idle.  The 128 -> 64 layer (conv2_tr) loses there (52-56 vs 49 us), and with EVERY stride-1 layer on
   // the wave-split kernel the step was 1.27 -> 1.33 ms (its workgroups leave no room for the side streams' kernels under
   // the encoder).
-  if (level <= 0) return (variant == 3 && cin == 64 && cout == 64) ? (8 | 64) : 0;
+  // Round 6: 48-ROW UNITS of 4 wavefronts (kernel_tag 8 | 128) instead of half tiles: with the partial tiles combined two row
+  // blocks at a time the workgroup needs 41 KiB of LDS and 145 VGPRs -- three per CU like the half tiles, with 18 KiB of
+  // operands per 72 MFMAs instead of 16 per 48.  In isolation 136-142 -> 124-130 us (whole tiles at two wavefronts per SIMD:
+  // 139-149; at three, kernel_tag 8 | 256: 140-143); pair step, A/B/C/D three times over on one box: half tiles 1.1706 /
+  // 1.1699 / 1.1694, units 1.1640 / 1.1637 / 1.1654, whole tiles x 3: 1.1717 / 1.1609 / 1.1690, x 2: 1.1749 / 1.1779 / 1.1699.
+  // IMF_L0_TAG (diagnostic): another tag for these two layers (72 = half tiles, 264, 8).
+  static const int l0_tag = getenv("IMF_L0_TAG") ? atoi(getenv("IMF_L0_TAG")) : (8 | 128);
+  if (level <= 0) return (variant == 3 && cin == 64 && cout == 64) ? l0_tag : 0;
   // ONE fragment per forward (the reference's call pattern, resunet.py:163 from generate_desc.py:99): its stride-2/4/8 levels
   // have 219 / 61 / 17 tiles -- as half-tile workgroups of 4 wavefronts (kernel_tag 8 | 64, spconv_w.hip RB 2) they reach twice
   // as many CUs: forward 0.93 -> 0.87 ms.  A pair's levels (438 / 120 / 34 tiles) are NOT faster that way (+0.5-1 %: the

@@ -868,7 +868,8 @@ int imf_spconv_fwd(const imf_conv_args *a, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->ev_begin) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_begin, st));
   if (wsplit) {
-    launch_spconv_w(p, grid.x, wsplit, st, (a->kernel_tag & 1) | ((a->kernel_tag & 64) ? 2 : 0) | ((a->kernel_tag & 128) ? 4 : 0));
+    launch_spconv_w(p, grid.x, wsplit, st, (a->kernel_tag & 1) | ((a->kernel_tag & 64) ? 2 : 0) | ((a->kernel_tag & 128) ? 4 : 0) |
+                                             ((a->kernel_tag & 256) ? 8 : 0));
   } else if (dma0 || a->variant == 3) {
     launch_spconv_g(p, grid, CB, st, a->kernel_tag & 1);
   } else if (a->variant == 6) {

@@ -37,6 +37,10 @@
                       // (parts = raw bits), 256 no LDS fragment reads
 #endif
 
+#ifndef IMF_W_EXP
+#define IMF_W_EXP 0   // experiment (OCC 3 whole tiles): 2 = half B of t requested behind the split (no gain: LAB_NOTES 4g-8)
+#endif
+
 namespace imf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -98,15 +102,24 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 // RB 3 (every arithmetic) = 48-row UNITS that ignore the tile boundaries (unit u = slots 48 u .. 48 u + 47; it walks the union of the offset
 // lists of the one or two tiles it touches): 2 176 rows are 46 units instead of 34 tiles, x 4 slabs = 184 workgroups with
 // 3 / 4 of a tile's work each.
-template <bool CAT, int W, int AR = kArF16x2, int USE = 0, int RB = 4>
-__global__ void __launch_bounds__(64 * W, RB == 2 ? 3 : 2)
+// OCC (round 6, 4 wavefronts of bf16x3): the register budget in wavefronts per SIMD.  48-row units fit three at 145 VGPRs; whole
+// tiles need 168 for it, reached (without spills in the loop) by reading the row indices of t + 1 at the head of t instead of
+// between the two MFMA groups.  A separate symbol: where the side streams' kernels run beside a layer, two wavefronts per SIMD
+// and the CU space they leave measured better.
+template <bool CAT, int W, int AR = kArF16x2, int USE = 0, int RB = 4, int OCC = (RB == 2 || (RB == 3 && W == 4 && AR == kArBf16x3)) ? 3 : 2>
+__global__ void __launch_bounds__(64 * W, OCC)
 k_spconv_w(const ConvParams p) {
+  static_assert(OCC == 2 || RB == 2 || (W == 4 && AR == kArBf16x3), "three wavefronts per SIMD: the 4-wavefront bf16x3 kernels");
   static_assert(RB == 4 || RB == 3 || (RB == 2 && AR == kArBf16x3), "half tiles: bf16x3 only (its weights need no LDS region)");
   constexpr int UR = 16 * RB;                        // rows (slots) per workgroup: the UNIT
   constexpr bool PRE = AR == kArF16x2Pre;
   constexpr unsigned SUB_BYTES = AR == kArBf16x3 ? 12288u : 8192u;   // weight image bytes per (offset, 32-channel) sub-stage
   constexpr int NT = 64 * W;
-  constexpr int REG_F4 = (RB == 4 || AR != kArBf16x3) ? 1024 : 256 * RB;  // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512 (part tiles, bf16x3: rows 128 RB; the partial tile 256 RB)
+  // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512.  bf16x3 keeps no weights in LDS: its region is the rows
+  // (128 RB float4) or one PASS of the partial tile (PB row blocks, 256 float4 each), whichever is larger -- with the tile
+  // combined two row blocks at a time a 4-wavefront workgroup of 48- or 64-row units needs 41 KiB: three per CU (round 6)
+  constexpr int PB = (AR == kArBf16x3 && RB > 2 && W == 4) ? 2 : RB;  // row blocks per pass of the combine (W 8: LDS is not what limits it)
+  constexpr int REG_F4 = AR != kArBf16x3 ? 1024 : (128 * RB > 256 * PB ? 128 * RB : 256 * PB);
   constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
   constexpr int TAB_F4 = (kSubTab + 3) / 4;
   constexpr int KL_F4 = (kKCache + 3) / 4;
@@ -258,14 +271,16 @@ k_spconv_w(const ConvParams p) {
   // ... and one 6 KiB half of its weights (column blocks 2 h, 2 h + 1) straight into REGISTERS: the image is in fragment
   // order and the block is this wavefront's alone, so the six 1 KiB pieces are six plain buffer loads -- no LDS-DMA piece
   // (~100 cycles of issue each in a phase that carries row pieces and fragment reads, MI355X_MICROARCH.md), no LDS write,
-  // no ds_read, no hand-counted wait (the compiler waits for the registers)
+  // no ds_read, no hand-counted wait (the compiler waits for the registers).  Units of 3 / 4 row blocks carry the piece offset on
+  // the scalar side (one address VGPR instead of six: 150 -> 145 / 182 -> 176 VGPRs); half tiles keep six (measured: 136 vs 139 us)
 #define IMF_W_LD_WHALF(dst, e, h)                                                                                  \
   {                                                                                                                \
     const unsigned wso = wslab + ((unsigned)(e) & 511u) * SUB_BYTES + (unsigned)(h) * 6144u;                       \
     _Pragma("unroll") for (int cb_ = 0; cb_ < 2; ++cb_)                                                            \
         _Pragma("unroll") for (int h_ = 0; h_ < 3; ++h_)                                                           \
-            (dst)[cb_][h_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                     \
-                rs_w, woff + 1024u * (unsigned)(3 * cb_ + h_), wso, 0));                                           \
+            (dst)[cb_][h_] = __builtin_bit_cast(bf16x8, RB == 2                                                    \
+                ? __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff + 1024u * (unsigned)(3 * cb_ + h_), wso, 0)     \
+                : __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff, wso + 1024u * (unsigned)(3 * cb_ + h_), 0));   \
   }
 
   // this wavefront's range of the tile's sub-stages
@@ -321,8 +336,12 @@ k_spconv_w(const ConvParams p) {
 #pragma unroll 1
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
-      if (!(IMF_W_ABL & 16) || t == t0) IMF_W_LD_WHALF(bB, e_cur, 1)   // half B of t: lands under the first 48 MFMAs
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");           // rows of t have landed (the two weight halves may be in flight)
+      constexpr bool LATE_B = (IMF_W_EXP & 2) && RB == 4 && W == 4;
+      constexpr bool HEAD_ROWS = RB == 4 && OCC == 3;
+      if (!LATE_B) { if (!(IMF_W_ABL & 16) || t == t0) IMF_W_LD_WHALF(bB, e_cur, 1) }   // half B of t: lands under the first 48 MFMAs
+      if (HEAD_ROWS) IMF_W_ROWS(rows_nxt, e_nxt)
+      if (LATE_B) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // rows of t have landed (the two weight halves may be in flight)
       float4 a0[RB], a1[RB];
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
@@ -346,6 +365,7 @@ k_spconv_w(const ConvParams p) {
           split_b3(a0[b], a1[b], ap[b][0], ap[b][1], ap[b][2]);
         }
       }
+      if (LATE_B) { __builtin_amdgcn_sched_barrier(0); IMF_W_LD_WHALF(bB, e_cur, 1) __builtin_amdgcn_sched_barrier(0); }
 #define IMF_W_TERM(I, J)                                                                                 \
   _Pragma("unroll") for (int b = 0; b < RB; ++b)                                                          \
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                                                 \
@@ -362,7 +382,7 @@ k_spconv_w(const ConvParams p) {
       if (!(IMF_W_ABL & 16)) IMF_W_LD_WHALF(bA, e_nxt, 0)         // half A of t + 1: lands under the second 48 MFMAs
       e_cur = e_nxt;
       e_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)w_lds_u32(&stab[t + 2 < kSubTab ? t + 2 : kSubTab - 1]));
-      IMF_W_ROWS(rows_nxt, e_nxt)
+      if (!HEAD_ROWS) IMF_W_ROWS(rows_nxt, e_nxt)
       __builtin_amdgcn_sched_barrier(0);
       {
         constexpr int CB0 = 2;
@@ -458,71 +478,80 @@ k_spconv_w(const ConvParams p) {
   // ---- the W partial tiles meet in LDS (each wavefront's own 16 KiB: its DMAs have all landed and been read) ----
   // element (row, col) of wavefront w at float index  w * 4096 + row * 64 + (((col >> 2) ^ f(row)) << 2) + (col & 3),
   // f(row) = 4 * ((row >> 2) & 1): conflict-free for the ds_write_b32 of the accumulator layout and the ds_read_b128 below
-  {
-    float *const mine = reinterpret_cast<float *>(areg);
-#pragma unroll
-    for (int b = 0; b < RB; ++b)
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * b + 4 * q4 + r, col = 16 * cb + r16;
-          mine[row * 64 + ((((col >> 2) ^ (((row >> 2) & 1) << 2))) << 2) + (col & 3)] = acc[b][cb][r];
-        }
-  }
-  __syncthreads();
-  constexpr int PT = (256 * RB + NT - 1) / NT;       // float4 per thread: 2 (W 8) / 4 (W 4)
+  constexpr int PT = (256 * PB + NT - 1) / NT;       // float4 per thread and pass
   const float un = p.w_unscale ? *p.w_unscale : 1.f;
 #pragma unroll
-  for (int i = 0; i < PT; ++i) {
-    const int idx = i * NT + tid, row = idx >> 4, c4 = idx & 15;
-    if ((256 * RB) % NT != 0 && idx >= 256 * RB) break;
-    const int col = y * 64 + 4 * c4;
-    const int phys = row * 16 + (c4 ^ (((row >> 2) & 1) << 2));
-    float4 s = w_lds16(&smem[phys]);
+  for (int b0 = 0; b0 < RB; b0 += PB) {              // PB row blocks per pass (bf16x3 units of 3 / 4 blocks: two passes)
+    const int nb = RB - b0 < PB ? RB - b0 : PB;
+    if (b0) __syncthreads();                         // the previous pass has been read
+    {
+      float *const mine = reinterpret_cast<float *>(areg);
 #pragma unroll
-    for (int w = 1; w < W; ++w) {                    // wavefront order: fixed, deterministic
-      const float4 v = w_lds16(&smem[w * REG_F4 + phys]);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      for (int bb = 0; bb < PB; ++bb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (bb >= nb) continue;
+            const int row = 16 * bb + 4 * q4 + r, col = 16 * cb + r16;
+            mine[row * 64 + ((((col >> 2) ^ (((row >> 2) & 1) << 2))) << 2) + (col & 3)] = acc[b0 + bb][cb][r];
+          }
     }
-    const int orow = row0 + row < slots_act ? row_of_slot(p, row0 + row) : -1;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + col);
-    if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + col);
-    s.x = (s.x * un) * sc.x + sh.x; s.y = (s.y * un) * sc.y + sh.y;
-    s.z = (s.z * un) * sc.z + sh.z; s.w = (s.w * un) * sc.w + sh.w;
-    if (p.residual && orow >= 0) {
-      const float4 rr = p.res_split ? load_split4(p.residual, orow, p.cout, col)
-                                    : *reinterpret_cast<const float4 *>(p.residual + (long long)orow * p.cout + col);
-      s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
-    }
-    if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-    if (range_guard(p)) {                            // range guard for the consumer's f16 operands
-      const bool bad = orow >= 0 && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) ||
-                                     out_of_f16_range(s.w));
-      if (__ballot(bad) != 0ull && lane == 0) atomicOr(p.err, 32);
-    }
-    if (p.l2norm) {                                  // cout == 64: the row is these 16 consecutive lanes
-      float ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
-      ss += __shfl_xor(ss, 1, 64);
-      ss += __shfl_xor(ss, 2, 64);
-      ss += __shfl_xor(ss, 4, 64);
-      ss += __shfl_xor(ss, 8, 64);
-      const float nrm = sqrtf(ss);
-      s.x /= nrm; s.y /= nrm; s.z /= nrm; s.w /= nrm;   // no eps: resunet.py:230
-    }
-    if (orow >= 0) {
-      if (p.out_split) store_split4(p.out, orow, p.cout, col, make_float4(s.x, s.y, s.z, s.w));
-      else *reinterpret_cast<float4 *>(p.out + (long long)orow * p.cout + col) = s;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int idx = i * NT + tid, lrow = idx >> 4, c4 = idx & 15;
+      if (((256 * PB) % NT != 0 || nb != PB) && idx >= 256 * nb) break;
+      const int row = 16 * b0 + lrow;
+      const int col = y * 64 + 4 * c4;
+      const int phys = lrow * 16 + (c4 ^ (((lrow >> 2) & 1) << 2));
+      float4 s = w_lds16(&smem[phys]);
+#pragma unroll
+      for (int w = 1; w < W; ++w) {                  // wavefront order: fixed, deterministic
+        const float4 v = w_lds16(&smem[w * REG_F4 + phys]);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int orow = row0 + row < slots_act ? row_of_slot(p, row0 + row) : -1;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.scale) sc = *reinterpret_cast<const float4 *>(p.scale + col);
+      if (p.shift) sh = *reinterpret_cast<const float4 *>(p.shift + col);
+      s.x = (s.x * un) * sc.x + sh.x; s.y = (s.y * un) * sc.y + sh.y;
+      s.z = (s.z * un) * sc.z + sh.z; s.w = (s.w * un) * sc.w + sh.w;
+      if (p.residual && orow >= 0) {
+        const float4 rr = p.res_split ? load_split4(p.residual, orow, p.cout, col)
+                                      : *reinterpret_cast<const float4 *>(p.residual + (long long)orow * p.cout + col);
+        s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
+      }
+      if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+      if (range_guard(p)) {                          // range guard for the consumer's f16 operands
+        const bool bad = orow >= 0 && (out_of_f16_range(s.x) || out_of_f16_range(s.y) || out_of_f16_range(s.z) ||
+                                       out_of_f16_range(s.w));
+        if (__ballot(bad) != 0ull && lane == 0) atomicOr(p.err, 32);
+      }
+      if (p.l2norm) {                                // cout == 64: the row is these 16 consecutive lanes
+        float ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+        ss += __shfl_xor(ss, 8, 64);
+        const float nrm = sqrtf(ss);
+        s.x /= nrm; s.y /= nrm; s.z /= nrm; s.w /= nrm;   // no eps: resunet.py:230
+      }
+      if (orow >= 0) {
+        if (p.out_split) store_split4(p.out, orow, p.cout, col, make_float4(s.x, s.y, s.z, s.w));
+        else *reinterpret_cast<float4 *>(p.out + (long long)orow * p.cout + col) = s;
+      }
     }
   }
 }
 
 // grid = (tiles, cout / 64); `waves` = 8 (512 threads, one workgroup per CU) or 4 (256 threads, two per CU)
 void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st, int use) {
-  // use bit 1: half-tile workgroups (RB 2; bf16x3 with 4 wavefronts only); bit 2: 48-row units (RB 3; bf16x3, 8 wavefronts)
+  // use bit 1: half-tile workgroups (RB 2; bf16x3 with 4 wavefronts only); bit 2: 48-row units (RB 3; 8 wavefronts, bf16x3 also 4);
+  // bit 3: whole tiles of 4 wavefronts under the three-wavefronts-per-SIMD register budget (bf16x3)
   const bool half = (use & 2) != 0 && waves == 4 && p_in.arith == kArBf16x3;
-  const bool u48 = (use & 4) != 0 && waves == 8 && !half;
+  const bool u48 = (use & 4) != 0 && (waves == 8 || (waves == 4 && p_in.arith == kArBf16x3)) && !half;
+  const bool occ3 = (use & 8) != 0 && waves == 4 && p_in.arith == kArBf16x3 && !half && !u48;   // whole tiles, three wavefronts per SIMD
   use &= 1;
   if (half) tiles *= 2;
   if (u48) tiles = (tiles * 4u + 2u) / 3u;
@@ -561,10 +590,18 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
     else     k_spconv_w<false, 8, AR, 0, 3><<<grid, 512, 0, st>>>(p);       \
   } while (0)
     if (ar == kArF32) IMF_W_LAUNCH_U(kArF32);
+    else if (ar == kArBf16x3 && waves == 4) {
+      if (cat) k_spconv_w<true, 4, kArBf16x3, 0, 3><<<grid, 256, 0, st>>>(p);
+      else     k_spconv_w<false, 4, kArBf16x3, 0, 3><<<grid, 256, 0, st>>>(p);
+    }
     else if (ar == kArBf16x3) IMF_W_LAUNCH_U(kArBf16x3);
     else if (ar == kArF16x2Pre) IMF_W_LAUNCH_U(kArF16x2Pre);
     else IMF_W_LAUNCH_U(kArF16x2);
 #undef IMF_W_LAUNCH_U
+  }
+  else if (occ3) {
+    if (cat) k_spconv_w<true, 4, kArBf16x3, 0, 4, 3><<<grid, 256, 0, st>>>(p);
+    else     k_spconv_w<false, 4, kArBf16x3, 0, 4, 3><<<grid, 256, 0, st>>>(p);
   }
   else if (ar == kArBf16x3) IMF_W_LAUNCH(kArBf16x3);
   else if (ar == kArF16x2Pre) IMF_W_LAUNCH(kArF16x2Pre);
