@@ -172,7 +172,20 @@ using namespace imf;
 
 extern "C" {
 
+static int conv_kernel_tag_rule(int level, int kvol, int cin, int cout, int variant, int n_items);
+
 int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int variant, int n_items) {
+  // half tiles (8 | 64): the build for four wavefronts per SIMD (bit 8: 127 VGPRs, 25 KiB of LDS, the partial tiles combined one
+  // row block at a time; the same sums).  Isolated, the shapes of a single fragment 299.8 / 298.2 -> 293.8 / 287.1 us in sum, of a
+  // pair 479 / 488 -> 478 / 464; in the step, A/B three times over on one box: one fragment 0.8367 / 0.8424 / 0.8383 -> 0.8282 /
+  // 0.8296 / 0.8313 ms, a pair (its two up-convolutions) 1.1987 / 1.1955 / 1.1917 -> 1.1930 / 1.1783 / 1.1897.
+  // IMF_HALF_OCC4=0 (diagnostic): the three-wavefront build of round 5.
+  static const bool occ4 = !getenv("IMF_HALF_OCC4") || atoi(getenv("IMF_HALF_OCC4")) != 0;
+  const int tag = conv_kernel_tag_rule(level, kvol, cin, cout, variant, n_items);
+  return (occ4 && variant == 3 && (tag & (8 | 64 | 128)) == (8 | 64)) ? (tag | 256) : tag;
+}
+
+static int conv_kernel_tag_rule(int level, int kvol, int cin, int cout, int variant, int n_items) {
   if ((variant != 6 && variant != 0 && variant != 3) || kvol <= 1 || cout % 64 != 0) return 0;   // (variants 0 / 3: the same kernels, other AR)
   // Stride-1 level: k_spconv_g, except bf16x3's two 64 -> 64 layers (block1_tr): with its weight halves loaded straight
   // into registers the wave-split kernel takes 126-136 us for such a layer in isolation (half-tile / whole-tile workgroups)

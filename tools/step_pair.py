@@ -7,6 +7,8 @@ import bench, torch
 from imfnet_amd import ops
 dev = torch.device('cuda', 0)
 pts2, imgs2 = bench.load_pair(1.7)
+if os.environ.get('SINGLE'):          # SINGLE=1: one fragment per forward (the reference's call pattern)
+    pts2, imgs2 = pts2[:1], imgs2[:1]
 sync = torch.cuda.synchronize
 with torch.no_grad():
     m0, _ = bench.build_model(dev)
