@@ -208,7 +208,10 @@ static int conv_kernel_tag_rule(int level, int kvol, int cin, int cout, int vari
   // wavefronts of a half tile have half the MFMAs per request to hide its latency under) and keep whole tiles.
   // n_items is static in every mode (the batch of a forward), so exact mode, capacity mode and a replay still agree bit
   // for bit.
-  if (variant == 3 && n_items == 1) return 8 | 64;
+  // Round 6: its stride-4 / 8 levels (61 / 17 tiles) on half tiles of EIGHT wavefronts built for four per SIMD (4 | 64 | 256: two
+  // workgroups per CU, twice the wavefronts on a tile's offset list): 128 -> 128 28.6 -> 23.5 us, 256 -> 256 45.1 -> 36.0,
+  // 128 -> 256 25.2 -> 21.2, 256 -> 128 16.8 -> 14.8; the stride-2 level (219 tiles) stays on 4 wavefronts (23.0 vs 24.5 us).
+  if (variant == 3 && n_items == 1) return level >= 2 ? (4 | 64 | 256) : (8 | 64);
   // A pair's (or triple's) stride-8 level: 34 tiles x 4 slabs = 136 workgroups for 256 CUs, and every tile-aligned way of
   // cutting them finer gives 17 x 2^n units.  48-row UNITS that ignore the tile boundaries (kernel_tag 4 | 128, spconv_w.hip
   // RB 3; a unit walks the union of its two tiles' offset lists) are 46 x 4 = 184 workgroups of 3 / 4 of the work: the

@@ -109,7 +109,7 @@ __device__ __forceinline__ unsigned w_lds_u32(const unsigned *__restrict__ src) 
 template <bool CAT, int W, int AR = kArF16x2, int USE = 0, int RB = 4, int OCC = (RB == 2 || (RB == 3 && W == 4 && AR == kArBf16x3)) ? 3 : 2>
 __global__ void __launch_bounds__(64 * W, OCC)
 k_spconv_w(const ConvParams p) {
-  static_assert(OCC == 2 || (OCC == 3 && RB == 2) || (W == 4 && AR == kArBf16x3 && (OCC == 3 || RB == 2)), "three (half tiles: four) wavefronts per SIMD: the 4-wavefront bf16x3 kernels");
+  static_assert(OCC == 2 || (OCC == 3 && RB == 2) || (AR == kArBf16x3 && ((W == 4 && OCC == 3) || RB == 2)), "three (half tiles: four) wavefronts per SIMD: the bf16x3 kernels");
   static_assert(RB == 4 || RB == 3 || (RB == 2 && AR == kArBf16x3), "half tiles: bf16x3 only (its weights need no LDS region)");
   constexpr int UR = 16 * RB;                        // rows (slots) per workgroup: the UNIT
   constexpr bool PRE = AR == kArF16x2Pre;
@@ -118,7 +118,7 @@ k_spconv_w(const ConvParams p) {
   // per wavefront: rows 512 float4 (4 blocks x 2 KiB) + weights 512.  bf16x3 keeps no weights in LDS: its region is the rows
   // (128 RB float4) or one PASS of the partial tile (PB row blocks, 256 float4 each), whichever is larger -- with the tile
   // combined two row blocks at a time a 4-wavefront workgroup of 48- or 64-row units needs 41 KiB: three per CU (round 6)
-  constexpr int PB = (AR == kArBf16x3 && W == 4) ? (RB > 2 ? 2 : (OCC == 4 ? 1 : RB)) : RB;  // row blocks per pass of the combine (W 8: LDS is not what limits it)
+  constexpr int PB = AR == kArBf16x3 ? ((RB > 2 && W == 4) ? 2 : (OCC == 4 ? 1 : RB)) : RB;  // row blocks per pass of the combine (W 8: LDS is not what limits it)
   constexpr int REG_F4 = AR != kArBf16x3 ? 1024 : (128 * RB > 256 * PB ? 128 * RB : 256 * PB);
   constexpr int NBR_F4 = kKCache * IMF_TILE_ROWS / 4;
   constexpr int TAB_F4 = (kSubTab + 3) / 4;
@@ -549,7 +549,8 @@ k_spconv_w(const ConvParams p) {
 void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st, int use) {
   // use bit 1: half-tile workgroups (RB 2; bf16x3 with 4 wavefronts only); bit 2: 48-row units (RB 3; 8 wavefronts, bf16x3 also 4);
   // bit 3: whole tiles of 4 wavefronts under the three-wavefronts-per-SIMD register budget (bf16x3)
-  const bool half = (use & 2) != 0 && waves == 4 && p_in.arith == kArBf16x3;
+  const bool half8 = (use & 2) != 0 && (use & 8) != 0 && waves == 8 && p_in.arith == kArBf16x3;   // half tiles of 8 wavefronts, two workgroups per CU
+  const bool half = ((use & 2) != 0 && waves == 4 && p_in.arith == kArBf16x3) || half8;
   const bool u48 = (use & 4) != 0 && (waves == 8 || (waves == 4 && p_in.arith == kArBf16x3)) && !half;
   const bool occ_bit = (use & 8) != 0;
   const bool occ3 = occ_bit && waves == 4 && p_in.arith == kArBf16x3 && !half && !u48;   // whole tiles, three wavefronts per SIMD
@@ -580,6 +581,10 @@ void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStrea
     }                                                                       \
   } while (0)
   if (ar == kArF32 && !u48) IMF_W_LAUNCH(kArF32);
+  else if (half8) {
+    if (cat) k_spconv_w<true, 8, kArBf16x3, 0, 2, 4><<<grid, 512, 0, st>>>(p);
+    else     k_spconv_w<false, 8, kArBf16x3, 0, 2, 4><<<grid, 512, 0, st>>>(p);
+  }
   else if (half && occ_bit) {                        // half tiles under the four-wavefronts-per-SIMD budget (127 VGPRs, 25 KiB)
     if (cat) k_spconv_w<true, 4, kArBf16x3, 0, 2, 4><<<grid, 256, 0, st>>>(p);
     else     k_spconv_w<false, 4, kArBf16x3, 0, 2, 4><<<grid, 256, 0, st>>>(p);

@@ -433,7 +433,7 @@ def conv_kernel_name(variant, cin, cout, staging=None, kernel_tag=0):
         return "k_pointwise_head_b3" if variant == 3 else "k_pointwise_head"
     suffix = {0: "/f32", 3: "/b3"}.get(variant, "")
     regs0 = variant == 0 and (kernel_tag & 2 or staging == "regs")
-    if variant in (0, 3, 6) and not regs0 and (kernel_tag & 12 or staging in ("wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4")):
+    if variant in (0, 3, 6) and not regs0 and (kernel_tag & 12 or staging in ("wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4", "wave8h4")):
         return f"k_spconv_w<{8 if (kernel_tag & 4 or staging == 'wave8') else 4}>" + suffix
     if variant == 3:
         return f"k_spconv_g<{4 if cout % 64 == 0 else 2}, 0>" + suffix
@@ -493,14 +493,14 @@ def spconv(in_a, w_packed, cout, rb, in_b=None, scale=None, shift=None, residual
     a.out = out.data_ptr()
     L = _lib.lib()
     split = 1 if variant == 1 else (int(split_k) if split_k else L.imf_spconv_auto_split(rb.n_slots, cout, rb.max_active))
-    if rb.kvol == 1 or staging in ("wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4"):
+    if rb.kvol == 1 or staging in ("wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4", "wave8h4"):
         split = 1
     a.split_k, a.variant = split, int(variant)
     a.operand_format = int(operand_format)
     a.dyn_err = None if flags is None else flags.data_ptr()
-    if staging not in (None, "dma", "regs", "wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4"):
+    if staging not in (None, "dma", "regs", "wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4", "wave8h4"):
         raise ImfError(f"spconv: staging={staging!r}")
-    a.kernel_tag = {"regs": 2, "wave8": 4, "wave4": 8, "wave4h": 8 | 64, "wave8u": 4 | 128, "wave4u": 8 | 128, "wave4o": 8 | 256, "wave4h4": 8 | 64 | 256}.get(staging, 0)
+    a.kernel_tag = {"regs": 2, "wave8": 4, "wave4": 8, "wave4h": 8 | 64, "wave8u": 4 | 128, "wave4u": 8 | 128, "wave4o": 8 | 256, "wave4h4": 8 | 64 | 256, "wave8h4": 4 | 64 | 256}.get(staging, 0)
     ws = None
     nbytes = L.imf_spconv_workspace_bytes(rb.n_slots, cout, split)   # split-K partials / balanced-tail partials
     if nbytes:

@@ -305,7 +305,8 @@ typedef struct imf_conv_args {
                              of the tiles it touches (8 wavefronts: a pair's stride-8 level, 184 workgroups instead of 136;
                              4 wavefronts: the 64 -> 64 layers of level 0, three workgroups per CU).
                              bit 8 (256), with bit 3 and variant 3: the build for one more wavefront per SIMD -- whole tiles
-                             for three (168 VGPRs), with bit 6 half tiles for four (127 VGPRs, 25 KiB of LDS); the same
+                             for three (168 VGPRs), with bit 6 half tiles for four (127 VGPRs, 25 KiB of LDS; also with bit 2: half tiles of
+                             8 wavefronts, two workgroups per CU); the same
                              sums as without the bit, bit for bit */
   int32_t *dyn_err;       /* optional device flag word (any mode): IMF_FLAG_SPLIT_COVER when the rule asks for more
                              partitions than split_k covers; IMF_FLAG_RANGE when an OUTPUT value is NaN or |y| >= 65504,
@@ -572,7 +573,7 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
  * the value for imf_conv_args.kernel_tag.  Level 0 (thousands of 64-row tiles): k_spconv_g, unsplit (variant 3: the
  * wave-split kernel with 4 wavefronts and 48-row units, kernel_tag 8 | 128, for the 64 -> 64 layers).  Level 1: the
  * wave-split kernel with 4 wavefronts per workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4); variant 3 with
- * ONE fragment in the forward (n_items == 1): half-tile workgroups of 4 wavefronts (8 | 64 | 256) on levels 1-3; every variant
+ * ONE fragment in the forward (n_items == 1): half-tile workgroups of 4 wavefronts (8 | 64 | 256) on level 1 and of 8 (4 | 64 | 256) on levels 2-3; every variant
  * with two or more fragments: 48-row units (4 | 128) on level 3, and from three fragments on 4 wavefronts on level 2.  The choice is
  * a function of the LEVEL, the layer's channel counts and the batch size only -- never of the row count -- so exact mode,
  * capacity mode and a graph replay form every sum in the

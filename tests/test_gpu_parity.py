@@ -173,7 +173,7 @@ def _rb_and_ref(cm, g, which):
 
 
 @pytest.mark.parametrize("mode", ["auto", "split1", "split5", "split5_fused", "simple", "f32_regs", "f32_regs_split5",
-                                  "f32_wave8", "f32_wave4", "b3", "b3_split1", "b3_split5", "b3_wave8", "b3_wave4", "b3_wave4h", "b3_wave8u", "b3_wave4u", "b3_wave4o", "b3_wave4h4",
+                                  "f32_wave8", "f32_wave4", "b3", "b3_split1", "b3_split5", "b3_wave8", "b3_wave4", "b3_wave4h", "b3_wave8u", "b3_wave4u", "b3_wave4o", "b3_wave4h4", "b3_wave8h4",
                                   "h3", "h3_split1", "h3_split5", "h3_wave8", "h3_wave4"])
 @pytest.mark.parametrize("ca,cb,cout,which", CONV_CASES)
 def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
@@ -198,12 +198,13 @@ def test_spconv_matches_oracle(ops, geom_s5, ca, cb, cout, which, mode):
           # round 6: 48-row units of 4 wavefronts; whole tiles under the three-wavefronts-per-SIMD register budget
           "b3_wave4u": {"variant": 3, "staging": "wave4u"}, "b3_wave4o": {"variant": 3, "staging": "wave4o"},
           "b3_wave4h4": {"variant": 3, "staging": "wave4h4"},          # half tiles built for four wavefronts per SIMD
+          "b3_wave8h4": {"variant": 3, "staging": "wave8h4"},          # ... of eight wavefronts (a single fragment's coarse levels)
           "h3": {"variant": 6},
           "h3_split1": {"variant": 6, "split_k": 1}, "h3_split5": {"variant": 6, "split_k": 5},
           # variant 6 = the LDS-DMA kernel k_spconv_g (the register-staged k_spconv_h3 lives in diagnostic builds only)
           # the wave-split kernel of the coarse levels (csrc/spconv_w.hip): whole tile per workgroup, 8 / 4 wavefronts
           "h3_wave8": {"variant": 6, "staging": "wave8"}, "h3_wave4": {"variant": 6, "staging": "wave4"}}[mode]
-    if mode.endswith(("wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4")) and (kvol == 1 or cout % 64):
+    if mode.endswith(("wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4", "wave8h4")) and (kvol == 1 or cout % 64):
         pytest.skip("the wave-split kernel covers kvol > 1 and cout % 64 == 0")
     if mode in ("split5", "split5_fused", "h3_split5", "f32_regs_split5", "b3_split5") and kvol == 1:
         pytest.skip("pointwise convolution has a single offset")
@@ -331,7 +332,9 @@ def test_spconv_bf16x3_is_fp32_class(ops, clouds):
                                                  (64, 64, 128, cm.conv_rulebook(2, 3, 1), n1, "wave4o", 1.0),
                                                  (64, 0, 64, cm.conv_rulebook(1, 3, 1), n0, "wave4o", 1e6),
                                                  (64, 64, 128, cm.conv_rulebook(2, 3, 1), n1, "wave4h4", 1.0),
-                                                 (64, 0, 64, cm.conv_rulebook(1, 3, 1), n0, "wave4h4", 1e6)):
+                                                 (64, 0, 64, cm.conv_rulebook(1, 3, 1), n0, "wave4h4", 1e6),
+                                                 (64, 64, 128, cm.conv_rulebook(2, 3, 1), n1, "wave8h4", 1.0),
+                                                 (64, 0, 64, cm.conv_rulebook(1, 3, 1), n0, "wave8h4", 1e6)):
         fa, fb = _rand((n_in, ca), 90).to(DEV) * amp, (_rand((n_in, cb), 91).to(DEV) * amp if cb else None)
         w = _rand((rb.kvol, ca + cb, cout), 92, 0.05).to(DEV) / amp
         b3 = ops.spconv(fa, ops.pack_weights(w, variant=3), cout, rb, in_b=fb, variant=3, split_k=1, staging=staging)
@@ -358,16 +361,17 @@ def test_spconv_bf16x3_is_fp32_class(ops, clouds):
             kw = dict(in_b=fb, variant=3, split_k=1, scale=sc, shift=sh, residual=res, relu=True)
             u, t = ops.spconv(fa, w3, cout, rb, staging=staging, **kw), ops.spconv(fa, w3, cout, rb, staging=staging[:5], **kw)
             assert (u - t).abs().max().item() <= 4e-6 * scale * float(sc.max()) + 1e-7 * amp
-        if staging in ("wave4h", "wave4o", "wave4h4"):
+        if staging in ("wave4h", "wave4o", "wave4h4", "wave8h4"):
             # half-tile workgroups walk their tile's offset list with the same four wavefront ranges: the SAME sums as the
             # whole-tile launch, bit for bit -- plain and through the fused epilogue (scale / shift / residual / ReLU); so does
             # the whole-tile kernel built for three wavefronts per SIMD (wave4o: other register budget, same instructions' sums)
             w3 = ops.pack_weights(w, variant=3)
-            assert torch.equal(b3, ops.spconv(fa, w3, cout, rb, in_b=fb, variant=3, split_k=1, staging="wave4"))
+            whole = "wave8" if staging == "wave8h4" else "wave4"
+            assert torch.equal(b3, ops.spconv(fa, w3, cout, rb, in_b=fb, variant=3, split_k=1, staging=whole))
             sc, sh = (_rand((cout,), 93).abs() + 0.5).to(DEV), _rand((cout,), 94).to(DEV)
             res = _rand((rb.n_out, cout), 95).to(DEV) * amp
             kw = dict(in_b=fb, variant=3, split_k=1, scale=sc, shift=sh, residual=res, relu=True)
-            assert torch.equal(ops.spconv(fa, w3, cout, rb, staging=staging, **kw), ops.spconv(fa, w3, cout, rb, staging="wave4", **kw))
+            assert torch.equal(ops.spconv(fa, w3, cout, rb, staging=staging, **kw), ops.spconv(fa, w3, cout, rb, staging=whole, **kw))
 
 
 def test_spconv_operand_images(ops, clouds):

@@ -43,7 +43,7 @@ for name, ca, cb, cout, kind, i in SHAPES:
     out = torch.empty(rb.n_out, cout, device=dev)
     cols = []
     for staging in stagings:
-        if staging in ("wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4") and (rb.kvol == 1 or cout % 64):
+        if staging in ("wave8", "wave4", "wave4h", "wave8u", "wave4u", "wave4o", "wave4h4", "wave8h4") and (rb.kvol == 1 or cout % 64):
             cols.append(None)
             continue
         kw = dict(in_b=fb, scale=sc, shift=sh, relu=True, variant=VARIANT, out=out, staging=staging)
