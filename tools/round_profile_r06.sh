@@ -20,5 +20,5 @@ for arith in ${@:-bf16x3 f16x2 f32}; do
   cp $out/r06_kernel_stats_$arith.txt $out/r06_pmc_traffic_$arith.json $out/r06_pmc_counters_$arith.txt profiles/
 done
 unset IMF_CONV_VARIANT
-timeout 1200 python bench.py > $out/r06_bench.json 2> $out/r06_bench.err; echo "bench rc=$?"; tail -3 $out/r06_bench.err
+timeout 1200 python bench.py > $out/r06_bench.json 2> $out/r06_bench.err; echo "bench rc=$?"; tail -c 600 $out/r06_bench.json
 ls -la $out
