@@ -475,8 +475,8 @@ k_spconv_w(const ConvParams p) {
 #undef IMF_W_ROWS
 
   if ((IMF_W_ABL & 4) && acc[0][0][0] != 12345.f) return;
-  // ---- the W partial tiles meet in LDS (each wavefront's own 16 KiB: its DMAs have all landed and been read) ----
-  // element (row, col) of wavefront w at float index  w * 4096 + row * 64 + (((col >> 2) ^ f(row)) << 2) + (col & 3),
+  // ---- the W partial tiles meet in LDS (each wavefront's own region: its DMAs have all landed and been read), PB row blocks per
+  // pass ---- element (row, col) of wavefront w and the pass at float index  w * 4 REG_F4 + row * 64 + (((col >> 2) ^ f(row)) << 2) + (col & 3),
   // f(row) = 4 * ((row >> 2) & 1): conflict-free for the ds_write_b32 of the accumulator layout and the ds_read_b128 below
   constexpr int PT = (256 * PB + NT - 1) / NT;       // float4 per thread and pass
   const float un = p.w_unscale ? *p.w_unscale : 1.f;
@@ -547,8 +547,8 @@ k_spconv_w(const ConvParams p) {
 
 // grid = (tiles, cout / 64); `waves` = 8 (512 threads, one workgroup per CU) or 4 (256 threads, two per CU)
 void launch_spconv_w(const ConvParams &p_in, unsigned tiles, int waves, hipStream_t st, int use) {
-  // use bit 1: half-tile workgroups (RB 2; bf16x3 with 4 wavefronts only); bit 2: 48-row units (RB 3; 8 wavefronts, bf16x3 also 4);
-  // bit 3: whole tiles of 4 wavefronts under the three-wavefronts-per-SIMD register budget (bf16x3)
+  // use bit 1: half-tile workgroups (RB 2; bf16x3: 4 wavefronts, with bit 3 also 8); bit 2: 48-row units (RB 3; 8 wavefronts, bf16x3
+  // also 4); bit 3 (bf16x3): the build for one more wavefront per SIMD -- whole tiles of 4 wavefronts for three, half tiles for four
   const bool half8 = (use & 2) != 0 && (use & 8) != 0 && waves == 8 && p_in.arith == kArBf16x3;   // half tiles of 8 wavefronts, two workgroups per CU
   const bool half = ((use & 2) != 0 && waves == 4 && p_in.arith == kArBf16x3) || half8;
   const bool u48 = (use & 4) != 0 && (waves == 8 || (waves == 4 && p_in.arith == kArBf16x3)) && !half;
