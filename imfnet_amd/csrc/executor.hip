@@ -528,7 +528,6 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   // k + 1 queued behind 240 us of sorts and the steps lost what the twins gain).  Otherwise: at the end of the side chain.
   hipStream_t sort_stream = side;
   if (fctx && fctx->imgs && fctx->imgs != side && fctx->imgs != main && items_event >= 0) sort_stream = fctx->imgs;
-  const bool one_event = sort_stream != side && sort_stream != main && !getenv("IMF_TWIN_EVENTS");   // (IMF_TWIN_EVENTS=1, diagnostic: an event and a wait per twin)
   auto issue_sorts = [&]() -> int {
     if (!(twin[0] || twin[1] || twin[2])) return IMF_OK;
     if (sort_stream != side) {
@@ -548,22 +547,10 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
                                                rb_k3s[i].tile_rows, rb_k3s[i].nbr, rb_k3s[i].tile_mask, sort_ws, sort_ws_bytes,
                                                sort_stream);
       if (rc2) return rc2;
-      if (sort_stream != main && !one_event) {
+      if (sort_stream != main) {
         IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[ev], sort_stream));
         rb_k3s[i].ready_event = ev++;
       }
-    }
-    // Image stream: ONE event behind the last sort, waited for by the decoder block that comes first (the coarsest twin's); the
-    // sorts run in one stream, so it covers the other twins.  A wait per twin cost the main stream ~6 us in front of each
-    // decoder block (rocprofv3 timeline, tools/kernel_timeline.py: gaps of 5.9 / 6.8 / 6.1 us where every other launch follows
-    // its predecessor without one) although the sorts end ~100 us before the first of them.  (Measured and dropped: no wait at
-    // all, the twins riding on the join in front of the fusion -- the fusion then waits for the sorts, which end too close to
-    // it: headline leg 1.1557 / 1.1607 / 1.1585 -> 1.1652 / 1.1702 / 1.1748 ms.)
-    if (one_event) {
-      IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[ev], sort_stream));
-      for (int i = 2; i >= 0; --i)
-        if (twin[i]) { rb_k3s[i].ready_event = ev; break; }
-      ++ev;
     }
     return IMF_OK;
   };
