@@ -221,6 +221,7 @@ SIGNATURES = {
     "imf_rulebook_sorted_workspace_bytes": (C.c_size_t, [_L]),
     "imf_rulebook_sort_by_occupancy": (_I, [_P, _I, _L, _L, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "imf_resunet_sorted_maps": (_I, [_I]),
+    "imf_resunet_sorted_maps_n": (_I, [_I, _I]),
     "imf_rulebook_transpose_slots": (_L, [_L]),
     "imf_rulebook_transpose": (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P]),
     "imf_packed_weight_floats": (_L, [_I, _I, _I]),

@@ -238,9 +238,17 @@ int imf_resunet_sorted_maps(int variant) {
   // bf16x3 1.1919 / 1.1886 -> 1.1735 / 1.1733 ms (level 0 alone: 1.1787), fp32 1.914 -> 1.973, split-f16 0.914 -> 0.958: their
   // coarse-level kernels hold a CU's whole LDS, as the sort's workgroups do, and lose more to the sorts running beside them
   // than the decoder gains.  IMF_SORTED_MAP overrides for every arithmetic (A/B; 0 = none).
+  return imf_resunet_sorted_maps_n(variant, 2);
+}
+
+int imf_resunet_sorted_maps_n(int variant, int n_items) {
   static const int env = getenv("IMF_SORTED_MAP") ? (int)strtol(getenv("IMF_SORTED_MAP"), nullptr, 0) & 0x07 : -1;
   if (env >= 0) return env;
-  return variant == 3 ? IMF_SORTED_MAPS_DEFAULT : 0;
+  if (variant != 3) return 0;
+  // ONE fragment per forward: its decoder starts ~0.35 ms into the forward, when the sorts of the coarse levels have barely
+  // ended, and their blocks are short -- level 0 alone.  A/B x 4 on one box (tools/step_pair.py SINGLE=1, ms): all three
+  // 0.8166 / 0.8091 / 0.8182 / 0.8019, level 0 alone 0.8027 / 0.7951 / 0.7915 / 0.7948, none 0.8061 / 0.8046 / 0.8007 / 0.7941.
+  return n_items == 1 ? (IMF_SORTED_MAPS_DEFAULT & 1) : IMF_SORTED_MAPS_DEFAULT;
 }
 
 size_t imf_resunet_int_arena_bytes(const imf_resunet_desc *net, const int64_t *n, const int32_t *bbox) {
@@ -338,7 +346,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
   // ~100 %.  The ENCODER's blocks walk the maps as built (a sort in front of them sits on the step's critical path: measured
   // +65 us per sorted level, round 6); the DECODER's blocks (block4_tr on level 2, block3_tr on level 1, block2_tr on level 0)
   // walk the twins, which are sorted at the END of the side stream's chain, under the encoder and the fusion.
-  const int sorted_maps = imf_resunet_sorted_maps(net->conv[19].variant);
+  const int sorted_maps = imf_resunet_sorted_maps_n(net->conv[19].variant, io->n_items);
   bool twin[3];
   for (int i = 0; i < 3; ++i) {
     twin[i] = ((sorted_maps >> i) & 1) != 0 && (i > 0 || s.small_first);

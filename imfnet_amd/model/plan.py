@@ -163,7 +163,7 @@ class FusedPlan:
         rb_id = _RB(slots[0], n[0], 1, 1)
         # occupancy-sorted twins of the stride-1 maps of levels 0-2 for the decoder's blocks (csrc/rulebook_sort.hip), exactly
         # as the native executors build and use them (imf_resunet_sorted_maps says which levels): bit-identical descriptors
-        sorted_maps = L.imf_resunet_sorted_maps(int(self.convs["block2_tr.conv1"][0].variant))
+        sorted_maps = L.imf_resunet_sorted_maps_n(int(self.convs["block2_tr.conv1"][0].variant), self._n_items)
         rb_k3s = [_RB(slots[i], n[i], 27, 27, level=i) if ((sorted_maps >> i) & 1 and (i > 0 or self.small_first)) else None
                   for i in range(3)]
         sort_ws_bytes = L.imf_rulebook_sorted_workspace_bytes(slots[0])

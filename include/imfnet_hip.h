@@ -593,6 +593,10 @@ int imf_resunet_conv_kernel_tag(int level, int kvol, int cin, int cout, int vari
  * (IMF_SORTED_MAP overrides) only, so every execution mode walks the same maps and forms the same sums.  Replaces: nothing in
  * the reference. */
 int imf_resunet_sorted_maps(int variant);
+/* ... and of the batch size of the forward (static per call, like imf_resunet_conv_kernel_tag's n_items): with ONE fragment
+ * only level 0 has a twin (its decoder reaches the coarse levels before their sorts would pay).  imf_resunet_sorted_maps(v) is
+ * imf_resunet_sorted_maps_n(v, 2): the superset, which sizes the arenas. */
+int imf_resunet_sorted_maps_n(int variant, int n_items);
 
 typedef struct imf_resunet_io {        /* per fragment */
   imf_level level[4];                  /* tensor strides 1, 2, 4, 8 (imf_pyramid_build) */
