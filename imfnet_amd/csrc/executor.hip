@@ -201,6 +201,13 @@ static int conv_kernel_tag_rule(int level, int kvol, int cin, int cout, int vari
   // 1.1699 / 1.1694, units 1.1640 / 1.1637 / 1.1654, whole tiles x 3: 1.1717 / 1.1609 / 1.1690, x 2: 1.1749 / 1.1779 / 1.1699.
   // IMF_L0_TAG (diagnostic): another tag for these two layers (72 = half tiles, 264, 8).
   static const int l0_tag = getenv("IMF_L0_TAG") ? atoi(getenv("IMF_L0_TAG")) : (8 | 128);
+  // ... and (round 6) the stride-1 up-convolution conv2_tr (128 -> 64 over the parity-grouped transposed map) on half tiles of 4
+  // wavefronts built for four per SIMD: round 5's wave-split kernels lost to k_spconv_g there (52-56 vs 49 us), these do not --
+  // headline leg of bench.py, A/B/C/D three times over on one box: k_spconv_g 1.2005 / 1.2076 / 1.2031 ms, half tiles x 4
+  // 1.1693 / 1.1692 / 1.1686 (-2.9 %), 48-row units 1.1680 / 1.1701 / 1.1666, whole tiles 1.1785 / 1.1743 / 1.1762; one fragment
+  // per forward 0.8117 / 0.8177 / 0.8153 -> 0.7689 / 0.7882 / 0.7681.  IMF_L0_UP_TAG (diagnostic): another tag, 0 = k_spconv_g.
+  static const int l0_up_tag = getenv("IMF_L0_UP_TAG") ? atoi(getenv("IMF_L0_UP_TAG")) : (8 | 64);
+  if (level <= 0 && variant == 3 && cin > cout && cout == 64) return l0_up_tag;
   if (level <= 0) return (variant == 3 && cin == 64 && cout == 64) ? l0_tag : 0;
   // ONE fragment per forward (the reference's call pattern, resunet.py:163 from generate_desc.py:99): its stride-2/4/8 levels
   // have 219 / 61 / 17 tiles -- as half-tile workgroups of 4 wavefronts (kernel_tag 8 | 64, spconv_w.hip RB 2) they reach twice
