@@ -228,15 +228,25 @@ static int conv_kernel_tag_rule(int level, int kvol, int cin, int cout, int vari
   // Larger batches too (units are 3 / 4 of a tile: shorter tails): four fragments per forward 2.197 -> 2.128 ms, eight
   // 3.978 -> 3.858 ms; and from three fragments on the stride-4 level (>= 180 tiles x 2 slabs: more than one round of
   // 8-wavefront workgroups) runs on 4-wavefront workgroups, two per CU: 2.128 -> 2.089 ms and 3.858 -> 3.828 ms.
+  {   // (diagnostic, A/B in the step: IMF_L1_TAG / IMF_L2_TAG / IMF_L3_TAG replace the rule below for a level's cin <= cout layers)
+    static const int lt[4] = {0, getenv("IMF_L1_TAG") ? atoi(getenv("IMF_L1_TAG")) : 0, getenv("IMF_L2_TAG") ? atoi(getenv("IMF_L2_TAG")) : 0,
+                              getenv("IMF_L3_TAG") ? atoi(getenv("IMF_L3_TAG")) : 0};
+    if (level >= 1 && level <= 3 && lt[level] && cin <= cout && variant == 3 && n_items >= 2) return lt[level];
+  }
   if (level == 3 && n_items >= 2) return 4 | 128;
   if (level == 2 && n_items >= 3) return 8;
   // the decoder's up-convolutions (cin > cout: conv3_tr 256 -> 64, conv4_tr 256 -> 128): their tiles are grouped by parity
   // class and walk 1-8 offsets -- short loops, so twice the workgroups help: half tiles 36.1 -> 31.7 us and 24.4 -> 21.8 us
   // in isolation, pair step -0.8 % (A/B/A/B on one box)
-  if (variant == 3 && cin > cout) return 8 | 64;
+  static const int up_tag = getenv("IMF_UP_TAG") ? atoi(getenv("IMF_UP_TAG")) : (8 | 64);   // (IMF_UP_TAG: diagnostic)
+  if (variant == 3 && cin > cout) return up_tag;
   // measured on the S50k pair (profiles/r03_conv_isolated.txt, r05_conv_isolated_*.txt): level 1 (438 tiles) is fastest
   // with two 4-wavefront workgroups per CU, levels 2 and 3 (<= 128 tiles) with one 8-wavefront workgroup
-  return level == 1 ? 8 : 4;
+  // (round 6, bf16x3: level 1 on the whole-tile build for three wavefronts per SIMD, kernel_tag 8 | 256 -- the same sums; headline
+  // leg of bench.py, A/B four times over on one box: 1.1302 / 1.1331 / 1.1342 / 1.1346 -> 1.1236 / 1.1291 / 1.1316 / 1.1316 ms;
+  // half tiles x 4 there: 1.152, 48-row units 1.157; levels 2 / 3 on half tiles of 8 or 4 wavefronts: +0.3 ... +4 %)
+  if (level == 1) return variant == 3 ? (8 | 256) : 8;
+  return 4;
 }
 
 int imf_resunet_sorted_maps(int variant) {

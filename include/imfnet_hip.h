@@ -573,7 +573,7 @@ typedef struct imf_net_trace {         /* optional per-convolution measurement r
  * the value for imf_conv_args.kernel_tag.  Level 0 (thousands of 64-row tiles): k_spconv_g, unsplit (variant 3: the
  * wave-split kernel with 4 wavefronts and 48-row units, kernel_tag 8 | 128, for the 64 -> 64 layers; with half tiles,
  * 8 | 64 | 256, for the 128 -> 64 up-convolution).  Level 1: the
- * wave-split kernel with 4 wavefronts per workgroup (kernel_tag 8); levels 2 and 3: with 8 (kernel_tag 4); variant 3 with
+ * wave-split kernel with 4 wavefronts per workgroup (kernel_tag 8; variant 3: 8 | 256); levels 2 and 3: with 8 (kernel_tag 4); variant 3 with
  * ONE fragment in the forward (n_items == 1): half-tile workgroups of 4 wavefronts (8 | 64 | 256) on level 1 and of 8 (4 | 64 | 256) on levels 2-3; every variant
  * with two or more fragments: 48-row units (4 | 128) on level 3, and from three fragments on 4 wavefronts on level 2.  The choice is
  * a function of the LEVEL, the layer's channel counts and the batch size only -- never of the row count -- so exact mode,

@@ -54,7 +54,7 @@ def test_kernel_policy_is_static_per_layer_and_batch():
     tag = _lib.lib().imf_resunet_conv_kernel_tag
     for v in (0, 3, 6):
         assert tag(0, 1, 96, 64, v, 2) == 0 and tag(2, 27, 64, 32, v, 2) == 0           # pointwise / 32 output channels
-        assert tag(1, 27, 64, 64, v, 2) == 8 and tag(2, 27, 128, 128, v, 2) == 4        # a pair: level 1 on 4, level 2 on 8 wavefronts
+        assert tag(1, 27, 64, 64, v, 2) == (8 | 256 if v == 3 else 8) and tag(2, 27, 128, 128, v, 2) == 4   # a pair: level 1 on 4 (bf16x3: the build for three per SIMD), level 2 on 8 wavefronts
         assert tag(3, 27, 256, 256, v, 2) == (4 | 128) == tag(3, 27, 128, 256, v, 8)    # 48-row units on level 3 from two fragments on
         assert tag(2, 27, 128, 128, v, 3) == 8 == tag(2, 27, 128, 128, v, 8)            # level 2 on 4 wavefronts from three on
         assert tag(0, 27, 32, 32, v, 2) == 0 and tag(0, 27, 128, 64, v, 2) == ((8 | 64 | 256) if v == 3 else 0)   # stride 1: k_spconv_g (bf16x3's conv2_tr: half tiles, round 6)
