@@ -215,6 +215,11 @@ static int conv_kernel_tag_rule(int level, int kvol, int cin, int cout, int vari
   // wavefronts of a half tile have half the MFMAs per request to hide its latency under) and keep whole tiles.
   // n_items is static in every mode (the batch of a forward), so exact mode, capacity mode and a replay still agree bit
   // for bit.
+  {   // (diagnostic, A/B in the step: IMF_L1_TAG / IMF_L2_TAG / IMF_L3_TAG replace the rule below for a level's cin <= cout layers)
+    static const int lt[4] = {0, getenv("IMF_L1_TAG") ? atoi(getenv("IMF_L1_TAG")) : 0, getenv("IMF_L2_TAG") ? atoi(getenv("IMF_L2_TAG")) : 0,
+                              getenv("IMF_L3_TAG") ? atoi(getenv("IMF_L3_TAG")) : 0};
+    if (level >= 1 && level <= 3 && lt[level] && cin <= cout && variant == 3) return lt[level];
+  }
   // Round 6: its stride-4 / 8 levels (61 / 17 tiles) on half tiles of EIGHT wavefronts built for four per SIMD (4 | 64 | 256: two
   // workgroups per CU, twice the wavefronts on a tile's offset list): 128 -> 128 28.6 -> 23.5 us, 256 -> 256 45.1 -> 36.0,
   // 128 -> 256 25.2 -> 21.2, 256 -> 128 16.8 -> 14.8; the stride-2 level (219 tiles) stays on 4 wavefronts (23.0 vs 24.5 us).
@@ -228,11 +233,6 @@ static int conv_kernel_tag_rule(int level, int kvol, int cin, int cout, int vari
   // Larger batches too (units are 3 / 4 of a tile: shorter tails): four fragments per forward 2.197 -> 2.128 ms, eight
   // 3.978 -> 3.858 ms; and from three fragments on the stride-4 level (>= 180 tiles x 2 slabs: more than one round of
   // 8-wavefront workgroups) runs on 4-wavefront workgroups, two per CU: 2.128 -> 2.089 ms and 3.858 -> 3.828 ms.
-  {   // (diagnostic, A/B in the step: IMF_L1_TAG / IMF_L2_TAG / IMF_L3_TAG replace the rule below for a level's cin <= cout layers)
-    static const int lt[4] = {0, getenv("IMF_L1_TAG") ? atoi(getenv("IMF_L1_TAG")) : 0, getenv("IMF_L2_TAG") ? atoi(getenv("IMF_L2_TAG")) : 0,
-                              getenv("IMF_L3_TAG") ? atoi(getenv("IMF_L3_TAG")) : 0};
-    if (level >= 1 && level <= 3 && lt[level] && cin <= cout && variant == 3 && n_items >= 2) return lt[level];
-  }
   if (level == 3 && n_items >= 2) return 4 | 128;
   if (level == 2 && n_items >= 3) return 8;
   // the decoder's up-convolutions (cin > cout: conv3_tr 256 -> 64, conv4_tr 256 -> 128): their tiles are grouped by parity
