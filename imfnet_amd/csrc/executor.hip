@@ -215,10 +215,10 @@ static int conv_kernel_tag_rule(int level, int kvol, int cin, int cout, int vari
   // wavefronts of a half tile have half the MFMAs per request to hide its latency under) and keep whole tiles.
   // n_items is static in every mode (the batch of a forward), so exact mode, capacity mode and a replay still agree bit
   // for bit.
-  {   // (diagnostic, A/B in the step: IMF_L1_TAG / IMF_L2_TAG / IMF_L3_TAG replace the rule below for a level's cin <= cout layers)
-    static const int lt[4] = {0, getenv("IMF_L1_TAG") ? atoi(getenv("IMF_L1_TAG")) : 0, getenv("IMF_L2_TAG") ? atoi(getenv("IMF_L2_TAG")) : 0,
-                              getenv("IMF_L3_TAG") ? atoi(getenv("IMF_L3_TAG")) : 0};
-    if (level >= 1 && level <= 3 && lt[level] && cin <= cout && variant == 3) return lt[level];
+  {   // (diagnostic, A/B in the step: IMF_L1_TAG replaces the rule for level 1's cin <= cout layers.  Settled the same way and removed
+      // again: overrides for levels 2 / 3 and for the strided convolutions -- LAB_NOTES 4g-10 has the arms.)
+    static const int l1 = getenv("IMF_L1_TAG") ? atoi(getenv("IMF_L1_TAG")) : 0;
+    if (level == 1 && l1 && cin <= cout && variant == 3) return l1;
   }
   // Round 6: its stride-4 / 8 levels (61 / 17 tiles) on half tiles of EIGHT wavefronts built for four per SIMD (4 | 64 | 256: two
   // workgroups per CU, twice the wavefronts on a tile's offset list): 128 -> 128 28.6 -> 23.5 us, 256 -> 256 45.1 -> 36.0,
