@@ -416,39 +416,75 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     if ((rc = build_conv(rb_k3[0], 0, 0, 3, side))) return rc;
     if ((rc = mark(rb_k3[0]))) return rc;
   }
-  for (int i = 0; i < 3; ++i) {
-    if (pyr && (rc = pyramid_coarse_level(*pyr, i + 1, side))) return rc;
-    if ((rc = build_conv(rb_dn[i], i, i + 1, 3, side))) return rc;
-    if ((rc = build_conv(rb_k3[i + 1], i + 1, i + 1, 3, side))) return rc;
-    if ((rc = mark(rb_dn[i]))) return rc;
-  }
-  if (pyr) {   // first row of every item at every level (the fusion reads the stride-8 ones)
-    if ((rc = pyramid_item_starts(*pyr, side, 0, 4))) return rc;
-  }
-  for (int i = 2; i >= 0; --i) {
-    const imf_level &co = io->level[i + 1], &fi = io->level[i];
-    if (dyn)
-      rc = imf_rulebook_transpose_dyn(co.table, co.capacity, fi.coords, s.n[i], meta + 2 * i, 1 << i, 3,
-                                      rb_up[i].tile_rows, rb_up[i].nbr, rb_up[i].tile_mask, rb_up[i].n_slots,
-                                      counters + 16 * i, side);
-    else
-      rc = imf_rulebook_transpose(co.table, co.capacity, fi.coords, s.n[i], 1 << i, 3, rb_up[i].tile_rows,
-                                  rb_up[i].nbr, rb_up[i].tile_mask, rb_up[i].n_slots, counters + 16 * i, side);
-    if (rc) return rc;
-    if (!pyr && (rc = mark(rb_up[i]))) return rc;
-  }
+  // The side chain in pieces: level i + 1 (coordinates, strided map, stride-1 map: what the encoder needs next) and the tail
+  // (item starts, the three transposed maps, the join).  Fragment forward with sorts off the side stream (round 6): each piece is
+  // ISSUED right before the first main-stream launch that waits for it instead of all of them up front -- on the GPU nothing
+  // changes while the host runs ahead (the streaming pipeline, the bench's steps), but a forward issued into an idle GPU (the
+  // synchronous extract_features call) starts its first convolution ~35 launches = ~0.1 ms of host time earlier: that call
+  // 1.522 -> 1.446 ms host to host, 1.129 -> 1.086 with the inputs on the device (tools/sync_phases.py; the pair step and the
+  // single-fragment step back to back: unchanged).  IMF_EAGER_SIDE=1 (diagnostic): everything up front.  (Deferring the
+  // ISSUE of the image branch's launches the same way, behind block1's: measured, no further gain -- 0.970 instead of 0.950 of
+  // the eager call -- and dropped.)
+  int side_levels_issued = 0;
+  bool side_tail_issued = false;
+  auto side_level = [&](int i) -> int {
+    int rc2;
+    if (pyr && (rc2 = pyramid_coarse_level(*pyr, i + 1, side))) return rc2;
+    if ((rc2 = build_conv(rb_dn[i], i, i + 1, 3, side))) return rc2;
+    if ((rc2 = build_conv(rb_k3[i + 1], i + 1, i + 1, 3, side))) return rc2;
+    return mark(rb_dn[i]);
+  };
+  auto side_tail = [&]() -> int {
+    int rc2 = IMF_OK;
+    if (pyr) {   // first row of every item at every level (the fusion reads the stride-8 ones)
+      if ((rc2 = pyramid_item_starts(*pyr, side, 0, 4))) return rc2;
+    }
+    for (int i = 2; i >= 0; --i) {
+      const imf_level &co = io->level[i + 1], &fi = io->level[i];
+      if (dyn)
+        rc2 = imf_rulebook_transpose_dyn(co.table, co.capacity, fi.coords, s.n[i], meta + 2 * i, 1 << i, 3,
+                                         rb_up[i].tile_rows, rb_up[i].nbr, rb_up[i].tile_mask, rb_up[i].n_slots,
+                                         counters + 16 * i, side);
+      else
+        rc2 = imf_rulebook_transpose(co.table, co.capacity, fi.coords, s.n[i], 1 << i, 3, rb_up[i].tile_rows,
+                                     rb_up[i].nbr, rb_up[i].tile_mask, rb_up[i].n_slots, counters + 16 * i, side);
+      if (rc2) return rc2;
+      if (!pyr && (rc2 = mark(rb_up[i]))) return rc2;
+    }
+    if (pyr) {
+      // Fragment forward: ONE join with the side stream for everything the second half of the step needs (item starts for
+      // the fusion, the three transposed rulebooks for the decoder), waited for right before the fusion.  A stream-wait
+      // costs the main stream ~5 us even when its event completed long ago (tools/conv_gaps.py: 10.6 us instead of 5.3 in
+      // front of every convolution that carried one); the side stream's chain ends ~150 us before the main stream gets there.
+      // The image branch joins the SIDE stream here (it was forked before this call, its end event is recorded), so the
+      // main stream waits once, not twice, in front of the fusion.
+      if (image_joined_side) IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->image_ready, 0));
+      IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[8], side));
+    }
+    side_tail_issued = true;
+    return IMF_OK;
+  };
+  // issue the side chain up to (and including) level `upto` (1 .. 3); with `tail` the tail as well
+  auto ensure_side = [&](int upto, bool tail) -> int {
+    for (; side_levels_issued < upto; ++side_levels_issued) {
+      const int rc2 = side_level(side_levels_issued);
+      if (rc2) return rc2;
+    }
+    if (tail && !side_tail_issued) {
+      for (; side_levels_issued < 3; ++side_levels_issued) {
+        const int rc2 = side_level(side_levels_issued);
+        if (rc2) return rc2;
+      }
+      return side_tail();
+    }
+    return IMF_OK;
+  };
   if (pyr) {
-    // Fragment forward: ONE join with the side stream for everything the second half of the step needs (item starts for
-    // the fusion, the three transposed rulebooks for the decoder), waited for right before the fusion.  A stream-wait
-    // costs the main stream ~5 us even when its event completed long ago (tools/conv_gaps.py: 10.6 us instead of 5.3 in
-    // front of every convolution that carried one); the side stream's chain ends ~150 us before the main stream gets there.
-    // The image branch joins the SIDE stream here (it was forked before this call, its end event is recorded), so the
-    // main stream waits once, not twice, in front of the fusion.
     image_joined_side = io->image_ready && fctx->fork_after < 0 && side != main;
-    if (image_joined_side) IMF_CHECK_HIP(hipStreamWaitEvent(side, (hipEvent_t)io->image_ready, 0));
-    IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[8], side));
     items_event = 8;
   }
+  const bool lazy_side = pyr && fctx->imgs && fctx->imgs != side && fctx->imgs != main && side != main && !getenv("IMF_EAGER_SIDE");
+  if (!lazy_side && (rc = ensure_side(3, true))) return rc;
 
   // ---- feature buffers in the float arena ------------------------------------------------------
   size_t cnt[NBUF];
@@ -590,6 +626,14 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     IMF_REQUIRE(st.c_a + st.c_b == c.cin, "imf_resunet_forward: conv %d expects %d input channels, got %d",
                 st.conv, c.cin, st.c_a + st.c_b);
     Rb &rb = *st.rb;
+    if (lazy_side) {   // the side chain's piece this launch (or a later one on the same map) waits for
+      int rc2 = IMF_OK;
+      for (int i = 0; i < 3; ++i)
+        if (&rb == &rb_dn[i] || &rb == &rb_k3[i + 1] || (i < 2 && &rb == &rb_k3s[i + 1])) rc2 = ensure_side(i + 1, false);
+      for (int i = 0; i < 3; ++i)
+        if (&rb == &rb_up[i]) rc2 = ensure_side(3, true);
+      if (rc2) return rc2;
+    }
     if (rb.ready_event >= 0) {
       IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->events[rb.ready_event], 0));
       rb.ready_event = -1;
@@ -638,6 +682,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     // the level-2 map (conv3, the consumer of rb_dn[1]) -- see issue_sorts
     if (sched[i].rb == &rb_dn[1]) saw_conv3 = true;
     if (sort_stream != side && !sorts_issued && saw_conv3 && i >= fctx->fork_after) {
+      if (lazy_side && (rc = ensure_side(2, false))) return rc;
       if ((rc = issue_sorts())) return rc;
       sorts_issued = true;
     }
@@ -645,6 +690,7 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
 
   // ---- bottleneck fusion (model/resunet.py:237-273) ----------------------------------------------------
   // diagnostic marks (tools/branch_times.py hands events[11], [12] in): the main stream's arrival at the join, the fusion's end
+  if (lazy_side && (rc = ensure_side(3, true))) return rc;
   const bool diag_marks = pyr && io->events[11] && io->events[12];
   if (diag_marks) IMF_CHECK_HIP(hipEventRecord((hipEvent_t)io->events[11], main));
   if (io->image_ready && !image_joined_side) IMF_CHECK_HIP(hipStreamWaitEvent(main, (hipEvent_t)io->image_ready, 0));
