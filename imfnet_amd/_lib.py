@@ -133,7 +133,7 @@ class FragmentIO(C.Structure):
                 ("float_arena_bytes", C.c_size_t), ("out", C.c_void_p), ("events", C.c_void_p * 16),
                 ("main_stream", C.c_void_p), ("side_stream", C.c_void_p), ("image_stream", C.c_void_p),
                 ("trace", C.POINTER(NetTrace)), ("levels", LevelDesc * 4), ("serialize", C.c_int32),
-                ("fp32_buffers", C.c_int32), ("head_on_side", C.c_int32), ("reserved0", C.c_int32),
+                ("fp32_buffers", C.c_int32), ("head_on_side", C.c_int32), ("gpu_idle_hint", C.c_int32),
                 ("inputs_event", C.c_void_p), ("reuse_event", C.c_void_p)]
 
 

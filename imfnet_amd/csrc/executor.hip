@@ -483,7 +483,13 @@ int imf_resunet_forward(const imf_resunet_desc *net, const imf_resunet_io *io) {
     image_joined_side = io->image_ready && fctx->fork_after < 0 && side != main;
     items_event = 8;
   }
-  const bool lazy_side = pyr && fctx->imgs && fctx->imgs != side && fctx->imgs != main && side != main && !getenv("IMF_EAGER_SIDE");
+  // ... so only THEN: imf_fragment_io.gpu_idle_hint (the pipeline sets it when no earlier forward is still running; with work
+  // queued the host is ahead anyway and the chain goes up front as before -- the streaming pipeline's host span measured 1-2 %
+  // worse with the pieces interleaved: 1.198 / 1.183 -> 1.216 / 1.204 ms per pair on one box).  IMF_EAGER_SIDE=1 / 0 (diagnostic)
+  // forces either order.
+  bool main_idle = fctx && fctx->fio->gpu_idle_hint != 0;
+  if (const char *e = getenv("IMF_EAGER_SIDE")) main_idle = atoi(e) == 0;
+  const bool lazy_side = pyr && fctx->imgs && fctx->imgs != side && fctx->imgs != main && side != main && main_idle;
   if (!lazy_side && (rc = ensure_side(3, true))) return rc;
 
   // ---- feature buffers in the float arena ------------------------------------------------------

@@ -112,6 +112,7 @@ struct Pipeline {
   std::vector<Ticket> tickets;
   std::deque<int> queue;     // submitted, forward not issued yet
   std::deque<int> pending;   // forward issued, download deferred
+  hipEvent_t last_fwd = nullptr;   // end of the last forward issued (a ticket's e_fwd; tickets live as long as the pipeline)
   std::mutex mu;
   std::condition_variable cv_work, cv_done;
   std::thread worker;
@@ -149,9 +150,16 @@ int issue_forward(Pipeline &p, Ticket &t) {
   } else {
     IMF_CHECK_HIP(hipStreamWaitEvent(p.main, t.e_in, 0));
   }
+  // is the GPU idle?  (no earlier forward, or the last one issued has ended: the executor then issues its side chain piecewise)
+  j.io->gpu_idle_hint = 1;
+  if (p.last_fwd) {
+    j.io->gpu_idle_hint = hipEventQuery(p.last_fwd) == hipSuccess ? 1 : 0;
+    (void)hipGetLastError();                         // (hipErrorNotReady is the other answer, not an error)
+  }
   IMF_CHECK_HIP(hipEventRecord(t.e_begin, p.main));
   j.io->main_stream = p.main;
   int rc = imf_fragment_forward(j.net, j.img, j.caps, j.io);
+  j.io->gpu_idle_hint = 0;
   j.io->inputs_event = nullptr;       // (the ticket's event: not the caller's to keep)
   if (rc) return rc;
   if (j.sel) {
@@ -160,6 +168,7 @@ int issue_forward(Pipeline &p, Ticket &t) {
     if (rc) return rc;
   }
   IMF_CHECK_HIP(hipEventRecord(t.e_fwd, p.main));
+  p.last_fwd = t.e_fwd;
   return IMF_OK;
 }
 

@@ -450,7 +450,12 @@ class FragmentRunner:
                     evs = [ops._Ev() for _ in range(23)]
                     for i, e in enumerate(evs):
                         trace[i].ev_begin, trace[i].ev_end, trace[i].launched = e.begin, e.end, 0
+                # imf_fragment_io.gpu_idle_hint: nothing of this runner's is still running (its last forward's end event has
+                # fired) -- a synchronous call; the executor then issues its side chain piecewise (LAB_NOTES 4g-11)
+                last = getattr(self, "_last_done", None)
+                b.io.gpu_idle_hint = 1 if (last is None or (last is not False and last.query())) else 0
                 b.enqueue(self, stream, trace, reuse_event=reuse_event)
+                b.io.gpu_idle_hint = 0
                 self.stats["eager"] += 1
             else:
                 if not b.graph:
@@ -470,6 +475,7 @@ class FragmentRunner:
                     host, done = torch.zeros(META_WORDS, dtype=torch.int32).pin_memory(), torch.cuda.Event()
                 host.copy_(b.meta, non_blocking=True)
                 done.record(stream)
+            self._last_done = done if meta_to is None else False   # (the caller's event: recorded by the caller, later -- no hint)
         b.launches += 1
         res = FragmentResult(b, n_points, n_items, host, done, pooled=meta_to is None)
         if trace_list is not None:

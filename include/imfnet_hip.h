@@ -694,7 +694,11 @@ typedef struct imf_fragment_io {       /* [host]; all buffers device memory owne
    * work on ANY stream no longer touches this bucket's buffers (the end of its previous forward and of whatever read its
    * outputs).  Not inside a hipGraph capture. */
   int32_t head_on_side;
-  int32_t reserved0;
+  /* Hint, 0 or 1: the GPU is idle when this forward is issued (a synchronous call: nothing queued on main_stream).  The executor
+   * then issues the side stream's pieces (coarse levels, rulebooks, transposed maps) right before the first main-stream launch
+   * that waits for each instead of all of them ahead of conv1 -- same streams, events and results; the first convolution starts
+   * ~0.1 ms of host time earlier.  With work queued ahead (a stream of forwards) leave it 0.  imf_pipeline_* sets it per job. */
+  int32_t gpu_idle_hint;
   void *inputs_event, *reuse_event;
 } imf_fragment_io;
 
