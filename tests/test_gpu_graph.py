@@ -261,3 +261,35 @@ def test_strict_fp32_capacity_mode_equals_its_exact_mode(seeded_sd, clouds, imag
     n0 = res.items()[0][1]
     _, F_ref = O.extract_features(sd, pts[0], 0.05, images[0])
     assert np.abs(F_exact[:n0].cpu().numpy() - F_ref.numpy()).max() < 1e-4
+
+
+def test_side_chain_issue_order_does_not_change_the_descriptors(clouds):
+    """imf_fragment_io.gpu_idle_hint (round 6): with nothing queued ahead the executor issues the side stream's pieces right
+    before the first launch that waits for each, otherwise all of them ahead of conv1 -- same streams, same events, same order
+    within each stream: the descriptors of a pair and of one fragment are the same bits either way (IMF_EAGER_SIDE forces the
+    order per call), and both equal the exact path."""
+    import bench
+    dev = torch.device("cuda:0")
+    model, _ = bench.build_model(dev)
+    pts, imgs = bench.load_pair(1.0)
+    old = os.environ.get("IMF_EAGER_SIDE")
+    try:
+        with torch.no_grad():
+            for sel in ([0], [0, 1]):
+                wl = bench.Workload(model, dev, [pts[i] for i in sel], imgs[sel], 0.025)
+                F = wl.prepare_graph().clone()
+                wl.runner.use_graph = False
+                got = {}
+                for flag in ("1", "0"):
+                    os.environ["IMF_EAGER_SIDE"] = flag
+                    for _ in range(2):                                     # (twice: an idle GPU, then work queued ahead)
+                        r = wl.graph_step()
+                    torch.cuda.synchronize()
+                    assert r.flags == 0
+                    got[flag] = r.F.clone()
+                assert torch.equal(got["1"], got["0"]) and torch.equal(got["1"], F), sel
+    finally:
+        if old is None:
+            os.environ.pop("IMF_EAGER_SIDE", None)
+        else:
+            os.environ["IMF_EAGER_SIDE"] = old
